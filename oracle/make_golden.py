@@ -1,0 +1,190 @@
+"""Generate tests/golden/*.npz by running the REAL reference modules in the build container.
+
+Run from the repo root:  python oracle/make_golden.py
+Needs /root/reference (read-only).  It never runs on the GPU box; only the vectors
+(inputs + expected outputs) are committed.  The same run asserts that the oracle
+restatement (oracle/depth_oracle.py) reproduces the reference to fp32 round-off,
+which is what "pinned" means in the oracle header.
+
+Reference entry points exercised
+  d_anything.dpt.DPT_DINOv2              bands/d_anything/dpt.py:139-166
+  vision_transformer.vit_large(depth=4)  .../facebookresearch_dinov2_main/vision_transformer.py:367-378
+  d_anything.dpt.DPTHead                 bands/d_anything/dpt.py:22-136
+  common.encode.heat_to_rgb/process_flow bands/common/encode.py:13-33,113-126
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+warnings.filterwarnings("ignore")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REF, "bands"))
+sys.path.insert(0, os.path.join(REF, "bands/d_anything/torchhub/facebookresearch_dinov2_main"))
+os.chdir(REF)                                   # dpt.py:147 uses a cwd-relative hub path
+
+import torch  # noqa: E402
+
+from oracle import depth_oracle as O  # noqa: E402
+from prisma_amd import synth  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def load_into(module, weights, prefix=""):
+    sd = {k[len(prefix):]: torch.from_numpy(v) for k, v in weights.items() if k.startswith(prefix)}
+    missing, unexpected = module.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def hook_stages(model):
+    """Forward hooks that record the stages the oracle also reports."""
+    st = {}
+
+    def rec(name):
+        def f(_m, _i, o):
+            st[name] = (o[0] if isinstance(o, (tuple, list)) else o).detach().numpy().copy()
+        return f
+
+    vit, head = model.pretrained, model.depth_head
+    vit.patch_embed.register_forward_hook(rec("patch_embed"))
+    for i, b in enumerate(vit.blocks):
+        b.register_forward_hook(rec(f"block{i}"))
+    for i in range(4):
+        getattr(head.scratch, f"layer{i + 1}_rn").register_forward_hook(rec(f"layer{i + 1}_rn"))
+        getattr(head.scratch, f"refinenet{i + 1}").register_forward_hook(rec(f"path{i + 1}"))
+    head.scratch.output_conv1.register_forward_hook(rec("output_conv1"))
+    head.scratch.output_conv2[1].register_forward_hook(rec("output_conv2_0"))
+    head.scratch.output_conv2[2].register_forward_hook(rec("pre_relu"))
+    return st
+
+
+class RefAssembled(torch.nn.Module):
+    """Reference classes assembled by hand so depth != 24 is possible (DPT_DINOv2 hard-wires hub models)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        import vision_transformer as vits
+        from d_anything.dpt import DPTHead
+        from dinov2.layers import MemEffAttention, NestedTensorBlock
+        from functools import partial
+        self.pretrained = vits.DinoVisionTransformer(
+            img_size=518, patch_size=14, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.heads,
+            mlp_ratio=4, init_values=1.0, ffn_layer="mlp", block_chunks=0,
+            block_fn=partial(NestedTensorBlock, attn_class=MemEffAttention),
+            num_register_tokens=0, interpolate_antialias=False, interpolate_offset=0.1)
+        self.depth_head = DPTHead(1, cfg.embed_dim, cfg.features, False, out_channels=list(cfg.out_channels),
+                                  use_clstoken=False)
+
+    def forward(self, x):
+        from d_anything.dpt import DPT_DINOv2
+        return DPT_DINOv2.forward(self, x)
+
+
+def build_ref(cfg_name):
+    from d_anything.dpt import DPT_DINOv2
+    cfg = synth.DEPTH_CFGS[cfg_name]
+    w = synth.depth_anything_weights(cfg, seed=1234)
+    if cfg_name in ("vits", "vitb", "vitl"):
+        m = DPT_DINOv2(encoder=cfg_name, features=cfg.features, out_channels=list(cfg.out_channels))
+    else:
+        m = RefAssembled(cfg)
+    load_into(m, w)
+    return cfg, w, m.eval()
+
+
+def small_case(cfg_name, hgt, wid, seed):
+    cfg, w, m = build_ref(cfg_name)
+    st_ref = hook_stages(m)
+    x = np.random.default_rng(seed).standard_normal((1, 3, hgt, wid)).astype(np.float32)
+    with torch.no_grad():
+        d_ref = m(torch.from_numpy(x)).numpy()
+    d_or, st_or = O.model_forward(w, x, cfg.depth, cfg.heads, return_stages=True)
+    worst = relerr(d_or, d_ref)
+    for k in st_ref:
+        if k in st_or:
+            worst = max(worst, relerr(st_or[k], st_ref[k]))
+    print(f"[{cfg_name} {hgt}x{wid}] oracle vs reference worst rel err {worst:.2e}; depth range "
+          f"{d_ref.min():.4f}..{d_ref.max():.4f}")
+    assert worst < 2e-5, worst
+    keep = ["patch_embed", "block0", f"block{cfg.depth - 1}", "layer1_rn", "layer4_rn", "path4", "path1",
+            "output_conv1", "pre_relu"]
+    out = {"x": x, "depth": d_ref}
+    for k in keep:
+        v = st_ref[k]
+        if v.size > 60000:                      # keep fixtures small: strided sample + full-tensor moments
+            out["sum_" + k] = np.array([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum()])
+            v = v.reshape(-1)[:: max(1, v.size // 20000)]
+        out["st_" + k] = v
+    np.savez_compressed(os.path.join(GOLD, f"depth_{cfg_name}_{hgt}x{wid}.npz"), **out)
+
+
+def full_case():
+    """ViT-L at the 518x924 network size both BASELINE resolutions map to, from a 720p frame."""
+    cfg, w, m = build_ref("vitl")
+    frame = synth.frames(1, 720, 1280, seed=0)[0]
+    x = O.preprocess(frame)[None]
+    assert x.shape == (1, 3, 518, 924)
+    with torch.no_grad():
+        d_net = m(torch.from_numpy(x))
+        d_ref = torch.nn.functional.interpolate(d_net[None], (720, 1280), mode="bilinear",
+                                                align_corners=False)[0, 0].numpy()
+    d_or = O.infer(w, frame, cfg.depth, cfg.heads)
+    e = relerr(d_or, d_ref)
+    print(f"[vitl 720p] oracle vs reference rel err {e:.2e}; depth {d_ref.min():.4f}..{d_ref.max():.4f} "
+          f"mean {d_ref.mean():.4f}")
+    assert e < 5e-5, e
+    rgb, dmin, dmax = O.encode_depth_video(d_ref, flip=True)
+    np.savez_compressed(
+        os.path.join(GOLD, "depth_vitl_720p.npz"),
+        frame_seed=np.array(0), depth_s8=d_ref[::8, ::8].copy(), net_s8=d_net[0].numpy()[::8, ::8].copy(),
+        depth_sum=np.array([d_ref.astype(np.float64).sum(), np.abs(d_ref.astype(np.float64)).sum()]),
+        minmax=np.array([dmin, dmax]), rgb_s8=rgb[::8, ::8].copy())
+
+
+def encode_case():
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))   # common/encode.py:10 imports cv2 for Sobel only
+    from common import encode as E
+    ramp = np.linspace(0.0, 1.0, 4096).reshape(64, 64)
+    heat = (E.heat_to_rgb(ramp) * 255).astype(np.uint8)
+    g = np.random.default_rng(7)
+    pred = (g.standard_normal((45, 80)).astype(np.float32) * 3 + 10).astype(np.float32)
+    dmin, dmax = pred.min(), pred.max()
+    d = 1.0 - (pred - dmin) / (dmax - dmin)
+    vid = (E.heat_to_rgb(d.astype(np.float64)) * 255).astype(np.uint8)
+    mine, a, b = O.encode_depth_video(pred, flip=True)
+    assert np.array_equal(mine, vid) and a == float(dmin) and b == float(dmax)
+    assert np.array_equal((O.heat_to_rgb(ramp) * 255).astype(np.uint8), heat)
+    flow = g.standard_normal((40, 64, 2)).astype(np.float32) * 5
+    frgb, fmax = E.process_flow(flow.copy())
+    with np.errstate(all="ignore"):
+        zrgb, zmax = E.process_flow(np.zeros((8, 8, 2), np.float32))
+    np.savez_compressed(os.path.join(GOLD, "encode.npz"), ramp=ramp, heat=heat, pred=pred, vid=vid,
+                        flow=flow, flow_rgb=frgb, flow_max=np.array(fmax), zero_rgb=zrgb, zero_max=np.array(zmax),
+                        float_to_rgb=np.array(E.float_to_rgb(12.5, 0.0, 1000.0)))
+    print("[encode] oracle == reference (bit exact)")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full"]
+    if "encode" in which:
+        encode_case()
+    if "vits" in which:
+        small_case("vits", 70, 98, 11)
+    if "vitl_d4" in which:
+        small_case("vitl_d4", 70, 98, 12)
+    if "full" in which:
+        full_case()

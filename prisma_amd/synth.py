@@ -1,0 +1,175 @@
+"""Seeded synthetic weights and frames for the bands engine.
+
+There is no network on the build or GPU boxes, so neither the Depth-Anything
+nor the RAFT checkpoints can be fetched.  This module generates weights with
+the *same key names and shapes* as the reference checkpoints
+(Depth-Anything: `pretrained.*` / `depth_head.*`, see
+/root/reference/bands/d_anything/dpt.py:139-166; RAFT: `fnet.* cnet.*
+update_block.*`, see /root/reference/bands/raft/raft.py:24-58) from a numpy
+PCG64 stream keyed by (seed, crc32(param name)).  The stream only depends on
+the name, so the oracle script (which loads the tensors into the reference
+torch modules), the tests and bench.py on the GPU box all see bit-identical
+weights without shipping a checkpoint.
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------
+# Depth-Anything (DINOv2 ViT + DPT head) configurations.
+# Encoder table: reference hubconf vit_small/base/large
+# (/root/reference/bands/d_anything/torchhub/facebookresearch_dinov2_main/vision_transformer.py:340-378)
+# DPT table: the HF configs used by DepthAnything.from_pretrained
+# (LiheYoung/depth_anything_vit{s,b,l}14: features / out_channels).
+# ----------------------------------------------------------------------------
+@dataclass(frozen=True)
+class DepthCfg:
+    name: str = "vitl"
+    embed_dim: int = 1024
+    depth: int = 24
+    heads: int = 16
+    mlp_ratio: int = 4
+    patch: int = 14
+    pos_grid: int = 37                      # 518 / 14, pos_embed has 1 + 37*37 rows
+    features: int = 256
+    out_channels: Tuple[int, int, int, int] = (256, 512, 1024, 1024)
+    n_taps: int = 4                         # get_intermediate_layers(x, 4)
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.heads
+
+
+DEPTH_CFGS: Dict[str, DepthCfg] = {
+    "vits": DepthCfg("vits", 384, 12, 6, 4, 14, 37, 64, (48, 96, 192, 384)),
+    "vitb": DepthCfg("vitb", 768, 12, 12, 4, 14, 37, 128, (96, 192, 384, 768)),
+    "vitl": DepthCfg("vitl", 1024, 24, 16, 4, 14, 37, 256, (256, 512, 1024, 1024)),
+    # ViT-L widths with only 4 blocks: same kernels/shapes as vitl, cheap on CPU.
+    "vitl_d4": DepthCfg("vitl_d4", 1024, 4, 16, 4, 14, 37, 256, (256, 512, 1024, 1024)),
+}
+
+
+def depth_param_shapes(cfg: DepthCfg) -> List[Tuple[str, Tuple[int, ...]]]:
+    D = cfg.embed_dim
+    H = D * cfg.mlp_ratio
+    F = cfg.features
+    oc = cfg.out_channels
+    out: List[Tuple[str, Tuple[int, ...]]] = [
+        ("pretrained.cls_token", (1, 1, D)),
+        ("pretrained.pos_embed", (1, 1 + cfg.pos_grid * cfg.pos_grid, D)),
+        ("pretrained.mask_token", (1, D)),
+        ("pretrained.patch_embed.proj.weight", (D, 3, cfg.patch, cfg.patch)),
+        ("pretrained.patch_embed.proj.bias", (D,)),
+    ]
+    for i in range(cfg.depth):
+        p = f"pretrained.blocks.{i}."
+        out += [
+            (p + "norm1.weight", (D,)), (p + "norm1.bias", (D,)),
+            (p + "attn.qkv.weight", (3 * D, D)), (p + "attn.qkv.bias", (3 * D,)),
+            (p + "attn.proj.weight", (D, D)), (p + "attn.proj.bias", (D,)),
+            (p + "ls1.gamma", (D,)),
+            (p + "norm2.weight", (D,)), (p + "norm2.bias", (D,)),
+            (p + "mlp.fc1.weight", (H, D)), (p + "mlp.fc1.bias", (H,)),
+            (p + "mlp.fc2.weight", (D, H)), (p + "mlp.fc2.bias", (D,)),
+            (p + "ls2.gamma", (D,)),
+        ]
+    out += [("pretrained.norm.weight", (D,)), ("pretrained.norm.bias", (D,))]
+    h = "depth_head."
+    for i in range(4):
+        out += [(h + f"projects.{i}.weight", (oc[i], D, 1, 1)), (h + f"projects.{i}.bias", (oc[i],))]
+    out += [
+        (h + "resize_layers.0.weight", (oc[0], oc[0], 4, 4)), (h + "resize_layers.0.bias", (oc[0],)),
+        (h + "resize_layers.1.weight", (oc[1], oc[1], 2, 2)), (h + "resize_layers.1.bias", (oc[1],)),
+        (h + "resize_layers.3.weight", (oc[3], oc[3], 3, 3)), (h + "resize_layers.3.bias", (oc[3],)),
+    ]
+    for i in range(4):
+        out.append((h + f"scratch.layer{i + 1}_rn.weight", (F, oc[i], 3, 3)))
+    for r in range(1, 5):
+        p = h + f"scratch.refinenet{r}."
+        out += [(p + "out_conv.weight", (F, F, 1, 1)), (p + "out_conv.bias", (F,))]
+        for u in (1, 2):
+            for c in (1, 2):
+                out += [(p + f"resConfUnit{u}.conv{c}.weight", (F, F, 3, 3)),
+                        (p + f"resConfUnit{u}.conv{c}.bias", (F,))]
+    out += [
+        (h + "scratch.output_conv1.weight", (F // 2, F, 3, 3)), (h + "scratch.output_conv1.bias", (F // 2,)),
+        (h + "scratch.output_conv2.0.weight", (32, F // 2, 3, 3)), (h + "scratch.output_conv2.0.bias", (32,)),
+        (h + "scratch.output_conv2.2.weight", (1, 32, 1, 1)), (h + "scratch.output_conv2.2.bias", (1,)),
+    ]
+    return out
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.default_rng([seed & 0xFFFFFFFF, zlib.crc32(name.encode())])
+
+
+def _fan_in(name: str, shape: Tuple[int, ...]) -> int:
+    if len(shape) == 4:
+        if "resize_layers.0" in name or "resize_layers.1" in name:   # ConvTranspose2d: (in, out, kh, kw)
+            return shape[0]
+        return shape[1] * shape[2] * shape[3]
+    if len(shape) == 2:
+        return shape[1]
+    return 1
+
+
+def _depth_tensor(seed: int, name: str, shape: Tuple[int, ...]) -> np.ndarray:
+    g = _rng(seed, name)
+    n = lambda s: g.standard_normal(shape, dtype=np.float32) * np.float32(s)
+    if name.endswith("cls_token") or name.endswith("pos_embed"):
+        return n(0.2)
+    if name.endswith("mask_token"):
+        return np.zeros(shape, np.float32)
+    if ".norm" in name and name.endswith("weight") and len(shape) == 1:
+        return (1.0 + n(0.1)).astype(np.float32)
+    if ".gamma" in name:
+        # LayerScale: trained DINOv2 gammas are O(0.1..1); keeps 24 residual adds well-conditioned.
+        return (0.25 + 0.1 * g.random(shape, dtype=np.float32)).astype(np.float32)
+    if name.endswith("output_conv2.2.bias"):
+        # default torch init lands < 0 and the trailing ReLU zeroes the depth map
+        # (SURVEY.md section 8 a-4); keep the output strictly inside the ReLU's active range.
+        return np.full(shape, 1.0, np.float32)
+    if name.endswith("output_conv2.2.weight"):
+        return (0.05 + n(0.1)).astype(np.float32)     # mean-positive: most pixels stay above the ReLU
+    if name.endswith("bias"):
+        return n(0.1)
+    return n(1.0 / np.sqrt(_fan_in(name, shape)))
+
+
+def depth_anything_weights(cfg: DepthCfg | str = "vitl", seed: int = 1234) -> Dict[str, np.ndarray]:
+    """name -> float32 ndarray, reference state_dict naming."""
+    if isinstance(cfg, str):
+        cfg = DEPTH_CFGS[cfg]
+    return {name: _depth_tensor(seed, name, shape) for name, shape in depth_param_shapes(cfg)}
+
+
+# ----------------------------------------------------------------------------
+# Synthetic frames
+# ----------------------------------------------------------------------------
+def frames(n: int, height: int, width: int, seed: int = 0) -> np.ndarray:
+    """n RGB uint8 frames [n, H, W, 3] = smooth seeded blobs + noise.
+
+    Pure white noise gives the ViT nothing spatially coherent to respond to; a
+    low-frequency texture plus noise gives depth maps with a healthy range.
+    """
+    g = np.random.default_rng([seed, 0xF4A3E5])
+    out = np.empty((n, height, width, 3), np.uint8)
+    yy = np.linspace(0.0, 1.0, height, dtype=np.float32)[:, None]
+    xx = np.linspace(0.0, 1.0, width, dtype=np.float32)[None, :]
+    for i in range(n):
+        img = np.zeros((height, width, 3), np.float32)
+        for _ in range(6):
+            fx, fy = g.uniform(0.5, 6.0, 2)
+            ph = g.uniform(0, 2 * np.pi, 3)
+            amp = g.uniform(0.2, 1.0, 3)
+            for c in range(3):
+                img[..., c] += amp[c] * np.sin(2 * np.pi * (fx * xx + fy * yy) + ph[c])
+        img = (img - img.min()) / (img.max() - img.min() + 1e-6)
+        noise = g.integers(0, 64, (height, width, 3), dtype=np.int32)
+        out[i] = np.clip(img * 191.0 + noise, 0, 255).astype(np.uint8)
+    return out
