@@ -1,0 +1,145 @@
+/*
+ * prisma_bands.h - C ABI of libprisma_bands.so (MI355X / gfx950 "bands" engine).
+ *
+ * The reference (patriciogonzalezvivo/prisma) has no native boundary: a band is a Python
+ * script exposing init_model()/infer() and a per-frame loop.  This header is the boundary a
+ * maintainer would bind from those scripts (ctypes stub: INTEGRATION.md).  Each entry point
+ * cites the reference code it replaces; paths are relative to the reference checkout.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative pb_status; pb_last_error() holds the
+ *     message of the last failure on the calling thread.
+ *   - the caller owns every host buffer; the library owns device memory, streams and events
+ *     inside pb_ctx.  One pb_ctx per GPU per process; a ctx is not re-entrant.
+ *   - no CPU fallback: without a usable HIP device pb_create fails (PB_ERR_DEVICE).
+ */
+#ifndef PRISMA_BANDS_H
+#define PRISMA_BANDS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pb_ctx pb_ctx;
+
+typedef enum {
+    PB_OK = 0,
+    PB_ERR_ARG = -1,      /* bad argument / shape / missing weight            */
+    PB_ERR_DEVICE = -2,   /* no HIP device, HIP call failed                   */
+    PB_ERR_MEMORY = -3,   /* device or host allocation failed                 */
+    PB_ERR_STATE = -4     /* call sequence error (e.g. wrong band for ctx)    */
+} pb_status;
+
+typedef enum { PB_F32 = 0, PB_F16 = 1, PB_U8 = 2, PB_I32 = 3 } pb_dtype;
+
+/* One named weight tensor, reference state_dict naming
+ * (Depth-Anything: `pretrained.*`, `depth_head.*` - bands/d_anything/dpt.py:139-166;
+ *  RAFT: `fnet.*`, `cnet.*`, `update_block.*` - bands/raft/raft.py:24-58, without the
+ *  `module.` prefix that bands/flow_raft.py:42-44 strips).  data is host memory, float32,
+ *  C-contiguous; it is consumed (packed + uploaded) during pb_create and not referenced after. */
+typedef struct {
+    const char *name;
+    int32_t dtype;        /* pb_dtype, PB_F32 only today */
+    int32_t ndim;
+    int64_t shape[6];
+    const void *data;
+} pb_tensor;
+
+/* Depth-Anything geometry (bands/depth_anything.py:257-264 `--encoder`; the HF config that
+ * DepthAnything.from_pretrained reads: encoder / features / out_channels). */
+typedef struct {
+    int32_t embed_dim;        /* 384 / 768 / 1024                       */
+    int32_t depth;            /* 12 / 12 / 24 transformer blocks        */
+    int32_t heads;            /* 6 / 12 / 16 (head_dim is always 64)    */
+    int32_t features;         /* DPT head width 64 / 128 / 256          */
+    int32_t out_channels[4];  /* DPT reassemble widths                  */
+    int32_t pos_grid;         /* 37 (pos_embed rows = 1 + 37*37)        */
+    int32_t max_batch;        /* frames per launch the arena is sized for (>= 1) */
+} pb_depth_cfg;
+
+const char *pb_last_error(void);
+int pb_version(void);
+/* Number of visible HIP devices (0 on a CPU-only box; never fails). */
+int pb_device_count(void);
+
+/* init_model(): bands/depth_anything.py:48-76 (+ bands/d_anything/dpt.py:139-171).
+ * band = "depth_anything".  Packs weights to fp16 MFMA layouts and uploads them. */
+int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *weights,
+              int n_weights, const void *cfg, size_t cfg_bytes);
+void pb_destroy(pb_ctx *ctx);
+
+/* infer() + the per-frame post-process of process_video():
+ * bands/depth_anything.py:100-143 and :215-221 (min/max, normalise, flip, heat_to_rgb).
+ *   frames   : n x H x W x 3 uint8 RGB (decoder layout)            [host]
+ *   depth_out: n x H x W float32 relative depth, or NULL           [host]
+ *   rgb_out  : n x H x W x 3 uint8 heat-encoded frame, or NULL     [host]
+ *   min_out / max_out: n floats each, or NULL                      [host]
+ *   flip     : 1 for the relative model (bands/depth_anything.py:188) */
+int pb_depth_infer_batch(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W,
+                         float *depth_out, uint8_t *rgb_out, float *min_out, float *max_out, int flip);
+
+/* Same contract with every pointer in device memory of ctx's GPU (frames already resident
+ * in HBM; used by bench.py and by pipelines that decode on the GPU).  Asynchronous on the
+ * ctx stream; pb_sync() waits for it. */
+int pb_depth_infer_batch_dev(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W,
+                             float *depth_out, uint8_t *rgb_out, float *min_out, float *max_out, int flip);
+int pb_sync(pb_ctx *ctx);
+
+/* Network input size for an H x W frame: keep-aspect lower-bound resize to 518, each side a
+ * multiple of 14 (bands/d_anything/util/transform.py:100-166). */
+int pb_depth_net_size(int H, int W, int *net_h, int *net_w);
+
+/* Debug/parity: copy a named intermediate of the last pb_depth_infer_batch* call to the host
+ * as float32 in the reference's layout ([n, C, h, w] for maps, [n, tokens, D] for tokens).
+ * Names: "tokens", "block<i>", "feat<i>", "layer<i>_rn", "path<i>", "output_conv1", "net_depth".
+ * shape_out receives up to 4 dims; returns the element count or a negative pb_status. */
+int64_t pb_depth_get_stage(pb_ctx *ctx, const char *name, float *out, int64_t cap, int64_t shape_out[4]);
+
+/* Device memory helpers so a Python host without torch can keep frames resident. */
+int pb_dev_alloc(pb_ctx *ctx, void **ptr, size_t bytes);
+int pb_dev_free(pb_ctx *ctx, void *ptr);
+int pb_memcpy_h2d(pb_ctx *ctx, void *dst, const void *src, size_t bytes);
+int pb_memcpy_d2h(pb_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+/* Timing of the kernels launched by the last infer call, measured with HIP events on the ctx
+ * stream: fills up to cap entries; returns the count.  name points into static storage. */
+typedef struct {
+    const char *name;     /* kernel family, e.g. "gemm_f16", "attention", "conv3x3"      */
+    double ms;            /* summed event time of that family in the last call            */
+    double flops;         /* algorithmic FLOPs those launches performed                   */
+    double bytes;         /* algorithmic HBM bytes (compulsory traffic) of those launches */
+    int32_t launches;
+} pb_kernel_stat;
+int pb_set_profiling(pb_ctx *ctx, int enabled);
+int pb_get_kernel_stats(pb_ctx *ctx, pb_kernel_stat *out, int cap);
+
+/* ---- single-kernel entry points (host buffers) used by the -m gpu parity tests ---------- */
+/* C[M,N] = act(A[M,K] @ W[N,K]^T + bias) with fp16 operands, fp32 accumulate (MFMA).       */
+int pb_op_gemm(pb_ctx *ctx, const float *A, const float *W, const float *bias, float *C,
+               int M, int N, int K, int act /*0 none,1 relu,2 gelu*/, int tile /*0 auto,1 128x128,2 256x256*/);
+/* LayerNorm over the last dim, eps 1e-6 (vision_transformer.py:95). */
+int pb_op_layernorm(pb_ctx *ctx, const float *x, const float *g, const float *b, float *y, int rows, int D);
+/* softmax(q k^T * 64^-0.5) v per (batch, head); q,k,v,o: [B, heads, N, 64] float32
+ * (dinov2/layers/attention.py:49-62). */
+int pb_op_attention(pb_ctx *ctx, const float *q, const float *k, const float *v, float *o,
+                    int B, int heads, int N);
+/* NCHW float32 conv2d via NHWC fp16 implicit GEMM: x [B,Ci,H,W], w [Co,Ci,kh,kw]. */
+int pb_op_conv2d(pb_ctx *ctx, const float *x, const float *w, const float *bias, float *y,
+                 int B, int Ci, int H, int W, int Co, int ksize, int stride, int pad, int relu_in, int relu_out);
+/* bilinear resize NCHW float32, align_corners 0/1 (torch F.interpolate semantics). */
+int pb_op_bilinear(pb_ctx *ctx, const float *x, float *y, int B, int C, int H, int W, int OH, int OW,
+                   int align_corners);
+/* uint8 frame -> normalised network input [3, net_h, net_w] float32
+ * (bands/depth_anything.py:122-126). */
+int pb_op_preprocess(pb_ctx *ctx, const uint8_t *frame, int H, int W, float *out, int net_h, int net_w);
+/* float32 depth [n,H,W] -> heat RGB + min/max (bands/depth_anything.py:215-221). */
+int pb_op_encode_depth(pb_ctx *ctx, const float *depth, int n, int H, int W, int flip,
+                       uint8_t *rgb, float *mn, float *mx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRISMA_BANDS_H */

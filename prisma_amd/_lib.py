@@ -1,0 +1,88 @@
+"""ctypes binding of libprisma_bands.so (include/prisma_bands.h).
+
+The library is the product; there is no Python/torch/numpy fallback.  If the shared object is
+missing or was built without its kernels this module raises at import of the symbols, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprisma_bands.so")
+
+
+class pb_tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 6), ("data", C.c_void_p)]
+
+
+class pb_depth_cfg(C.Structure):
+    _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32), ("features", C.c_int32),
+                ("out_channels", C.c_int32 * 4), ("pos_grid", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class pb_kernel_stat(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double),
+                ("launches", C.c_int32)]
+
+
+# every symbol include/prisma_bands.h declares: (restype, argtypes)
+_P = C.c_void_p
+_F = C.POINTER(C.c_float)
+_U8 = C.POINTER(C.c_uint8)
+SYMBOLS = {
+    "pb_last_error": (C.c_char_p, []),
+    "pb_version": (C.c_int, []),
+    "pb_device_count": (C.c_int, []),
+    "pb_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.POINTER(pb_tensor), C.c_int, _P, C.c_size_t]),
+    "pb_destroy": (None, [_P]),
+    "pb_depth_infer_batch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int]),
+    "pb_depth_infer_batch_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int]),
+    "pb_sync": (C.c_int, [_P]),
+    "pb_depth_net_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pb_depth_get_stage": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "pb_dev_alloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
+    "pb_dev_free": (C.c_int, [_P, _P]),
+    "pb_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "pb_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "pb_set_profiling": (C.c_int, [_P, C.c_int]),
+    "pb_get_kernel_stats": (C.c_int, [_P, C.POINTER(pb_kernel_stat), C.c_int]),
+    "pb_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pb_op_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),
+    "pb_op_attention": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "pb_op_conv2d": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 10),
+    "pb_op_bilinear": (C.c_int, [_P, _P, _P] + [C.c_int] * 7),
+    "pb_op_preprocess": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int]),
+    "pb_op_encode_depth": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class PrismaBandsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PrismaBandsError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C prisma_amd/csrc).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc < 0:
+        raise PrismaBandsError(f"libprisma_bands: {load().pb_last_error().decode()} (status {rc})")
+    return rc

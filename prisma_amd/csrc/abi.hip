@@ -1,0 +1,366 @@
+// C ABI of libprisma_bands.so (include/prisma_bands.h).
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "engine.h"
+
+static thread_local char g_err[1024] = "";
+
+void pb_cubic_taps(int src, int dst, int *idx, float *wt);   // engine.hip
+
+void pb_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct pb_ctx {
+    int device = 0;
+    DepthEngine *depth = nullptr;
+    hipStream_t stream = nullptr;   // == depth->stream when a band is loaded
+    f16 *zero = nullptr;
+    bool own_stream = false;
+};
+
+namespace {
+struct DevMem {
+    void *p = nullptr;
+    ~DevMem() { if (p) hipFree(p); }
+    int alloc(size_t bytes) {
+        PB_HIP(hipMalloc(&p, bytes < 256 ? 256 : bytes));
+        PB_HIP(hipMemset(p, 0, bytes < 256 ? 256 : bytes));
+        PB_HIP(hipDeviceSynchronize());     // memset runs on the null stream; kernels use the ctx stream
+        return 0;
+    }
+    template <class T> T *as() { return (T *)p; }
+};
+#define PB_TRY(expr) do { int _r = (expr); if (_r) return _r; } while (0)
+}  // namespace
+
+extern "C" {
+
+const char *pb_last_error(void) { return g_err; }
+int pb_version(void) { return 100; }
+
+int pb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *weights, int n_weights, const void *cfg,
+              size_t cfg_bytes) {
+    PB_CHECK(out && band, PB_ERR_ARG, "pb_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    PB_CHECK(e == hipSuccess && ndev > 0, PB_ERR_DEVICE, "no HIP device available (%s); this library has no CPU path",
+             e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    PB_CHECK(device_id >= 0 && device_id < ndev, PB_ERR_ARG, "device %d out of range (%d devices)", device_id, ndev);
+    PB_HIP(hipSetDevice(device_id));
+    pb_ctx *c = new pb_ctx();
+    c->device = device_id;
+    if (!strcmp(band, "depth_anything")) {
+        if (!cfg || cfg_bytes != sizeof(pb_depth_cfg) || !weights || n_weights <= 0) {
+            delete c;
+            PB_CHECK(false, PB_ERR_ARG, "depth_anything: needs a pb_depth_cfg (%zu bytes, got %zu) and weights",
+                     sizeof(pb_depth_cfg), cfg_bytes);
+        }
+        c->depth = new DepthEngine(device_id, *(const pb_depth_cfg *)cfg);
+        int r = c->depth->load(weights, n_weights);
+        if (r) {
+            delete c->depth;
+            delete c;
+            return r;
+        }
+        c->stream = c->depth->stream;
+        c->zero = (f16 *)c->depth->zero_page();
+    } else if (!strcmp(band, "ops")) {
+        // kernel-level context for the parity tests: a stream and a zero page, no model
+        hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        void *z = nullptr;
+        hipError_t e2 = hipMalloc(&z, 4096);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            delete c;
+            PB_CHECK(false, PB_ERR_DEVICE, "ops context: stream/alloc failed");
+        }
+        hipMemset(z, 0, 4096);
+        hipDeviceSynchronize();
+        c->zero = (f16 *)z;
+        c->own_stream = true;
+    } else {
+        delete c;
+        PB_CHECK(false, PB_ERR_ARG, "unknown band '%s' (depth_anything | ops)", band);
+    }
+    *out = c;
+    return 0;
+}
+
+void pb_destroy(pb_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->depth) delete c->depth;
+    if (c->own_stream) {
+        hipStreamSynchronize(c->stream);
+        hipFree(c->zero);
+        hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+int pb_sync(pb_ctx *c) {
+    PB_CHECK(c, PB_ERR_ARG, "null ctx");
+    PB_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pb_depth_infer_batch_dev(pb_ctx *c, const uint8_t *frames, int n, int H, int W, float *depth_out, uint8_t *rgb_out,
+                             float *min_out, float *max_out, int flip) {
+    PB_CHECK(c && c->depth, PB_ERR_STATE, "ctx has no depth_anything band");
+    return c->depth->infer(frames, n, H, W, depth_out, rgb_out, min_out, max_out, flip);
+}
+
+int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, float *depth_out, uint8_t *rgb_out,
+                         float *min_out, float *max_out, int flip) {
+    PB_CHECK(c && c->depth, PB_ERR_STATE, "ctx has no depth_anything band");
+    PB_CHECK(frames && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "infer: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const size_t px = (size_t)H * W;
+    DevMem dF, dD, dR, dM;
+    PB_TRY(dF.alloc(n * px * 3));
+    if (depth_out) PB_TRY(dD.alloc(n * px * 4));
+    if (rgb_out) PB_TRY(dR.alloc(n * px * 3));
+    PB_TRY(dM.alloc((size_t)n * 8));
+    PB_HIP(hipMemcpy(dF.p, frames, n * px * 3, hipMemcpyHostToDevice));
+    float *mn = dM.as<float>(), *mx = mn + n;
+    PB_TRY(c->depth->infer(dF.as<uint8_t>(), n, H, W, dD.as<float>(), dR.as<uint8_t>(), mn, mx, flip));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    if (depth_out) PB_HIP(hipMemcpy(depth_out, dD.p, n * px * 4, hipMemcpyDeviceToHost));
+    if (rgb_out) PB_HIP(hipMemcpy(rgb_out, dR.p, n * px * 3, hipMemcpyDeviceToHost));
+    if (min_out) PB_HIP(hipMemcpy(min_out, mn, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (max_out) PB_HIP(hipMemcpy(max_out, mx, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int64_t pb_depth_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap, int64_t shape_out[4]) {
+    PB_CHECK(c && c->depth && name && out && shape_out, PB_ERR_ARG, "get_stage: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    return c->depth->get_stage(name, out, cap, shape_out);
+}
+
+int pb_set_profiling(pb_ctx *c, int enabled) {
+    PB_CHECK(c && c->depth, PB_ERR_STATE, "ctx has no band");
+    c->depth->timer.enabled = enabled != 0;
+    c->depth->debug = (enabled & 2) != 0;
+    return 0;
+}
+
+int pb_get_kernel_stats(pb_ctx *c, pb_kernel_stat *out, int cap) {
+    PB_CHECK(c && c->depth && out, PB_ERR_STATE, "ctx has no band");
+    return c->depth->stats(out, cap);
+}
+
+int pb_dev_alloc(pb_ctx *c, void **ptr, size_t bytes) {
+    PB_CHECK(c && ptr, PB_ERR_ARG, "dev_alloc: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    hipError_t e = hipMalloc(ptr, bytes);
+    PB_CHECK(e == hipSuccess, PB_ERR_MEMORY, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return 0;
+}
+int pb_dev_free(pb_ctx *c, void *ptr) {
+    PB_CHECK(c, PB_ERR_ARG, "null ctx");
+    PB_HIP(hipSetDevice(c->device));
+    PB_HIP(hipFree(ptr));
+    return 0;
+}
+int pb_memcpy_h2d(pb_ctx *c, void *dst, const void *src, size_t bytes) {
+    PB_CHECK(c, PB_ERR_ARG, "null ctx");
+    PB_HIP(hipSetDevice(c->device));
+    PB_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int pb_memcpy_d2h(pb_ctx *c, void *dst, const void *src, size_t bytes) {
+    PB_CHECK(c, PB_ERR_ARG, "null ctx");
+    PB_HIP(hipSetDevice(c->device));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- single-kernel entry points ---------------------------------------------------------------
+int pb_op_gemm(pb_ctx *c, const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act,
+               int tile) {
+    PB_CHECK(c && A && W && C && M > 0 && N > 0 && K > 0 && N % 8 == 0, PB_ERR_ARG, "op_gemm: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const int Kp = (int)round_up(K, 64), Np = (int)round_up(N, 256);
+    const int64_t Mp = round_up(M, 256);
+    DevMem a32, w32, b32, a16, w16, c16, c32;
+    PB_TRY(a32.alloc((size_t)M * K * 4)); PB_TRY(w32.alloc((size_t)N * K * 4));
+    PB_TRY(a16.alloc((size_t)Mp * Kp * 2)); PB_TRY(w16.alloc((size_t)Np * Kp * 2));
+    PB_TRY(c16.alloc((size_t)Mp * N * 2)); PB_TRY(c32.alloc((size_t)M * N * 4));
+    PB_HIP(hipMemcpy(a32.p, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(w32.p, W, (size_t)N * K * 4, hipMemcpyHostToDevice));
+    if (bias) {
+        PB_TRY(b32.alloc((size_t)N * 4));
+        PB_HIP(hipMemcpy(b32.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    }
+    PB_TRY(launch_f32_to_f16(c->stream, a32.as<float>(), a16.as<f16>(), M, K, Kp));
+    PB_TRY(launch_f32_to_f16(c->stream, w32.as<float>(), w16.as<f16>(), N, K, Kp));
+    GemmArgs g;
+    g.A = a16.as<f16>(); g.lda = Kp; g.W = w16.as<f16>(); g.K = Kp; g.M = M; g.N = N;
+    g.bias = b32.as<float>(); g.out = c16.as<f16>(); g.ldo = N; g.act = act; g.zero = c->zero;
+    PB_TRY(launch_gemm(c->stream, A_DENSE, EPI_STD, tile, g));
+    PB_TRY(launch_f16_to_f32(c->stream, c16.as<f16>(), c32.as<float>(), M, N, N));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(C, c32.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pb_op_layernorm(pb_ctx *c, const float *x, const float *g, const float *b, float *y, int rows, int D) {
+    PB_CHECK(c && x && g && b && y && rows > 0, PB_ERR_ARG, "op_layernorm: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    DevMem dx, dg, db, dy, dy32;
+    PB_TRY(dx.alloc((size_t)rows * D * 4)); PB_TRY(dg.alloc((size_t)D * 4)); PB_TRY(db.alloc((size_t)D * 4));
+    PB_TRY(dy.alloc((size_t)rows * D * 2)); PB_TRY(dy32.alloc((size_t)rows * D * 4));
+    PB_HIP(hipMemcpy(dx.p, x, (size_t)rows * D * 4, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dg.p, g, (size_t)D * 4, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(db.p, b, (size_t)D * 4, hipMemcpyHostToDevice));
+    PB_TRY(launch_layernorm(c->stream, dx.as<float>(), dg.as<float>(), db.as<float>(), dy.as<f16>(), 1, rows, rows, D,
+                            1e-6f, 0));
+    PB_TRY(launch_f16_to_f32(c->stream, dy.as<f16>(), dy32.as<float>(), rows, D, D));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(y, dy32.p, (size_t)rows * D * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pb_op_attention(pb_ctx *c, const float *q, const float *k, const float *v, float *o, int B, int heads, int N) {
+    PB_CHECK(c && q && k && v && o && B > 0 && heads > 0 && N > 0, PB_ERR_ARG, "op_attention: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const int ntp = (int)round_up(N, 16), D = heads * 64;
+    const size_t bh = (size_t)B * heads;
+    // host-side relayout to the engine's Q / K / Vt buffers (q pre-scaled by 64^-0.5 like the qkv epilogue)
+    std::vector<f16> hq(bh * ntp * 64, (f16)0.f), hk(bh * ntp * 64, (f16)0.f), hv(bh * 64 * ntp, (f16)0.f);
+    for (size_t i = 0; i < bh; ++i)
+        for (int t = 0; t < N; ++t)
+            for (int d = 0; d < 64; ++d) {
+                const size_t s = (i * N + t) * 64 + d;
+                hq[(i * ntp + t) * 64 + d] = (f16)(q[s] * 0.125f);
+                hk[(i * ntp + t) * 64 + d] = (f16)k[s];
+                hv[(i * 64 + d) * ntp + t] = (f16)v[s];
+            }
+    DevMem dq, dk, dv, dout, dout32;
+    const size_t slack = 32768;
+    PB_TRY(dq.alloc(hq.size() * 2 + slack)); PB_TRY(dk.alloc(hk.size() * 2 + slack)); PB_TRY(dv.alloc(hv.size() * 2 + slack));
+    PB_TRY(dout.alloc((size_t)B * ntp * D * 2)); PB_TRY(dout32.alloc((size_t)B * ntp * D * 4));
+    PB_HIP(hipMemcpy(dq.p, hq.data(), hq.size() * 2, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dk.p, hk.data(), hk.size() * 2, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dv.p, hv.data(), hv.size() * 2, hipMemcpyHostToDevice));
+    PB_TRY(launch_attention(c->stream, dq.as<f16>(), dk.as<f16>(), dv.as<f16>(), dout.as<f16>(), B, heads, ntp, N, D));
+    PB_TRY(launch_f16_to_f32(c->stream, dout.as<f16>(), dout32.as<float>(), (int64_t)B * ntp, D, D));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    std::vector<float> ho((size_t)B * ntp * D);
+    PB_HIP(hipMemcpy(ho.data(), dout32.p, ho.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < heads; ++h)
+            for (int t = 0; t < N; ++t)
+                for (int d = 0; d < 64; ++d)
+                    o[(((size_t)b * heads + h) * N + t) * 64 + d] = ho[((size_t)b * ntp + t) * D + h * 64 + d];
+    return 0;
+}
+
+int pb_op_conv2d(pb_ctx *c, const float *x, const float *w, const float *bias, float *y, int B, int Ci, int H, int W,
+                 int Co, int ks, int stride, int pad, int relu_in, int relu_out) {
+    PB_CHECK(c && x && w && y && Co % 8 == 0 && (ks == 1 || ks == 3), PB_ERR_ARG, "op_conv2d: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const int cip = (int)round_up(Ci, 64), cop = (int)round_up(Co, 64), K = ks * ks * cip;
+    const int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1;
+    std::vector<f16> hw((size_t)round_up(Co, 256) * K, (f16)0.f);
+    for (int o = 0; o < Co; ++o)
+        for (int ci = 0; ci < Ci; ++ci)
+            for (int t = 0; t < ks * ks; ++t)
+                hw[(size_t)o * K + t * cip + ci] = (f16)w[((size_t)o * Ci + ci) * ks * ks + t];
+    DevMem dx32, dx, dw, db, dy, dy32;
+    PB_TRY(dx32.alloc((size_t)B * Ci * H * W * 4)); PB_TRY(dx.alloc((size_t)round_up((int64_t)B * H * W, 256) * cip * 2));
+    PB_TRY(dw.alloc(hw.size() * 2)); PB_TRY(dy.alloc((size_t)round_up((int64_t)B * OH * OW, 256) * cop * 2));
+    PB_TRY(dy32.alloc((size_t)B * Co * OH * OW * 4));
+    PB_HIP(hipMemcpy(dx32.p, x, (size_t)B * Ci * H * W * 4, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dw.p, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    if (bias) {
+        PB_TRY(db.alloc((size_t)Co * 4));
+        PB_HIP(hipMemcpy(db.p, bias, (size_t)Co * 4, hipMemcpyHostToDevice));
+    }
+    PB_TRY(launch_nchw_f32_to_nhwc_f16(c->stream, dx32.as<float>(), dx.as<f16>(), B, Ci, H, W, cip, relu_in));
+    GemmArgs g;
+    g.A = dx.as<f16>(); g.W = dw.as<f16>(); g.K = K; g.M = B * OH * OW; g.N = Co;
+    g.cH = H; g.cW = W; g.cC = cip; g.cOH = OH; g.cOW = OW; g.cKW = ks; g.cStride = stride; g.cPad = pad;
+    g.zero = c->zero; g.bias = db.as<float>(); g.out = dy.as<f16>(); g.ldo = cop; g.act = relu_out ? ACT_RELU : ACT_NONE;
+    PB_TRY(launch_gemm(c->stream, A_CONV, EPI_STD, TILE_128, g));
+    PB_TRY(launch_nhwc_f16_to_nchw_f32(c->stream, dy.as<f16>(), dy32.as<float>(), B, Co, OH, OW, cop));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(y, dy32.p, (size_t)B * Co * OH * OW * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pb_op_bilinear(pb_ctx *c, const float *x, float *y, int B, int C, int H, int W, int OH, int OW, int align) {
+    PB_CHECK(c && x && y && C % 8 == 0, PB_ERR_ARG, "op_bilinear: bad arguments (C %% 8)");
+    PB_HIP(hipSetDevice(c->device));
+    DevMem dx32, dx, dy, dy32;
+    PB_TRY(dx32.alloc((size_t)B * C * H * W * 4)); PB_TRY(dx.alloc((size_t)B * C * H * W * 2));
+    PB_TRY(dy.alloc((size_t)B * C * OH * OW * 2)); PB_TRY(dy32.alloc((size_t)B * C * OH * OW * 4));
+    PB_HIP(hipMemcpy(dx32.p, x, (size_t)B * C * H * W * 4, hipMemcpyHostToDevice));
+    PB_TRY(launch_nchw_f32_to_nhwc_f16(c->stream, dx32.as<float>(), dx.as<f16>(), B, C, H, W, C, 0));
+    PB_TRY(launch_bilinear_nhwc(c->stream, dx.as<f16>(), dy.as<f16>(), B, H, W, OH, OW, C, C, align));
+    PB_TRY(launch_nhwc_f16_to_nchw_f32(c->stream, dy.as<f16>(), dy32.as<float>(), B, C, OH, OW, C));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(y, dy32.p, (size_t)B * C * OH * OW * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pb_op_preprocess(pb_ctx *c, const uint8_t *frame, int H, int W, float *out, int net_h, int net_w) {
+    PB_CHECK(c && frame && out, PB_ERR_ARG, "op_preprocess: bad arguments");
+    int nh, nw;
+    PB_TRY(pb_depth_net_size(H, W, &nh, &nw));
+    PB_CHECK(nh == net_h && nw == net_w, PB_ERR_ARG, "op_preprocess: net size is %dx%d, caller passed %dx%d", nh, nw,
+             net_h, net_w);
+    PB_HIP(hipSetDevice(c->device));
+    std::vector<int> xi((size_t)nw * 4), yi((size_t)nh * 4);
+    std::vector<float> xw((size_t)nw * 4), yw((size_t)nh * 4);
+    pb_cubic_taps(W, nw, xi.data(), xw.data());
+    pb_cubic_taps(H, nh, yi.data(), yw.data());
+    DevMem df, dxi, dxw, dyi, dyw, dout;
+    PB_TRY(df.alloc((size_t)H * W * 3)); PB_TRY(dxi.alloc(xi.size() * 4)); PB_TRY(dxw.alloc(xw.size() * 4));
+    PB_TRY(dyi.alloc(yi.size() * 4)); PB_TRY(dyw.alloc(yw.size() * 4)); PB_TRY(dout.alloc((size_t)3 * nh * nw * 4));
+    PB_HIP(hipMemcpy(df.p, frame, (size_t)H * W * 3, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dxi.p, xi.data(), xi.size() * 4, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dxw.p, xw.data(), xw.size() * 4, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dyi.p, yi.data(), yi.size() * 4, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dyw.p, yw.data(), yw.size() * 4, hipMemcpyHostToDevice));
+    PB_TRY(launch_preprocess(c->stream, df.as<uint8_t>(), 1, H, W, nh, nw, dxi.as<int>(), dxw.as<float>(), dyi.as<int>(),
+                             dyw.as<float>(), nullptr, 640, dout.as<float>()));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(out, dout.p, (size_t)3 * nh * nw * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pb_op_encode_depth(pb_ctx *c, const float *depth, int n, int H, int W, int flip, uint8_t *rgb, float *mn, float *mx) {
+    PB_CHECK(c && depth && n > 0, PB_ERR_ARG, "op_encode_depth: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const size_t px = (size_t)H * W;
+    DevMem dd, dr, dm, dmn;
+    PB_TRY(dd.alloc(n * px * 4)); PB_TRY(dr.alloc(n * px * 3)); PB_TRY(dm.alloc((size_t)n * 8)); PB_TRY(dmn.alloc((size_t)n * 8));
+    PB_HIP(hipMemcpy(dd.p, depth, n * px * 4, hipMemcpyHostToDevice));
+    PB_TRY(launch_init_minmax(c->stream, dm.as<unsigned>(), n));
+    PB_TRY(launch_minmax_only(c->stream, dd.as<float>(), n, (int64_t)px, dm.as<unsigned>()));
+    PB_TRY(launch_heat_encode(c->stream, dd.as<float>(), n, H, W, dm.as<unsigned>(), flip, dr.as<uint8_t>(),
+                              dmn.as<float>(), dmn.as<float>() + n));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    if (rgb) PB_HIP(hipMemcpy(rgb, dr.p, n * px * 3, hipMemcpyDeviceToHost));
+    if (mn) PB_HIP(hipMemcpy(mn, dmn.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (mx) PB_HIP(hipMemcpy(mx, dmn.as<float>() + n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

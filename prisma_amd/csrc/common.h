@@ -1,0 +1,58 @@
+// Shared device/host helpers for libprisma_bands (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define PB_WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void pb_set_error(const char *fmt, ...);
+
+#define PB_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            pb_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -2;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+#define PB_CHECK(cond, code, ...)                                                             \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            pb_set_error(__VA_ARGS__);                                                        \
+            return (code);                                                                    \
+        }                                                                                     \
+    } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- device helpers --------------------------------------------------------------------------
+#if defined(__HIPCC__)
+// Direct HBM -> LDS copy of 16 bytes per lane.  The LDS destination is wave-uniform `lds_base`
+// + lane * 16 (hardware adds the lane term); the global source is per lane.
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+#endif

@@ -1,0 +1,381 @@
+// HBM-bound kernels of the depth_anything band for gfx950: pre-process, LayerNorm, bilinear
+// resizes, per-frame min/max, heat-map encode, layout converters.  All of them are one pass over
+// their data with 8/16-byte per-lane accesses; none is reshaped into a GEMM.
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per token row (D <= 1024, D % 4 == 0), fp32 in, fp16 out.
+// reference: nn.LayerNorm(eps=1e-6) in dinov2 blocks (block.py:82-107) and the final norm
+// applied to the 4 taps (vision_transformer.py:297-321).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                        const float *__restrict__ bt, f16 *__restrict__ y, int B,
+                                                        int ntp, int ntok, int D, float eps, int drop_cls) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (int64_t)B * ntok) return;
+    const int b = (int)(r / ntok), t = (int)(r - (int64_t)b * ntok);
+    if (drop_cls && t == 0) return;
+    const float *xr = x + ((int64_t)b * ntp + t) * D;
+    f16 *yr = drop_cls ? y + ((int64_t)b * (ntok - 1) + (t - 1)) * D : y + ((int64_t)b * ntp + t) * D;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < D) {
+            v[j] = *(const f32x4 *)(xr + c);
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[j][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < D) {
+            const f32x4 gg = *(const f32x4 *)(g + c), bb = *(const f32x4 *)(bt + c);
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (f16)((v[j][e] - mean) * rstd * gg[e] + bb[e]);
+            *(f16x4 *)(yr + c) = o;
+        }
+    }
+}
+
+__global__ void cls_rows_kernel(float *resid, const float *cls, const float *pos, int B, int ntp, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, c = i - b * D;
+    resid[(int64_t)b * ntp * D + c] = cls[c] + pos[c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pre-process (bands/depth_anything.py:122-126): /255 -> cv2.resize(INTER_CUBIC) -> normalise ->
+// CHW, fused with the im2col of the 14x14/s14 patch embedding: thread per network pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ frames, int B, int H, int W,
+                                                         int nh, int nw, const int *__restrict__ xi,
+                                                         const float *__restrict__ xw, const int *__restrict__ yi,
+                                                         const float *__restrict__ yw, f16 *__restrict__ out, int Kp,
+                                                         float *__restrict__ chw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * nh * nw) return;
+    const int x = (int)(i % nw);
+    const int y = (int)((i / nw) % nh);
+    const int b = (int)(i / ((int64_t)nw * nh));
+    const uint8_t *img = frames + (int64_t)b * H * W * 3;
+    int xs[4];
+    float wx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { xs[t] = xi[x * 4 + t] * 3; wx[t] = xw[x * 4 + t]; }
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+        const uint8_t *row = img + (int64_t)yi[y * 4 + ty] * W * 3;
+        float r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tx = 0; tx < 4; ++tx)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[c] += (float)row[xs[tx] + c] * wx[tx];
+        const float wy = yw[y * 4 + ty];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += r[c] * wy;
+    }
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
+    const int gw = nw / 14;
+    const int gy = y / 14, py = y - gy * 14, gx = x / 14, px = x - gx * 14;
+    const int64_t prow = ((int64_t)b * (nh / 14) * gw + gy * gw + gx) * Kp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = (acc[c] * (1.f / 255.f) - mean[c]) * istd[c];
+        if (out) out[prow + c * 196 + py * 14 + px] = (f16)v;
+        if (chw) chw[((int64_t)(b * 3 + c) * nh + y) * nw + x] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear resize, NHWC fp16, 8 channels (16 B) per thread.  torch upsample_bilinear2d semantics.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilerp_src(int dst, float scale, int in, int align, int &i0, int &i1, float &l1) {
+    float src = align ? scale * (float)dst : fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+__host__ __device__ inline float bilerp_scale(int in, int out, int align) {
+    if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    return (float)in / (float)out;
+}
+
+__global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int B,
+                                                            int H, int W, int OH, int OW, int C8, int ldc, int align,
+                                                            float sy, float sx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * OH * OW * C8) return;
+    const int c = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilerp_src(oy, sy, H, align, y0, y1, ly);
+    bilerp_src(ox, sx, W, align, x0, x1, lx);
+    const f16 *base = x + (int64_t)b * H * W * ldc + c * 8;
+    const f16x8 v00 = *(const f16x8 *)(base + ((int64_t)y0 * W + x0) * ldc);
+    const f16x8 v01 = *(const f16x8 *)(base + ((int64_t)y0 * W + x1) * ldc);
+    const f16x8 v10 = *(const f16x8 *)(base + ((int64_t)y1 * W + x0) * ldc);
+    const f16x8 v11 = *(const f16x8 *)(base + ((int64_t)y1 * W + x1) * ldc);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        o[j] = (f16)(hy * (hx * (float)v00[j] + lx * (float)v01[j]) + ly * (hx * (float)v10[j] + lx * (float)v11[j]));
+    *(f16x8 *)(y + pix * ldc + c * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Band tail (bands/depth_anything.py:132, 215-216): bilinear(align_corners=False) to the frame
+// size + per-frame min/max via order-preserving uint atomics.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__device__ __forceinline__ void block_minmax(float lo, float hi, unsigned *mm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(mm, f2ord(lo));
+        atomicMax(mm + 1, f2ord(hi));
+    }
+}
+
+__global__ __launch_bounds__(256) void depth_resize_minmax_kernel(const float *__restrict__ net, int nh, int nw,
+                                                                  float *__restrict__ out, int H, int W, float sy,
+                                                                  float sx, unsigned *mm) {
+    const int b = blockIdx.y;
+    const float *src = net + (int64_t)b * nh * nw;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)H * W;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % W), oy = (int)(i / W);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilerp_src(oy, sy, nh, 0, y0, y1, ly);
+        bilerp_src(ox, sx, nw, 0, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float v = hy * (hx * src[y0 * nw + x0] + lx * src[y0 * nw + x1]) +
+                        ly * (hx * src[y1 * nw + x0] + lx * src[y1 * nw + x1]);
+        out[(int64_t)b * H * W + i] = v;
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    block_minmax(lo, hi, mm + 2 * b);
+}
+
+__global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, int64_t per, unsigned *mm) {
+    const int b = blockIdx.y;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[(int64_t)b * per + i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    block_minmax(lo, hi, mm + 2 * b);
+}
+
+__global__ void init_minmax_kernel(unsigned *mm, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { mm[2 * i] = 0xFFFFFFFFu; mm[2 * i + 1] = 0u; }
+}
+
+// heat_to_rgb(1 - (p - min) / (max - min)) * 255 -> uint8 (truncation).
+// bands/depth_anything.py:215-220 + bands/common/encode.py:13-33: normalise / flip in float32,
+// colour ramp in float64 with numpy's operation order; explicit _rn intrinsics keep the compiler
+// from contracting mul+add into FMAs so that the bytes equal the reference's.
+__global__ __launch_bounds__(256) void heat_encode_kernel(const float *__restrict__ depth, int64_t per,
+                                                          const unsigned *__restrict__ mm, int flip,
+                                                          uint8_t *__restrict__ rgb, float *mn, float *mx) {
+    const int b = blockIdx.y;
+    const float dmin = ord2f(mm[2 * b]), dmax = ord2f(mm[2 * b + 1]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (mn) mn[b] = dmin;
+        if (mx) mx[b] = dmax;
+    }
+    if (!rgb) return;
+    const float range = __fsub_rn(dmax, dmin);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+        float d = __fdiv_rn(__fsub_rn(depth[(int64_t)b * per + i], dmin), range);
+        if (flip) d = __fsub_rn(1.0f, d);
+        const double hue = __dmul_rn(__dsub_rn(1.0, (double)d), 0.65);
+        const double h6 = __dmul_rn(hue, 6.0);
+        const double off[3] = {0.0, 4.0, 2.0};
+        uint8_t o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = __dadd_rn(h6, off[c]);
+            v = fmod(v, 6.0);
+            if (v < 0.0) v = __dadd_rn(v, 6.0);
+            v = __dsub_rn(fabs(__dsub_rn(v, 3.0)), 1.0);
+            v = fmin(fmax(v, 0.0), 1.0);
+            v = __dmul_rn(v, 255.0);
+            o[c] = (v == v) ? (uint8_t)(int)v : (uint8_t)0;      // NaN (max == min) -> 0 like numpy on x86
+        }
+        uint8_t *dst = rgb + ((int64_t)b * per + i) * 3;
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout converters (tests / stage dumps)
+// ------------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float *x, f16 *y, int B, int C, int H, int W, int ldc, int relu) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * C * H * W) return;
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    const int64_t hw = (int64_t)H * W;
+    const int b = (int)(pix / hw);
+    const int64_t p = pix - b * hw;
+    float v = x[((int64_t)b * C + c) * hw + p];
+    if (relu) v = fmaxf(v, 0.f);
+    y[pix * ldc + c] = (f16)v;
+}
+__global__ void nhwc_to_nchw_kernel(const f16 *x, float *y, int B, int C, int H, int W, int ldc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * C * H * W) return;
+    const int64_t hw = (int64_t)H * W;
+    const int64_t p = i % hw;
+    const int c = (int)((i / hw) % C);
+    const int b = (int)(i / (hw * C));
+    y[i] = (float)x[((int64_t)b * hw + p) * ldc + c];
+}
+__global__ void f32_to_f16_kernel(const float *x, f16 *y, int64_t rows, int cols, int ld_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    y[r * ld_out + c] = (f16)x[i];
+}
+__global__ void f16_to_f32_kernel(const f16 *x, float *y, int64_t rows, int cols, int ld_in) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    y[i] = (float)x[r * ld_in + c];
+}
+
+inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+
+}  // namespace
+
+int launch_layernorm(hipStream_t s, const float *x, const float *g, const float *b, f16 *y, int B, int ntp, int ntok,
+                     int D, float eps, int drop_cls) {
+    PB_CHECK(D % 4 == 0 && D <= 1024, -1, "layernorm: D=%d unsupported", D);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(nblk((int64_t)B * ntok, 4)), dim3(256), 0, s, x, g, b, y, B, ntp, ntok,
+                       D, eps, drop_cls);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_cls_rows(hipStream_t s, float *resid, const float *cls, const float *pos, int B, int ntp, int D) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(nblk((int64_t)B * D)), dim3(256), 0, s, resid, cls, pos, B, ntp, D);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_preprocess(hipStream_t s, const uint8_t *frames, int B, int H, int W, int nh, int nw, const int *xi,
+                      const float *xw, const int *yi, const float *yw, f16 *out, int Kp, float *chw_out) {
+    hipLaunchKernelGGL(preprocess_kernel, dim3(nblk((int64_t)B * nh * nw)), dim3(256), 0, s, frames, B, H, W, nh, nw,
+                       xi, xw, yi, yw, out, Kp, chw_out);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_bilinear_nhwc(hipStream_t s, const f16 *x, f16 *y, int B, int H, int W, int OH, int OW, int C, int ldc,
+                         int align) {
+    PB_CHECK(C % 8 == 0 && ldc % 8 == 0, -1, "bilinear: C=%d ldc=%d must be multiples of 8", C, ldc);
+    const float sy = bilerp_scale(H, OH, align), sx = bilerp_scale(W, OW, align);
+    hipLaunchKernelGGL(bilinear_nhwc_kernel, dim3(nblk((int64_t)B * OH * OW * (C / 8))), dim3(256), 0, s, x, y, B, H,
+                       W, OH, OW, C / 8, ldc, align, sy, sx);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_init_minmax(hipStream_t s, unsigned *mm, int B) {
+    hipLaunchKernelGGL(init_minmax_kernel, dim3(nblk(B)), dim3(256), 0, s, mm, B);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_depth_resize_minmax(hipStream_t s, const float *net, int B, int nh, int nw, float *out, int H, int W,
+                               unsigned *mm) {
+    const float sy = bilerp_scale(nh, H, 0), sx = bilerp_scale(nw, W, 0);
+    unsigned gx = nblk((int64_t)H * W);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(depth_resize_minmax_kernel, dim3(gx, B), dim3(256), 0, s, net, nh, nw, out, H, W, sy, sx, mm);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_minmax_only(hipStream_t s, const float *x, int B, int64_t per, unsigned *mm) {
+    unsigned gx = nblk(per);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(minmax_kernel, dim3(gx, B), dim3(256), 0, s, x, per, mm);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_heat_encode(hipStream_t s, const float *depth, int B, int H, int W, const unsigned *mm, int flip,
+                       uint8_t *rgb, float *mn, float *mx) {
+    unsigned gx = nblk((int64_t)H * W);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(heat_encode_kernel, dim3(gx, B), dim3(256), 0, s, depth, (int64_t)H * W, mm, flip, rgb, mn, mx);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_nchw_f32_to_nhwc_f16(hipStream_t s, const float *x, f16 *y, int B, int C, int H, int W, int ldc, int relu) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblk((int64_t)B * C * H * W)), dim3(256), 0, s, x, y, B, C, H, W, ldc,
+                       relu);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+int launch_nhwc_f16_to_nchw_f32(hipStream_t s, const f16 *x, float *y, int B, int C, int H, int W, int ldc) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblk((int64_t)B * C * H * W)), dim3(256), 0, s, x, y, B, C, H, W,
+                       ldc);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+int launch_f32_to_f16(hipStream_t s, const float *x, f16 *y, int64_t rows, int cols, int ld_out) {
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(nblk(rows * cols)), dim3(256), 0, s, x, y, rows, cols, ld_out);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+int launch_f16_to_f32(hipStream_t s, const f16 *x, float *y, int64_t rows, int cols, int ld_in) {
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk(rows * cols)), dim3(256), 0, s, x, y, rows, cols, ld_in);
+    PB_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,105 @@
+// Depth-Anything band engine: weight packing, arena planning and the per-batch launch sequence.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/prisma_bands.h"
+#include "common.h"
+#include "gemm.h"
+#include "kernels.h"
+
+struct PackedW {
+    f16 *w = nullptr;        // [Npad, K] fp16, K % 64 == 0
+    float *bias = nullptr;   // [N] fp32 or null
+    int N = 0, K = 0, Kreal = 0;
+};
+
+struct Stage {
+    const void *ptr;
+    int kind;                // 0: fp32 rows [n, rows, cols] with batch stride; 1: NHWC fp16 map; 2: fp32 map [n,h,w]; 3: fp16 rows
+    int64_t n, c, h, w, ld, bstride;
+};
+
+struct KernelTimer {
+    struct Rec { int fam; hipEvent_t a, b; double flops, bytes; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    bool enabled = false;
+    hipEvent_t get();
+    void reset() { recs.clear(); used = 0; }
+    ~KernelTimer();
+};
+
+class DepthEngine {
+  public:
+    DepthEngine(int device, const pb_depth_cfg &cfg);
+    ~DepthEngine();
+    int load(const pb_tensor *w, int n);
+    int infer(const uint8_t *frames_dev, int n, int H, int W, float *depth_out, uint8_t *rgb_out, float *mn,
+              float *mx, int flip);
+    int64_t get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]);
+    int stats(pb_kernel_stat *out, int cap);
+
+    hipStream_t stream = nullptr;
+    int device = 0;
+    bool debug = false;
+    KernelTimer timer;
+
+    // scratch for op-level tests
+    int dev_alloc(void **p, size_t bytes);
+    const f16 *zero_page() const { return zero_; }
+
+  private:
+    int prepare(int B, int H, int W);
+    int run_chunk(const uint8_t *frames, int n, float *depth_out, uint8_t *rgb_out, float *mn, float *mx, int flip);
+    int vit(int n);
+    int head(int n);
+    int gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int tile = TILE_AUTO);
+    int conv3(const f16 *in, int inC, int n, int H, int W, const PackedW &w, f16 *out, f16 *out2, const f16 *add1,
+              const f16 *add2, int act, int stride, int outC);
+    void *carve(size_t bytes);
+    int upload_f32(const float *src, size_t n, float **dst);
+    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias);
+    const pb_tensor *find(const std::string &name) const;
+    void tic(int fam, double flops, double bytes);
+    void toc();
+    void snapshot(const std::string &name);
+
+    pb_depth_cfg cfg_;
+    std::map<std::string, const pb_tensor *> tmap_;
+    std::vector<void *> owned_;                 // permanent device allocations (weights)
+    // weights
+    PackedW patch_;
+    float *cls_ = nullptr;
+    std::vector<float> pos_host_;               // [1 + g*g, D]
+    struct Block { float *ln1g, *ln1b, *ln2g, *ln2b, *ls1, *ls2; PackedW qkv, proj, fc1, fc2; };
+    std::vector<Block> blocks_;
+    float *normg_ = nullptr, *normb_ = nullptr;
+    PackedW proj_[4], rs0_, rs1_, rs3_, rn_[4], outc_[4], rcu_[4][2][2], oc1_, oc2_;
+    float *w2_ = nullptr;
+    float b2_ = 0.f;
+    f16 *zero_ = nullptr;
+
+    // plan
+    int pB_ = 0, pH_ = 0, pW_ = 0, last_n_ = 0;
+    int nh_ = 0, nw_ = 0, gh_ = 0, gw_ = 0, ntok_ = 0, ntp_ = 0, P_ = 0;
+    int lh_[4] = {0, 0, 0, 0}, lw_[4] = {0, 0, 0, 0};      // DPT level sizes (level 0 = finest)
+    char *arena_ = nullptr;
+    size_t arena_bytes_ = 0, arena_off_ = 0;
+    bool planning_ = false;
+    // arena buffers
+    int *xi_ = nullptr, *yi_ = nullptr;
+    float *xw_ = nullptr, *yw_ = nullptr, *pos_ = nullptr;
+    f16 *patchA_ = nullptr, *Y_ = nullptr, *Q_ = nullptr, *K_ = nullptr, *Vt_ = nullptr, *AO_ = nullptr, *Hd_ = nullptr;
+    float *X_ = nullptr;
+    f16 *feat_[4] = {nullptr, nullptr, nullptr, nullptr};
+    f16 *pj_[4] = {}, *lay_[4] = {}, *rnraw_[4] = {}, *rnrelu_[4] = {}, *tmp_[4] = {}, *sraw_[4] = {}, *srelu_[4] = {},
+        *yb_[4] = {}, *ocb_[4] = {}, *path_[4] = {};
+    f16 *o1_ = nullptr, *up_ = nullptr;
+    float *netd_ = nullptr, *full_ = nullptr;
+    unsigned *mm_ = nullptr;
+    std::map<std::string, Stage> stages_;
+    std::map<std::string, float *> snaps_;
+};

@@ -1,0 +1,45 @@
+// fp16 MFMA GEMM / implicit-GEMM convolution for gfx950: C[M,N] = A[M,K] * W[N,K]^T (+ fused epilogue).
+#pragma once
+#include "common.h"
+
+enum { A_DENSE = 0, A_CONV = 1 };
+enum { EPI_STD = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_PIXSHUF = 3, EPI_PATCH = 4, EPI_HEAD = 5 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3 };
+
+struct GemmArgs {
+    // operands: A row-major fp16 [M, lda] (dense) or NHWC image (conv); W fp16 [Npad, K], K % 64 == 0
+    const f16 *A = nullptr;
+    int64_t lda = 0;
+    const f16 *W = nullptr;
+    int K = 0, M = 0, N = 0;              // N = columns actually written (multiple of 8)
+    // implicit-GEMM convolution: input [B, cH, cW, cC] (cC % 64 == 0), K = KH*KW*cC, rows = (b, oy, ox)
+    int cH = 0, cW = 0, cC = 0, cOH = 0, cOW = 0, cKW = 1, cStride = 1, cPad = 0;
+    const f16 *zero = nullptr;            // >= 16 bytes of zeros: source of padded taps / rows >= M
+    // epilogue
+    const float *bias = nullptr;          // [N]
+    const float *gamma = nullptr;         // LayerScale [N] (EPI_RESID)
+    f16 *out = nullptr;                   // act(v) -> out[m*ldo + n]
+    f16 *out2 = nullptr;                  // relu(v) copy (same layout)
+    const f16 *add1 = nullptr, *add2 = nullptr;   // v += add[m*ldo + n]
+    int64_t ldo = 0;
+    int act = ACT_NONE;
+    float *resid = nullptr;               // fp32 residual stream [rows, ldr]
+    int64_t ldr = 0;
+    // EPI_QKV: Q,K -> [b, head, ntp, 64]; V -> [b, head, 64, ntp] (transposed); q scaled by qscale
+    f16 *q = nullptr, *k = nullptr, *vt = nullptr;
+    int ntp = 0, heads = 0, D = 0;
+    float qscale = 1.f;
+    // EPI_PIXSHUF: rows = (b, y, x) of a [B, ps_h, ps_w] grid; cols = (dy, dx, co); kernel == stride == ps_s
+    int ps_s = 1, ps_h = 0, ps_w = 0, ps_co = 0;
+    // EPI_PATCH: rows = (b, patch); writes resid[b*ntp + 1 + patch] = v + bias + pos[1 + patch]
+    const float *pos = nullptr;
+    int ppi = 0;
+    // EPI_HEAD: depth[m] = relu(sum_n relu(v + bias)[n] * w2[n] + b2), N == 32
+    const float *w2 = nullptr;
+    float b2 = 0.f;
+    float *depth = nullptr;
+};
+
+// Launches the kernel on `stream`.  tile: TILE_AUTO picks from the shape.
+int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a);

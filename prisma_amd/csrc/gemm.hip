@@ -1,0 +1,354 @@
+// fp16 MFMA GEMM and implicit-GEMM convolution kernels for gfx950 (CDNA4).
+//
+// One kernel template serves every matmul-shaped op of the bands engine: the ViT linears
+// (qkv / proj / fc1 / fc2, reference dinov2/layers/attention.py:49-62, mlp.py:35-41), the patch
+// embedding (patch_embed.py:66-82), and the DPT head's 1x1 / 3x3 / transposed convolutions
+// (bands/d_anything/dpt.py:103-136, blocks.py:69-153) as NHWC implicit GEMM.
+//
+// Structure (per workgroup): BM x BN output tile, K in steps of 64 halfs.
+//   * A and W tiles go HBM -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR round
+//     trip), double buffered, one barrier per K step; the next step's loads are issued before
+//     the current step's MFMAs.
+//   * LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7, applied
+//     on the global SOURCE address (the LDS image of a DMA is lane-linear) and again on the
+//     ds_read_b128 fragment reads, which makes those reads bank-conflict free.
+//   * v_mfma_f32_32x32x16_f16, fp32 accumulators; wave tile (BM/WM) x (BN/WN).
+//   * Epilogue: accumulators -> per-wave LDS patch -> each lane owns 8 consecutive columns of
+//     one row (16-byte stores), with the op-specific fusion (bias, GELU, ReLU, LayerScale +
+//     residual, q/k/v split with V transposed, pixel-shuffle for transposed convs, ...).
+//   * blockIdx is remapped so that each XCD (private L2) works on a contiguous range of tiles.
+#include "gemm.h"
+
+namespace {
+
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmArgs &p, int m, int n, float (&v)[8]) {
+    if constexpr (EPI == EPI_STD) {
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += p.bias[n + j];
+        }
+        const int64_t o = (int64_t)m * p.ldo + n;
+        if (p.add1) {
+            const f16x8 a = *(const f16x8 *)(p.add1 + o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)a[j];
+        }
+        if (p.add2) {
+            const f16x8 a = *(const f16x8 *)(p.add2 + o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)a[j];
+        }
+        if (p.out) {
+            f16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = v[j];
+                if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+                else if (p.act == ACT_GELU) x = gelu_erf(x);
+                r[j] = (f16)x;
+            }
+            *(f16x8 *)(p.out + o) = r;
+        }
+        if (p.out2) {
+            f16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (f16)fmaxf(v[j], 0.f);
+            *(f16x8 *)(p.out2 + o) = r;
+        }
+    } else if constexpr (EPI == EPI_RESID) {
+        float *r = p.resid + (int64_t)m * p.ldr + n;
+        f32x4 r0 = *(f32x4 *)r, r1 = *(f32x4 *)(r + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r0[j] += p.gamma[n + j] * (v[j] + p.bias[n + j]);
+            r1[j] += p.gamma[n + 4 + j] * (v[4 + j] + p.bias[n + 4 + j]);
+        }
+        *(f32x4 *)r = r0;
+        *(f32x4 *)(r + 4) = r1;
+    } else if constexpr (EPI == EPI_QKV) {
+        // q / k rows only; the V third is handled by the transposed path in the kernel
+        const int which = n / p.D;
+        const int hn = n - which * p.D;
+        const int head = hn >> 6, d = hn & 63;
+        const int b = m / p.ntp, t = m - b * p.ntp;
+        const float s = which == 0 ? p.qscale : 1.f;
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (f16)((v[j] + p.bias[n + j]) * s);
+        f16 *dst = (which == 0 ? p.q : p.k) + (((int64_t)b * p.heads + head) * p.ntp + t) * 64 + d;
+        *(f16x8 *)dst = r;
+    } else if constexpr (EPI == EPI_PIXSHUF) {
+        const int hw = p.ps_h * p.ps_w;
+        const int b = m / hw, rem = m - b * hw;
+        const int y = rem / p.ps_w, x = rem - y * p.ps_w;
+        const int tap = n / p.ps_co, co = n - tap * p.ps_co;
+        const int dy = tap / p.ps_s, dx = tap - dy * p.ps_s;
+        const int64_t row = ((int64_t)b * p.ps_h * p.ps_s + (y * p.ps_s + dy)) * (p.ps_w * p.ps_s) + (x * p.ps_s + dx);
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (f16)(v[j] + p.bias[co + j]);
+        *(f16x8 *)(p.out + row * p.ldo + co) = r;
+    } else if constexpr (EPI == EPI_PATCH) {
+        const int b = m / p.ppi, pi = m - b * p.ppi;
+        float *r = p.resid + ((int64_t)b * p.ntp + 1 + pi) * p.ldr + n;
+        const float *pe = p.pos + (int64_t)(1 + pi) * p.D + n;
+        f32x4 r0, r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r0[j] = v[j] + p.bias[n + j] + pe[j];
+            r1[j] = v[4 + j] + p.bias[n + 4 + j] + pe[4 + j];
+        }
+        *(f32x4 *)r = r0;
+        *(f32x4 *)(r + 4) = r1;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;       // 16-byte chunks per thread per stage
+    constexpr int ES = TN * 32 + 4;                         // epilogue patch row stride (floats)
+    constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * ES * 4;
+    static_assert(NA >= 1 && NB >= 1, "tile too small for the block");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- tile id with XCD-contiguous remap (bijective for any grid size) ----
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int tile_m = swz / tilesN, tile_n = swz - tile_m * tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread staging addresses ----
+    const int srow = tid >> 3;                              // + i * (NT/8)
+    const int cg = (tid & 7) ^ ((tid >> 4) & 7);            // swizzled global chunk for this LDS slot
+    const f16 *a_ptr[NA];
+    int a_iy0[NA], a_ix0[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + srow + i * (NT / 8);
+        if constexpr (AMODE == A_DENSE) {
+            const int mc = m < p.M ? m : p.M - 1;
+            a_ptr[i] = p.A + (int64_t)mc * p.lda + cg * 8;
+            a_ok[i] = true;
+            a_iy0[i] = a_ix0[i] = 0;
+        } else {
+            const int ohw = p.cOH * p.cOW;
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+            a_ok[i] = m < p.M;
+            a_ptr[i] = p.A + (int64_t)b * p.cH * p.cW * p.cC + cg * 8;
+            a_iy0[i] = oy * p.cStride - p.cPad;
+            a_ix0[i] = ox * p.cStride - p.cPad;
+        }
+    }
+    const f16 *b_ptr[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_ptr[i] = p.W + (int64_t)(n0 + srow + i * (NT / 8)) * p.K + cg * 8;
+
+    int c_ky = 0, c_kx = 0, c_c0 = 0;                       // conv tap state of the NEXT stage call
+    const int nk = p.K >> 6;
+
+    auto stage = [&](int buf, int kt) {
+        char *sA = smem + buf * STAGE + wave * 1024;
+        char *sB = smem + buf * STAGE + A_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const f16 *src;
+            if constexpr (AMODE == A_DENSE) {
+                src = a_ptr[i] + kt * 64;
+            } else {
+                const int iy = a_iy0[i] + c_ky, ix = a_ix0[i] + c_kx;
+                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+                src = ok ? a_ptr[i] + ((iy * p.cW + ix) * p.cC + c_c0) : p.zero;
+            }
+            glds16(src, sA + i * (NT * 16));
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) glds16(b_ptr[i] + kt * 64, sB + i * (NT * 16));
+        if constexpr (AMODE == A_CONV) {
+            c_c0 += 64;
+            if (c_c0 >= p.cC) {
+                c_c0 = 0;
+                if (++c_kx == p.cKW) { c_kx = 0; ++c_ky; }
+            }
+        }
+    };
+
+    // ---- fragment read offsets ----
+    const int li = lane & 31, lh = lane >> 5;
+    const int fsw = (li >> 1) & 7;
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) a_off[t] = ((wm * TM + t) * 32 + li) * 128;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) b_off[t] = A_BYTES + ((wn * TN + t) * 32 + li) * 128;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char *sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ((2 * ks + lh) ^ fsw) * 16;
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) af[t] = *(const f16x8 *)(sb + a_off[t] + c);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) bf[t] = *(const f16x8 *)(sb + b_off[t] + c);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();            // staging buffers are dead; reuse LDS for the epilogue patches
+
+    float *es = (float *)(smem + wave * EPIB);
+    const int wave_m0 = m0 + wm * TM * 32, wave_n0 = n0 + wn * TN * 32;
+
+    if constexpr (EPI == EPI_QKV) {
+        if (n0 >= 2 * p.D) {
+            // V third: transpose through LDS so that stores run along the token axis of Vt.
+#pragma unroll
+            for (int tmi = 0; tmi < TM; ++tmi) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 w4;
+                        const float bb = p.bias[wave_n0 + tn * 32 + li];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w4[j] = acc[tmi][tn][g * 4 + j] + bb;
+                        *(f32x4 *)(es + (tn * 32 + li) * 36 + 8 * g + 4 * lh) = w4;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < TN * 2; ++it) {
+                    const int item = it * 64 + lane;
+                    const int nr = item >> 2, mc = item & 3;
+                    const f32x4 x0 = *(const f32x4 *)(es + nr * 36 + mc * 8);
+                    const f32x4 x1 = *(const f32x4 *)(es + nr * 36 + mc * 8 + 4);
+                    const int m = wave_m0 + tmi * 32 + mc * 8;
+                    const int n = wave_n0 + nr - 2 * p.D;
+                    if (m < p.M) {
+                        const int b = m / p.ntp, t = m - b * p.ntp;
+                        f16x8 r;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { r[j] = (f16)x0[j]; r[4 + j] = (f16)x1[j]; }
+                        *(f16x8 *)(p.vt + (((int64_t)b * p.heads + (n >> 6)) * 64 + (n & 63)) * p.ntp + t) = r;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            return;
+        }
+    }
+
+#pragma unroll
+    for (int tmi = 0; tmi < TM; ++tmi) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + tn * 32 + li] = acc[tmi][tn][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int CPR = TN * 4;                         // 8-column chunks per patch row
+#pragma unroll
+        for (int it = 0; it < 32 * CPR / 64; ++it) {
+            const int item = it * 64 + lane;
+            const int row = item / CPR, ch = item % CPR;
+            const f32x4 x0 = *(const f32x4 *)(es + row * ES + ch * 8);
+            const f32x4 x1 = *(const f32x4 *)(es + row * ES + ch * 8 + 4);
+            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            const int m = wave_m0 + tmi * 32 + row, n = wave_n0 + ch * 8;
+            if constexpr (EPI == EPI_HEAD) {
+                // N == 32: the 4 lanes of a row hold its 32 channels
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += fmaxf(v[j] + p.bias[n + j], 0.f) * p.w2[n + j];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                if (ch == 0 && m < p.M) p.depth[m] = fmaxf(s + p.b2, 0.f);
+            } else {
+                if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+int launch_t(hipStream_t stream, const GemmArgs &a) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TN = BN / WN / 32;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * (TN * 32 + 4) * 4;
+    constexpr int SMEM = 2 * STAGE > WM * WN * EPIB ? 2 * STAGE : WM * WN * EPIB;
+    auto kern = gemm_kernel<BM, BN, WM, WN, AMODE, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(NT), SMEM, stream, a);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int AMODE, int EPI>
+int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
+    if constexpr (EPI == EPI_HEAD) {
+        return launch_t<256, 32, 4, 1, AMODE, EPI>(s, a);
+    } else {
+        if (tile == TILE_256) return launch_t<256, 256, 2, 4, AMODE, EPI>(s, a);
+        return launch_t<128, 128, 2, 2, AMODE, EPI>(s, a);
+    }
+}
+
+}  // namespace
+
+int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a) {
+    PB_CHECK(a.K > 0 && a.K % 64 == 0, -1, "gemm: K=%d must be a positive multiple of 64", a.K);
+    PB_CHECK(a.M > 0 && a.N > 0 && a.N % 8 == 0, -1, "gemm: bad M=%d N=%d", a.M, a.N);
+    if (amode == A_CONV) PB_CHECK(a.cC % 64 == 0 && a.zero, -1, "conv: channel stride %d must be a multiple of 64", a.cC);
+    if (tile == TILE_AUTO) {
+        // 256x256 needs wide N and enough tiles to fill 256 CUs; the q/k/v split needs D % BN == 0
+        const bool wide = a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256;
+        tile = wide && (epi != EPI_QKV || a.D % 256 == 0) ? TILE_256 : TILE_128;
+    }
+    if (epi == EPI_QKV) PB_CHECK(a.D % (tile == TILE_256 ? 256 : 128) == 0 && a.ntp % 8 == 0, -1, "qkv epilogue: D=%d ntp=%d", a.D, a.ntp);
+#define PB_CASE(AM, EP) \
+    if (amode == AM && epi == EP) return launch_tile<AM, EP>(stream, tile, a)
+    PB_CASE(A_DENSE, EPI_STD);
+    PB_CASE(A_DENSE, EPI_RESID);
+    PB_CASE(A_DENSE, EPI_QKV);
+    PB_CASE(A_DENSE, EPI_PIXSHUF);
+    PB_CASE(A_DENSE, EPI_PATCH);
+    PB_CASE(A_CONV, EPI_STD);
+    PB_CASE(A_CONV, EPI_HEAD);
+#undef PB_CASE
+    PB_CHECK(false, -1, "gemm: unsupported amode/epilogue %d/%d", amode, epi);
+}

@@ -1,0 +1,39 @@
+// Launchers of the non-GEMM kernels (elementwise.hip, attention.hip).
+#pragma once
+#include "common.h"
+
+int launch_attention(hipStream_t s, const f16 *q, const f16 *k, const f16 *vt, f16 *o, int B, int heads, int ntp,
+                     int ntok, int ldo);
+
+// LayerNorm(eps) of fp32 rows -> fp16 rows.  Input row r = (b, t) of [B, ntp, D]; only t < ntok are
+// normalised.  drop_cls = 0: output row = input row (same [B, ntp] indexing, ld = D).
+// drop_cls = 1: output is compact [B, ntok-1, D] without the class token (DPT taps).
+int launch_layernorm(hipStream_t s, const float *x, const float *g, const float *b, f16 *y, int B, int ntp, int ntok,
+                     int D, float eps, int drop_cls);
+
+// resid[b, 0, :] = cls + pos[0]
+int launch_cls_rows(hipStream_t s, float *resid, const float *cls, const float *pos, int B, int ntp, int D);
+
+// uint8 RGB frames -> bicubic resize -> normalise -> patch-major fp16 matrix [B * gh*gw, Kp]
+// (k = c*196 + py*14 + px, zero padded to Kp).  Tap tables: idx [n,4] int, w [n,4] float.
+int launch_preprocess(hipStream_t s, const uint8_t *frames, int B, int H, int W, int nh, int nw, const int *xi,
+                      const float *xw, const int *yi, const float *yw, f16 *out, int Kp, float *chw_out);
+
+// NHWC fp16 bilinear resize (torch F.interpolate semantics), C % 8 == 0 with channel stride ldc.
+int launch_bilinear_nhwc(hipStream_t s, const f16 *x, f16 *y, int B, int H, int W, int OH, int OW, int C, int ldc,
+                         int align_corners);
+
+// net depth [B, nh, nw] fp32 -> bilinear(align_corners=False) -> [B, H, W] fp32 (optional) and
+// per-frame min/max (ordered-uint atomics in mm[2*B]); then heat encode to uint8 RGB.
+int launch_depth_resize_minmax(hipStream_t s, const float *net, int B, int nh, int nw, float *out, int H, int W,
+                               unsigned *mm);
+int launch_minmax_only(hipStream_t s, const float *x, int B, int64_t per, unsigned *mm);
+int launch_heat_encode(hipStream_t s, const float *depth, int B, int H, int W, const unsigned *mm, int flip,
+                       uint8_t *rgb, float *mn, float *mx);
+int launch_init_minmax(hipStream_t s, unsigned *mm, int B);
+
+// layout converters used by the op-level tests and the stage dumps
+int launch_nchw_f32_to_nhwc_f16(hipStream_t s, const float *x, f16 *y, int B, int C, int H, int W, int ldc, int relu);
+int launch_nhwc_f16_to_nchw_f32(hipStream_t s, const f16 *x, float *y, int B, int C, int H, int W, int ldc);
+int launch_f32_to_f16(hipStream_t s, const float *x, f16 *y, int64_t rows, int cols, int ld_out);
+int launch_f16_to_f32(hipStream_t s, const f16 *x, float *y, int64_t rows, int cols, int ld_in);

@@ -1,0 +1,213 @@
+"""Python host side of the bands engine: thin, typed wrappers over the C ABI.
+
+`DepthAnything` mirrors what bands/depth_anything.py builds in init_model() and calls in
+infer() (reference lines 48-76, 100-143); all arithmetic runs in libprisma_bands.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .synth import DEPTH_CFGS, DepthCfg
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count() -> int:
+    return _lib.load().pb_device_count()
+
+
+def net_size(H: int, W: int) -> Tuple[int, int]:
+    """(net_h, net_w) of the network input for an HxW frame (transform.py:100-166)."""
+    nh, nw = C.c_int(), C.c_int()
+    check(_lib.load().pb_depth_net_size(H, W, C.byref(nh), C.byref(nw)))
+    return nh.value, nw.value
+
+
+class _Ctx:
+    def __init__(self):
+        self.lib = _lib.load()
+        self.ctx = C.c_void_p()
+
+    def close(self):
+        if self.ctx:
+            self.lib.pb_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # device memory helpers (frames resident in HBM for bench / pipelines)
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        check(self.lib.pb_dev_alloc(self.ctx, C.byref(p), nbytes))
+        return p.value
+
+    def dev_free(self, ptr: int):
+        check(self.lib.pb_dev_free(self.ctx, C.c_void_p(ptr)))
+
+    def h2d(self, ptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        check(self.lib.pb_memcpy_h2d(self.ctx, C.c_void_p(ptr), _ptr(arr), arr.nbytes))
+
+    def d2h(self, arr: np.ndarray, ptr: int):
+        assert arr.flags.c_contiguous
+        check(self.lib.pb_memcpy_d2h(self.ctx, _ptr(arr), C.c_void_p(ptr), arr.nbytes))
+
+    def sync(self):
+        check(self.lib.pb_sync(self.ctx))
+
+
+class Ops(_Ctx):
+    """Single-kernel entry points (pb_op_*) used by the parity tests."""
+
+    def __init__(self, device: int = 0):
+        super().__init__()
+        check(self.lib.pb_create(C.byref(self.ctx), device, b"ops", None, 0, None, 0))
+
+    def gemm(self, A, W, bias=None, act: int = 0, tile: int = 0) -> np.ndarray:
+        A, W = _f32(A), _f32(W)
+        M, K = A.shape
+        N = W.shape[0]
+        out = np.empty((M, N), np.float32)
+        b = None if bias is None else _f32(bias)
+        check(self.lib.pb_op_gemm(self.ctx, _ptr(A), _ptr(W), _ptr(b), _ptr(out), M, N, K, act, tile))
+        return out
+
+    def layernorm(self, x, g, b) -> np.ndarray:
+        x, g, b = _f32(x), _f32(g), _f32(b)
+        out = np.empty_like(x)
+        check(self.lib.pb_op_layernorm(self.ctx, _ptr(x), _ptr(g), _ptr(b), _ptr(out), x.shape[0], x.shape[1]))
+        return out
+
+    def attention(self, q, k, v) -> np.ndarray:
+        q, k, v = _f32(q), _f32(k), _f32(v)
+        B, Hh, N, d = q.shape
+        assert d == 64
+        out = np.empty_like(q)
+        check(self.lib.pb_op_attention(self.ctx, _ptr(q), _ptr(k), _ptr(v), _ptr(out), B, Hh, N))
+        return out
+
+    def conv2d(self, x, w, bias=None, stride=1, pad=None, relu_in=False, relu_out=False) -> np.ndarray:
+        x, w = _f32(x), _f32(w)
+        B, Ci, H, W = x.shape
+        Co, _, ks, _ = w.shape
+        pad = ks // 2 if pad is None else pad
+        OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        out = np.empty((B, Co, OH, OW), np.float32)
+        b = None if bias is None else _f32(bias)
+        check(self.lib.pb_op_conv2d(self.ctx, _ptr(x), _ptr(w), _ptr(b), _ptr(out), B, Ci, H, W, Co, ks, stride, pad,
+                                    int(relu_in), int(relu_out)))
+        return out
+
+    def bilinear(self, x, OH: int, OW: int, align_corners: bool) -> np.ndarray:
+        x = _f32(x)
+        B, Cc, H, W = x.shape
+        out = np.empty((B, Cc, OH, OW), np.float32)
+        check(self.lib.pb_op_bilinear(self.ctx, _ptr(x), _ptr(out), B, Cc, H, W, OH, OW, int(align_corners)))
+        return out
+
+    def preprocess(self, frame: np.ndarray) -> np.ndarray:
+        frame = np.ascontiguousarray(frame, np.uint8)
+        H, W = frame.shape[:2]
+        nh, nw = net_size(H, W)
+        out = np.empty((3, nh, nw), np.float32)
+        check(self.lib.pb_op_preprocess(self.ctx, _ptr(frame), H, W, _ptr(out), nh, nw))
+        return out
+
+    def encode_depth(self, depth, flip: bool = True):
+        depth = _f32(depth)
+        if depth.ndim == 2:
+            depth = depth[None]
+        n, H, W = depth.shape
+        rgb = np.empty((n, H, W, 3), np.uint8)
+        mn, mx = np.empty(n, np.float32), np.empty(n, np.float32)
+        check(self.lib.pb_op_encode_depth(self.ctx, _ptr(depth), n, H, W, int(flip), _ptr(rgb), _ptr(mn), _ptr(mx)))
+        return rgb, mn, mx
+
+
+class DepthAnything(_Ctx):
+    """Depth-Anything (DINOv2 ViT + DPT) band on one GPU.
+
+    weights: reference state_dict naming -> float32 ndarray (bands/d_anything/dpt.py:139-171).
+    """
+
+    def __init__(self, weights: Dict[str, np.ndarray], cfg: DepthCfg | str = "vitl", device: int = 0,
+                 max_batch: int = 1):
+        super().__init__()
+        self.cfg = DEPTH_CFGS[cfg] if isinstance(cfg, str) else cfg
+        c = _lib.pb_depth_cfg(self.cfg.embed_dim, self.cfg.depth, self.cfg.heads, self.cfg.features,
+                              (C.c_int32 * 4)(*self.cfg.out_channels), self.cfg.pos_grid, max_batch)
+        keep: List[np.ndarray] = []
+        arr = (_lib.pb_tensor * len(weights))()
+        for i, (name, w) in enumerate(weights.items()):
+            w = _f32(w)
+            keep.append(w)
+            arr[i].name = name.encode()
+            arr[i].dtype = 0
+            arr[i].ndim = w.ndim
+            for j, s in enumerate(w.shape):
+                arr[i].shape[j] = s
+            arr[i].data = w.ctypes.data
+        check(self.lib.pb_create(C.byref(self.ctx), device, b"depth_anything", arr, len(weights), C.byref(c),
+                                 C.sizeof(c)))
+        self.max_batch = max_batch
+
+    def infer_batch(self, frames: np.ndarray, want_depth: bool = True, want_rgb: bool = True, flip: bool = True):
+        """frames uint8 [n,H,W,3] RGB -> (depth f32 [n,H,W] | None, rgb u8 [n,H,W,3] | None, min [n], max [n])."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, H, W, ch = frames.shape
+        assert ch == 3
+        depth = np.empty((n, H, W), np.float32) if want_depth else None
+        rgb = np.empty((n, H, W, 3), np.uint8) if want_rgb else None
+        mn, mx = np.empty(n, np.float32), np.empty(n, np.float32)
+        check(self.lib.pb_depth_infer_batch(self.ctx, _ptr(frames), n, H, W, _ptr(depth), _ptr(rgb), _ptr(mn),
+                                            _ptr(mx), int(flip)))
+        return depth, rgb, mn, mx
+
+    def infer(self, img: np.ndarray, normalize: bool = False) -> np.ndarray:
+        """bands/depth_anything.py:100-143 `infer(img, normalize)` for the relative model."""
+        d = self.infer_batch(img[None], want_depth=True, want_rgb=False)[0][0]
+        if normalize:
+            lo, hi = d.min(), d.max()
+            if hi - lo > np.finfo("float").eps:
+                d = (d - lo) / (hi - lo)
+        return d
+
+    def infer_dev(self, frames_ptr: int, n: int, H: int, W: int, depth_ptr: int = 0, rgb_ptr: int = 0,
+                  min_ptr: int = 0, max_ptr: int = 0, flip: bool = True):
+        """All pointers are device addresses; asynchronous on the ctx stream (call sync())."""
+        v = lambda p: C.c_void_p(p) if p else None
+        check(self.lib.pb_depth_infer_batch_dev(self.ctx, v(frames_ptr), n, H, W, v(depth_ptr), v(rgb_ptr),
+                                                v(min_ptr), v(max_ptr), int(flip)))
+
+    def set_profiling(self, timing: bool = True, debug_stages: bool = False):
+        check(self.lib.pb_set_profiling(self.ctx, (1 if timing else 0) | (2 if debug_stages else 0)))
+
+    def kernel_stats(self) -> List[dict]:
+        arr = (_lib.pb_kernel_stat * 16)()
+        n = check(self.lib.pb_get_kernel_stats(self.ctx, arr, 16))
+        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes,
+                     launches=arr[i].launches) for i in range(n)]
+
+    def stage(self, name: str, cap: int = 1 << 26) -> np.ndarray:
+        out = np.empty(cap, np.float32)
+        shape = (C.c_int64 * 4)()
+        n = check(self.lib.pb_depth_get_stage(self.ctx, name.encode(), _ptr(out), cap, shape))
+        dims = [int(s) for s in shape]
+        while len(dims) > 1 and dims[-1] == 1:
+            dims.pop()
+        return out[:n].reshape(dims).copy()

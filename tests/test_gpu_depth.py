@@ -1,0 +1,107 @@
+"""GPU: the depth_anything band end to end through the C ABI vs the oracle and the committed
+reference vectors.  Tolerance: BASELINE.json asks for 1e-3 relative on float depth; the
+metric used here is max|d - ref| / max|ref| (error relative to the depth range, which is what
+the min/max-normalised heat encoding sees) plus the relative L2 error."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import depth_oracle as O
+from prisma_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_RANGE = 2e-3      # max abs error / depth range   (fp16 MFMA operands, fp32 accumulate)
+TOL_L2 = 1e-3         # ||d - ref|| / ||ref||
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def rell2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def report(tag, a, b):
+    print(f"  {tag:14s} relmax {relmax(a, b):.3e}  relL2 {rell2(a, b):.3e}")
+
+
+@pytest.mark.parametrize("cfg,hw,seed", [("vits", (96, 128), 11), ("vitl_d4", (90, 120), 12)])
+def test_small_models_stagewise(cfg, hw, seed, golden_dir):
+    c = synth.DEPTH_CFGS[cfg]
+    w = synth.depth_anything_weights(c, seed=1234)
+    frame = synth.frames(1, hw[0], hw[1], seed=seed)[0]
+    net = engine.DepthAnything(w, c, device=0, max_batch=2)
+    net.set_profiling(timing=False, debug_stages=True)
+    depth, rgb, mn, mx = net.infer_batch(frame[None])
+    x = O.preprocess(frame)[None]
+    d_net, st = O.model_forward(w, x, c.depth, c.heads, return_stages=True)
+    print(f"\n[{cfg}] stage errors vs oracle")
+    worst = 0.0
+    for name, key in [("tokens", "tokens"), ("block0", "block0"), (f"block{c.depth - 1}", f"block{c.depth - 1}"),
+                      ("feat0", "feat0"), ("feat3", "feat3"), ("layer1_rn", "layer1_rn"), ("layer4_rn", "layer4_rn"),
+                      ("path4", "path4"), ("path3", "path3"), ("path2", "path2"), ("output_conv1", "output_conv1"),
+                      ("net_depth", None)]:
+        got = net.stage(name)
+        ref = d_net if key is None else st[key]
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        report(name, got, ref)
+        worst = max(worst, relmax(got, ref))
+    ref = O.infer(w, frame, c.depth, c.heads)
+    report("depth", depth[0], ref)
+    z = np.load(os.path.join(golden_dir, f"depth_{cfg}_{hw[0]}x{hw[1]}.npz"))
+    report("depth/golden", depth[0], z["depth"])
+    assert relmax(depth[0], z["depth"]) < TOL_RANGE and rell2(depth[0], z["depth"]) < TOL_L2
+    assert worst < 1e-2
+    assert abs(mn[0] - depth[0].min()) == 0 and abs(mx[0] - depth[0].max()) == 0
+    ref_rgb, _, _ = O.encode_depth_video(depth[0], flip=True)
+    assert np.array_equal(rgb[0], ref_rgb)          # the fused encode is bit exact on the engine's own depth
+    net.close()
+
+
+def test_batch_matches_single():
+    c = synth.DEPTH_CFGS["vits"]
+    w = synth.depth_anything_weights(c, seed=1234)
+    frames = synth.frames(3, 90, 160, seed=5)
+    net = engine.DepthAnything(w, c, device=0, max_batch=2)     # 3 frames with max_batch 2 -> two chunks
+    d3, rgb3, mn3, mx3 = net.infer_batch(frames)
+    for i in range(3):
+        d1, rgb1, mn1, mx1 = net.infer_batch(frames[i:i + 1])
+        assert np.array_equal(d1[0], d3[i]) and np.array_equal(rgb1[0], rgb3[i]) and mn1[0] == mn3[i]
+    ref = O.infer(w, frames[2], c.depth, c.heads)
+    assert relmax(d3[2], ref) < TOL_RANGE
+    net.close()
+
+
+def test_vitl_720p_against_reference_vectors(golden_dir):
+    z = np.load(os.path.join(golden_dir, "depth_vitl_720p.npz"))
+    c = synth.DEPTH_CFGS["vitl"]
+    w = synth.depth_anything_weights(c, seed=1234)
+    frame = synth.frames(1, 720, 1280, seed=int(z["frame_seed"]))[0]
+    net = engine.DepthAnything(w, c, device=0, max_batch=1)
+    depth, rgb, mn, mx = net.infer_batch(frame[None])
+    print()
+    report("vitl 720p", depth[0][::8, ::8], z["depth_s8"])
+    assert relmax(depth[0][::8, ::8], z["depth_s8"]) < TOL_RANGE
+    assert rell2(depth[0][::8, ::8], z["depth_s8"]) < TOL_L2
+    assert abs(mx[0] - z["minmax"][1]) < TOL_RANGE * z["minmax"][1]
+    # size-independent properties at full size: encode is a pure function of (depth, min, max)
+    ref_rgb, lo, hi = O.encode_depth_video(depth[0], flip=True)
+    assert np.array_equal(rgb[0], ref_rgb) and lo == mn[0] and hi == mx[0]
+    net.close()
+
+
+def test_1080p_maps_to_same_network_and_runs():
+    c = synth.DEPTH_CFGS["vits"]
+    w = synth.depth_anything_weights(c, seed=1234)
+    net = engine.DepthAnything(w, c, device=0, max_batch=1)
+    f = synth.frames(1, 1080, 1920, seed=2)
+    d, rgb, mn, mx = net.infer_batch(f)
+    assert d.shape == (1, 1080, 1920) and np.isfinite(d).all() and mx[0] > mn[0]
+    ref = O.infer(w, f[0], c.depth, c.heads)
+    assert relmax(d[0], ref) < TOL_RANGE
+    net.close()

@@ -1,0 +1,138 @@
+"""GPU: every HIP kernel of the band, called through the C ABI (pb_op_*), against the oracle's
+arithmetic on the same seeded inputs.  Inputs are pre-rounded to fp16 so that the comparison
+isolates the kernel (fp32 accumulate, fp16 store) from input quantisation."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import depth_oracle as O
+from prisma_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def h(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    o = engine.Ops(0)
+    yield o
+    o.close()
+
+
+@pytest.mark.parametrize("M,N,K,act,tile", [
+    (64, 128, 64, 0, 1), (300, 128, 192, 1, 1), (2448, 384, 1024, 2, 1), (1000, 1024, 640, 0, 1),
+    (256, 256, 64, 0, 2), (2448, 3072, 1024, 0, 2), (777, 512, 4096, 2, 2), (513, 64, 128, 0, 1),
+])
+def test_gemm(ops, M, N, K, act, tile):
+    g = np.random.default_rng(M + N + K)
+    A, W, b = h(g.standard_normal((M, K))), h(g.standard_normal((N, K)) / np.sqrt(K)), g.standard_normal(N).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + b
+    if act == 1:
+        ref = np.maximum(ref, 0)
+    elif act == 2:
+        ref = F.gelu(torch.from_numpy(ref)).numpy()
+    out = ops.gemm(A, W, b, act=act, tile=tile)
+    assert relmax(out, ref) < 1.5e-3, relmax(out, ref)
+
+
+def test_gemm_asymmetric_layout(ops):
+    # transpose / row-col swap detector: A = identity block, W asymmetric
+    M = N = K = 128
+    A = np.eye(M, K, dtype=np.float32)
+    W = h(np.arange(N * K, dtype=np.float32).reshape(N, K) % 251 / 64.0)
+    out = ops.gemm(A, W, None, tile=1)
+    assert relmax(out, W.T) < 1e-3
+
+
+@pytest.mark.parametrize("rows,D", [(7, 384), (100, 768), (2443, 1024)])
+def test_layernorm(ops, rows, D):
+    g = np.random.default_rng(rows)
+    x = (g.standard_normal((rows, D)) * 2 + 0.5).astype(np.float32)
+    gm, bt = (1 + 0.1 * g.standard_normal(D)).astype(np.float32), (0.1 * g.standard_normal(D)).astype(np.float32)
+    ref = F.layer_norm(torch.from_numpy(x).double(), (D,), torch.from_numpy(gm).double(), torch.from_numpy(bt).double(), 1e-6).numpy()
+    assert relmax(ops.layernorm(x, gm, bt), ref) < 1e-3
+
+
+@pytest.mark.parametrize("B,Hh,N", [(1, 2, 64), (2, 3, 200), (1, 6, 1370), (1, 2, 2443)])
+def test_attention(ops, B, Hh, N):
+    g = np.random.default_rng(N)
+    q, k, v = [h(g.standard_normal((B, Hh, N, 64)) * s) for s in (2.0, 2.0, 1.0)]
+    qd, kd, vd = [torch.from_numpy(t).double() for t in (h(q * 0.125) * 8.0, k, v)]
+    a = (qd * 0.125) @ kd.transpose(-1, -2)
+    ref = (a.softmax(-1) @ vd).numpy()
+    out = ops.attention(q, k, v)
+    assert relmax(out, ref) < 3e-3, relmax(out, ref)
+
+
+def test_attention_spiked_row(ops):
+    # forces the online-softmax rescale: one key dominates late in the sequence
+    g = np.random.default_rng(5)
+    q, k, v = [h(g.standard_normal((1, 1, 300, 64))) for _ in range(3)]
+    k[0, 0, 270] = h(q[0, 0, 17] * 6.0)
+    a = (torch.from_numpy(q).double() * 0.125) @ torch.from_numpy(k).double().transpose(-1, -2)
+    ref = (a.softmax(-1) @ torch.from_numpy(v).double()).numpy()
+    assert relmax(ops.attention(q, k, v), ref) < 3e-3
+
+
+@pytest.mark.parametrize("B,Ci,H,W,Co,ks,stride,relu_in,relu_out", [
+    (1, 64, 9, 13, 64, 3, 1, 0, 0), (2, 48, 20, 28, 64, 3, 1, 1, 1), (1, 256, 37, 49, 256, 3, 1, 0, 0),
+    (1, 384, 37, 49, 384, 3, 2, 0, 0), (2, 128, 16, 16, 32, 1, 1, 0, 0), (1, 96, 30, 22, 128, 3, 1, 0, 1),
+])
+def test_conv2d(ops, B, Ci, H, W, Co, ks, stride, relu_in, relu_out):
+    g = np.random.default_rng(Ci + H)
+    x = h(g.standard_normal((B, Ci, H, W)))
+    w = h(g.standard_normal((Co, Ci, ks, ks)) / np.sqrt(Ci * ks * ks))
+    b = g.standard_normal(Co).astype(np.float32)
+    xin = torch.from_numpy(x).double()
+    if relu_in:
+        xin = xin.relu()
+    ref = F.conv2d(xin, torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=stride, padding=ks // 2)
+    if relu_out:
+        ref = ref.relu()
+    out = ops.conv2d(x, w, b, stride=stride, relu_in=bool(relu_in), relu_out=bool(relu_out))
+    assert out.shape == tuple(ref.shape)
+    assert relmax(out, ref.numpy()) < 1.5e-3, relmax(out, ref.numpy())
+
+
+@pytest.mark.parametrize("H,W,OH,OW,align", [(3, 4, 5, 7, 1), (19, 33, 37, 66, 1), (20, 28, 40, 56, 1),
+                                              (296, 392, 518, 686, 1), (37, 49, 90, 120, 0)])
+def test_bilinear(ops, H, W, OH, OW, align):
+    x = h(np.random.default_rng(H).standard_normal((2, 16, H, W)))
+    ref = F.interpolate(torch.from_numpy(x), (OH, OW), mode="bilinear", align_corners=bool(align)).numpy()
+    assert relmax(ops.bilinear(x, OH, OW, bool(align)), ref) < 1.5e-3
+
+
+@pytest.mark.parametrize("H,W", [(96, 128), (720, 1280), (1080, 1920), (600, 333)])
+def test_preprocess(ops, H, W):
+    frame = synth.frames(1, H, W, seed=H)[0]
+    ref = O.preprocess(frame)
+    out = ops.preprocess(frame)
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() < 2e-4, np.abs(out - ref).max()
+
+
+def test_encode_depth_bit_exact(ops, golden_dir):
+    z = np.load(os.path.join(golden_dir, "encode.npz"))
+    rgb, mn, mx = ops.encode_depth(z["pred"], flip=True)
+    assert np.array_equal(rgb[0], z["vid"])
+    assert mn[0] == z["pred"].min() and mx[0] == z["pred"].max()
+    g = np.random.default_rng(3)
+    d = (g.standard_normal((3, 270, 480)) * 4).astype(np.float32)
+    rgb, mn, mx = ops.encode_depth(d, flip=False)
+    for i in range(3):
+        ref, lo, hi = O.encode_depth_video(d[i], flip=False)
+        assert np.array_equal(rgb[i], ref) and mn[i] == lo and mx[i] == hi
+    # degenerate frame: max == min -> NaN -> 0 like the reference
+    rgb, mn, mx = ops.encode_depth(np.full((1, 8, 8), 2.5, np.float32))
+    assert not rgb.any() and mn[0] == mx[0] == 2.5
