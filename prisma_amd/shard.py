@@ -1,0 +1,59 @@
+"""Multi-GPU plumbing of the bands: static contiguous frame shards + one scalar all-gather.
+
+The reference processes one frame at a time in one process (bands/depth_anything.py:203-225) and
+carries no cross-frame state for depth (min/max normalisation is per frame, :215-217), so frames
+shard embarrassingly.  Each rank runs its own pb_ctx on its own GPU; the only exchange is the
+per-frame (min, max) pair that rank 0 needs, in frame order, for <band>_min.csv / _max.csv
+(:232-238).  torch.distributed is the transport ("nccl" = RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests); payload = 8 bytes per frame, one collective per video, so the default algorithm is
+fine - xGMI bandwidth is irrelevant at this size.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+
+def shard_range(n_frames: int, rank: int, world: int, halo: int = 0) -> Tuple[int, int]:
+    """[start, stop) of the contiguous block of ceil(n/world) frames owned by `rank`.
+
+    halo > 0 extends the start backwards (flow needs frame i-1 for pair i: bands/flow_raft.py:103-113).
+    """
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    per = -(-n_frames // world)
+    start = min(rank * per, n_frames)
+    stop = min(start + per, n_frames)
+    return max(0, start - halo) if stop > start else start, stop
+
+
+def gather_frame_scalars(local: np.ndarray, n_frames: int, device=None) -> np.ndarray | None:
+    """All-gather per-frame scalar rows ([n_local, k] float32) into frame order; rank 0 gets [n_frames, k].
+
+    Shards have ceil(n/world) frames except the tail; every rank pads to that length so one
+    fixed-size all_gather_into_tensor suffices.
+    """
+    import torch
+    import torch.distributed as dist
+    local = np.ascontiguousarray(local, np.float32)
+    if local.ndim == 1:
+        local = local[:, None]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local[:n_frames]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = -(-n_frames // world)
+    k = local.shape[1]
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    buf = torch.zeros((per, k), dtype=torch.float32, device=dev)
+    buf[: local.shape[0]] = torch.from_numpy(local).to(dev)
+    out = torch.empty((world * per, k), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, buf)
+    if rank != 0:
+        return None
+    rows: List[np.ndarray] = []
+    o = out.cpu().numpy()
+    for r in range(world):
+        s, e = shard_range(n_frames, r, world)
+        rows.append(o[r * per: r * per + (e - s)])
+    return np.concatenate(rows, 0)
