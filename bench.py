@@ -28,7 +28,7 @@ def cpu_baseline(weights, cfg, H, W):
     """Oracle (CPU restatement of the reference, torch fp32 on the host cores) on a bounded sample."""
     from oracle import depth_oracle as O
     from prisma_amd import synth
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)      # torch CPU GEMMs stop scaling (and regress) past ~32 threads
     torch.set_num_threads(cores)
     frame = synth.frames(1, H, W, seed=99)[0]
     t0 = time.time()
@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--encoder", default="vitl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256, 4 simple 256")
+    ap.add_argument("--conv-tile", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -68,6 +70,8 @@ def main():
     weights = synth.depth_anything_weights(cfg, seed=1234)
     B, H, W = args.batch, args.height, args.width
     net = engine.DepthAnything(weights, cfg, device=local_rank, max_batch=B)
+    net.set_option("gemm_tile", args.gemm_tile)
+    net.set_option("conv_tile", args.conv_tile)
 
     # synthetic frames, distinct per rank, resident in HBM before the timed region
     base = synth.frames(min(B, 4), H, W, seed=1000 + rank)

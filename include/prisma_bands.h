@@ -114,6 +114,9 @@ typedef struct {
     int32_t launches;
 } pb_kernel_stat;
 int pb_set_profiling(pb_ctx *ctx, int enabled);
+/* Tuning / A-B switches: "gemm_tile", "conv_tile" = 0 auto, 1 128x128, 2 256x256 ping-pong,
+ * 4 256x256 single-barrier. */
+int pb_set_option(pb_ctx *ctx, const char *key, int value);
 int pb_get_kernel_stats(pb_ctx *ctx, pb_kernel_stat *out, int cap);
 
 /* ---- single-kernel entry points (host buffers) used by the -m gpu parity tests ---------- */

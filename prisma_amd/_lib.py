@@ -47,6 +47,7 @@ SYMBOLS = {
     "pb_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "pb_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "pb_set_profiling": (C.c_int, [_P, C.c_int]),
+    "pb_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "pb_get_kernel_stats": (C.c_int, [_P, C.POINTER(pb_kernel_stat), C.c_int]),
     "pb_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pb_op_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),

@@ -23,6 +23,7 @@ struct pb_ctx {
     hipStream_t stream = nullptr;   // == depth->stream when a band is loaded
     f16 *zero = nullptr;
     bool own_stream = false;
+    int gemm_tile = TILE_AUTO, conv_tile = TILE_AUTO;
 };
 
 namespace {
@@ -155,6 +156,15 @@ int pb_set_profiling(pb_ctx *c, int enabled) {
     PB_CHECK(c && c->depth, PB_ERR_STATE, "ctx has no band");
     c->depth->timer.enabled = enabled != 0;
     c->depth->debug = (enabled & 2) != 0;
+    return 0;
+}
+
+int pb_set_option(pb_ctx *c, const char *key, int value) {
+    PB_CHECK(c && key, PB_ERR_ARG, "set_option: bad arguments");
+    int *g = c->depth ? &c->depth->gemm_tile : &c->gemm_tile, *v = c->depth ? &c->depth->conv_tile : &c->conv_tile;
+    if (!strcmp(key, "gemm_tile")) *g = value;
+    else if (!strcmp(key, "conv_tile")) *v = value;
+    else PB_CHECK(false, PB_ERR_ARG, "unknown option '%s'", key);
     return 0;
 }
 
@@ -297,7 +307,7 @@ int pb_op_conv2d(pb_ctx *c, const float *x, const float *w, const float *bias, f
     g.A = dx.as<f16>(); g.W = dw.as<f16>(); g.K = K; g.M = B * OH * OW; g.N = Co;
     g.cH = H; g.cW = W; g.cC = cip; g.cOH = OH; g.cOW = OW; g.cKW = ks; g.cStride = stride; g.cPad = pad;
     g.zero = c->zero; g.bias = db.as<float>(); g.out = dy.as<f16>(); g.ldo = cop; g.act = relu_out ? ACT_RELU : ACT_NONE;
-    PB_TRY(launch_gemm(c->stream, A_CONV, EPI_STD, TILE_128, g));
+    PB_TRY(launch_gemm(c->stream, A_CONV, EPI_STD, c->conv_tile ? c->conv_tile : TILE_128, g));
     PB_TRY(launch_nhwc_f16_to_nchw_f32(c->stream, dy.as<f16>(), dy32.as<float>(), B, Co, OH, OW, cop));
     PB_HIP(hipStreamSynchronize(c->stream));
     PB_HIP(hipMemcpy(y, dy32.p, (size_t)B * Co * OH * OW * 4, hipMemcpyDeviceToHost));

@@ -45,6 +45,7 @@ class DepthEngine {
     hipStream_t stream = nullptr;
     int device = 0;
     bool debug = false;
+    int gemm_tile = TILE_AUTO, conv_tile = TILE_AUTO;
     KernelTimer timer;
 
     // scratch for op-level tests

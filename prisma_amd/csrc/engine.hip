@@ -405,6 +405,7 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
     const double flops = 2.0 * a.M * (double)a.N * w.Kreal;
     const double bytes = 2.0 * ((double)a.M * w.Kreal + (double)a.N * w.Kreal + (double)a.M * a.N);
     tic(amode == A_CONV ? F_CONV : F_GEMM, flops, bytes);
+    if (tile == TILE_AUTO) tile = amode == A_CONV ? conv_tile : gemm_tile;
     int r = launch_gemm(stream, amode, epi, tile, a);
     toc();
     return r;
@@ -418,7 +419,7 @@ int DepthEngine::conv3(const f16 *in, int inC, int n, int H, int W, const Packed
     a.cOH = (H + 2 - 3) / stride + 1; a.cOW = (W + 2 - 3) / stride + 1;
     a.M = n * a.cOH * a.cOW;
     a.out = out; a.out2 = out2; a.add1 = add1; a.add2 = add2; a.act = act; a.ldo = outC;
-    return gemm(A_CONV, EPI_STD, a, w, TILE_128);
+    return gemm(A_CONV, EPI_STD, a, w, TILE_AUTO);
 }
 
 void DepthEngine::snapshot(const std::string &name) {
@@ -542,7 +543,7 @@ int DepthEngine::head(int n) {
         {   // out_conv (1x1) commutes with the bilinear resize (both linear, taps sum to 1): run it at low res
             GemmArgs a;
             a.A = yb_[lv]; a.lda = Fp; a.M = n * h * w; a.out = ocb_[lv]; a.ldo = Fp;
-            if ((r = gemm(A_DENSE, EPI_STD, a, outc_[lv], TILE_128))) return r;
+            if ((r = gemm(A_DENSE, EPI_STD, a, outc_[lv]))) return r;
         }
         const int th = lv == 0 ? 2 * h : lh_[lv - 1], tw = lv == 0 ? 2 * w : lw_[lv - 1];
         if ((r = bil(ocb_[lv], path_[lv], h, w, th, tw, F, Fp))) return r;

@@ -104,6 +104,87 @@ __device__ __forceinline__ void epi_store(const GemmArgs &p, int m, int n, float
     }
 }
 
+// Accumulators -> per-wave LDS patch -> 8-column chunks -> fused store.  `smem` must be free of live
+// staging data (callers barrier first).  TM x TN = 32x32 MFMA tiles per wave.
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM][TN], char *smem, int wave, int lane,
+                                             int wave_m0, int wave_n0, int n0) {
+    constexpr int ES = TN * 32 + 4;
+    constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * ES * 4;
+    const int li = lane & 31, lh = lane >> 5;
+    float *es = (float *)(smem + wave * EPIB);
+
+    if constexpr (EPI == EPI_QKV) {
+        if (n0 >= 2 * p.D) {
+            // V third: transpose through LDS so that stores run along the token axis of Vt.
+#pragma unroll
+            for (int tmi = 0; tmi < TM; ++tmi) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 w4;
+                        const float bb = p.bias[wave_n0 + tn * 32 + li];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w4[j] = acc[tmi][tn][g * 4 + j] + bb;
+                        *(f32x4 *)(es + (tn * 32 + li) * 36 + 8 * g + 4 * lh) = w4;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < TN * 2; ++it) {
+                    const int item = it * 64 + lane;
+                    const int nr = item >> 2, mc = item & 3;
+                    const f32x4 x0 = *(const f32x4 *)(es + nr * 36 + mc * 8);
+                    const f32x4 x1 = *(const f32x4 *)(es + nr * 36 + mc * 8 + 4);
+                    const int m = wave_m0 + tmi * 32 + mc * 8;
+                    const int n = wave_n0 + nr - 2 * p.D;
+                    if (m < p.M) {
+                        const int b = m / p.ntp, t = m - b * p.ntp;
+                        f16x8 r;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { r[j] = (f16)x0[j]; r[4 + j] = (f16)x1[j]; }
+                        *(f16x8 *)(p.vt + (((int64_t)b * p.heads + (n >> 6)) * 64 + (n & 63)) * p.ntp + t) = r;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            return;
+        }
+    }
+
+#pragma unroll
+    for (int tmi = 0; tmi < TM; ++tmi) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + tn * 32 + li] = acc[tmi][tn][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int CPR = TN * 4;                         // 8-column chunks per patch row
+#pragma unroll
+        for (int it = 0; it < 32 * CPR / 64; ++it) {
+            const int item = it * 64 + lane;
+            const int row = item / CPR, ch = item % CPR;
+            const f32x4 x0 = *(const f32x4 *)(es + row * ES + ch * 8);
+            const f32x4 x1 = *(const f32x4 *)(es + row * ES + ch * 8 + 4);
+            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            const int m = wave_m0 + tmi * 32 + row, n = wave_n0 + ch * 8;
+            if constexpr (EPI == EPI_HEAD) {
+                // N == 32: the 4 lanes of a row hold its 32 channels
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += fmaxf(v[j] + p.bias[n + j], 0.f) * p.w2[n + j];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                if (ch == 0 && m < p.M) p.depth[m] = fmaxf(s + p.b2, 0.f);
+            } else {
+                if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int NT = WM * WN * 64;
@@ -225,78 +306,241 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     }
     __syncthreads();            // staging buffers are dead; reuse LDS for the epilogue patches
 
-    float *es = (float *)(smem + wave * EPIB);
-    const int wave_m0 = m0 + wm * TM * 32, wave_n0 = n0 + wn * TN * 32;
+    run_epilogue<EPI, TM, TN>(p, acc, smem, wave, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, n0);
+}
 
-    if constexpr (EPI == EPI_QKV) {
-        if (n0 >= 2 * p.D) {
-            // V third: transpose through LDS so that stores run along the token axis of Vt.
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 "ping-pong" kernel: 8 waves = 2 wave groups (rows 0-127 / 128-255) staggered by
+// one barrier, so on every SIMD one wave runs its 8-MFMA cluster while its partner issues the
+// ds_reads and LDS-DMA of its next cluster.  Per K tile each wave walks its 128 x 64 output in four
+// 64 x 32 quadrants (phases p0..p3):
+//     p0: read B(j0)[4] + A(i0)[8] | mfma (i0,j0)      p1: read B(j1)[4] | mfma (i0,j1)
+//     p2: read A(i1)[8]            | mfma (i1,j1)      p3: -              | mfma (i1,j0)
+// LDS: 2 K-tile buffers x {A 32 KB, B 32 KB}; each buffer is staged as four 16 KB "half tiles"
+// A_i = rows {64 i .. +64} of both wave groups, B_j = rows {64 wc + 32 j .. +32} of the four wave
+// columns, one half tile (2 global_load_lds per thread) per phase, in consumption order and 5-6
+// phases ahead of first use:
+//     p0: B_1(t+1)   p1: A_1(t+1)   p2: A_0(t+2)   p3: B_0(t+2)
+// A region is re-staged >= 2 phases after its last ds_read (WAR) and read >= 1 phase after the
+// issuing waves' counted s_waitcnt vmcnt + barrier (RAW); vmcnt never drains to 0 in steady state
+// (8 DMAs = 4 half tiles stay in flight).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vm_wait_halftiles(int n) {
+    if (n >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+#define PB_BAR()                                  \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        asm volatile("s_barrier" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int BUF = 65536, BOFF = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int tile_m = swz / tilesN, tile_n = swz - tile_m * tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging geometry: half tile h in {A_0, A_1, B_0, B_1}, two DMAs (u = 0, 1) per thread ----
+    // DMA (wave, u) covers the 8 LDS rows starting at row0; lane -> row0 + (lane >> 3), chunk lane & 7.
+    const int lrow = lane >> 3;
+    int a_row0[2][2], b_row0[2][2];                  // [half][u], tile-local row of the DMA's first row
 #pragma unroll
-            for (int tmi = 0; tmi < TM; ++tmi) {
+    for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 w4;
-                        const float bb = p.bias[wave_n0 + tn * 32 + li];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) w4[j] = acc[tmi][tn][g * 4 + j] + bb;
-                        *(f32x4 *)(es + (tn * 32 + li) * 36 + 8 * g + 4 * lh) = w4;
-                    }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int it = 0; it < TN * 2; ++it) {
-                    const int item = it * 64 + lane;
-                    const int nr = item >> 2, mc = item & 3;
-                    const f32x4 x0 = *(const f32x4 *)(es + nr * 36 + mc * 8);
-                    const f32x4 x1 = *(const f32x4 *)(es + nr * 36 + mc * 8 + 4);
-                    const int m = wave_m0 + tmi * 32 + mc * 8;
-                    const int n = wave_n0 + nr - 2 * p.D;
-                    if (m < p.M) {
-                        const int b = m / p.ntp, t = m - b * p.ntp;
-                        f16x8 r;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { r[j] = (f16)x0[j]; r[4 + j] = (f16)x1[j]; }
-                        *(f16x8 *)(p.vt + (((int64_t)b * p.heads + (n >> 6)) * 64 + (n & 63)) * p.ntp + t) = r;
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            return;
+        for (int u = 0; u < 2; ++u) {
+            const int g = wave * 2 + u;
+            a_row0[hf][u] = (g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8;
+            b_row0[hf][u] = (g >> 2) * 64 + hf * 32 + (g & 3) * 8;
         }
-    }
+    // swizzled global chunk of this lane's LDS slot: row0 is a multiple of 8 with (row0 >> 3) & 1 == u
+    int cgu[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) cgu[u] = (lane & 7) ^ ((4 * u + (lane >> 4)) & 7);
 
+    const f16 *a_ptr[2][2];
+    int a_iy0[2][2], a_ix0[2][2];
+    bool a_ok[2][2];
+    const f16 *b_ptr[2][2];
 #pragma unroll
-    for (int tmi = 0; tmi < TM; ++tmi) {
+    for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + tn * 32 + li] = acc[tmi][tn][r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        constexpr int CPR = TN * 4;                         // 8-column chunks per patch row
-#pragma unroll
-        for (int it = 0; it < 32 * CPR / 64; ++it) {
-            const int item = it * 64 + lane;
-            const int row = item / CPR, ch = item % CPR;
-            const f32x4 x0 = *(const f32x4 *)(es + row * ES + ch * 8);
-            const f32x4 x1 = *(const f32x4 *)(es + row * ES + ch * 8 + 4);
-            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            const int m = wave_m0 + tmi * 32 + row, n = wave_n0 + ch * 8;
-            if constexpr (EPI == EPI_HEAD) {
-                // N == 32: the 4 lanes of a row hold its 32 channels
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s += fmaxf(v[j] + p.bias[n + j], 0.f) * p.w2[n + j];
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                if (ch == 0 && m < p.M) p.depth[m] = fmaxf(s + p.b2, 0.f);
+        for (int u = 0; u < 2; ++u) {
+            const int m = m0 + a_row0[hf][u] + lrow;
+            if constexpr (AMODE == A_DENSE) {
+                const int mc = m < p.M ? m : p.M - 1;
+                a_ptr[hf][u] = p.A + (int64_t)mc * p.lda + cgu[u] * 8;
+                a_ok[hf][u] = true;
+                a_iy0[hf][u] = a_ix0[hf][u] = 0;
             } else {
-                if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v);
+                const int ohw = p.cOH * p.cOW;
+                const int b = m / ohw, rem = m - b * ohw;
+                const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+                a_ok[hf][u] = m < p.M;
+                a_ptr[hf][u] = p.A + (int64_t)b * p.cH * p.cW * p.cC + cgu[u] * 8;
+                a_iy0[hf][u] = oy * p.cStride - p.cPad;
+                a_ix0[hf][u] = ox * p.cStride - p.cPad;
             }
+            b_ptr[hf][u] = p.W + (int64_t)(n0 + b_row0[hf][u] + lrow) * p.K + cgu[u] * 8;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int nk = p.K >> 6;
+    const int cpt = AMODE == A_CONV ? p.cC >> 6 : 1;     // K tiles per conv tap
+
+    auto stage_a = [&](int hf, int kt) {
+        char *base = smem + (kt & 1) * BUF;
+        int ky = 0, kx = 0, c0 = 0;
+        if constexpr (AMODE == A_CONV) {
+            const int tap = kt / cpt;
+            c0 = (kt - tap * cpt) << 6;
+            ky = tap / p.cKW;
+            kx = tap - ky * p.cKW;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f16 *src;
+            if constexpr (AMODE == A_DENSE) {
+                src = a_ptr[hf][u] + kt * 64;
+            } else {
+                const int iy = a_iy0[hf][u] + ky, ix = a_ix0[hf][u] + kx;
+                const bool ok = a_ok[hf][u] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+                src = ok ? a_ptr[hf][u] + ((iy * p.cW + ix) * p.cC + c0) : p.zero;
+            }
+            const int g = wave * 2 + u;
+            glds16(src, base + ((g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8) * 128);
+        }
+    };
+    auto stage_b = [&](int hf, int kt) {
+        char *base = smem + (kt & 1) * BUF + BOFF;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = wave * 2 + u;
+            glds16(b_ptr[hf][u] + kt * 64, base + ((g >> 2) * 64 + hf * 32 + (g & 3) * 8) * 128);
+        }
+    };
+
+    // ---- fragment addressing: chunk(ks) = (lh ^ fsw) ^ 2 ks  ->  byte offset = c0 ^ (32 ks) ----
+    const int li = lane & 31, lh = lane >> 5;
+    const int c0 = (lh ^ ((li >> 1) & 7)) * 16;
+    const int a_base = (wr * 128 + li) * 128;            // + i*8192 + rt*4096
+    const int b_base = BOFF + (wc * 64 + li) * 128;      // + j*4096
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f16x8 fa[2][4], fb0[4], fb1[4];
+
+    const int S = 4 * nk;                                // half tiles this block stages in total
+    // prologue: A_0(0) B_0(0) B_1(0) A_1(0) A_0(1) B_0(1)
+    stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+    if (nk > 1) { stage_a(0, 1); stage_b(0, 1); }
+    vm_wait_halftiles(nk > 1 ? 4 : 2);                   // A_0(0), B_0(0) landed (this wave's share)
+    PB_BAR();
+    if (wr == 1) PB_BAR();                               // stagger the second wave group by one barrier
+
+    for (int t = 0; t < nk; ++t) {
+        const char *sb = smem + (t & 1) * BUF;
+        // ================= p0 =================
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb0[ks] = *(const f16x8 *)(sb + b_base + (c0 ^ (ks * 32)));
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const f16x8 *)(sb + a_base + rt * 4096 + (c0 ^ (ks * 32)));
+        if (t + 1 < nk) stage_b(1, t + 1);
+        vm_wait_halftiles(S - (4 * t + 3));
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[rt][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
+        // ================= p1 =================
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb1[ks] = *(const f16x8 *)(sb + b_base + 4096 + (c0 ^ (ks * 32)));
+        if (t + 1 < nk) stage_a(1, t + 1);
+        vm_wait_halftiles(S - (4 * t + 4));
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[rt][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
+        // ================= p2 =================
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                fa[rt][ks] = *(const f16x8 *)(sb + a_base + 8192 + rt * 4096 + (c0 ^ (ks * 32)));
+        if (t + 2 < nk) stage_a(0, t + 2);
+        vm_wait_halftiles(S - (4 * t + 4));
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[2 + rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[2 + rt][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
+        // ================= p3 =================
+        if (t + 2 < nk) stage_b(0, t + 2);
+        vm_wait_halftiles(S - (4 * t + 6));
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[2 + rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[2 + rt][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
     }
+    if (wr == 0) PB_BAR();                               // re-align the two wave groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    run_epilogue<EPI, 4, 2>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, n0);
+}
+
+template <int AMODE, int EPI>
+int launch_g8(hipStream_t stream, const GemmArgs &a) {
+    constexpr int SMEM = 131072;
+    auto kern = gemm8_kernel<AMODE, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), SMEM, stream, a);
+    PB_HIP(hipGetLastError());
+    return 0;
 }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
@@ -323,7 +567,8 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
     if constexpr (EPI == EPI_HEAD) {
         return launch_t<256, 32, 4, 1, AMODE, EPI>(s, a);
     } else {
-        if (tile == TILE_256) return launch_t<256, 256, 2, 4, AMODE, EPI>(s, a);
+        if (tile == TILE_256) return launch_g8<AMODE, EPI>(s, a);
+        if (tile == TILE_256_SIMPLE) return launch_t<256, 256, 2, 4, AMODE, EPI>(s, a);
         return launch_t<128, 128, 2, 2, AMODE, EPI>(s, a);
     }
 }
@@ -339,7 +584,7 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         const bool wide = a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256;
         tile = wide && (epi != EPI_QKV || a.D % 256 == 0) ? TILE_256 : TILE_128;
     }
-    if (epi == EPI_QKV) PB_CHECK(a.D % (tile == TILE_256 ? 256 : 128) == 0 && a.ntp % 8 == 0, -1, "qkv epilogue: D=%d ntp=%d", a.D, a.ntp);
+    if (epi == EPI_QKV) PB_CHECK(a.D % (tile == TILE_128 ? 128 : 256) == 0 && a.ntp % 8 == 0, -1, "qkv epilogue: D=%d ntp=%d", a.D, a.ntp);
 #define PB_CASE(AM, EP) \
     if (amode == AM && epi == EP) return launch_tile<AM, EP>(stream, tile, a)
     PB_CASE(A_DENSE, EPI_STD);

@@ -70,6 +70,9 @@ class _Ctx:
     def sync(self):
         check(self.lib.pb_sync(self.ctx))
 
+    def set_option(self, key: str, value: int):
+        check(self.lib.pb_set_option(self.ctx, key.encode(), int(value)))
+
 
 class Ops(_Ctx):
     """Single-kernel entry points (pb_op_*) used by the parity tests."""

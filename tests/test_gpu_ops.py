@@ -33,6 +33,8 @@ def ops():
 @pytest.mark.parametrize("M,N,K,act,tile", [
     (64, 128, 64, 0, 1), (300, 128, 192, 1, 1), (2448, 384, 1024, 2, 1), (1000, 1024, 640, 0, 1),
     (256, 256, 64, 0, 2), (2448, 3072, 1024, 0, 2), (777, 512, 4096, 2, 2), (513, 64, 128, 0, 1),
+    (300, 256, 128, 0, 2), (1000, 512, 192, 1, 2), (515, 768, 576, 0, 2), (4096, 1024, 640, 0, 2),
+    (2448, 1024, 1024, 0, 4), (640, 256, 320, 2, 4),
 ])
 def test_gemm(ops, M, N, K, act, tile):
     g = np.random.default_rng(M + N + K)
@@ -107,6 +109,23 @@ def test_conv2d(ops, B, Ci, H, W, Co, ks, stride, relu_in, relu_out):
 
 @pytest.mark.parametrize("H,W,OH,OW,align", [(3, 4, 5, 7, 1), (19, 33, 37, 66, 1), (20, 28, 40, 56, 1),
                                               (296, 392, 518, 686, 1), (37, 49, 90, 120, 0)])
+@pytest.mark.parametrize("tile", [2, 4])
+def test_conv2d_wide_tiles(ops, tile):
+    ops.set_option("conv_tile", tile)
+    try:
+        g = np.random.default_rng(tile)
+        for (B, Ci, H, W, Co, stride) in [(1, 256, 37, 49, 256, 1), (2, 128, 24, 40, 512, 1), (1, 320, 33, 21, 256, 2)]:
+            x = h(g.standard_normal((B, Ci, H, W)))
+            w = h(g.standard_normal((Co, Ci, 3, 3)) / np.sqrt(Ci * 9))
+            b = g.standard_normal(Co).astype(np.float32)
+            ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                           stride=stride, padding=1).numpy()
+            out = ops.conv2d(x, w, b, stride=stride)
+            assert relmax(out, ref) < 1.5e-3, (tile, Ci, relmax(out, ref))
+    finally:
+        ops.set_option("conv_tile", 0)
+
+
 def test_bilinear(ops, H, W, OH, OW, align):
     x = h(np.random.default_rng(H).standard_normal((2, 16, H, W)))
     ref = F.interpolate(torch.from_numpy(x), (OH, OW), mode="bilinear", align_corners=bool(align)).numpy()
