@@ -123,6 +123,9 @@ int pb_get_kernel_stats(pb_ctx *ctx, pb_kernel_stat *out, int cap);
 /* C[M,N] = act(A[M,K] @ W[N,K]^T + bias) with fp16 operands, fp32 accumulate (MFMA).       */
 int pb_op_gemm(pb_ctx *ctx, const float *A, const float *W, const float *bias, float *C,
                int M, int N, int K, int act /*0 none,1 relu,2 gelu*/, int tile /*0 auto,1 128x128,2 256x256*/);
+/* Kernel micro-benchmark on device-resident uniform[-1,1) fp16 data: mean ms per launch over iters.
+ * epi: 0 fp16 store, 1 bias+GELU fp16 store, 2 LayerScale + fp32 residual read-modify-write. */
+int pb_op_gemm_bench(pb_ctx *ctx, int M, int N, int K, int tile, int epi, int iters, double *ms_out);
 /* LayerNorm over the last dim, eps 1e-6 (vision_transformer.py:95). */
 int pb_op_layernorm(pb_ctx *ctx, const float *x, const float *g, const float *b, float *y, int rows, int D);
 /* softmax(q k^T * 64^-0.5) v per (batch, head); q,k,v,o: [B, heads, N, 64] float32

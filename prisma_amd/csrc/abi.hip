@@ -229,6 +229,34 @@ int pb_op_gemm(pb_ctx *c, const float *A, const float *W, const float *bias, flo
     return 0;
 }
 
+int pb_op_gemm_bench(pb_ctx *c, int M, int N, int K, int tile, int epi, int iters, double *ms_out) {
+    PB_CHECK(c && M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0 && iters > 0 && ms_out, PB_ERR_ARG, "gemm_bench: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    DevMem a, w, o, r, b;
+    const int64_t Mp = round_up(M, 256), Np = round_up(N, 256);
+    PB_TRY(a.alloc((size_t)Mp * K * 2)); PB_TRY(w.alloc((size_t)Np * K * 2)); PB_TRY(o.alloc((size_t)Mp * N * 2));
+    PB_TRY(r.alloc((size_t)Mp * N * 4)); PB_TRY(b.alloc((size_t)Np * 4));
+    PB_TRY(launch_fill_random_f16(c->stream, a.as<f16>(), (int64_t)M * K, 1u, 1.f));
+    PB_TRY(launch_fill_random_f16(c->stream, w.as<f16>(), (int64_t)N * K, 2u, 0.05f));
+    GemmArgs g;
+    g.A = a.as<f16>(); g.lda = K; g.W = w.as<f16>(); g.K = K; g.M = M; g.N = N; g.zero = c->zero; g.bias = b.as<float>();
+    int e = EPI_STD;
+    if (epi == 2) { e = EPI_RESID; g.resid = r.as<float>(); g.ldr = N; g.gamma = b.as<float>(); }
+    else { g.out = o.as<f16>(); g.ldo = N; g.act = epi == 1 ? ACT_GELU : ACT_NONE; }
+    hipEvent_t e0, e1;
+    PB_HIP(hipEventCreate(&e0)); PB_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) PB_TRY(launch_gemm(c->stream, A_DENSE, e, tile, g));
+    PB_HIP(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; ++i) PB_TRY(launch_gemm(c->stream, A_DENSE, e, tile, g));
+    PB_HIP(hipEventRecord(e1, c->stream));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    PB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_out = ms / iters;
+    return 0;
+}
+
 int pb_op_layernorm(pb_ctx *c, const float *x, const float *g, const float *b, float *y, int rows, int D) {
     PB_CHECK(c && x && g && b && y && rows > 0, PB_ERR_ARG, "op_layernorm: bad arguments");
     PB_HIP(hipSetDevice(c->device));

@@ -287,6 +287,14 @@ __global__ void f16_to_f32_kernel(const f16 *x, float *y, int64_t rows, int cols
     y[i] = (float)x[r * ld_in + c];
 }
 
+__global__ void fill_random_f16_kernel(f16 *x, int64_t n, unsigned seed, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u ^ seed;
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        x[i] = (f16)(((float)(h >> 8) * (1.f / 8388608.f) - 1.f) * scale);
+    }
+}
+
 inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 
 }  // namespace
@@ -376,6 +384,12 @@ int launch_f32_to_f16(hipStream_t s, const float *x, f16 *y, int64_t rows, int c
 }
 int launch_f16_to_f32(hipStream_t s, const f16 *x, float *y, int64_t rows, int cols, int ld_in) {
     hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk(rows * cols)), dim3(256), 0, s, x, y, rows, cols, ld_in);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_fill_random_f16(hipStream_t s, f16 *x, int64_t n, unsigned seed, float scale) {
+    hipLaunchKernelGGL(fill_random_f16_kernel, dim3(4096), dim3(256), 0, s, x, n, seed, scale);
     PB_HIP(hipGetLastError());
     return 0;
 }

@@ -37,3 +37,4 @@ int launch_nchw_f32_to_nhwc_f16(hipStream_t s, const float *x, f16 *y, int B, in
 int launch_nhwc_f16_to_nchw_f32(hipStream_t s, const f16 *x, float *y, int B, int C, int H, int W, int ldc);
 int launch_f32_to_f16(hipStream_t s, const float *x, f16 *y, int64_t rows, int cols, int ld_out);
 int launch_f16_to_f32(hipStream_t s, const f16 *x, float *y, int64_t rows, int cols, int ld_in);
+int launch_fill_random_f16(hipStream_t s, f16 *x, int64_t n, unsigned seed, float scale);

@@ -90,6 +90,12 @@ class Ops(_Ctx):
         check(self.lib.pb_op_gemm(self.ctx, _ptr(A), _ptr(W), _ptr(b), _ptr(out), M, N, K, act, tile))
         return out
 
+    def gemm_bench(self, M: int, N: int, K: int, tile: int = 0, epi: int = 0, iters: int = 20) -> float:
+        """mean milliseconds per launch on device-resident random data."""
+        ms = C.c_double()
+        check(self.lib.pb_op_gemm_bench(self.ctx, M, N, K, tile, epi, iters, C.byref(ms)))
+        return ms.value
+
     def layernorm(self, x, g, b) -> np.ndarray:
         x, g, b = _f32(x), _f32(g), _f32(b)
         out = np.empty_like(x)

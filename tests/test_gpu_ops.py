@@ -107,8 +107,6 @@ def test_conv2d(ops, B, Ci, H, W, Co, ks, stride, relu_in, relu_out):
     assert relmax(out, ref.numpy()) < 1.5e-3, relmax(out, ref.numpy())
 
 
-@pytest.mark.parametrize("H,W,OH,OW,align", [(3, 4, 5, 7, 1), (19, 33, 37, 66, 1), (20, 28, 40, 56, 1),
-                                              (296, 392, 518, 686, 1), (37, 49, 90, 120, 0)])
 @pytest.mark.parametrize("tile", [2, 4])
 def test_conv2d_wide_tiles(ops, tile):
     ops.set_option("conv_tile", tile)
@@ -126,6 +124,8 @@ def test_conv2d_wide_tiles(ops, tile):
         ops.set_option("conv_tile", 0)
 
 
+@pytest.mark.parametrize("H,W,OH,OW,align", [(3, 4, 5, 7, 1), (19, 33, 37, 66, 1), (20, 28, 40, 56, 1),
+                                              (296, 392, 518, 686, 1), (37, 49, 90, 120, 0)])
 def test_bilinear(ops, H, W, OH, OW, align):
     x = h(np.random.default_rng(H).standard_normal((2, 16, H, W)))
     ref = F.interpolate(torch.from_numpy(x), (OH, OW), mode="bilinear", align_corners=bool(align)).numpy()
