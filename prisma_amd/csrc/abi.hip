@@ -1,5 +1,6 @@
 // C ABI of libprisma_bands.so (include/prisma_bands.h).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -246,6 +247,18 @@ int pb_op_gemm_bench(pb_ctx *c, int M, int N, int K, int tile, int epi, int iter
     hipEvent_t e0, e1;
     PB_HIP(hipEventCreate(&e0)); PB_HIP(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i) PB_TRY(launch_gemm(c->stream, A_DENSE, e, tile, g));
+    if (const char *dump = getenv("PB_GEMM_DBG")) {      // per-block stamps of one launch -> binary file
+        const int nblk = (int)((Mp / 256) * (Np / 256));
+        DevMem d;
+        PB_TRY(d.alloc((size_t)nblk * 64));
+        g.dbg = d.as<long long>();
+        PB_TRY(launch_gemm(c->stream, A_DENSE, e, tile, g));
+        PB_HIP(hipStreamSynchronize(c->stream));
+        std::vector<long long> h((size_t)nblk * 8);
+        PB_HIP(hipMemcpy(h.data(), d.p, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(dump, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        g.dbg = nullptr;
+    }
     PB_HIP(hipEventRecord(e0, c->stream));
     for (int i = 0; i < iters; ++i) PB_TRY(launch_gemm(c->stream, A_DENSE, e, tile, g));
     PB_HIP(hipEventRecord(e1, c->stream));

@@ -39,6 +39,8 @@ struct GemmArgs {
     const float *w2 = nullptr;
     float b2 = 0.f;
     float *depth = nullptr;
+    // optional per-block timing stamps (8 x int64 per block): see gemm8_kernel
+    long long *dbg = nullptr;
 };
 
 // Launches the kernel on `stream`.  tile: TILE_AUTO picks from the shape.

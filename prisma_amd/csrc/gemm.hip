@@ -21,32 +21,99 @@
 
 namespace {
 
+// ---- fused epilogues ---------------------------------------------------------------------------
+// A lane owns the same 8 output columns (n .. n+7) for every row it stores, so everything that
+// depends only on the column (bias, LayerScale gamma, head weights) is loaded ONCE per lane.  Row
+// dependent operands (residual stream, skip tensors, pos-embed) are fetched for all of a pass's
+// rows before the first store: the compiler cannot hoist a load above a store that may alias it, and
+// a load -> use -> store chain per row costs one full memory latency each (measured 23k-53k
+// cycles per 256x256 tile before this restructuring, 2-3x the MFMA main loop's share).
+struct EpiAux {
+    f16x8 a1, a2;       // EPI_STD skip tensors
+    f32x4 r0, r1;       // EPI_RESID residual / EPI_PATCH pos-embed
+};
+
+__device__ __forceinline__ float fast_gelu(float x) {
+    // x * Phi(x), erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7): one rcp, one exp, 5 fma
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float y = fmaf(t, 1.061405429f, -1.453152027f);
+    y = fmaf(t, y, 1.421413741f);
+    y = fmaf(t, y, -0.284496736f);
+    y = fmaf(t, y, 0.254829592f);
+    const float e = 1.0f - y * t * __expf(-z * z);        // erf(|x| / sqrt2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 template <int EPI>
-__device__ __forceinline__ void epi_store(const GemmArgs &p, int m, int n, float (&v)[8]) {
-    if constexpr (EPI == EPI_STD) {
+__device__ __forceinline__ void epi_cols(const GemmArgs &p, int n, bool nok, float (&cb)[8], float (&cg)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cb[j] = 0.f; cg[j] = 0.f; }
+    if (!nok) return;
+    if constexpr (EPI == EPI_PIXSHUF) {
+        const int co = n % p.ps_co;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cb[j] = p.bias[co + j];
+    } else {
         if (p.bias) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += p.bias[n + j];
+            for (int j = 0; j < 8; ++j) cb[j] = p.bias[n + j];
         }
-        const int64_t o = (int64_t)m * p.ldo + n;
-        if (p.add1) {
-            const f16x8 a = *(const f16x8 *)(p.add1 + o);
+    }
+    if constexpr (EPI == EPI_RESID) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += (float)a[j];
+        for (int j = 0; j < 8; ++j) cg[j] = p.gamma[n + j];
+    }
+    if constexpr (EPI == EPI_HEAD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cg[j] = p.w2[n + j];
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_prefetch(const GemmArgs &p, int m, int n, EpiAux &x) {
+    if constexpr (EPI == EPI_STD) {
+        const int64_t o = (int64_t)m * p.ldo + n;
+        if (p.add1) x.a1 = *(const f16x8 *)(p.add1 + o);
+        if (p.add2) x.a2 = *(const f16x8 *)(p.add2 + o);
+    } else if constexpr (EPI == EPI_RESID) {
+        const float *r = p.resid + (int64_t)m * p.ldr + n;
+        x.r0 = *(const f32x4 *)r;
+        x.r1 = *(const f32x4 *)(r + 4);
+    } else if constexpr (EPI == EPI_PATCH) {
+        const int b = m / p.ppi, pi = m - b * p.ppi;
+        const float *pe = p.pos + (int64_t)(1 + pi) * p.D + n;
+        x.r0 = *(const f32x4 *)pe;
+        x.r1 = *(const f32x4 *)(pe + 4);
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, float (&v)[8], const EpiAux &x,
+                                           const float (&cb)[8], const float (&cg)[8]) {
+    if constexpr (EPI == EPI_STD) {
+        const int64_t o = (int64_t)m * p.ldo + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += cb[j];
+        if (p.add1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)x.a1[j];
         }
         if (p.add2) {
-            const f16x8 a = *(const f16x8 *)(p.add2 + o);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += (float)a[j];
+            for (int j = 0; j < 8; ++j) v[j] += (float)x.a2[j];
         }
         if (p.out) {
             f16x8 r;
+            if (p.act == ACT_GELU) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float x = v[j];
-                if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
-                else if (p.act == ACT_GELU) x = gelu_erf(x);
-                r[j] = (f16)x;
+                for (int j = 0; j < 8; ++j) r[j] = (f16)fast_gelu(v[j]);
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (f16)fmaxf(v[j], 0.f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (f16)v[j];
             }
             *(f16x8 *)(p.out + o) = r;
         }
@@ -58,16 +125,16 @@ __device__ __forceinline__ void epi_store(const GemmArgs &p, int m, int n, float
         }
     } else if constexpr (EPI == EPI_RESID) {
         float *r = p.resid + (int64_t)m * p.ldr + n;
-        f32x4 r0 = *(f32x4 *)r, r1 = *(f32x4 *)(r + 4);
+        f32x4 r0 = x.r0, r1 = x.r1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            r0[j] += p.gamma[n + j] * (v[j] + p.bias[n + j]);
-            r1[j] += p.gamma[n + 4 + j] * (v[4 + j] + p.bias[n + 4 + j]);
+            r0[j] += cg[j] * (v[j] + cb[j]);
+            r1[j] += cg[4 + j] * (v[4 + j] + cb[4 + j]);
         }
         *(f32x4 *)r = r0;
         *(f32x4 *)(r + 4) = r1;
     } else if constexpr (EPI == EPI_QKV) {
-        // q / k rows only; the V third is handled by the transposed path in the kernel
+        // q / k rows only; the V third is handled by the transposed path below
         const int which = n / p.D;
         const int hn = n - which * p.D;
         const int head = hn >> 6, d = hn & 63;
@@ -75,29 +142,28 @@ __device__ __forceinline__ void epi_store(const GemmArgs &p, int m, int n, float
         const float s = which == 0 ? p.qscale : 1.f;
         f16x8 r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (f16)((v[j] + p.bias[n + j]) * s);
+        for (int j = 0; j < 8; ++j) r[j] = (f16)((v[j] + cb[j]) * s);
         f16 *dst = (which == 0 ? p.q : p.k) + (((int64_t)b * p.heads + head) * p.ntp + t) * 64 + d;
         *(f16x8 *)dst = r;
     } else if constexpr (EPI == EPI_PIXSHUF) {
         const int hw = p.ps_h * p.ps_w;
         const int b = m / hw, rem = m - b * hw;
-        const int y = rem / p.ps_w, x = rem - y * p.ps_w;
+        const int y = rem / p.ps_w, xx = rem - y * p.ps_w;
         const int tap = n / p.ps_co, co = n - tap * p.ps_co;
         const int dy = tap / p.ps_s, dx = tap - dy * p.ps_s;
-        const int64_t row = ((int64_t)b * p.ps_h * p.ps_s + (y * p.ps_s + dy)) * (p.ps_w * p.ps_s) + (x * p.ps_s + dx);
+        const int64_t row = ((int64_t)b * p.ps_h * p.ps_s + (y * p.ps_s + dy)) * (p.ps_w * p.ps_s) + (xx * p.ps_s + dx);
         f16x8 r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (f16)(v[j] + p.bias[co + j]);
+        for (int j = 0; j < 8; ++j) r[j] = (f16)(v[j] + cb[j]);
         *(f16x8 *)(p.out + row * p.ldo + co) = r;
     } else if constexpr (EPI == EPI_PATCH) {
         const int b = m / p.ppi, pi = m - b * p.ppi;
         float *r = p.resid + ((int64_t)b * p.ntp + 1 + pi) * p.ldr + n;
-        const float *pe = p.pos + (int64_t)(1 + pi) * p.D + n;
         f32x4 r0, r1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            r0[j] = v[j] + p.bias[n + j] + pe[j];
-            r1[j] = v[4 + j] + p.bias[n + 4 + j] + pe[4 + j];
+            r0[j] = v[j] + cb[j] + x.r0[j];
+            r1[j] = v[4 + j] + cb[4 + j] + x.r1[j];
         }
         *(f32x4 *)r = r0;
         *(f32x4 *)(r + 4) = r1;
@@ -117,6 +183,9 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
     if constexpr (EPI == EPI_QKV) {
         if (n0 >= 2 * p.D) {
             // V third: transpose through LDS so that stores run along the token axis of Vt.
+            float bb[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bb[tn] = p.bias[wave_n0 + tn * 32 + li];
 #pragma unroll
             for (int tmi = 0; tmi < TM; ++tmi) {
 #pragma unroll
@@ -124,9 +193,8 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 w4;
-                        const float bb = p.bias[wave_n0 + tn * 32 + li];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) w4[j] = acc[tmi][tn][g * 4 + j] + bb;
+                        for (int j = 0; j < 4; ++j) w4[j] = acc[tmi][tn][g * 4 + j] + bb[tn];
                         *(f32x4 *)(es + (tn * 32 + li) * 36 + 8 * g + 4 * lh) = w4;
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -152,6 +220,15 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
         }
     }
 
+    constexpr int CPR = TN * 4;                             // 8-column chunks per patch row
+    constexpr int NIT = 32 * CPR / 64;                      // rows per lane per pass
+    constexpr int RSTEP = 64 / CPR;
+    const int ch = lane % CPR, row0 = lane / CPR;
+    const int n = wave_n0 + ch * 8;
+    const bool nok = n < p.N;
+    float cb[8], cg[8];
+    epi_cols<EPI>(p, n, nok, cb, cg);
+
 #pragma unroll
     for (int tmi = 0; tmi < TM; ++tmi) {
 #pragma unroll
@@ -160,25 +237,31 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
             for (int r = 0; r < 16; ++r)
                 es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + tn * 32 + li] = acc[tmi][tn][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        constexpr int CPR = TN * 4;                         // 8-column chunks per patch row
+        float v[NIT][8];
+        EpiAux aux[NIT];
 #pragma unroll
-        for (int it = 0; it < 32 * CPR / 64; ++it) {
-            const int item = it * 64 + lane;
-            const int row = item / CPR, ch = item % CPR;
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RSTEP + row0;
             const f32x4 x0 = *(const f32x4 *)(es + row * ES + ch * 8);
             const f32x4 x1 = *(const f32x4 *)(es + row * ES + ch * 8 + 4);
-            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            const int m = wave_m0 + tmi * 32 + row, n = wave_n0 + ch * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[it][j] = x0[j]; v[it][4 + j] = x1[j]; }
+            const int m = wave_m0 + tmi * 32 + row;
+            if (m < p.M && nok) epi_prefetch<EPI>(p, m, n, aux[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int m = wave_m0 + tmi * 32 + it * RSTEP + row0;
             if constexpr (EPI == EPI_HEAD) {
                 // N == 32: the 4 lanes of a row hold its 32 channels
                 float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += fmaxf(v[j] + p.bias[n + j], 0.f) * p.w2[n + j];
+                for (int j = 0; j < 8; ++j) s += fmaxf(v[it][j] + cb[j], 0.f) * cg[j];
                 s += __shfl_xor(s, 1);
                 s += __shfl_xor(s, 2);
                 if (ch == 0 && m < p.M) p.depth[m] = fmaxf(s + p.b2, 0.f);
             } else {
-                if (m < p.M && n < p.N) epi_store<EPI>(p, m, n, v);
+                if (m < p.M && nok) epi_finish<EPI>(p, m, n, v[it], aux[it], cb, cg);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -340,7 +423,8 @@ __device__ __forceinline__ void vm_wait_halftiles(int n) {
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-template <int AMODE, int EPI>
+// VAR != 0 are timing-only ablations (wrong results): 1 no DMA in the loop, 2 no vmcnt waits, 3 no ds_reads.
+template <int AMODE, int EPI, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     constexpr int BM = 256, BN = 256;
     constexpr int BUF = 65536, BOFF = 32768;
@@ -350,6 +434,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int wr = wave >> 2, wc = wave & 3;
+    long long ts0 = 0, ts1 = 0, ts2 = 0, tr0 = 0;
+    if (p.dbg) { ts0 = __builtin_readcyclecounter(); tr0 = wall_clock64(); }
 
     const int tilesN = (p.N + BN - 1) / BN;
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -457,18 +543,21 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     vm_wait_halftiles(nk > 1 ? 4 : 2);                   // A_0(0), B_0(0) landed (this wave's share)
     PB_BAR();
     if (wr == 1) PB_BAR();                               // stagger the second wave group by one barrier
+    if (p.dbg) ts1 = __builtin_readcyclecounter();
 
     for (int t = 0; t < nk; ++t) {
         const char *sb = smem + (t & 1) * BUF;
         // ================= p0 =================
+        if (VAR != 3 || t == 0) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fb0[ks] = *(const f16x8 *)(sb + b_base + (c0 ^ (ks * 32)));
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const f16x8 *)(sb + a_base + rt * 4096 + (c0 ^ (ks * 32)));
-        if (t + 1 < nk) stage_b(1, t + 1);
-        vm_wait_halftiles(S - (4 * t + 3));
+        }
+        if (VAR != 1 && t + 1 < nk) stage_b(1, t + 1);
+        if (VAR == 0 || VAR == 3) vm_wait_halftiles(S - (4 * t + 3));
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -479,10 +568,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
         // ================= p1 =================
+        if (VAR != 3 || t == 0) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fb1[ks] = *(const f16x8 *)(sb + b_base + 4096 + (c0 ^ (ks * 32)));
-        if (t + 1 < nk) stage_a(1, t + 1);
-        vm_wait_halftiles(S - (4 * t + 4));
+        }
+        if (VAR != 1 && t + 1 < nk) stage_a(1, t + 1);
+        if (VAR == 0 || VAR == 3) vm_wait_halftiles(S - (4 * t + 4));
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -493,13 +584,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
         // ================= p2 =================
+        if (VAR != 3)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 fa[rt][ks] = *(const f16x8 *)(sb + a_base + 8192 + rt * 4096 + (c0 ^ (ks * 32)));
-        if (t + 2 < nk) stage_a(0, t + 2);
-        vm_wait_halftiles(S - (4 * t + 4));
+        if (VAR != 1 && t + 2 < nk) stage_a(0, t + 2);
+        if (VAR == 0 || VAR == 3) vm_wait_halftiles(S - (4 * t + 4));
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -510,8 +602,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
         // ================= p3 =================
-        if (t + 2 < nk) stage_b(0, t + 2);
-        vm_wait_halftiles(S - (4 * t + 6));
+        if (VAR != 1 && t + 2 < nk) stage_b(0, t + 2);
+        if (VAR == 0 || VAR == 3) vm_wait_halftiles(S - (4 * t + 6));
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -525,13 +617,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     if (wr == 0) PB_BAR();                               // re-align the two wave groups
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (p.dbg) ts2 = __builtin_readcyclecounter();
     run_epilogue<EPI, 4, 2>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, n0);
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long *d = p.dbg + (long long)blockIdx.x * 8;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter(); d[4] = tr0; d[5] = wall_clock64();
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        d[6] = hw; d[7] = swz;
+    }
 }
 
-template <int AMODE, int EPI>
+template <int AMODE, int EPI, int VAR = 0>
 int launch_g8(hipStream_t stream, const GemmArgs &a) {
     constexpr int SMEM = 131072;
-    auto kern = gemm8_kernel<AMODE, EPI>;
+    auto kern = gemm8_kernel<AMODE, EPI, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
         PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -585,6 +686,11 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         tile = wide && (epi != EPI_QKV || a.D % 256 == 0) ? TILE_256 : TILE_128;
     }
     if (epi == EPI_QKV) PB_CHECK(a.D % (tile == TILE_128 ? 128 : 256) == 0 && a.ntp % 8 == 0, -1, "qkv epilogue: D=%d ntp=%d", a.D, a.ntp);
+    if (amode == A_DENSE && epi == EPI_STD && tile > 16) {      // timing-only ablations of the ping-pong kernel
+        if (tile == 18) return launch_g8<A_DENSE, EPI_STD, 1>(stream, a);
+        if (tile == 34) return launch_g8<A_DENSE, EPI_STD, 2>(stream, a);
+        if (tile == 50) return launch_g8<A_DENSE, EPI_STD, 3>(stream, a);
+    }
 #define PB_CASE(AM, EP) \
     if (amode == AM && epi == EP) return launch_tile<AM, EP>(stream, tile, a)
     PB_CASE(A_DENSE, EPI_STD);
