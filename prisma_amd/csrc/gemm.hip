@@ -441,7 +441,20 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    const int tile_m = swz / tilesN, tile_n = swz - tile_m * tilesN;
+    // Within an XCD's contiguous range, walk 8 (M) x GN (N) super-tiles so that the ~32 tiles in flight on
+    // the XCD share few A and W panels (fewer L2 misses -> less MALL/HBM traffic; loop time is unchanged).
+    int tile_m, tile_n;
+    {
+        const int GN = tilesN < 4 ? tilesN : 4;
+        const int per_band = 8 * tilesN;                 // tiles in a band of 8 M-panels
+        const int band = swz / per_band, rem = swz - band * per_band;
+        const int tilesM = nwg / tilesN;
+        const int bh = (tilesM - band * 8) < 8 ? (tilesM - band * 8) : 8;   // M-panels in this band
+        const int grp = rem / (bh * GN), r2 = rem - grp * bh * GN;
+        const int gw = (tilesN - grp * GN) < GN ? (tilesN - grp * GN) : GN; // N-panels in this group
+        tile_m = band * 8 + r2 / gw;
+        tile_n = grp * GN + r2 % gw;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- staging geometry: half tile h in {A_0, A_1, B_0, B_1}, two DMAs (u = 0, 1) per thread ----
