@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""depth_anything band - drop-in for /root/reference/bands/depth_anything.py on MI355X.
+
+Same CLI (reference :254-292), same outputs (<BAND>.mp4|png, <BAND>_min.csv, <BAND>_max.csv,
+metadata.json entries, :157-166, :232-251), same module-level API (BAND, init_model(), infer()).
+The PyTorch model and the numpy post-process are replaced by libprisma_bands.so through
+prisma_amd.engine (C ABI, include/prisma_bands.h); frames are pushed in batches instead of one by one.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_depth  # noqa: E402
+from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
+from prisma_amd import engine, synth  # noqa: E402
+
+BAND = "depth_anything"
+BATCH = int(os.environ.get("PRISMA_BATCH", "32"))
+
+model = None
+data = None
+args = None
+
+
+def heat_to_rgb(heat):
+    """bands/common/encode.py:13-33 (used only for still images; the video path encodes on the GPU)."""
+    hue = (1.0 - np.asarray(heat, np.float64)) * 0.65
+    rgb = np.stack([hue * 6.0, hue * 6.0 + 4.0, hue * 6.0 + 2.0], axis=-1)
+    return np.clip(np.abs(np.mod(rgb, 6.0) - 3.0) - 1.0, 0.0, 1.0)
+
+
+def load_weights(encoder, path=""):
+    """{reference state_dict name: float32 ndarray}.  The reference pulls LiheYoung/depth_anything_*14
+    from the HF hub (:60); offline we read models/depth_anything_<enc>14.{npz,pth} if present and fall
+    back to the seeded synthetic weights with a warning."""
+    cands = [path] if path else [os.path.join("models", f"depth_anything_{encoder}14.npz"),
+                                 os.path.join("models", f"depth_anything_{encoder}14.pth")]
+    for c in cands:
+        if c and os.path.exists(c):
+            if c.endswith(".npz"):
+                z = np.load(c)
+                return {k: z[k].astype(np.float32) for k in z.files}
+            import torch
+            sd = torch.load(c, map_location="cpu")
+            return {k: v.float().numpy() for k, v in sd.items()}
+    print(f"[{BAND}] no checkpoint found ({cands}); using seeded synthetic weights", file=sys.stderr)
+    return synth.depth_anything_weights(encoder, seed=1234)
+
+
+def init_model(encoder=None, weights="", device=0, max_batch=BATCH):
+    global model
+    encoder = encoder or (args.encoder if args else "vitl")
+    if args is not None and getattr(args, "metric", "none") != "none":
+        raise NotImplementedError("--metric indoor|outdoor (ZoeDepth head) is not built yet: SURVEY.md section 8(f)")
+    model = engine.DepthAnything(load_weights(encoder, weights), encoder, device=device, max_batch=max_batch)
+    return model
+
+
+def infer(img, normalize=False):
+    """uint8 RGB HxWx3 -> float32 HxW relative depth (reference :100-143)."""
+    if model is None:
+        init_model()
+    return model.infer(img, normalize=normalize)
+
+
+def process_image(a):
+    img = open_rgb(a.input)
+    out_folder = os.path.dirname(a.output)
+    pred = infer(img)
+    if data:
+        data["bands"][BAND]["values"] = {"min": {"value": float(pred.min()), "type": "float"},
+                                         "max": {"value": float(pred.max()), "type": "float"}}
+    if a.npy:
+        np.save(os.path.join(out_folder, BAND + ".npy"), pred)
+    write_depth(a.output, pred, heat_to_rgb, normalize=True, heatmap=True, encode_range=True, flip=True)
+
+
+def process_video(a):
+    src = FrameReader(a.input)
+    n = len(src)
+    h, w = src[0].shape[:2]
+    out = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=a.output)
+    out_folder = os.path.dirname(a.output)
+    if a.subpath:
+        if data:
+            data["bands"][BAND]["folder"] = a.subpath
+        a.subpath = os.path.join(out_folder, a.subpath)
+        create_folder(a.subpath)
+    if model is None:
+        init_model()
+    lo, hi = [], []
+    for s in range(0, n, BATCH):
+        frames = np.stack([src[i] for i in range(s, min(n, s + BATCH))])
+        want_depth = bool(a.npy or a.subpath)
+        depth, rgb, mn, mx = model.infer_batch(frames, want_depth=want_depth, want_rgb=True, flip=True)
+        for j in range(len(frames)):
+            out.write(rgb[j])
+            if a.npy and a.subpath:
+                np.save(os.path.join(a.subpath, "{:05d}.npy".format(s + j)), depth[j])
+            if a.subpath:
+                write_depth(os.path.join(a.subpath, "{:05d}.png".format(s + j)), depth[j], heat_to_rgb,
+                            normalize=True, flip=True, heatmap=True, encode_range=True)
+        lo += [float(v) for v in mn]
+        hi += [float(v) for v in mx]
+    out.close()
+    with open(os.path.join(out_folder, BAND + "_min.csv"), "w") as f:
+        f.writelines("{}\n".format(v) for v in lo)
+    with open(os.path.join(out_folder, BAND + "_max.csv"), "w") as f:
+        f.writelines("{}\n".format(v) for v in hi)
+    if data:
+        data["bands"][BAND]["values"] = {"min": {"type": "float", "url": BAND + "_min.csv"},
+                                         "max": {"type": "float", "url": BAND + "_max.csv"}}
+
+
+def main(argv=None):
+    global args, data
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--input", "-i", help="Input image/video", type=str, required=True)
+    ap.add_argument("--output", "-o", help="Output image/video", type=str, default="")
+    ap.add_argument("--npy", "-n", help="Save numpy data", action="store_true")
+    ap.add_argument("--ply", "-p", help="Create point cloud PLY", action="store_true")
+    ap.add_argument("--subpath", "-d", help="subpath to frames", type=str, default="")
+    ap.add_argument("--encoder", type=str, default="vitl", choices=["vits", "vitb", "vitl"])
+    ap.add_argument("--metric", help="Use a metric model", type=str, default="none", choices=["none", "indoor", "outdoor"])
+    ap.add_argument("--weights", help="checkpoint (.npz / .pth state dict); default models/ or synthetic", default="")
+    args = ap.parse_args(argv)
+    if args.ply:
+        raise NotImplementedError("--ply (point cloud export) is out of scope: SURVEY.md section 2.1 geom/colmap")
+    data = load_metadata(args.input)
+    if data:
+        print("PRISMA metadata found and loaded")
+        folder = args.input
+        args.input = get_url(folder, data, "rgba")
+        args.output = get_target(args.input, data, band=BAND, target=args.output, force_extension="png")
+        meta_path = folder
+    else:
+        meta_path = args.input
+        if not args.output:
+            ext = os.path.basename(args.input).rsplit(".", 1)[1]
+            args.output = os.path.join(os.path.dirname(args.input), BAND + "." + (ext if is_video(args.input) else "png"))
+    check_overwrite(args.output)
+    init_model(args.encoder, args.weights)
+    if is_video(args.output):
+        process_video(args)
+    else:
+        process_image(args)
+    write_metadata(meta_path, data)
+
+
+if __name__ == "__main__":
+    main()

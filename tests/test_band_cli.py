@@ -1,0 +1,70 @@
+"""Band script: folder/metadata contract on CPU, full CLI run on the GPU."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "bands"))
+
+from common import meta  # noqa: E402
+from common.io import float_to_rgb  # noqa: E402
+
+
+def test_metadata_contract(tmp_path):
+    folder = str(tmp_path / "clip")
+    data = meta.create_metadata(folder)
+    assert data == {"bands": {}}
+    # reference behaviour (bands/common/meta.py:70-93): target name = <band>.<ext of the rgba url>
+    meta.add_band(data, "rgba", url="rgba.mp4")
+    rgba = os.path.join(folder, "rgba.mp4")
+    assert meta.get_url(folder, data, "rgba") == rgba
+    assert meta.get_target(rgba, data, band="depth_anything", force_extension="png") == os.path.join(folder, "depth_anything.mp4")
+    assert data["bands"]["depth_anything"]["url"] == "depth_anything.mp4"
+    assert meta.get_target(os.path.join(folder, "rgba.png"), data, band="mask", force_extension="png").endswith("mask.png")
+    assert meta.get_target(rgba, data, band="flow_raft", force_extension="csv").endswith("flow_raft.csv")
+    meta.write_metadata(folder, data)
+    assert json.load(open(os.path.join(folder, "metadata.json")))["bands"]["rgba"]["url"] == "rgba.mp4"
+    meta.set_default_band(folder, "depth", "depth_anything")
+    assert meta.load_metadata(folder)["bands"]["depth"]["url"] == "depth_anything.mp4"
+    assert meta.is_video("x.mp4") and not meta.is_video("x.png")
+
+
+def test_float_to_rgb_known_answer(golden_dir):
+    z = np.load(os.path.join(golden_dir, "encode.npz"))
+    assert np.allclose(float_to_rgb(12.5, 0.0, 1000.0), z["float_to_rgb"], rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+def test_cli_video_and_image(tmp_path):
+    import depth_anything as band
+    from prisma_amd import synth
+    folder = tmp_path / "clip"
+    folder.mkdir()
+    frames = synth.frames(5, 90, 160, seed=3)
+    np.save(folder / "rgba.npy", frames)
+    (folder / "metadata.json").write_text(json.dumps({"bands": {"rgba": {"url": "rgba.npy"}}}))
+    os.environ["PRISMA_OVERWRITE"] = "1"
+    band.model = None
+    band.main(["-i", str(folder), "--encoder", "vits"])
+    out = np.load(folder / "depth_anything.npy")
+    assert out.shape == frames.shape and out.dtype == np.uint8
+    lo = [float(x) for x in open(folder / "depth_anything_min.csv")]
+    hi = [float(x) for x in open(folder / "depth_anything_max.csv")]
+    assert len(lo) == len(hi) == 5 and all(b > a for a, b in zip(lo, hi))
+    md = json.load(open(folder / "metadata.json"))
+    assert md["bands"]["depth_anything"]["url"] == "depth_anything.npy"
+    assert md["bands"]["depth_anything"]["values"]["min"] == {"type": "float", "url": "depth_anything_min.csv"}
+    # per-frame API agrees with the batched video path
+    d = band.infer(frames[2])
+    assert abs(d.min() - lo[2]) < 1e-6 and abs(d.max() - hi[2]) < 1e-6
+    # still image
+    from PIL import Image
+    Image.fromarray(frames[0]).save(tmp_path / "img.png")
+    band.main(["-i", str(tmp_path / "img.png"), "--encoder", "vits"])
+    png = np.asarray(Image.open(tmp_path / "depth_anything.png"))
+    assert png.shape == (90, 160, 3)
+    band.model.close()
+    band.model = None
