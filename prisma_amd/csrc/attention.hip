@@ -7,7 +7,7 @@
 //   Vt   : [b, head, 64, ntp] fp16 (V transposed: keys contiguous)
 //   O    : [b * ntp, heads * 64] fp16 row-major (the proj GEMM's A operand)
 //
-// Workgroup = 4 waves = 256 query rows of one (b, head); each wave owns 64 query rows (2 q-tiles).
+// Workgroup = 4 waves = 128 query rows of one (b, head); each wave owns 32 query rows.
 // Per 64-key tile:
 //   S^T[key][q] = K Q^T  with v_mfma_f32_32x32x16_f16 (A = K rows, B = Q rows): a lane then holds
 //                 32 scores of ONE query column, so the row max / row sum are in-lane plus one
@@ -20,6 +20,8 @@
 // through the source address exactly like gemm.hip.  Keys >= ntok are masked to -inf.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct AttnArgs {
@@ -28,9 +30,8 @@ struct AttnArgs {
     int ntp, ntok, heads, ldo;
 };
 
-// Wave = 64 query rows (two 32-row q-tiles) so every K / Vt fragment read from LDS feeds two MFMAs;
-// workgroup = 4 waves = 256 query rows of one (b, head).
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // 2 x (K tile 8 KB + Vt tile 8 KB)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -40,18 +41,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     const f16 *Q = p.q + bh * p.ntp * 64;
     const f16 *K = p.k + bh * p.ntp * 64;
     const f16 *Vt = p.vt + bh * 64 * p.ntp;
-    constexpr float L2E = 1.4426950408889634f;
 
     // ---- Q fragments (B operand of S^T): lane (q = li, half lh) holds Q[q][16*s + 8*lh .. +8] ----
-    int qrow[2];
-    f16x8 qf[2][4];
+    const int qrow = qblk * 128 + wave * 32 + li;
+    const int qrc = qrow < p.ntp ? qrow : p.ntp - 1;
+    f16x8 qf[4];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        qrow[qi] = qblk * 256 + wave * 64 + qi * 32 + li;
-        const int qrc = qrow[qi] < p.ntp ? qrow[qi] : p.ntp - 1;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[qi][s] = *(const f16x8 *)(Q + (int64_t)qrc * 64 + 16 * s + 8 * lh);
-    }
+    for (int s = 0; s < 4; ++s) qf[s] = *(const f16x8 *)(Q + (int64_t)qrc * 64 + 16 * s + 8 * lh);
 
     // ---- staging: each thread moves 2 chunks of K and 2 of Vt per tile ----
     const int srow = tid >> 3;                               // 0..31 (+32 for the second chunk)
@@ -73,14 +69,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     const int kperm = (li & 19) | ((li & 4) << 1) | ((li & 8) >> 1);
     const int fswk = (kperm >> 1) & 7;
 
-    f32x16 oacc[2][2];
+    f32x16 oacc[2];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
+    for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[qi][d][r] = 0.f;
-    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float mrun = -1e30f, lrun = 0.f;
+    constexpr float L2E = 1.4426950408889634f;
 
     const int nt = (p.ntok + 63) >> 6;
     stage(0, 0);
@@ -91,94 +86,80 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
         const char *sK = smem + (t & 1) * 16384;
         const char *sV = sK + 8192;
 
-        f16x8 kf[2][4];
+        // ---- S^T = K Q^T : two 32-key sub-tiles ----
+        f32x16 s[2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                kf[kt][ks] = *(const f16x8 *)(sK + (kt * 32 + kperm) * 128 + (((2 * ks + lh) ^ fswk) * 16));
-
-        f16x8 pf[2][4];
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            // ---- S^T = K Q^T : two 32-key sub-tiles ----
-            f32x16 s[2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[qi][ks], s[kt], 0, 0, 0);
-            // register g of sub-tile kt in lane (q, lh) is key  t*64 + 32*kt + 16*(g>>3) + 8*lh + (g&7)
-            if (t == nt - 1) {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        const int key = t * 64 + 32 * kt + 16 * (g >> 3) + 8 * lh + (g & 7);
-                        if (key >= p.ntok) s[kt][g] = -1e30f;
-                    }
+            for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 kf = *(const f16x8 *)(sK + (kt * 32 + kperm) * 128 + (((2 * ks + lh) ^ fswk) * 16));
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
             }
-            float mx = s[0][0];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) mx = fmaxf(mx, s[kt][g]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            if (__any(mx > mrun[qi])) {                      // wave-uniform: rescale only when a row max grew
-                const float mnew = fmaxf(mrun[qi], mx);
-                const float alpha = exp2f((mrun[qi] - mnew) * L2E);
-                mrun[qi] = mnew;
-                lrun[qi] *= alpha;
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[qi][d][r] *= alpha;
-            }
-            const float ml = mrun[qi] * L2E;
-            float psum = 0.f;
+        }
+        // register g of sub-tile kt in lane (q, lh) is key  t*64 + 32*kt + 16*(g>>3) + 8*lh + (g&7)
+        if (t == nt - 1) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
-                    const float e = exp2f(fmaf(s[kt][g], L2E, -ml));
-                    psum += e;
-                    pf[qi][kt * 2 + (g >> 3)][g & 7] = (f16)e;
+                    const int key = t * 64 + 32 * kt + 16 * (g >> 3) + 8 * lh + (g & 7);
+                    if (key >= p.ntok) s[kt][g] = -1e30f;
                 }
-            lrun[qi] += psum;
         }
+        float mx = s[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, s[kt][g]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__any(mx > mrun)) {                              // wave-uniform: rescale only when a row max grew
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = exp2f((mrun - mnew) * L2E);
+            mrun = mnew;
+            lrun *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
+        const float ml = mrun * L2E;                         // p = 2^(s*log2e - m*log2e): one fma + one v_exp
+        float psum = 0.f;
+        f16x8 pf[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][g], L2E, -ml));
+                psum += e;
+                pf[kt * 2 + (g >> 3)][g & 7] = (f16)e;
+            }
+        lrun += psum;
 
-        // ---- O^T += Vt P^T : 4 k-steps of 16 keys, 2 d-tiles, both q-tiles share each Vt fragment ----
+        // ---- O^T += Vt P^T : 4 k-steps of 16 keys, 2 d-tiles ----
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
                 const f16x8 vf = *(const f16x8 *)(sV + (d * 32 + li) * 128 + (((2 * j + lh) ^ fsw) * 16));
-#pragma unroll
-                for (int qi = 0; qi < 2; ++qi)
-                    oacc[qi][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qi][j], oacc[qi][d], 0, 0, 0);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[j], oacc[d], 0, 0, 0);
             }
     }
 
+    const float ltot = lrun + __shfl_xor(lrun, 32);
+    const float inv = 1.f / ltot;
+    if (qrow < p.ntok) {
+        f16 *orow = p.o + ((int64_t)b * p.ntp + qrow) * p.ldo + head * 64;
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        const float ltot = lrun[qi] + __shfl_xor(lrun[qi], 32);
-        const float inv = 1.f / ltot;
-        if (qrow[qi] < p.ntok) {
-            f16 *orow = p.o + ((int64_t)b * p.ntp + qrow[qi]) * p.ldo + head * 64;
+        for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+            for (int g = 0; g < 4; ++g) {
+                f16x4 r;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f16x4 r;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) r[j] = (f16)(oacc[qi][d][g * 4 + j] * inv);
-                    *(f16x4 *)(orow + d * 32 + 8 * g + 4 * lh) = r;
-                }
-        }
+                for (int j = 0; j < 4; ++j) r[j] = (f16)(oacc[d][g * 4 + j] * inv);
+                *(f16x4 *)(orow + d * 32 + 8 * g + 4 * lh) = r;
+            }
     }
 }
 
@@ -187,8 +168,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
 int launch_attention(hipStream_t stream, const f16 *q, const f16 *k, const f16 *vt, f16 *o, int B, int heads,
                      int ntp, int ntok, int ldo) {
     AttnArgs a{q, k, vt, o, ntp, ntok, heads, ldo};
-    dim3 grid((ntok + 255) / 256, heads, B);
-    hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, stream, a);
+    dim3 grid((ntok + 127) / 128, heads, B);
+    static int variant = -1;
+    if (variant < 0) { const char *e = getenv("PB_ATTN_OCC"); variant = e ? atoi(e) : 2; }
+    if (variant == 3) hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_kernel<2>, grid, dim3(256), 0, stream, a);
     PB_HIP(hipGetLastError());
     return 0;
 }
