@@ -183,9 +183,48 @@ def encode_case():
     print("[encode] oracle == reference (bit exact)")
 
 
+def raft_case(hgt=125, wid=157, seed=21, iters=12):
+    """Reference RAFT (bands/raft/raft.py) + InputPadder (bands/common/flow.py) on a seeded frame pair,
+    fwd and bwd in one batch exactly like bands/flow_raft.py:105-107 (scale = 1: cv2 is absent here)."""
+    import argparse
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    from raft.raft import RAFT
+    from common.flow import InputPadder
+    from oracle import raft_oracle as R
+    w = synth.raft_weights(seed=4321)
+    m = RAFT(argparse.Namespace()).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
+    fr = synth.frame_pair_sequence(2, hgt, wid, seed=seed)
+    a = torch.from_numpy(fr[0]).permute(2, 0, 1).float()[None]
+    c = torch.from_numpy(fr[1]).permute(2, 0, 1).float()[None]
+    i1, i2 = torch.cat([a, c], 0), torch.cat([c, a], 0)
+    padder = InputPadder(i1.shape)
+    p1, p2 = padder.pad(i1, i2)
+    assert list(padder._pad) == R.pad_amounts(hgt, wid)
+    with torch.no_grad():
+        lo, up = m(p1, p2, iters=iters, test_mode=True)
+        fwd = padder.unpad(up[0]).permute(1, 2, 0).numpy()
+        bwd = padder.unpad(up[1]).permute(1, 2, 0).numpy()
+    lo_o, up_o, st = R.raft_forward(w, p1.numpy(), p2.numpy(), iters, return_stages=True)
+    f_o, b_o = R.infer_pair(w, fr[0], fr[1], scale=1.0, iters=iters)
+    e = max(relerr(lo_o, lo.numpy()), relerr(up_o, up.numpy()), relerr(f_o, fwd), relerr(b_o, bwd))
+    print(f"[raft {hgt}x{wid} pad {padder._pad}] oracle vs reference rel err {e:.2e}; |flow| max {np.abs(fwd).max():.2f} px, "
+          f"mean fwd {fwd.reshape(-1, 2).mean(0)}")
+    assert e < 2e-4, e
+    sys.path.insert(0, os.path.join(REF, "bands"))
+    from common import encode as E
+    rgb, mx = E.process_flow(fwd.copy())
+    rgb_o, mx_o = R.process_flow(fwd)
+    assert np.array_equal(rgb, rgb_o) and mx == mx_o
+    np.savez_compressed(os.path.join(GOLD, f"raft_{hgt}x{wid}.npz"), frame_seed=np.array(seed), hw=np.array([hgt, wid]),
+                        iters=np.array(iters), flow_lo=lo.numpy(), fwd=fwd, bwd=bwd, fwd_rgb=rgb, fwd_max=np.array(mx),
+                        fmap1=st["fmap1"][:, ::4].copy(), net0=st["net0"][:, ::4].copy(), corr0=st["corr0"][:, ::3].copy(),
+                        flow_it0=st["flow_it0"])
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full"]
+    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full", "raft"]
     if "encode" in which:
         encode_case()
     if "vits" in which:
@@ -194,3 +233,5 @@ if __name__ == "__main__":
         small_case("vitl_d4", 90, 120, 12)
     if "full" in which:
         full_case()
+    if "raft" in which:
+        raft_case()

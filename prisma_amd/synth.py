@@ -173,3 +173,114 @@ def frames(n: int, height: int, width: int, seed: int = 0) -> np.ndarray:
         noise = g.integers(0, 64, (height, width, 3), dtype=np.int32)
         out[i] = np.clip(img * 191.0 + noise, 0, 255).astype(np.uint8)
     return out
+
+
+# ----------------------------------------------------------------------------
+# RAFT (basic, hdim = cdim = 128, 4 levels, radius 4): /root/reference/bands/raft/raft.py:24-58,
+# extractor.py:118-192, update.py:79-136.  Checkpoint naming without the `module.` prefix that
+# bands/flow_raft.py:42-44 strips.
+# ----------------------------------------------------------------------------
+def raft_param_shapes() -> List[Tuple[str, Tuple[int, ...]]]:
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def conv(name, co, ci, kh, kw):
+        out.append((name + ".weight", (co, ci, kh, kw)))
+        out.append((name + ".bias", (co,)))
+
+    def bn(name, c):
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            out.append((f"{name}.{s}", (c,)))
+        out.append((name + ".num_batches_tracked", ()))
+
+    for enc, has_bn in (("fnet", False), ("cnet", True)):
+        if has_bn:
+            bn(enc + ".norm1", 64)
+        conv(enc + ".conv1", 64, 3, 7, 7)
+        cin = 64
+        for li, (dim, stride) in enumerate(((64, 1), (96, 2), (128, 2)), start=1):
+            for bi in range(2):
+                p = f"{enc}.layer{li}.{bi}"
+                ci = cin if bi == 0 else dim
+                conv(p + ".conv1", dim, ci, 3, 3)
+                conv(p + ".conv2", dim, dim, 3, 3)
+                if has_bn:
+                    bn(p + ".norm1", dim)
+                    bn(p + ".norm2", dim)
+                    if bi == 0 and stride != 1:
+                        bn(p + ".norm3", dim)
+                if bi == 0 and stride != 1:
+                    conv(p + ".downsample.0", dim, ci, 1, 1)
+                    if has_bn:
+                        bn(p + ".downsample.1", dim)
+            cin = dim
+        conv(enc + ".conv2", 256, 128, 1, 1)
+    u = "update_block."
+    conv(u + "encoder.convc1", 256, 324, 1, 1)
+    conv(u + "encoder.convc2", 192, 256, 3, 3)
+    conv(u + "encoder.convf1", 128, 2, 7, 7)
+    conv(u + "encoder.convf2", 64, 128, 3, 3)
+    conv(u + "encoder.conv", 126, 256, 3, 3)
+    for g in ("z", "r", "q"):
+        conv(u + f"gru.conv{g}1", 128, 384, 1, 5)
+        conv(u + f"gru.conv{g}2", 128, 384, 5, 1)
+    conv(u + "flow_head.conv1", 256, 128, 3, 3)
+    conv(u + "flow_head.conv2", 2, 256, 3, 3)
+    conv(u + "mask.0", 256, 128, 3, 3)
+    conv(u + "mask.2", 576, 256, 1, 1)
+    return out
+
+
+def raft_weights(seed: int = 4321) -> Dict[str, np.ndarray]:
+    """name -> ndarray (float32; int64 scalar for num_batches_tracked), reference state_dict naming.
+
+    `layerN.0.norm3.*` and `layerN.0.downsample.1.*` are the same module in the reference
+    (extractor.py:32-44), so they get identical tensors.
+    """
+    w: Dict[str, np.ndarray] = {}
+    for name, shape in raft_param_shapes():
+        key = name.replace(".downsample.1.", ".norm3.")
+        g = _rng(seed, key)
+        if name.endswith("num_batches_tracked"):
+            w[name] = np.array(1, np.int64)
+        elif name.endswith("running_var"):
+            w[name] = (0.5 + g.random(shape, dtype=np.float32)).astype(np.float32)
+        elif name.endswith("running_mean"):
+            w[name] = (g.standard_normal(shape, dtype=np.float32) * np.float32(0.1))
+        elif len(shape) == 1 and (".norm" in name or ".downsample.1." in name):
+            if name.endswith("weight"):
+                w[name] = (1.0 + 0.1 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+            else:
+                w[name] = (0.1 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        elif name.endswith("bias"):
+            w[name] = (0.05 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+            gain = 1.4                                   # ~He init keeps ReLU stacks at unit scale
+            if "flow_head.conv2" in name:
+                gain = 0.2                               # ~1 px (1/8 res) updates per iteration: contractive recurrence
+            elif ".gru." in name or "mask.2" in name or name.endswith("conv2.weight") and name.count(".") == 2:
+                gain = 1.0
+            w[name] = (g.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(fan_in)))
+    return w
+
+
+def frame_pair_sequence(n: int, height: int, width: int, seed: int = 0, shift: Tuple[float, float] = (2.5, -1.5)) -> np.ndarray:
+    """n frames of a smooth seeded texture translated by `shift` pixels per frame (dx, dy): flow is non-degenerate."""
+    g = np.random.default_rng([seed, 0xF10])
+    H, W = height + 64, width + 64
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    tex = np.zeros((H, W, 3), np.float32)
+    for _ in range(24):
+        fx, fy = g.uniform(0.01, 0.25, 2)
+        ph, amp = g.uniform(0, 2 * np.pi, 3), g.uniform(0.2, 1.0, 3)
+        for c in range(3):
+            tex[..., c] += amp[c] * np.sin(fx * xx + fy * yy * (1 if c != 1 else -1) + ph[c])
+    tex = (tex - tex.min()) / (tex.max() - tex.min())
+    out = np.empty((n, height, width, 3), np.uint8)
+    from scipy.ndimage import map_coordinates
+    for i in range(n):
+        ys = yy[:height, :width] + 32 + shift[1] * i
+        xs = xx[:height, :width] + 32 + shift[0] * i
+        for c in range(3):
+            out[i, ..., c] = np.clip(map_coordinates(tex[..., c], [ys, xs], order=1) * 255.0, 0, 255).astype(np.uint8)
+    return out
