@@ -92,6 +92,25 @@ int pb_sync(pb_ctx *ctx);
  * multiple of 14 (bands/d_anything/util/transform.py:100-166). */
 int pb_depth_net_size(int H, int W, int *net_h, int *net_w);
 
+/* flow_raft band (band = "flow_raft", cfg = NULL; weights: fnet.*, cnet.*, update_block.*).
+ * Replaces bands/flow_raft.py:98-113 (frame loop: cv2.resize(fx=fy=scale, INTER_CUBIC), [prev,curr] /
+ * [curr,prev] batch), :51-62 infer (InputPadder, RAFT(iters, test_mode=True), unpad) and
+ * bands/common/flow.py:64-88 write_flow -> encode.py:98-126 process_flow.
+ *   frames     : F x H x W x 3 uint8 RGB, consecutive frames of one clip (F >= 2)
+ *   outputs    : for pair i = (frame i, frame i+1) and direction d (0 = forward i -> i+1, 1 = backward when
+ *                `backward` != 0), index i*dirs + d:
+ *     flow_out   [F-1, dirs, sh, sw, 2] float32 (u, v) pixels at the scaled resolution, or NULL
+ *     rgb_out    [F-1, dirs, sh, sw, 3] uint8 process_flow encoding, or NULL
+ *     maxdisp_out[F-1, dirs] float32 max displacement (the band's CSV value), or NULL
+ *   (sh, sw) = pb_flow_out_size(H, W, scale). */
+int pb_flow_out_size(int H, int W, float scale, int *sh, int *sw);
+int pb_flow_infer_sequence(pb_ctx *ctx, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
+                           float *flow_out, uint8_t *rgb_out, float *maxdisp_out);
+int pb_flow_infer_sequence_dev(pb_ctx *ctx, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
+                               float *flow_out, uint8_t *rgb_out, float *maxdisp_out);
+/* Stages of the last flow call: "fmap" [F,256,h/8,w/8], "flow_lo" [pairs*dirs, h/8*w/8, 2]. */
+int64_t pb_flow_get_stage(pb_ctx *ctx, const char *name, float *out, int64_t cap, int64_t shape_out[4]);
+
 /* Debug/parity: copy a named intermediate of the last pb_depth_infer_batch* call to the host
  * as float32 in the reference's layout ([n, C, h, w] for maps, [n, tokens, D] for tokens).
  * Names: "tokens", "block<i>", "feat<i>", "layer<i>_rn", "path<i>", "output_conv1", "net_depth".

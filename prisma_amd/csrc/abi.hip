@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "raft_engine.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -21,6 +22,7 @@ void pb_set_error(const char *fmt, ...) {
 struct pb_ctx {
     int device = 0;
     DepthEngine *depth = nullptr;
+    RaftEngine *raft = nullptr;
     hipStream_t stream = nullptr;   // == depth->stream when a band is loaded
     f16 *zero = nullptr;
     bool own_stream = false;
@@ -80,6 +82,20 @@ int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *we
         }
         c->stream = c->depth->stream;
         c->zero = (f16 *)c->depth->zero_page();
+    } else if (!strcmp(band, "flow_raft")) {
+        if (!weights || n_weights <= 0) {
+            delete c;
+            PB_CHECK(false, PB_ERR_ARG, "flow_raft: needs weights");
+        }
+        c->raft = new RaftEngine(device_id);
+        int r = c->raft->load(weights, n_weights);
+        if (r) {
+            delete c->raft;
+            delete c;
+            return r;
+        }
+        c->stream = c->raft->stream;
+        c->zero = (f16 *)c->raft->zero_page();
     } else if (!strcmp(band, "ops")) {
         // kernel-level context for the parity tests: a stream and a zero page, no model
         hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -95,7 +111,7 @@ int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *we
         c->own_stream = true;
     } else {
         delete c;
-        PB_CHECK(false, PB_ERR_ARG, "unknown band '%s' (depth_anything | ops)", band);
+        PB_CHECK(false, PB_ERR_ARG, "unknown band '%s' (depth_anything | flow_raft | ops)", band);
     }
     *out = c;
     return 0;
@@ -105,6 +121,7 @@ void pb_destroy(pb_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->depth) delete c->depth;
+    if (c->raft) delete c->raft;
     if (c->own_stream) {
         hipStreamSynchronize(c->stream);
         hipFree(c->zero);
@@ -154,15 +171,56 @@ int64_t pb_depth_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap,
 }
 
 int pb_set_profiling(pb_ctx *c, int enabled) {
-    PB_CHECK(c && c->depth, PB_ERR_STATE, "ctx has no band");
-    c->depth->timer.enabled = enabled != 0;
-    c->depth->debug = (enabled & 2) != 0;
+    PB_CHECK(c && (c->depth || c->raft), PB_ERR_STATE, "ctx has no band");
+    if (c->depth) { c->depth->timer.enabled = enabled != 0; c->depth->debug = (enabled & 2) != 0; }
+    if (c->raft) { c->raft->timer.enabled = enabled != 0; c->raft->debug = (enabled & 2) != 0; }
     return 0;
+}
+
+int pb_flow_out_size(int H, int W, float scale, int *sh, int *sw) {
+    PB_CHECK(H > 0 && W > 0 && scale > 0.f && sh && sw, PB_ERR_ARG, "flow_out_size: bad arguments");
+    RaftEngine::out_size(H, W, scale, sh, sw);
+    return 0;
+}
+
+int pb_flow_infer_sequence_dev(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
+                               float *flow_out, uint8_t *rgb_out, float *maxdisp_out) {
+    PB_CHECK(c && c->raft, PB_ERR_STATE, "ctx has no flow_raft band");
+    return c->raft->infer(frames, F, H, W, scale, iters, backward, flow_out, rgb_out, maxdisp_out);
+}
+
+int pb_flow_infer_sequence(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
+                           float *flow_out, uint8_t *rgb_out, float *maxdisp_out) {
+    PB_CHECK(c && c->raft, PB_ERR_STATE, "ctx has no flow_raft band");
+    PB_CHECK(frames && F >= 2 && H > 0 && W > 0, PB_ERR_ARG, "flow infer: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    int sh, sw;
+    RaftEngine::out_size(H, W, scale, &sh, &sw);
+    const size_t nd = (size_t)(F - 1) * (backward ? 2 : 1), px = (size_t)sh * sw;
+    DevMem dF, dO, dR, dM;
+    PB_TRY(dF.alloc((size_t)F * H * W * 3));
+    if (flow_out) PB_TRY(dO.alloc(nd * px * 8));
+    if (rgb_out) PB_TRY(dR.alloc(nd * px * 3));
+    PB_TRY(dM.alloc(nd * 4));
+    PB_HIP(hipMemcpy(dF.p, frames, (size_t)F * H * W * 3, hipMemcpyHostToDevice));
+    PB_TRY(c->raft->infer(dF.as<uint8_t>(), F, H, W, scale, iters, backward, dO.as<float>(), dR.as<uint8_t>(), dM.as<float>()));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    if (flow_out) PB_HIP(hipMemcpy(flow_out, dO.p, nd * px * 8, hipMemcpyDeviceToHost));
+    if (rgb_out) PB_HIP(hipMemcpy(rgb_out, dR.p, nd * px * 3, hipMemcpyDeviceToHost));
+    if (maxdisp_out) PB_HIP(hipMemcpy(maxdisp_out, dM.p, nd * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int64_t pb_flow_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap, int64_t shape_out[4]) {
+    PB_CHECK(c && c->raft && name && out && shape_out, PB_ERR_ARG, "flow get_stage: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    return c->raft->get_stage(name, out, cap, shape_out);
 }
 
 int pb_set_option(pb_ctx *c, const char *key, int value) {
     PB_CHECK(c && key, PB_ERR_ARG, "set_option: bad arguments");
-    int *g = c->depth ? &c->depth->gemm_tile : &c->gemm_tile, *v = c->depth ? &c->depth->conv_tile : &c->conv_tile;
+    int *g = c->depth ? &c->depth->gemm_tile : &c->gemm_tile;
+    int *v = c->depth ? &c->depth->conv_tile : (c->raft ? &c->raft->conv_tile : &c->conv_tile);
     if (!strcmp(key, "gemm_tile")) *g = value;
     else if (!strcmp(key, "conv_tile")) *v = value;
     else PB_CHECK(false, PB_ERR_ARG, "unknown option '%s'", key);
@@ -170,8 +228,8 @@ int pb_set_option(pb_ctx *c, const char *key, int value) {
 }
 
 int pb_get_kernel_stats(pb_ctx *c, pb_kernel_stat *out, int cap) {
-    PB_CHECK(c && c->depth && out, PB_ERR_STATE, "ctx has no band");
-    return c->depth->stats(out, cap);
+    PB_CHECK(c && (c->depth || c->raft) && out, PB_ERR_STATE, "ctx has no band");
+    return c->depth ? c->depth->stats(out, cap) : c->raft->stats(out, cap);
 }
 
 int pb_dev_alloc(pb_ctx *c, void **ptr, size_t bytes) {

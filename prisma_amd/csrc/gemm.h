@@ -3,8 +3,8 @@
 #include "common.h"
 
 enum { A_DENSE = 0, A_CONV = 1 };
-enum { EPI_STD = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_PIXSHUF = 3, EPI_PATCH = 4, EPI_HEAD = 5 };
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum { EPI_STD = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_PIXSHUF = 3, EPI_PATCH = 4, EPI_HEAD = 5, EPI_F32 = 6 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
 enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256_SIMPLE = 4 };
 
 struct GemmArgs {
@@ -14,7 +14,9 @@ struct GemmArgs {
     const f16 *W = nullptr;
     int K = 0, M = 0, N = 0;              // N = columns actually written (multiple of 8)
     // implicit-GEMM convolution: input [B, cH, cW, cC] (cC % 64 == 0), K = KH*KW*cC, rows = (b, oy, ox)
-    int cH = 0, cW = 0, cC = 0, cOH = 0, cOW = 0, cKW = 1, cStride = 1, cPad = 0;
+    // kernel KH x cKW (tap = ky * cKW + kx), padding (cPadY, cPadX); cLd = pixel stride in elements (0 = cC), so a
+    // channel slice [0, cC) of a wider NHWC buffer can be convolved in place
+    int cH = 0, cW = 0, cC = 0, cOH = 0, cOW = 0, cKW = 1, cStride = 1, cPad = 0, cPadX = -1, cLd = 0;
     const f16 *zero = nullptr;            // >= 16 bytes of zeros: source of padded taps / rows >= M
     // epilogue
     const float *bias = nullptr;          // [N]
@@ -24,6 +26,9 @@ struct GemmArgs {
     const f16 *add1 = nullptr, *add2 = nullptr;   // v += add[m*ldo + n]
     int64_t ldo = 0;
     int act = ACT_NONE;
+    int pre_relu = 0;                     // EPI_STD: v = relu(acc + bias) before the skip adds
+    float *out32 = nullptr;               // EPI_F32: out32[m*ldo + n] = (acc + bias) * scale
+    float scale = 1.f;
     float *resid = nullptr;               // fp32 residual stream [rows, ldr]
     int64_t ldr = 0;
     // EPI_QKV: Q,K -> [b, head, ntp, 64]; V -> [b, head, 64, ntp] (transposed); q scaled by qscale

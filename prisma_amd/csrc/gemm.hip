@@ -95,6 +95,10 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
         const int64_t o = (int64_t)m * p.ldo + n;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += cb[j];
+        if (p.pre_relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
         if (p.add1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += (float)x.a1[j];
@@ -111,6 +115,12 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
             } else if (p.act == ACT_RELU) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) r[j] = (f16)fmaxf(v[j], 0.f);
+            } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (f16)(1.f / (1.f + __expf(-v[j])));
+            } else if (p.act == ACT_TANH) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (f16)tanhf(v[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) r[j] = (f16)v[j];
@@ -123,6 +133,16 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
             for (int j = 0; j < 8; ++j) r[j] = (f16)fmaxf(v[j], 0.f);
             *(f16x8 *)(p.out2 + o) = r;
         }
+    } else if constexpr (EPI == EPI_F32) {
+        float *r = p.out32 + (int64_t)m * p.ldo + n;
+        f32x4 r0, r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r0[j] = (v[j] + cb[j]) * p.scale;
+            r1[j] = (v[4 + j] + cb[4 + j]) * p.scale;
+        }
+        *(f32x4 *)r = r0;
+        *(f32x4 *)(r + 4) = r1;
     } else if constexpr (EPI == EPI_RESID) {
         float *r = p.resid + (int64_t)m * p.ldr + n;
         f32x4 r0 = x.r0, r1 = x.r1;
@@ -293,6 +313,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-thread staging addresses ----
+    const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
     const int srow = tid >> 3;                              // + i * (NT/8)
     const int cg = (tid & 7) ^ ((tid >> 4) & 7);            // swizzled global chunk for this LDS slot
     const f16 *a_ptr[NA];
@@ -311,9 +332,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             const int b = m / ohw, rem = m - b * ohw;
             const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
             a_ok[i] = m < p.M;
-            a_ptr[i] = p.A + (int64_t)b * p.cH * p.cW * p.cC + cg * 8;
+            a_ptr[i] = p.A + (int64_t)b * p.cH * p.cW * cld + cg * 8;
             a_iy0[i] = oy * p.cStride - p.cPad;
-            a_ix0[i] = ox * p.cStride - p.cPad;
+            a_ix0[i] = ox * p.cStride - padx;
         }
     }
     const f16 *b_ptr[NB];
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             } else {
                 const int iy = a_iy0[i] + c_ky, ix = a_ix0[i] + c_kx;
                 const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
-                src = ok ? a_ptr[i] + ((iy * p.cW + ix) * p.cC + c_c0) : p.zero;
+                src = ok ? a_ptr[i] + ((iy * p.cW + ix) * cld + c_c0) : p.zero;
             }
             glds16(src, sA + i * (NT * 16));
         }
@@ -459,6 +480,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 
     // ---- staging geometry: half tile h in {A_0, A_1, B_0, B_1}, two DMAs (u = 0, 1) per thread ----
     // DMA (wave, u) covers the 8 LDS rows starting at row0; lane -> row0 + (lane >> 3), chunk lane & 7.
+    const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
     const int lrow = lane >> 3;
     int a_row0[2][2], b_row0[2][2];                  // [half][u], tile-local row of the DMA's first row
 #pragma unroll
@@ -493,9 +515,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 const int b = m / ohw, rem = m - b * ohw;
                 const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
                 a_ok[hf][u] = m < p.M;
-                a_ptr[hf][u] = p.A + (int64_t)b * p.cH * p.cW * p.cC + cgu[u] * 8;
+                a_ptr[hf][u] = p.A + (int64_t)b * p.cH * p.cW * cld + cgu[u] * 8;
                 a_iy0[hf][u] = oy * p.cStride - p.cPad;
-                a_ix0[hf][u] = ox * p.cStride - p.cPad;
+                a_ix0[hf][u] = ox * p.cStride - padx;
             }
             b_ptr[hf][u] = p.W + (int64_t)(n0 + b_row0[hf][u] + lrow) * p.K + cgu[u] * 8;
         }
@@ -519,7 +541,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             } else {
                 const int iy = a_iy0[hf][u] + ky, ix = a_ix0[hf][u] + kx;
                 const bool ok = a_ok[hf][u] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
-                src = ok ? a_ptr[hf][u] + ((iy * p.cW + ix) * p.cC + c0) : p.zero;
+                src = ok ? a_ptr[hf][u] + ((iy * p.cW + ix) * cld + c0) : p.zero;
             }
             const int g = wave * 2 + u;
             glds16(src, base + ((g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8) * 128);
@@ -692,7 +714,7 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
 int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a) {
     PB_CHECK(a.K > 0 && a.K % 64 == 0, -1, "gemm: K=%d must be a positive multiple of 64", a.K);
     PB_CHECK(a.M > 0 && a.N > 0 && a.N % 8 == 0, -1, "gemm: bad M=%d N=%d", a.M, a.N);
-    if (amode == A_CONV) PB_CHECK(a.cC % 64 == 0 && a.zero, -1, "conv: channel stride %d must be a multiple of 64", a.cC);
+    if (amode == A_CONV) PB_CHECK(a.cC % 64 == 0 && a.cLd % 8 == 0 && a.zero, -1, "conv: channels %d (x64) / pixel stride %d (x8)", a.cC, a.cLd);
     if (tile == TILE_AUTO) {
         // 256x256 needs wide N and enough tiles to fill 256 CUs; the q/k/v split needs D % BN == 0
         const bool wide = a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256;
@@ -713,6 +735,8 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
     PB_CASE(A_DENSE, EPI_PATCH);
     PB_CASE(A_CONV, EPI_STD);
     PB_CASE(A_CONV, EPI_HEAD);
+    PB_CASE(A_CONV, EPI_F32);
+    PB_CASE(A_DENSE, EPI_F32);
 #undef PB_CASE
     PB_CHECK(false, -1, "gemm: unsupported amode/epilogue %d/%d", amode, epi);
 }

@@ -1,0 +1,551 @@
+// RaftEngine: the flow_raft band on one MI355X.
+// Reference call stack being replaced: bands/flow_raft.py:98-113 (per-frame loop: resize, [prev,curr] /
+// [curr,prev] batch, infer) -> :51-62 (pad, RAFT(test_mode), unpad) -> bands/raft/raft.py:87-146 ->
+// extractor.py / corr.py / update.py -> bands/common/flow.py:64-88 + encode.py:98-126 (process_flow).
+//
+// Differences in schedule, not in arithmetic:
+//   * every frame goes through fnet and cnet ONCE per sequence (the reference re-encodes both frames of
+//     every pair, twice when it also computes the backward flow);
+//   * the mask head (152.9 of 1559.6 GFLOP per pair at 720p) runs only after the last iteration - in
+//     test_mode the reference computes it every iteration and discards all but the last (raft.py:136-144);
+//   * cnet's eval-mode BatchNorm is folded into its convolutions at pack time; fnet's InstanceNorm uses
+//     run-time statistics and stays a separate pass.
+#include "raft_engine.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace {
+enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_COUNT = 6 };
+const char *kFamR[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost"};
+inline int cp64(int c) { return (int)round_up(c, 64); }
+
+void cubic_taps_u8(int src, int dst, double scale, std::vector<int> &idx, std::vector<int> &co) {
+    // OpenCV 8-bit INTER_CUBIC: float32 coefficients (A = -0.75) -> saturate_cast<short>(c * 2048)
+    idx.resize((size_t)dst * 4);
+    co.resize((size_t)dst * 4);
+    const double inv = 1.0 / scale;
+    const float A = -0.75f;
+    for (int d = 0; d < dst; ++d) {
+        float fx = (float)((d + 0.5) * inv - 0.5);
+        const int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        float c[4];
+        c[0] = ((A * (fx + 1.f) - 5.f * A) * (fx + 1.f) + 8.f * A) * (fx + 1.f) - 4.f * A;
+        c[1] = ((A + 2.f) * fx - (A + 3.f)) * fx * fx + 1.f;
+        c[2] = ((A + 2.f) * (1.f - fx) - (A + 3.f)) * (1.f - fx) * (1.f - fx) + 1.f;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+        for (int t = 0; t < 4; ++t) {
+            idx[(size_t)d * 4 + t] = std::min(std::max(sx - 1 + t, 0), src - 1);
+            co[(size_t)d * 4 + t] = (int)nearbyint((double)c[t] * 2048.0);
+        }
+    }
+}
+}  // namespace
+
+void RaftEngine::out_size(int H, int W, float scale, int *sh, int *sw) {
+    *sh = (int)nearbyint((double)H * scale);
+    *sw = (int)nearbyint((double)W * scale);
+}
+
+void RaftEngine::tic(int fam, double flops, double bytes) {
+    if (!timer.enabled) return;
+    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes};
+    hipEventRecord(r.a, stream);
+    timer.recs.push_back(r);
+}
+void RaftEngine::toc() {
+    if (!timer.enabled) return;
+    hipEventRecord(timer.recs.back().b, stream);
+}
+int RaftEngine::stats(pb_kernel_stat *out, int cap) {
+    if (hipStreamSynchronize(stream) != hipSuccess) return -2;
+    pb_kernel_stat acc[F_COUNT];
+    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFamR[i], 0, 0, 0, 0};
+    for (auto &r : timer.recs) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        acc[r.fam].ms += ms; acc[r.fam].flops += r.flops; acc[r.fam].bytes += r.bytes; acc[r.fam].launches++;
+    }
+    int n = 0;
+    for (int i = 0; i < F_COUNT && n < cap; ++i)
+        if (acc[i].launches) out[n++] = acc[i];
+    return n;
+}
+
+RaftEngine::~RaftEngine() {
+    hipSetDevice(device);
+    if (stream) hipStreamSynchronize(stream);
+    for (auto p : owned_) hipFree(p);
+    if (arena_) hipFree(arena_);
+    if (stream) hipStreamDestroy(stream);
+}
+
+int RaftEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias) {
+    const int64_t Np = round_up(N, 256);
+    std::vector<f16> h((size_t)Np * Kpad, (f16)0.f);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) h[(size_t)n * Kpad + k] = (f16)src[(size_t)n * K + k];
+    void *p = nullptr;
+    PB_HIP(hipMalloc(&p, h.size() * 2));
+    owned_.push_back(p);
+    PB_HIP(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    out.w = (f16 *)p; out.N = N; out.K = Kpad; out.Kreal = K; out.bias = nullptr;
+    if (bias) {
+        void *b = nullptr;
+        PB_HIP(hipMalloc(&b, std::max<size_t>((size_t)Np * 4, 256)));
+        owned_.push_back(b);
+        PB_HIP(hipMemset(b, 0, (size_t)Np * 4));
+        PB_HIP(hipMemcpy(b, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        out.bias = (float *)b;
+    }
+    return 0;
+}
+
+int RaftEngine::fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift) {
+    const char *sfx[4] = {".weight", ".bias", ".running_mean", ".running_var"};
+    const float *t[4];
+    for (int i = 0; i < 4; ++i) {
+        auto it = tmap_.find(bn + sfx[i]);
+        PB_CHECK(it != tmap_.end(), PB_ERR_ARG, "missing weight '%s%s'", bn.c_str(), sfx[i]);
+        t[i] = (const float *)it->second->data;
+    }
+    scale.resize(C); shift.resize(C);
+    for (int c = 0; c < C; ++c) {
+        const float s = t[0][c] / sqrtf(t[3][c] + 1e-5f);       // nn.BatchNorm2d eval, eps 1e-5 (extractor.py:24-28)
+        scale[c] = s;
+        shift[c] = t[1][c] - t[2][c] * s;
+    }
+    return 0;
+}
+
+// conv weight [co, ci, kh, kw] (+ bias) -> [co, (ky*kw + kx) * cp64(ci) + c], optional per-output affine (folded BN)
+int RaftEngine::pack_conv(const std::string &name, const float *scale, const float *shift, PackedW &out) {
+    auto iw = tmap_.find(name + ".weight"), ib = tmap_.find(name + ".bias");
+    PB_CHECK(iw != tmap_.end() && ib != tmap_.end() && iw->second->ndim == 4, PB_ERR_ARG, "missing conv '%s'", name.c_str());
+    const pb_tensor *t = iw->second;
+    const int co = (int)t->shape[0], ci = (int)t->shape[1], kh = (int)t->shape[2], kw = (int)t->shape[3];
+    const float *w = (const float *)t->data, *b = (const float *)ib->second->data;
+    const int cip = cp64(ci), K = kh * kw * cip;
+    std::vector<float> g((size_t)co * K, 0.f), bb(co);
+    for (int o = 0; o < co; ++o) {
+        const float s = scale ? scale[o] : 1.f;
+        for (int c = 0; c < ci; ++c)
+            for (int tp = 0; tp < kh * kw; ++tp) g[(size_t)o * K + tp * cip + c] = w[((size_t)o * ci + c) * kh * kw + tp] * s;
+        bb[o] = b[o] * s + (shift ? shift[o] : 0.f);
+    }
+    int r = pack(g.data(), co, K, K, out, bb.data());
+    out.Kreal = kh * kw * ci;
+    return r;
+}
+
+int RaftEngine::load(const pb_tensor *w, int n) {
+    PB_HIP(hipSetDevice(device));
+    PB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (int i = 0; i < n; ++i) {
+        PB_CHECK(w[i].data && w[i].name, PB_ERR_ARG, "weight %d: null", i);
+        if (w[i].dtype == PB_F32) tmap_[w[i].name] = &w[i];      // num_batches_tracked (int64) is not needed
+    }
+    {
+        void *z = nullptr;
+        PB_HIP(hipMalloc(&z, 4096));
+        PB_HIP(hipMemset(z, 0, 4096));
+        owned_.push_back(z);
+        zero_ = (f16 *)z;
+    }
+    int r;
+    const int dims[3] = {64, 96, 128};
+    for (int e = 0; e < 2; ++e) {
+        const std::string en = e == 0 ? "fnet" : "cnet";
+        Enc &E = e == 0 ? fnet_ : cnet_;
+        const bool bnf = e == 1;
+        std::vector<float> sc, sf;
+        {   // stem 7x7/s2: im2col order k = tap*3 + c, K 147 -> 192
+            auto iw = tmap_.find(en + ".conv1.weight"), ib = tmap_.find(en + ".conv1.bias");
+            PB_CHECK(iw != tmap_.end() && ib != tmap_.end(), PB_ERR_ARG, "missing %s.conv1", en.c_str());
+            if (bnf && (r = fold_bn(en + ".norm1", 64, sc, sf))) return r;
+            const float *wt = (const float *)iw->second->data, *bs = (const float *)ib->second->data;
+            std::vector<float> g((size_t)64 * 147), bb(64);
+            for (int o = 0; o < 64; ++o) {
+                const float s = bnf ? sc[o] : 1.f;
+                for (int c = 0; c < 3; ++c)
+                    for (int tp = 0; tp < 49; ++tp) g[(size_t)o * 147 + tp * 3 + c] = wt[((size_t)o * 3 + c) * 49 + tp] * s;
+                bb[o] = bs[o] * s + (bnf ? sf[o] : 0.f);
+            }
+            if ((r = pack(g.data(), 64, 147, 192, E.stem, bb.data()))) return r;
+        }
+        for (int li = 0; li < 3; ++li)
+            for (int bi = 0; bi < 2; ++bi) {
+                const std::string p = en + ".layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+                for (int c = 0; c < 2; ++c) {
+                    if (bnf && (r = fold_bn(p + ".norm" + std::to_string(c + 1), dims[li], sc, sf))) return r;
+                    if ((r = pack_conv(p + ".conv" + std::to_string(c + 1), bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr,
+                                       E.l[li][bi][c])))
+                        return r;
+                }
+                if (bi == 0 && li > 0) {
+                    if (bnf && (r = fold_bn(p + ".norm3", dims[li], sc, sf))) return r;
+                    if ((r = pack_conv(p + ".downsample.0", bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr, E.ds[li]))) return r;
+                }
+            }
+        if ((r = pack_conv(en + ".conv2", nullptr, nullptr, E.out))) return r;
+    }
+    const std::string u = "update_block.";
+    if ((r = pack_conv(u + "encoder.convc1", nullptr, nullptr, convc1_))) return r;
+    if ((r = pack_conv(u + "encoder.convc2", nullptr, nullptr, convc2_))) return r;
+    if ((r = pack_conv(u + "encoder.convf2", nullptr, nullptr, convf2_))) return r;
+    if ((r = pack_conv(u + "encoder.conv", nullptr, nullptr, convm_))) return r;
+    convm_.N = 128;                                         // 126 real outputs + 2 zero rows (N must be a multiple of 8)
+    {   // convf1 7x7 on the 2-channel flow: im2col order k = tap*2 + c, K 98 -> 128
+        auto iw = tmap_.find(u + "encoder.convf1.weight"), ib = tmap_.find(u + "encoder.convf1.bias");
+        PB_CHECK(iw != tmap_.end() && ib != tmap_.end(), PB_ERR_ARG, "missing convf1");
+        const float *wt = (const float *)iw->second->data;
+        std::vector<float> g((size_t)128 * 98);
+        for (int o = 0; o < 128; ++o)
+            for (int c = 0; c < 2; ++c)
+                for (int tp = 0; tp < 49; ++tp) g[(size_t)o * 98 + tp * 2 + c] = wt[((size_t)o * 2 + c) * 49 + tp];
+        if ((r = pack(g.data(), 128, 98, 128, convf1_, (const float *)ib->second->data))) return r;
+    }
+    for (int half = 0; half < 2; ++half) {
+        // z and r gates share their input: one GEMM with N = 256 ([z | r]); q separately
+        const std::string sfx = std::to_string(half + 1);
+        auto get = [&](const std::string &nm) -> const pb_tensor * {
+            auto it = tmap_.find(nm);
+            return it == tmap_.end() ? nullptr : it->second;
+        };
+        const pb_tensor *wz = get(u + "gru.convz" + sfx + ".weight"), *wr = get(u + "gru.convr" + sfx + ".weight");
+        const pb_tensor *bz = get(u + "gru.convz" + sfx + ".bias"), *br = get(u + "gru.convr" + sfx + ".bias");
+        PB_CHECK(wz && wr && bz && br, PB_ERR_ARG, "missing gru z/r weights");
+        const int K = 5 * 384;
+        std::vector<float> g((size_t)256 * K, 0.f), bb(256);
+        for (int part = 0; part < 2; ++part) {
+            const float *wt = (const float *)(part == 0 ? wz : wr)->data, *bs = (const float *)(part == 0 ? bz : br)->data;
+            for (int o = 0; o < 128; ++o) {
+                for (int c = 0; c < 384; ++c)
+                    for (int tp = 0; tp < 5; ++tp) g[(size_t)(part * 128 + o) * K + tp * 384 + c] = wt[((size_t)o * 384 + c) * 5 + tp];
+                bb[part * 128 + o] = bs[o];
+            }
+        }
+        if ((r = pack(g.data(), 256, K, K, zr_[half], bb.data()))) return r;
+        if ((r = pack_conv(u + "gru.convq" + sfx, nullptr, nullptr, q_[half]))) return r;
+    }
+    if ((r = pack_conv(u + "flow_head.conv1", nullptr, nullptr, fh1_))) return r;
+    if ((r = pack_conv(u + "flow_head.conv2", nullptr, nullptr, fh2_))) return r;
+    fh2_.N = 8;                                             // 2 real outputs, rows 2..7 are zero
+    if ((r = pack_conv(u + "mask.0", nullptr, nullptr, mk0_))) return r;
+    if ((r = pack_conv(u + "mask.2", nullptr, nullptr, mk2_))) return r;
+    tmap_.clear();
+    PB_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+void *RaftEngine::carve(size_t bytes) {
+    const size_t off = arena_off_;
+    arena_off_ += round_up((int64_t)bytes, 256);
+    return planning_ ? nullptr : (void *)(arena_ + off);
+}
+
+int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
+    if (F <= pF_ && H == pH_ && W == pW_ && scale == pS_ && dirs <= pD_) return 0;
+    PB_HIP(hipStreamSynchronize(stream));
+    out_size(H, W, scale, &sh_, &sw_);
+    const int ph = (((sh_ / 8) + 1) * 8 - sh_) % 8, pw = (((sw_ / 8) + 1) * 8 - sw_) % 8;   // InputPadder 'sintel' (flow.py:43-55)
+    padl_ = pw / 2; padt_ = ph / 2;
+    Hp_ = sh_ + ph; Wp_ = sw_ + pw;
+    h8_ = Hp_ / 8; w8_ = Wp_ / 8; P_ = h8_ * w8_;
+    PB_CHECK(h8_ >= 16 && w8_ >= 16, PB_ERR_ARG, "flow_raft: %dx%d is too small (the 4-level pyramid needs >= 128 px)", sh_, sw_);
+    PB_CHECK(P_ % 8 == 0, PB_ERR_ARG, "flow_raft: (H/8)*(W/8) = %d must be a multiple of 8", P_);
+    lh_[0] = h8_; lw_[0] = w8_;
+    for (int l = 1; l < 4; ++l) { lh_[l] = lh_[l - 1] / 2; lw_[l] = lw_[l - 1] / 2; }
+    const int64_t ND = (int64_t)(F - 1) * dirs;
+    const int h2 = Hp_ / 2, w2 = Wp_ / 2, h4 = Hp_ / 4, w4 = Wp_ / 4;
+    const size_t slack = 1 << 20;
+    for (int pass = 0; pass < 2; ++pass) {
+        planning_ = pass == 0;
+        arena_off_ = 0;
+        xi_ = (int *)carve((size_t)sw_ * 16); xc_ = (int *)carve((size_t)sw_ * 16);
+        yi_ = (int *)carve((size_t)sh_ * 16); yc_ = (int *)carve((size_t)sh_ * 16);
+        img_ = (f16 *)carve((size_t)F * Hp_ * Wp_ * 8);
+        colA_ = (f16 *)carve((size_t)round_up((int64_t)F * h2 * w2, 256) * 192 * 2);
+        for (auto &b : r1_) b = (f16 *)carve((size_t)round_up((int64_t)F * h2 * w2, 256) * 64 * 2);
+        for (auto &b : r2_) b = (f16 *)carve((size_t)round_up((int64_t)F * h4 * w4, 256) * 128 * 2);
+        for (auto &b : r3_) b = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 128 * 2);
+        for (auto &b : st_) b = (float *)carve((size_t)F * 256 * 2 * 4);
+        fmap_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2 + slack);
+        ctx_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2);
+        for (int l = 0; l < 4; ++l) pyr_[l] = (float *)carve((size_t)ND * P_ * lh_[l] * lw_[l] * 4 + slack);
+        const int64_t rows = round_up(ND * P_, 256);
+        h32_ = (float *)carve((size_t)rows * 128 * 4); flow_ = (float *)carve((size_t)rows * 2 * 4);
+        delta_ = (float *)carve((size_t)rows * 8 * 4); mask_ = (float *)carve((size_t)rows * 576 * 4);
+        hx_ = (f16 *)carve((size_t)rows * 384 * 2); hx2_ = (f16 *)carve((size_t)rows * 384 * 2);
+        corr_ = (f16 *)carve((size_t)rows * 384 * 2); c1_ = (f16 *)carve((size_t)rows * 256 * 2);
+        corflo_ = (f16 *)carve((size_t)rows * 256 * 2); fa_ = (f16 *)carve((size_t)rows * 128 * 2);
+        f1_ = (f16 *)carve((size_t)rows * 128 * 2); zrb_ = (f16 *)carve((size_t)rows * 256 * 2);
+        qb_ = (f16 *)carve((size_t)rows * 128 * 2); fh_ = (f16 *)carve((size_t)rows * 256 * 2);
+        m0_ = (f16 *)carve((size_t)rows * 256 * 2);
+        up_ = (float *)carve((size_t)ND * sh_ * sw_ * 2 * 4);
+        maxd_ = (unsigned *)carve((size_t)ND * 4);
+        if (pass == 0) {
+            if (arena_off_ > arena_bytes_) {
+                if (arena_) PB_HIP(hipFree(arena_));
+                arena_ = nullptr; arena_bytes_ = 0;
+                hipError_t e = hipMalloc((void **)&arena_, arena_off_);
+                PB_CHECK(e == hipSuccess, PB_ERR_MEMORY, "flow arena of %zu bytes: %s", arena_off_, hipGetErrorString(e));
+                arena_bytes_ = arena_off_;
+            }
+            PB_HIP(hipMemsetAsync(arena_, 0, arena_bytes_, stream));
+        }
+    }
+    if (scale != 1.f) {
+        std::vector<int> xi, xc, yi, yc;
+        cubic_taps_u8(W, sw_, scale, xi, xc);
+        cubic_taps_u8(H, sh_, scale, yi, yc);
+        PB_HIP(hipMemcpyAsync(xi_, xi.data(), xi.size() * 4, hipMemcpyHostToDevice, stream));
+        PB_HIP(hipMemcpyAsync(xc_, xc.data(), xc.size() * 4, hipMemcpyHostToDevice, stream));
+        PB_HIP(hipMemcpyAsync(yi_, yi.data(), yi.size() * 4, hipMemcpyHostToDevice, stream));
+        PB_HIP(hipMemcpyAsync(yc_, yc.data(), yc.size() * 4, hipMemcpyHostToDevice, stream));
+    }
+    PB_HIP(hipStreamSynchronize(stream));
+    pF_ = F; pH_ = H; pW_ = W; pS_ = scale; pD_ = dirs;
+    return 0;
+}
+
+int RaftEngine::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w,
+                     f16 *out, int ldo, int act, int pre_relu, const f16 *add1) {
+    GemmArgs a;
+    a.A = in; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_;
+    a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = kw; a.cStride = stride; a.cPad = kh / 2; a.cPadX = kw / 2;
+    a.cOH = (H + 2 * (kh / 2) - kh) / stride + 1; a.cOW = (W + 2 * (kw / 2) - kw) / stride + 1;
+    a.M = n * a.cOH * a.cOW;
+    a.out = out; a.ldo = ldo; a.act = act; a.pre_relu = pre_relu; a.add1 = add1;
+    PB_CHECK(w.K == kh * kw * cC, PB_ERR_STATE, "conv: packed K %d != %d*%d*%d", w.K, kh, kw, cC);
+    tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
+    int r = launch_gemm(stream, A_CONV, EPI_STD, conv_tile, a);
+    toc();
+    return r;
+}
+
+int RaftEngine::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act) {
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_; a.M = (int)M;
+    a.out = out; a.ldo = ldo; a.act = act;
+    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 0);
+    int r = launch_gemm(stream, A_DENSE, EPI_STD, TILE_AUTO, a);
+    toc();
+    return r;
+}
+
+int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward, float *flow_out,
+                      uint8_t *rgb_out, float *maxdisp) {
+    PB_CHECK(frames && F >= 2 && H > 0 && W > 0 && iters >= 1 && scale > 0.f, PB_ERR_ARG, "flow infer: bad arguments");
+    PB_HIP(hipSetDevice(device));
+    const int dirs = backward ? 2 : 1;
+    int r = prepare(F, H, W, scale, dirs);
+    if (r) return r;
+    timer.reset();
+    stages_.clear();
+    const int h2 = Hp_ / 2, w2 = Wp_ / 2, h4 = Hp_ / 4, w4 = Wp_ / 4;
+    const int ND = (F - 1) * dirs;
+    last_nd_ = ND;
+    const int64_t rows = (int64_t)ND * P_;
+
+    // ---- frame prep + stem im2col (shared by fnet and cnet) ----
+    tic(F_PP, 0, (double)F * H * W * 3);
+    r = launch_raft_prep(stream, frames, F, H, W, sh_, sw_, Hp_, Wp_, padl_, padt_, scale != 1.f, xi_, xc_, yi_, yc_, img_, nullptr);
+    toc();
+    if (r) return r;
+    tic(F_ELT, 0, 0);
+    r = launch_im2col7_img(stream, img_, F, Hp_, Wp_, h2, w2, colA_, 192);
+    toc();
+    if (r) return r;
+
+    // ---- the two encoders ----
+    for (int e = 0; e < 2; ++e) {
+        const Enc &E = e == 0 ? fnet_ : cnet_;
+        const bool inorm = e == 0;
+        auto norm_relu = [&](const f16 *t, float *st, f16 *y, int HW, int C, const f16 *b, const float *sb) -> int {
+            tic(F_ELT, 0, 0);
+            int rr = launch_in_apply(stream, t, st, b, sb, y, F, HW, C, C);
+            toc();
+            return rr;
+        };
+        auto stats = [&](const f16 *t, float *st, int HW, int C) -> int {
+            tic(F_ELT, 0, 0);
+            int rr = launch_in_stats(stream, t, F, HW, C, C, st);
+            toc();
+            return rr;
+        };
+        // stem (BasicEncoder.forward, extractor.py:171-192)
+        if ((r = dense(colA_, 192, (int64_t)F * h2 * w2, E.stem, r1_[5], 64, inorm ? ACT_NONE : ACT_RELU))) return r;
+        const f16 *x = r1_[5];
+        if (inorm) {
+            if ((r = stats(r1_[5], st_[0], h2 * w2, 64))) return r;
+            if ((r = norm_relu(r1_[5], st_[0], r1_[6], h2 * w2, 64, nullptr, nullptr))) return r;
+            x = r1_[6];
+        }
+        int H_ = h2, W_ = w2, C_ = 64;
+        for (int li = 0; li < 3; ++li) {
+            const int stride = li == 0 ? 1 : 2;
+            const int Cn = li == 0 ? 64 : 128;               // 96 is carried as 128 (zero padded channels)
+            f16 **R = li == 0 ? r1_ : (li == 1 ? r2_ : r3_);
+            for (int bi = 0; bi < 2; ++bi) {                  // ResidualBlock.forward (extractor.py:46-56)
+                const int s = bi == 0 ? stride : 1;
+                const int OH = (H_ - 1) / s + 1, OW = (W_ - 1) / s + 1;
+                const int Cin = bi == 0 ? C_ : Cn;
+                f16 *t1 = R[0], *t2 = R[1], *t3 = R[2], *outb = R[3 + bi];
+                if (inorm) {
+                    if ((r = conv(x, Cin, Cin, F, H_, W_, 3, 3, s, E.l[li][bi][0], t1, Cn, ACT_NONE))) return r;
+                    if ((r = stats(t1, st_[0], OH * OW, Cn))) return r;
+                    if ((r = norm_relu(t1, st_[0], t1, OH * OW, Cn, nullptr, nullptr))) return r;
+                    if ((r = conv(t1, Cn, Cn, F, OH, OW, 3, 3, 1, E.l[li][bi][1], t2, Cn, ACT_NONE))) return r;
+                    if ((r = stats(t2, st_[1], OH * OW, Cn))) return r;
+                    if (s != 1) {
+                        if ((r = conv(x, Cin, Cin, F, H_, W_, 1, 1, s, E.ds[li], t3, Cn, ACT_NONE))) return r;
+                        if ((r = stats(t3, st_[2], OH * OW, Cn))) return r;
+                        if ((r = norm_relu(t2, st_[1], outb, OH * OW, Cn, t3, st_[2]))) return r;
+                    } else {
+                        if ((r = norm_relu(t2, st_[1], outb, OH * OW, Cn, x, nullptr))) return r;
+                    }
+                } else {
+                    if ((r = conv(x, Cin, Cin, F, H_, W_, 3, 3, s, E.l[li][bi][0], t1, Cn, ACT_RELU))) return r;
+                    const f16 *xs = x;
+                    if (s != 1) {
+                        if ((r = conv(x, Cin, Cin, F, H_, W_, 1, 1, s, E.ds[li], t3, Cn, ACT_NONE))) return r;
+                        xs = t3;
+                    }
+                    if ((r = conv(t1, Cn, Cn, F, OH, OW, 3, 3, 1, E.l[li][bi][1], outb, Cn, ACT_RELU, 1, xs))) return r;
+                }
+                x = outb; H_ = OH; W_ = OW; C_ = Cn;
+            }
+        }
+        if ((r = dense(x, 128, (int64_t)F * P_, E.out, e == 0 ? fmap_ : ctx_, 256, ACT_NONE))) return r;
+    }
+    stages_["fmap"] = Stage{fmap_, 1, 0, 256, h8_, w8_, 256, 0};
+
+    // ---- all-pairs correlation volume + pyramid, recurrent state ----
+    for (int i = 0; i < F - 1; ++i)
+        for (int d = 0; d < dirs; ++d) {
+            const int n = i * dirs + d;
+            GemmArgs a;
+            a.A = fmap_ + (int64_t)(i + d) * P_ * 256; a.lda = 256; a.M = P_;
+            a.W = fmap_ + (int64_t)(i + 1 - d) * P_ * 256; a.K = 256; a.N = P_;
+            a.out32 = pyr_[0] + (int64_t)n * P_ * P_; a.ldo = P_; a.scale = 1.f / 16.f; a.zero = zero_;
+            tic(F_GEMM, 2.0 * P_ * (double)P_ * 256, 0);
+            r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
+            toc();
+            if (r) return r;
+            tic(F_ELT, 0, 0);
+            r = launch_init_state(stream, ctx_ + (int64_t)(i + d) * P_ * 256, h32_ + (int64_t)n * P_ * 128,
+                                  hx_ + (int64_t)n * P_ * 384, flow_ + (int64_t)n * P_ * 2, P_);
+            toc();
+            if (r) return r;
+        }
+    for (int l = 0; l < 3; ++l) {
+        tic(F_ELT, 0, 0);
+        r = launch_corr_pool(stream, pyr_[l], pyr_[l + 1], rows, lh_[l], lw_[l]);
+        toc();
+        if (r) return r;
+    }
+
+    // ---- GRU iterations (raft.py:124-144, update.py:122-136) ----
+    for (int it = 0; it < iters; ++it) {
+        tic(F_ELT, 0, 0);
+        r = launch_corr_lookup(stream, pyr_, lh_, lw_, flow_, P_, w8_, corr_, rows);
+        toc();
+        if (r) return r;
+        // BasicMotionEncoder
+        if ((r = conv(corr_, 384, 384, ND, h8_, w8_, 1, 1, 1, convc1_, c1_, 256, ACT_RELU))) return r;
+        if ((r = conv(c1_, 256, 256, ND, h8_, w8_, 3, 3, 1, convc2_, corflo_, 256, ACT_RELU))) return r;
+        tic(F_ELT, 0, 0);
+        r = launch_im2col7_flow(stream, flow_, ND, h8_, w8_, fa_, 128);
+        toc();
+        if (r) return r;
+        if ((r = dense(fa_, 128, rows, convf1_, f1_, 128, ACT_RELU))) return r;
+        if ((r = conv(f1_, 128, 128, ND, h8_, w8_, 3, 3, 1, convf2_, corflo_ + 192, 256, ACT_RELU))) return r;
+        if ((r = conv(corflo_, 256, 256, ND, h8_, w8_, 3, 3, 1, convm_, hx_ + 256, 384, ACT_RELU))) return r;
+        tic(F_ELT, 0, 0);
+        r = launch_put_flow(stream, flow_, hx_, rows);
+        toc();
+        if (r) return r;
+        // SepConvGRU: (1 x 5) then (5 x 1)
+        for (int half = 0; half < 2; ++half) {
+            const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1;
+            if ((r = conv(hx_, 384, 384, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_SIGMOID))) return r;
+            tic(F_ELT, 0, 0);
+            r = launch_gru_rh(stream, zrb_, h32_, hx_, hx2_, rows);
+            toc();
+            if (r) return r;
+            if ((r = conv(hx2_, 384, 384, ND, h8_, w8_, kh, kw, 1, q_[half], qb_, 128, ACT_TANH))) return r;
+            tic(F_ELT, 0, 0);
+            r = launch_gru_update(stream, zrb_, qb_, h32_, hx_, rows);
+            toc();
+            if (r) return r;
+        }
+        // FlowHead -> delta_flow (fp32), coords1 += delta
+        if ((r = conv(hx_, 128, 384, ND, h8_, w8_, 3, 3, 1, fh1_, fh_, 256, ACT_RELU))) return r;
+        {
+            GemmArgs a;
+            a.A = fh_; a.W = fh2_.w; a.K = fh2_.K; a.N = 8; a.bias = fh2_.bias; a.zero = zero_;
+            a.cH = h8_; a.cW = w8_; a.cC = 256; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cOH = h8_; a.cOW = w8_;
+            a.M = (int)rows; a.out32 = delta_; a.ldo = 8; a.scale = 1.f;
+            tic(F_CONV, 2.0 * rows * 2.0 * fh2_.Kreal, 0);
+            r = launch_gemm(stream, A_CONV, EPI_F32, TILE_128, a);
+            toc();
+            if (r) return r;
+        }
+        tic(F_ELT, 0, 0);
+        r = launch_flow_update(stream, flow_, delta_, rows);
+        toc();
+        if (r) return r;
+    }
+    stages_["flow_lo"] = Stage{flow_, 0, 0, P_, 1, 2, 2, (int64_t)P_ * 2};
+
+    // ---- mask head (last iteration only) + convex upsample + unpad + encode ----
+    if ((r = conv(hx_, 128, 384, ND, h8_, w8_, 3, 3, 1, mk0_, m0_, 256, ACT_RELU))) return r;
+    {
+        GemmArgs a;
+        a.A = m0_; a.lda = 256; a.W = mk2_.w; a.K = mk2_.K; a.N = 576; a.bias = mk2_.bias; a.zero = zero_; a.M = (int)rows;
+        a.out32 = mask_; a.ldo = 576; a.scale = 0.25f;
+        tic(F_GEMM, 2.0 * rows * 576.0 * 256, 0);
+        r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
+        toc();
+        if (r) return r;
+    }
+    float *up = flow_out ? flow_out : up_;
+    tic(F_PP, 0, (double)ND * sh_ * sw_ * 8);
+    r = launch_upsample(stream, flow_, mask_, ND, h8_, w8_, padl_, padt_, sh_, sw_, up, maxd_);
+    toc();
+    if (r) return r;
+    tic(F_PP, 0, (double)ND * sh_ * sw_ * 11);
+    r = launch_flow_encode(stream, up, ND, sh_, sw_, maxd_, rgb_out, maxdisp);
+    toc();
+    return r;
+}
+
+int64_t RaftEngine::get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]) {
+    auto it = stages_.find(name);
+    PB_CHECK(it != stages_.end(), PB_ERR_ARG, "unknown stage '%s'", name);
+    const Stage &s = it->second;
+    PB_HIP(hipStreamSynchronize(stream));
+    if (s.kind == 0) {
+        const int64_t total = (int64_t)last_nd_ * s.c * s.w;
+        shape[0] = last_nd_; shape[1] = s.c; shape[2] = s.w; shape[3] = 1;
+        PB_CHECK(total <= cap, PB_ERR_ARG, "stage buffer too small");
+        PB_HIP(hipMemcpy(out, s.ptr, total * 4, hipMemcpyDeviceToHost));
+        return total;
+    }
+    const int n = pF_;
+    const int64_t total = (int64_t)n * s.c * s.h * s.w;
+    shape[0] = n; shape[1] = s.c; shape[2] = s.h; shape[3] = s.w;
+    PB_CHECK(total <= cap, PB_ERR_ARG, "stage buffer too small");
+    float *tmp = nullptr;
+    PB_HIP(hipMalloc((void **)&tmp, total * 4));
+    int r = launch_nhwc_f16_to_nchw_f32(stream, (const f16 *)s.ptr, tmp, n, (int)s.c, (int)s.h, (int)s.w, (int)s.ld);
+    if (r) return r;
+    PB_HIP(hipStreamSynchronize(stream));
+    PB_HIP(hipMemcpy(out, tmp, total * 4, hipMemcpyDeviceToHost));
+    PB_HIP(hipFree(tmp));
+    return total;
+}

@@ -1,0 +1,451 @@
+// HBM / gather bound kernels of the flow_raft band for gfx950.
+// Reference being replaced: bands/flow_raft.py:99-107 (resize, pad), bands/raft/extractor.py (InstanceNorm),
+// bands/raft/corr.py:12-50 (pyramid + 9x9 lookup), bands/raft/update.py:33-60 (GRU gating),
+// bands/raft/raft.py:73-84 (convex upsample), bands/common/encode.py:98-126 (process_flow).
+#include "raft_kernels.h"
+
+namespace {
+
+inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+
+// ------------------------------------------------------------------------------------------------
+// frame prep: uint8 RGB frame -> [optional 8-bit fixed-point bicubic resize] -> replicate pad to /8 ->
+// 2*(x/255)-1 -> fp16 [F][Hp][Wp][4] (channel 3 = 0).  One thread per padded pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restrict__ frames, int F, int H, int W, int sh,
+                                                        int sw, int Hp, int Wp, int pad_l, int pad_t, int resize,
+                                                        const int *__restrict__ xi, const int *__restrict__ xc,
+                                                        const int *__restrict__ yi, const int *__restrict__ yc,
+                                                        f16 *__restrict__ out, uint8_t *__restrict__ scaled_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)F * Hp * Wp) return;
+    const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), f = (int)(i / ((int64_t)Wp * Hp));
+    int sy = y - pad_t, sx = x - pad_l;                       // position in the scaled (unpadded) frame
+    sy = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+    sx = sx < 0 ? 0 : (sx > sw - 1 ? sw - 1 : sx);
+    const uint8_t *img = frames + (int64_t)f * H * W * 3;
+    int v[3];
+    if (resize) {
+        int acc[3] = {0, 0, 0};
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty) {
+            const uint8_t *row = img + (int64_t)yi[sy * 4 + ty] * W * 3;
+            int r[3] = {0, 0, 0};
+#pragma unroll
+            for (int tx = 0; tx < 4; ++tx) {
+                const int o = xi[sx * 4 + tx] * 3, c = xc[sx * 4 + tx];
+                r[0] += row[o] * c; r[1] += row[o + 1] * c; r[2] += row[o + 2] * c;
+            }
+            const int cy = yc[sy * 4 + ty];
+            acc[0] += r[0] * cy; acc[1] += r[1] * cy; acc[2] += r[2] * cy;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int q = (acc[c] + (1 << 21)) >> 22;
+            v[c] = q < 0 ? 0 : (q > 255 ? 255 : q);
+        }
+    } else {
+        const uint8_t *px = img + ((int64_t)sy * W + sx) * 3;
+        v[0] = px[0]; v[1] = px[1]; v[2] = px[2];
+    }
+    f16x4 o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (f16)(2.f * ((float)v[c] / 255.f) - 1.f);
+    o[3] = (f16)0.f;
+    *(f16x4 *)(out + i * 4) = o;
+    if (scaled_out && y >= pad_t && y < pad_t + sh && x >= pad_l && x < pad_l + sw) {
+        uint8_t *d = scaled_out + (((int64_t)f * sh + (y - pad_t)) * sw + (x - pad_l)) * 3;
+        d[0] = (uint8_t)v[0]; d[1] = (uint8_t)v[1]; d[2] = (uint8_t)v[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col for the two 7x7 convolutions whose input has 3 (image, stride 2) or 2 (flow, stride 1) channels:
+// rows = output pixels, k = (ky*7 + kx)*C + c, zero padded to Kp.  One thread per (row, tap).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CS>
+__global__ __launch_bounds__(256) void im2col7_kernel(const T *__restrict__ x, int B, int H, int W, int C, int stride,
+                                                       int OH, int OW, f16 *__restrict__ out, int Kp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * OH * OW * 49) return;
+    const int tap = (int)(i % 49);
+    const int64_t row = i / 49;
+    const int ox = (int)(row % OW), oy = (int)((row / OW) % OH), b = (int)(row / ((int64_t)OW * OH));
+    const int ky = tap / 7, kx = tap - ky * 7;
+    const int iy = oy * stride - 3 + ky, ix = ox * stride - 3 + kx;
+    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const T *src = x + (((int64_t)b * H + iy) * W + ix) * CS;
+    f16 *dst = out + row * Kp + tap * C;
+    for (int c = 0; c < C; ++c) dst[c] = ok ? (f16)(float)src[c] : (f16)0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm2d (no affine, eps 1e-5, biased variance over H x W per sample and channel).
+// stats[b][c] = {sum, sum of squares}; blocks cover pixel chunks, threads cover (pixel lane, 8 channels).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void in_stats_kernel(const f16 *__restrict__ x, int HW, int C8, int ldc,
+                                                        float *__restrict__ stats, int chunk) {
+    __shared__ float red[256 * 16];
+    const int b = blockIdx.y;
+    const int c8 = threadIdx.x % C8, pl = threadIdx.x / C8, npl = blockDim.x / C8;
+    const int p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, HW);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (pl < npl) {
+        for (int p = p0 + pl; p < p1; p += npl) {
+            const f16x8 v = *(const f16x8 *)(x + ((int64_t)b * HW + p) * ldc + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s[j]; red[threadIdx.x * 16 + 8 + j] = q[j]; }
+    __syncthreads();
+    if (pl == 0) {
+        for (int o = 1; o < npl; ++o)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) red[c8 * 16 + j] += red[(o * C8 + c8) * 16 + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&stats[((int64_t)b * C8 * 8 + c8 * 8 + j) * 2 + 0], red[c8 * 16 + j]);
+            atomicAdd(&stats[((int64_t)b * C8 * 8 + c8 * 8 + j) * 2 + 1], red[c8 * 16 + 8 + j]);
+        }
+    }
+}
+
+// out = relu( relu(IN(a)) + (b ? (sb ? IN(b) : b) : 0) )   [second relu only when b is given]
+__global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a, const float *__restrict__ sa,
+                                                        const f16 *__restrict__ bsrc, const float *__restrict__ sb,
+                                                        f16 *__restrict__ out, int B, int HW, int C8, int ldc,
+                                                        float inv_hw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * HW * C8) return;
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int b = (int)(pix / HW);
+    const int64_t o = pix * ldc + c8 * 8;
+    const f16x8 va = *(const f16x8 *)(a + o);
+    f16x8 vb;
+    if (bsrc) vb = *(const f16x8 *)(bsrc + o);
+    f16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c8 * 8 + j;
+        const float *st = sa + ((int64_t)b * C8 * 8 + c) * 2;
+        const float mean = st[0] * inv_hw;
+        const float var = fmaxf(st[1] * inv_hw - mean * mean, 0.f);
+        float v = fmaxf(((float)va[j] - mean) * rsqrtf(var + 1e-5f), 0.f);
+        if (bsrc) {
+            float w = (float)vb[j];
+            if (sb) {
+                const float *s2 = sb + ((int64_t)b * C8 * 8 + c) * 2;
+                const float m2 = s2[0] * inv_hw;
+                const float v2 = fmaxf(s2[1] * inv_hw - m2 * m2, 0.f);
+                w = (w - m2) * rsqrtf(v2 + 1e-5f);
+            }
+            v = fmaxf(v + w, 0.f);
+        }
+        r[j] = (f16)v;
+    }
+    *(f16x8 *)(out + o) = r;
+}
+
+// cnet output [rows][256] fp16 -> net = tanh(c[:128]) (fp32 master + fp16 copy in HX[:, 0:128]),
+// inp = relu(c[128:]) in HX[:, 128:256]; flow = 0.
+__global__ __launch_bounds__(256) void init_state_kernel(const f16 *__restrict__ c, float *__restrict__ h32,
+                                                          f16 *__restrict__ hx, float *__restrict__ flow, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 32) return;
+    const int c8 = (int)(i % 32);
+    const int64_t r = i / 32;
+    const f16x8 v = *(const f16x8 *)(c + r * 256 + c8 * 8);
+    f16x8 o;
+    if (c8 < 16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = tanhf((float)v[j]);
+            h32[r * 128 + c8 * 8 + j] = t;
+            o[j] = (f16)t;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)fmaxf((float)v[j], 0.f);
+    }
+    *(f16x8 *)(hx + r * 384 + c8 * 8) = o;
+    if (c8 == 0) { flow[r * 2] = 0.f; flow[r * 2 + 1] = 0.f; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// correlation pyramid: level l+1 = avg_pool2d(level l, 2, 2) over the target dims (floor on odd sizes)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t NP,
+                                                         int h, int w, int oh, int ow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NP * oh * ow) return;
+    const int x = (int)(i % ow), y = (int)((i / ow) % oh);
+    const int64_t p = i / ((int64_t)ow * oh);
+    const float *s = src + p * h * w + (int64_t)(2 * y) * w + 2 * x;
+    dst[i] = 0.25f * ((s[0] + s[1]) + (s[w] + s[w + 1]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// 9x9 x 4-level lookup (corr.py:29-50): channel k = l*81 + i*9 + j samples x = cx/2^l + (i-4),
+// y = cy/2^l + (j-4) with bilinear weights in pixel coordinates and zeros outside the level.
+// One thread per (pixel, level, i): the 9 j-samples share the x taps; output fp16 [rows][384].
+// ------------------------------------------------------------------------------------------------
+struct PyrPtrs { const float *lv[4]; int h[4], w[4]; };
+
+__global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const float *__restrict__ flow, int P, int w8,
+                                                           f16 *__restrict__ out, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 36) return;
+    const int li = (int)(i % 36);
+    const int64_t r = i / 36;
+    const int l = li / 9, wi = li - l * 9;
+    const int p = (int)(r % P);
+    const float cx = (float)(p % w8) + flow[r * 2], cy = (float)(p / w8) + flow[r * 2 + 1];
+    const float inv = 1.f / (float)(1 << l);
+    const int h = py.h[l], w = py.w[l];
+    const float *vol = py.lv[l] + r * (int64_t)h * w;
+    // reproduce grid_sample's round trip: normalise then un-normalise (align_corners=True)
+    const float x = ((2.f * (cx * inv + (float)(wi - 4)) / (float)(w - 1) - 1.f) + 1.f) * 0.5f * (float)(w - 1);
+    const float x0f = floorf(x);
+    const int x0 = (int)x0f;
+    const float ax = x - x0f;
+    const bool okx0 = (unsigned)x0 < (unsigned)w, okx1 = (unsigned)(x0 + 1) < (unsigned)w;
+    f16 *dst = out + r * 384 + l * 81 + wi * 9;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const float y = ((2.f * (cy * inv + (float)(j - 4)) / (float)(h - 1) - 1.f) + 1.f) * 0.5f * (float)(h - 1);
+        const float y0f = floorf(y);
+        const int y0 = (int)y0f;
+        const float ay = y - y0f;
+        const bool oky0 = (unsigned)y0 < (unsigned)h, oky1 = (unsigned)(y0 + 1) < (unsigned)h;
+        const float v00 = (oky0 && okx0) ? vol[y0 * w + x0] : 0.f;
+        const float v01 = (oky0 && okx1) ? vol[y0 * w + x0 + 1] : 0.f;
+        const float v10 = (oky1 && okx0) ? vol[(y0 + 1) * w + x0] : 0.f;
+        const float v11 = (oky1 && okx1) ? vol[(y0 + 1) * w + x0 + 1] : 0.f;
+        dst[j] = (f16)(v00 * (1.f - ax) * (1.f - ay) + v01 * ax * (1.f - ay) + v10 * (1.f - ax) * ay + v11 * ax * ay);
+    }
+}
+
+// flow (fp32 [rows][2]) -> HX[:, 382:384] (the last two input channels of the GRU, update.py:97)
+__global__ void put_flow_kernel(const float *__restrict__ flow, f16 *__restrict__ hx, int64_t rows) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    f16x2 o;
+    o[0] = (f16)flow[r * 2]; o[1] = (f16)flow[r * 2 + 1];
+    *(f16x2 *)(hx + r * 384 + 382) = o;
+}
+
+// HX2[:, 0:128] = r * h ; HX2[:, 128:384] = HX[:, 128:384]        (zr = [z | r], fp16 [rows][256])
+__global__ __launch_bounds__(256) void gru_rh_kernel(const f16 *__restrict__ zr, const float *__restrict__ h32,
+                                                      const f16 *__restrict__ hx, f16 *__restrict__ hx2, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 48) return;
+    const int c8 = (int)(i % 48);
+    const int64_t r = i / 48;
+    if (c8 < 16) {
+        const f16x8 rr = *(const f16x8 *)(zr + r * 256 + 128 + c8 * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)rr[j] * h32[r * 128 + c8 * 8 + j]);
+        *(f16x8 *)(hx2 + r * 384 + c8 * 8) = o;
+    } else {
+        *(f16x8 *)(hx2 + r * 384 + c8 * 8) = *(const f16x8 *)(hx + r * 384 + c8 * 8);
+    }
+}
+
+// h = (1 - z) * h + z * q ; fp32 master + fp16 copy into HX[:, 0:128]
+__global__ __launch_bounds__(256) void gru_update_kernel(const f16 *__restrict__ zr, const f16 *__restrict__ q,
+                                                          float *__restrict__ h32, f16 *__restrict__ hx, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 16) return;
+    const int c8 = (int)(i % 16);
+    const int64_t r = i / 16;
+    const f16x8 z = *(const f16x8 *)(zr + r * 256 + c8 * 8);
+    const f16x8 qq = *(const f16x8 *)(q + r * 128 + c8 * 8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float zz = (float)z[j];
+        const float h = (1.f - zz) * h32[r * 128 + c8 * 8 + j] + zz * (float)qq[j];
+        h32[r * 128 + c8 * 8 + j] = h;
+        o[j] = (f16)h;
+    }
+    *(f16x8 *)(hx + r * 384 + c8 * 8) = o;
+}
+
+// coords1 += delta_flow  (flow = coords1 - coords0 is what is stored)
+__global__ void flow_update_kernel(float *__restrict__ flow, const float *__restrict__ delta, int64_t rows) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    flow[r * 2] += delta[r * 8];
+    flow[r * 2 + 1] += delta[r * 8 + 1];
+}
+
+// ------------------------------------------------------------------------------------------------
+// convex upsample (raft.py:73-84) fused with the unpad and the per-flow max displacement:
+// one thread per full-resolution pixel of the padded frame; mask fp32 [rows][576] (already * 0.25).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2ord_(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void upsample_kernel(const float *__restrict__ flow, const float *__restrict__ mask, int h8,
+                                                        int w8, int pad_l, int pad_t, int sh, int sw,
+                                                        float *__restrict__ out, unsigned *__restrict__ maxd) {
+    const int n = blockIdx.y;
+    const int P = h8 * w8;
+    float dmax = 0.f;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)sh * sw) {
+        const int ox = (int)(i % sw), oy = (int)(i / sw);
+        const int X = ox + pad_l, Y = oy + pad_t;
+        const int px = X >> 3, py = Y >> 3, sub = (Y & 7) * 8 + (X & 7);
+        const float *m = mask + ((int64_t)n * P + py * w8 + px) * 576 + sub;
+        float e[9], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { e[k] = m[k * 64]; mx = fmaxf(mx, e[k]); }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { e[k] = __expf(e[k] - mx); den += e[k]; }
+        float u = 0.f, v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = py + k / 3 - 1, xx = px + k % 3 - 1;
+            if ((unsigned)yy < (unsigned)h8 && (unsigned)xx < (unsigned)w8) {
+                const float *f = flow + ((int64_t)n * P + yy * w8 + xx) * 2;
+                const float wgt = e[k] / den;
+                u += wgt * (8.f * f[0]);
+                v += wgt * (8.f * f[1]);
+            }
+        }
+        float *o = out + ((int64_t)n * sh * sw + i) * 2;
+        o[0] = u; o[1] = v;
+        dmax = __fsqrt_rn(__fadd_rn(__fmul_rn(u, u), __fmul_rn(v, v)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxd + n, f2ord_(dmax));
+}
+
+// process_flow (encode.py:98-126): float32 distance / angle, float64 colour ramp + saturation blend, truncation.
+__global__ __launch_bounds__(256) void flow_encode_kernel(const float *__restrict__ flow, int64_t per,
+                                                           const unsigned *__restrict__ maxd, uint8_t *__restrict__ rgb,
+                                                           float *__restrict__ max_out) {
+    const int n = blockIdx.y;
+    const unsigned mu = maxd[n];
+    const float mx = __uint_as_float((mu & 0x80000000u) ? (mu & 0x7fffffffu) : ~mu);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && max_out) max_out[n] = mx;
+    if (!rgb) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+        const float *f = flow + ((int64_t)n * per + i) * 2;
+        const float dx = __fdiv_rn(f[0], mx), dy = __fdiv_rn(f[1], mx);
+        const float rad = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+        const float a = __fmul_rn(__fadd_rn(__fdiv_rn(atan2f(dy, dx), 3.14159265358979323846f), 1.0f), 0.5f);
+        const float h6 = __fmul_rn(a, 6.0f);
+        const float offs[3] = {0.f, 4.f, 2.f};
+        uint8_t o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = (double)(c == 0 ? h6 : __fadd_rn(h6, offs[c]));
+            v = fmod(v, 6.0);
+            if (v < 0.0) v = __dadd_rn(v, 6.0);
+            v = __dsub_rn(fabs(__dsub_rn(v, 3.0)), 1.0);
+            v = fmin(fmax(v, 0.0), 1.0);
+            v = __dadd_rn(__dmul_rn(v, (double)rad), (double)__fsub_rn(1.0f, rad));
+            v = __dmul_rn(v, 255.0);
+            o[c] = (v == v) ? (uint8_t)(int)v : (uint8_t)0;
+        }
+        uint8_t *d = rgb + ((int64_t)n * per + i) * 3;
+        d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
+    }
+}
+
+__global__ void fill_u32_kernel(unsigned *p, unsigned v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+#define LAUNCH_CHECK() do { PB_HIP(hipGetLastError()); return 0; } while (0)
+
+int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, int sh, int sw, int Hp, int Wp, int pad_l,
+                     int pad_t, int resize, const int *xi, const int *xc, const int *yi, const int *yc, f16 *out,
+                     uint8_t *scaled_out) {
+    hipLaunchKernelGGL(raft_prep_kernel, dim3(nblk((int64_t)F * Hp * Wp)), dim3(256), 0, s, frames, F, H, W, sh, sw, Hp, Wp,
+                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out);
+    LAUNCH_CHECK();
+}
+int launch_im2col7_img(hipStream_t s, const f16 *x, int B, int H, int W, int OH, int OW, f16 *out, int Kp) {
+    hipLaunchKernelGGL((im2col7_kernel<f16, 4>), dim3(nblk((int64_t)B * OH * OW * 49)), dim3(256), 0, s, x, B, H, W, 3, 2, OH,
+                       OW, out, Kp);
+    LAUNCH_CHECK();
+}
+int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp) {
+    hipLaunchKernelGGL((im2col7_kernel<float, 2>), dim3(nblk((int64_t)B * H * W * 49)), dim3(256), 0, s, x, B, H, W, 2, 1, H, W,
+                       out, Kp);
+    LAUNCH_CHECK();
+}
+int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *stats) {
+    PB_CHECK(C % 8 == 0 && C <= 256 && 256 % (C / 8) == 0, -1, "instance norm: C=%d unsupported", C);
+    PB_HIP(hipMemsetAsync(stats, 0, (size_t)B * C * 2 * 4, s));
+    const int chunk = 4096;
+    hipLaunchKernelGGL(in_stats_kernel, dim3((HW + chunk - 1) / chunk, B), dim3(256), 0, s, x, HW, C / 8, ldc, stats, chunk);
+    LAUNCH_CHECK();
+}
+int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, const float *sb, f16 *out, int B, int HW,
+                    int C, int ldc) {
+    hipLaunchKernelGGL(in_apply_kernel, dim3(nblk((int64_t)B * HW * (C / 8))), dim3(256), 0, s, a, sa, b, sb, out, B, HW, C / 8,
+                       ldc, 1.f / (float)HW);
+    LAUNCH_CHECK();
+}
+int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, float *flow, int64_t rows) {
+    hipLaunchKernelGGL(init_state_kernel, dim3(nblk(rows * 32)), dim3(256), 0, s, c, h32, hx, flow, rows);
+    LAUNCH_CHECK();
+}
+int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, int h, int w) {
+    hipLaunchKernelGGL(corr_pool_kernel, dim3(nblk(NP * (h / 2) * (w / 2))), dim3(256), 0, s, src, dst, NP, h, w, h / 2, w / 2);
+    LAUNCH_CHECK();
+}
+int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], const float *flow, int P,
+                       int w8, f16 *out, int64_t rows) {
+    PyrPtrs py;
+    for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; }
+    hipLaunchKernelGGL(corr_lookup_kernel, dim3(nblk(rows * 36)), dim3(256), 0, s, py, flow, P, w8, out, rows);
+    LAUNCH_CHECK();
+}
+int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, int64_t rows) {
+    hipLaunchKernelGGL(put_flow_kernel, dim3(nblk(rows)), dim3(256), 0, s, flow, hx, rows);
+    LAUNCH_CHECK();
+}
+int launch_gru_rh(hipStream_t s, const f16 *zr, const float *h32, const f16 *hx, f16 *hx2, int64_t rows) {
+    hipLaunchKernelGGL(gru_rh_kernel, dim3(nblk(rows * 48)), dim3(256), 0, s, zr, h32, hx, hx2, rows);
+    LAUNCH_CHECK();
+}
+int launch_gru_update(hipStream_t s, const f16 *zr, const f16 *q, float *h32, f16 *hx, int64_t rows) {
+    hipLaunchKernelGGL(gru_update_kernel, dim3(nblk(rows * 16)), dim3(256), 0, s, zr, q, h32, hx, rows);
+    LAUNCH_CHECK();
+}
+int launch_flow_update(hipStream_t s, float *flow, const float *delta, int64_t rows) {
+    hipLaunchKernelGGL(flow_update_kernel, dim3(nblk(rows)), dim3(256), 0, s, flow, delta, rows);
+    LAUNCH_CHECK();
+}
+int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, int h8, int w8, int pad_l, int pad_t, int sh,
+                    int sw, float *out, unsigned *maxd) {
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(nblk(N)), dim3(256), 0, s, maxd, 0u, N);
+    hipLaunchKernelGGL(upsample_kernel, dim3(nblk((int64_t)sh * sw), N), dim3(256), 0, s, flow, mask, h8, w8, pad_l, pad_t, sh,
+                       sw, out, maxd);
+    LAUNCH_CHECK();
+}
+int launch_flow_encode(hipStream_t s, const float *flow, int N, int sh, int sw, const unsigned *maxd, uint8_t *rgb,
+                       float *max_out) {
+    unsigned gx = nblk((int64_t)sh * sw);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(flow_encode_kernel, dim3(gx, N), dim3(256), 0, s, flow, (int64_t)sh * sw, maxd, rgb, max_out);
+    LAUNCH_CHECK();
+}

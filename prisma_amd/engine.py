@@ -220,3 +220,68 @@ class DepthAnything(_Ctx):
         while len(dims) > 1 and dims[-1] == 1:
             dims.pop()
         return out[:n].reshape(dims).copy()
+
+
+def flow_out_size(H: int, W: int, scale: float) -> Tuple[int, int]:
+    sh, sw = C.c_int(), C.c_int()
+    check(_lib.load().pb_flow_out_size(H, W, C.c_float(scale), C.byref(sh), C.byref(sw)))
+    return sh.value, sw.value
+
+
+class FlowRaft(_Ctx):
+    """RAFT optical-flow band on one GPU (bands/flow_raft.py:38-66 init_model / infer).
+
+    weights: reference checkpoint naming without the `module.` prefix (fnet.*, cnet.*, update_block.*).
+    """
+
+    def __init__(self, weights: Dict[str, np.ndarray], device: int = 0):
+        super().__init__()
+        keep = {k: _f32(v) for k, v in weights.items() if np.asarray(v).dtype.kind == "f"}
+        arr = (_lib.pb_tensor * len(keep))()
+        for i, (name, w) in enumerate(keep.items()):
+            arr[i].name = name.encode()
+            arr[i].dtype = 0
+            arr[i].ndim = w.ndim
+            for j, s in enumerate(w.shape):
+                arr[i].shape[j] = s
+            arr[i].data = w.ctypes.data
+        check(self.lib.pb_create(C.byref(self.ctx), device, b"flow_raft", arr, len(keep), None, 0))
+
+    def infer_sequence(self, frames: np.ndarray, scale: float = 0.75, iters: int = 12, backward: bool = False,
+                       want_flow: bool = True, want_rgb: bool = True):
+        """frames uint8 [F,H,W,3] -> (flow f32 [F-1,dirs,sh,sw,2] | None, rgb u8 [F-1,dirs,sh,sw,3] | None, maxdisp [F-1,dirs])."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        F, H, W, ch = frames.shape
+        assert ch == 3 and F >= 2
+        sh, sw = flow_out_size(H, W, scale)
+        d = 2 if backward else 1
+        flow = np.empty((F - 1, d, sh, sw, 2), np.float32) if want_flow else None
+        rgb = np.empty((F - 1, d, sh, sw, 3), np.uint8) if want_rgb else None
+        mx = np.empty((F - 1, d), np.float32)
+        check(self.lib.pb_flow_infer_sequence(self.ctx, _ptr(frames), F, H, W, C.c_float(scale), iters, int(backward),
+                                              _ptr(flow), _ptr(rgb), _ptr(mx)))
+        return flow, rgb, mx
+
+    def infer_sequence_dev(self, frames_ptr: int, F: int, H: int, W: int, scale: float, iters: int, backward: bool,
+                           flow_ptr: int = 0, rgb_ptr: int = 0, max_ptr: int = 0):
+        v = lambda p: C.c_void_p(p) if p else None
+        check(self.lib.pb_flow_infer_sequence_dev(self.ctx, v(frames_ptr), F, H, W, C.c_float(scale), iters, int(backward),
+                                                  v(flow_ptr), v(rgb_ptr), v(max_ptr)))
+
+    def set_profiling(self, timing: bool = True, debug_stages: bool = False):
+        check(self.lib.pb_set_profiling(self.ctx, (1 if timing else 0) | (2 if debug_stages else 0)))
+
+    def kernel_stats(self) -> List[dict]:
+        arr = (_lib.pb_kernel_stat * 16)()
+        n = check(self.lib.pb_get_kernel_stats(self.ctx, arr, 16))
+        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes,
+                     launches=arr[i].launches) for i in range(n)]
+
+    def stage(self, name: str, cap: int = 1 << 26) -> np.ndarray:
+        out = np.empty(cap, np.float32)
+        shape = (C.c_int64 * 4)()
+        n = check(self.lib.pb_flow_get_stage(self.ctx, name.encode(), _ptr(out), cap, shape))
+        dims = [int(s) for s in shape]
+        while len(dims) > 1 and dims[-1] == 1:
+            dims.pop()
+        return out[:n].reshape(dims).copy()
