@@ -40,6 +40,58 @@ def cpu_baseline(weights, cfg, H, W):
                       f"{dt:.1f} s wall"}
 
 
+def flow_leg(args, local_rank, world, rank, dist):
+    """Secondary line: flow_raft on 1280x720 frames, 12 GRU iterations, 8 forward pairs per GPU per step
+    (BASELINE.json configs[2]); no --scale so the reference's 1559.6 GFLOP/pair-direction figure applies."""
+    from prisma_amd import engine, synth
+    H, W, pairs, iters = 720, 1280, args.flow_pairs, 12
+    wts = synth.raft_weights(seed=4321)
+    net = engine.FlowRaft(wts, device=local_rank)
+    frames = synth.frame_pair_sequence(pairs + 1, H, W, seed=50 + rank)
+    d_frames = torch.from_numpy(frames).cuda()
+    d_rgb = torch.empty((pairs, H, W, 3), dtype=torch.uint8, device="cuda")
+    d_mx = torch.empty((pairs,), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        net.infer_sequence_dev(d_frames.data_ptr(), pairs + 1, H, W, 1.0, iters, False, 0, d_rgb.data_ptr(), d_mx.data_ptr())
+        net.sync()
+
+    step()
+    net.set_profiling(timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fam = {}
+    steps = max(1, args.steps // 2)
+    for _ in range(steps):
+        step()
+        for s in net.kernel_stats():
+            f = fam.setdefault(s["name"], dict(ms=0.0, flops=0.0))
+            f["ms"] += s["ms"]; f["flops"] += s["flops"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    mx = d_mx.cpu().numpy()
+    assert np.isfinite(mx).all() and (mx > 0).all()
+    out = {"metric": "frame-pairs/sec (flow_raft, 1280x720, 12 iters, forward)", "value": round(world * pairs * steps / dt, 3),
+           "unit": "pairs/s", "ms_per_step": round(dt / steps * 1e3, 3), "pairs_per_step_per_gpu": pairs,
+           "model_tflops": round(pairs * steps / dt * 1559.6 / 1e3, 2),
+           "kernel_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in sorted(fam.items())},
+           "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items() if v["flops"] > 0 and v["ms"] > 0}}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import raft_oracle as R
+        cores = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(cores)
+        t0 = time.time()
+        R.infer_pair(wts, frames[0], frames[1], scale=1.0, iters=iters)
+        dt = time.time() - t0
+        out["cpu_baseline"] = {"value": round(1.0 / dt, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+                               "sample": f"1 pair 1280x720 fwd+bwd, oracle/raft_oracle.py, {dt:.1f} s wall (2 directions)"}
+    net.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,6 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256, 4 simple 256")
     ap.add_argument("--conv-tile", type=int, default=0)
+    ap.add_argument("--flow-pairs", type=int, default=8, help="frame pairs per GPU per step of the flow_raft leg (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,6 +166,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    net.close()
+    flow = flow_leg(args, local_rank, world, rank, dist) if args.flow_pairs > 0 else None
+
     if rank == 0:
         fps = world * B * args.steps / dt
         mm = d_mm.cpu().numpy()
@@ -142,11 +198,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, cfg, H, W)
+        if flow:
+            out["flow_raft"] = flow
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    net.close()
 
 
 if __name__ == "__main__":

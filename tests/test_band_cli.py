@@ -68,3 +68,27 @@ def test_cli_video_and_image(tmp_path):
     assert png.shape == (90, 160, 3)
     band.model.close()
     band.model = None
+
+
+@pytest.mark.gpu
+def test_flow_cli_video(tmp_path):
+    import flow_raft as band
+    from prisma_amd import synth
+    folder = tmp_path / "clip"
+    folder.mkdir()
+    frames = synth.frame_pair_sequence(4, 176, 256, seed=6)
+    np.save(folder / "rgba.npy", frames)
+    (folder / "metadata.json").write_text(json.dumps({"bands": {"rgba": {"url": "rgba.npy"}}}))
+    os.environ["PRISMA_OVERWRITE"] = "1"
+    band.model = None
+    band.main(["-i", str(folder), "--iterations", "4", "--scale", "1.0", "-b"])
+    out = np.load(folder / "flow_raft.npy")
+    assert out.shape == (4, 176, 256, 3) and out.dtype == np.uint8 and not out[-1].any()
+    assert np.load(folder / "flow_raft_bwd.npy").shape == out.shape
+    dist = [float(x) for x in open(folder / "flow_raft.csv")]
+    assert len(dist) == 4 and dist[-1] == 0.0 and all(d > 0 for d in dist[:-1])
+    md = json.load(open(folder / "metadata.json"))
+    assert md["bands"]["flow_raft"]["values"]["dist"] == {"type": "float", "url": "flow_raft.csv"}
+    assert md["bands"]["flow_raft_bwd"]["url"] == "flow_raft_bwd.npy"
+    band.model.close()
+    band.model = None

@@ -9,7 +9,7 @@ from oracle import raft_oracle as R
 from prisma_amd import engine, synth
 
 pytestmark = pytest.mark.gpu
-TOL_RANGE, TOL_L2 = 5e-3, 3e-3
+TOL_RANGE, TOL_L2 = 3e-3, 2e-3
 
 
 def relmax(a, b):
