@@ -159,12 +159,22 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         int r;
         { NEED(wt, b + "attn.qkv.weight", (int64_t)3 * D * D); NEED(bs, b + "attn.qkv.bias", 3 * D);
           if ((r = pack(wt, 3 * D, D, D, B.qkv, bs))) return r; }
-        { NEED(wt, b + "attn.proj.weight", (int64_t)D * D); NEED(bs, b + "attn.proj.bias", D);
-          if ((r = pack(wt, D, D, D, B.proj, bs))) return r; }
+        // LayerScale (layer_scale.py:27-28) is folded into the weights: x + g*(W y + b) = x + (g.W) y + g.b, so the GEMM
+        // can accumulate straight onto the residual stream
+        auto pack_scaled = [&](const float *wt, const float *bs, const float *g, int N, int K, PackedW &out) -> int {
+            std::vector<float> ws((size_t)N * K), bb(N);
+            for (int n = 0; n < N; ++n) {
+                for (int k = 0; k < K; ++k) ws[(size_t)n * K + k] = wt[(size_t)n * K + k] * g[n];
+                bb[n] = bs[n] * g[n];
+            }
+            return pack(ws.data(), N, K, K, out, bb.data());
+        };
+        { NEED(wt, b + "attn.proj.weight", (int64_t)D * D); NEED(bs, b + "attn.proj.bias", D); NEED(g1, b + "ls1.gamma", D);
+          if ((r = pack_scaled(wt, bs, g1, D, D, B.proj))) return r; }
         { NEED(wt, b + "mlp.fc1.weight", (int64_t)Hd * D); NEED(bs, b + "mlp.fc1.bias", Hd);
           if ((r = pack(wt, Hd, D, D, B.fc1, bs))) return r; }
-        { NEED(wt, b + "mlp.fc2.weight", (int64_t)D * Hd); NEED(bs, b + "mlp.fc2.bias", D);
-          if ((r = pack(wt, D, Hd, Hd, B.fc2, bs))) return r; }
+        { NEED(wt, b + "mlp.fc2.weight", (int64_t)D * Hd); NEED(bs, b + "mlp.fc2.bias", D); NEED(g2, b + "ls2.gamma", D);
+          if ((r = pack_scaled(wt, bs, g2, D, Hd, B.fc2))) return r; }
     }
     UP(normg_, P + "norm.weight", D);
     UP(normb_, P + "norm.bias", D);

@@ -190,6 +190,33 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
     }
 }
 
+// EPI_RESID: X += A W'^T + b' with LayerScale pre-folded into W' and b'.  The accumulators START from the fp32
+// residual tile (loaded in the prologue, under the first DMAs' latency) and are stored straight back from the
+// MFMA layout (32 consecutive columns per half wave = 128-byte segments): no LDS transpose, no read in the epilogue.
+template <int TM, int TN, bool STORE>
+__device__ __forceinline__ void resid_io(const GemmArgs &p, f32x16 (&acc)[TM][TN], int wave_m0, int wave_n0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = wave_n0 + tn * 32 + li;
+        const bool nok = n < p.N;
+        const int nc = nok ? n : p.N - 1;                   // loads are unconditional (clamped address): a per-element
+        const float b = STORE ? 0.f : p.bias[nc];           // conditional load would serialise on vmcnt(0) each
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wave_m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (STORE) {
+                    if (nok && m < p.M) p.resid[(int64_t)m * p.ldr + n] = acc[tm][tn][r];
+                } else {
+                    const int mc = m < p.M ? m : p.M - 1;
+                    acc[tm][tn][r] = p.resid[(int64_t)mc * p.ldr + nc] + b;
+                }
+            }
+    }
+}
+
 // Accumulators -> per-wave LDS patch -> 8-column chunks -> fused store.  `smem` must be free of live
 // staging data (callers barrier first).  TM x TN = 32x32 MFMA tiles per wave.
 template <int EPI, int TM, int TN>
@@ -386,6 +413,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (EPI == EPI_RESID) resid_io<TM, TN, false>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
 
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -410,7 +438,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     }
     __syncthreads();            // staging buffers are dead; reuse LDS for the epilogue patches
 
-    run_epilogue<EPI, TM, TN>(p, acc, smem, wave, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, n0);
+    if constexpr (EPI == EPI_RESID) resid_io<TM, TN, true>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
+    else run_epilogue<EPI, TM, TN>(p, acc, smem, wave, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, n0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -569,6 +598,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (EPI == EPI_RESID) resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
     f16x8 fa[2][4], fb0[4], fb1[4];
 
     const int S = 4 * nk;                                // half tiles this block stages in total
@@ -653,7 +683,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (p.dbg) ts2 = __builtin_readcyclecounter();
-    run_epilogue<EPI, 4, 2>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, n0);
+    if constexpr (EPI == EPI_RESID) resid_io<4, 2, true>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+    else run_epilogue<EPI, 4, 2>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, n0);
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long *d = p.dbg + (long long)blockIdx.x * 8;
