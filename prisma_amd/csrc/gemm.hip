@@ -415,25 +415,33 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if constexpr (EPI == EPI_RESID) resid_io<TM, TN, false>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
 
+    // K loop: one barrier per K tile; inside a tile the fragments of k-step ks+1 are read from LDS while the
+    // MFMAs of k-step ks run (register double buffer), and the next tile's DMAs are issued behind the first reads.
+    f16x8 af[2][TM], bf[2][TN];
+    auto load_frags = [&](int buf, const char *sb, int ks) {
+        const int c = ((2 * ks + lh) ^ fsw) * 16;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[buf][t] = *(const f16x8 *)(sb + a_off[t] + c);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bf[buf][t] = *(const f16x8 *)(sb + b_off[t] + c);
+    };
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char *sb = smem + (kt & 1) * STAGE;
+        load_frags(0, sb, 0);
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int c = ((2 * ks + lh) ^ fsw) * 16;
-            f16x8 af[TM], bf[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t) af[t] = *(const f16x8 *)(sb + a_off[t] + c);
-#pragma unroll
-            for (int t = 0; t < TN; ++t) bf[t] = *(const f16x8 *)(sb + b_off[t] + c);
+            if (ks < 3) load_frags((ks + 1) & 1, sb, ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();            // staging buffers are dead; reuse LDS for the epilogue patches
@@ -473,7 +481,8 @@ __device__ __forceinline__ void vm_wait_halftiles(int n) {
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-// VAR != 0 are timing-only ablations (wrong results): 1 no DMA in the loop, 2 no vmcnt waits, 3 no ds_reads.
+// VAR != 0 are timing-only ablations (wrong results): 1 no DMA in the loop, 2 no vmcnt waits, 3 no ds_reads,
+// 5 DMA + barriers only (no ds_reads, no MFMAs), 6 MFMAs + barriers only.
 template <int AMODE, int EPI, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     constexpr int BM = 256, BN = 256;
@@ -613,7 +622,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     for (int t = 0; t < nk; ++t) {
         const char *sb = smem + (t & 1) * BUF;
         // ================= p0 =================
-        if (VAR != 3 || t == 0) {
+        if ((VAR != 3 && VAR != 5 && VAR != 6) || t == 0) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fb0[ks] = *(const f16x8 *)(sb + b_base + (c0 ^ (ks * 32)));
 #pragma unroll
@@ -621,10 +630,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const f16x8 *)(sb + a_base + rt * 4096 + (c0 ^ (ks * 32)));
         }
-        if (VAR != 1 && t + 1 < nk) stage_b(1, t + 1);
-        if (VAR == 0 || VAR == 3) vm_wait_halftiles(S - (4 * t + 3));
+        if (VAR != 1 && VAR != 6 && t + 1 < nk) stage_b(1, t + 1);
+        if (VAR == 0 || VAR == 3 || VAR == 5) vm_wait_halftiles(S - (4 * t + 3));
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
+        if (VAR != 5)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -633,14 +643,15 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
         // ================= p1 =================
-        if (VAR != 3 || t == 0) {
+        if ((VAR != 3 && VAR != 5 && VAR != 6) || t == 0) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fb1[ks] = *(const f16x8 *)(sb + b_base + 4096 + (c0 ^ (ks * 32)));
         }
-        if (VAR != 1 && t + 1 < nk) stage_a(1, t + 1);
-        if (VAR == 0 || VAR == 3) vm_wait_halftiles(S - (4 * t + 4));
+        if (VAR != 1 && VAR != 6 && t + 1 < nk) stage_a(1, t + 1);
+        if (VAR == 0 || VAR == 3 || VAR == 5) vm_wait_halftiles(S - (4 * t + 4));
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
+        if (VAR != 5)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -649,16 +660,17 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
         // ================= p2 =================
-        if (VAR != 3)
+        if (VAR != 3 && VAR != 5 && VAR != 6)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 fa[rt][ks] = *(const f16x8 *)(sb + a_base + 8192 + rt * 4096 + (c0 ^ (ks * 32)));
-        if (VAR != 1 && t + 2 < nk) stage_a(0, t + 2);
-        if (VAR == 0 || VAR == 3) vm_wait_halftiles(S - (4 * t + 4));
+        if (VAR != 1 && VAR != 6 && t + 2 < nk) stage_a(0, t + 2);
+        if (VAR == 0 || VAR == 3 || VAR == 5) vm_wait_halftiles(S - (4 * t + 4));
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
+        if (VAR != 5)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -667,10 +679,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
         // ================= p3 =================
-        if (VAR != 1 && t + 2 < nk) stage_b(0, t + 2);
-        if (VAR == 0 || VAR == 3) vm_wait_halftiles(S - (4 * t + 6));
+        if (VAR != 1 && VAR != 6 && t + 2 < nk) stage_b(0, t + 2);
+        if (VAR == 0 || VAR == 3 || VAR == 5) vm_wait_halftiles(S - (4 * t + 6));
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
+        if (VAR != 5)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -756,6 +769,8 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         if (tile == 18) return launch_g8<A_DENSE, EPI_STD, 1>(stream, a);
         if (tile == 34) return launch_g8<A_DENSE, EPI_STD, 2>(stream, a);
         if (tile == 50) return launch_g8<A_DENSE, EPI_STD, 3>(stream, a);
+        if (tile == 82) return launch_g8<A_DENSE, EPI_STD, 5>(stream, a);
+        if (tile == 98) return launch_g8<A_DENSE, EPI_STD, 6>(stream, a);
     }
 #define PB_CASE(AM, EP) \
     if (amode == AM && epi == EP) return launch_tile<AM, EP>(stream, tile, a)
