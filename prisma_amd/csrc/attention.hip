@@ -27,7 +27,7 @@ namespace {
 struct AttnArgs {
     const f16 *q, *k, *vt;
     f16 *o;
-    int ntp, ntok, heads, ldo;
+    int ntp, ntok, heads, ldo, nq, nb;
 };
 
 template <int OCC>
@@ -36,8 +36,15 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnArgs p) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int qblk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-    const int64_t bh = (int64_t)b * p.heads + head;
+    // All q-blocks of one (b, head) run on ONE XCD (blockIdx % 8) so its K / Vt stream is fetched into one L2 only:
+    // with the natural (qblk, head, b) order the 20 q-blocks of a head spread over all 8 XCDs and rocprofv3 showed
+    // 1.4 GB of fabric fetches per launch against 0.48 GB of q/k/v.
+    const int nq = p.nq, nbh = p.heads * p.nb;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bhi = (slot / nq) * 8 + xcd, qblk = slot % nq;
+    if (bhi >= nbh) return;
+    const int b = bhi / p.heads, head = bhi - b * p.heads;
+    const int64_t bh = bhi;
     const f16 *Q = p.q + bh * p.ntp * 64;
     const f16 *K = p.k + bh * p.ntp * 64;
     const f16 *Vt = p.vt + bh * 64 * p.ntp;
@@ -167,8 +174,9 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnArgs p) {
 
 int launch_attention(hipStream_t stream, const f16 *q, const f16 *k, const f16 *vt, f16 *o, int B, int heads,
                      int ntp, int ntok, int ldo) {
-    AttnArgs a{q, k, vt, o, ntp, ntok, heads, ldo};
-    dim3 grid((ntok + 127) / 128, heads, B);
+    const int nq = (ntok + 127) / 128;
+    AttnArgs a{q, k, vt, o, ntp, ntok, heads, ldo, nq, B};
+    dim3 grid(8 * nq * ((B * heads + 7) / 8));
     static int variant = -1;
     if (variant < 0) { const char *e = getenv("PB_ATTN_OCC"); variant = e ? atoi(e) : 2; }
     if (variant == 3) hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(256), 0, stream, a);
