@@ -320,3 +320,21 @@ def encode_depth_video(pred: np.ndarray, flip: bool = True):
             d = np.float32(1.0) - d
         rgb = (heat_to_rgb(d.astype(np.float64)) * 255).astype(np.uint8)
     return rgb, float(dmin), float(dmax)
+
+
+def rgb_to_heat(rgb_u8: np.ndarray) -> np.ndarray:
+    """Decode contract of the viewer (bands/common/encode.py:36-64 rgb_to_hsv / rgb_to_heat, used by
+    view.py:186-210): uint8 heat image -> heat in 0..1."""
+    rgb = rgb_u8.astype("float")
+    maxv, maxc = rgb.max(axis=2), rgb.argmax(axis=2)
+    minv, minc = rgb.min(axis=2), rgb.argmin(axis=2)
+    eps = np.spacing(1)
+    hue = np.zeros(maxv.shape)
+    h0 = ((rgb[..., 1] - rgb[..., 2]) * 60.0 / (maxv - minv + eps)) % 360.0
+    h1 = (rgb[..., 2] - rgb[..., 0]) * 60.0 / (maxv - minv + eps) + 120.0
+    h2 = (rgb[..., 0] - rgb[..., 1]) * 60.0 / (maxv - minv + eps) + 240.0
+    hue[maxc == 0] = h0[maxc == 0]
+    hue[maxc == 1] = h1[maxc == 1]
+    hue[maxc == 2] = h2[maxc == 2]
+    hue[maxc == minc] = 0.0
+    return np.clip(1.0 - hue / 360.0 * 1.538461538, 0.0, 1.0)

@@ -46,6 +46,7 @@ struct GemmArgs {
     float *depth = nullptr;
     // optional per-block timing stamps (8 x int64 per block): see gemm8_kernel
     long long *dbg = nullptr;
+    int stagger = 0;                      // first-wave workgroups sleep ((id >> 3) & 7) * stagger * 64 cycles: see gemm.hip
 };
 
 // Launches the kernel on `stream`.  tile: TILE_AUTO picks from the shape.

@@ -19,7 +19,21 @@
 //   * blockIdx is remapped so that each XCD (private L2) works on a contiguous range of tiles.
 #include "gemm.h"
 
+#include <stdlib.h>
+
 namespace {
+
+// All CUs start their first tile together and every tile of a launch takes the same time, so without help every
+// CU reaches its epilogue at the same moment: the whole chip writes 256 x (128..512 KB) at once and each epilogue
+// lasts as long as that HBM burst (measured 14k-38k cycles against a 51k-cycle main loop), while HBM idles during
+// the main loops.  Delaying the first-wave workgroups by eighths of a tile period de-phases the CUs for the rest
+// of the launch; stores then drain under other CUs' MFMA time.
+__device__ __forceinline__ void stagger_start(int stagger, int first_wave) {
+    if (stagger > 0 && (int)blockIdx.x < first_wave) {
+        const int n = ((blockIdx.x >> 3) & 7) * stagger;     // units of 64 cycles
+        for (int i = 0; i < n; i += 100) __builtin_amdgcn_s_sleep(100);
+    }
+}
 
 // ---- fused epilogues ---------------------------------------------------------------------------
 // A lane owns the same 8 output columns (n .. n+7) for every row it stores, so everything that
@@ -330,6 +344,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
+    stagger_start(p.stagger, BM == 128 ? 512 : 256);
 
     // ---- tile id with XCD-contiguous remap (bijective for any grid size) ----
     const int tilesN = (p.N + BN - 1) / BN;
@@ -494,6 +509,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     const int lane = tid & 63;
     const int wr = wave >> 2, wc = wave & 3;
     long long ts0 = 0, ts1 = 0, ts2 = 0, tr0 = 0;
+    stagger_start(p.stagger, 256);
     if (p.dbg) { ts0 = __builtin_readcyclecounter(); tr0 = wall_clock64(); }
 
     const int tilesN = (p.N + BN - 1) / BN;
@@ -755,10 +771,18 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
 
 }  // namespace
 
-int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a) {
+int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a_in) {
+    GemmArgs a = a_in;
     PB_CHECK(a.K > 0 && a.K % 64 == 0, -1, "gemm: K=%d must be a positive multiple of 64", a.K);
     PB_CHECK(a.M > 0 && a.N > 0 && a.N % 8 == 0, -1, "gemm: bad M=%d N=%d", a.M, a.N);
     if (amode == A_CONV) PB_CHECK(a.cC % 64 == 0 && a.cLd % 8 == 0 && a.zero, -1, "conv: channels %d (x64) / pixel stride %d (x8)", a.cC, a.cLd);
+    {   // experiment switch: PB_GEMM_STAGGER=<percent> de-phases the CUs by that share of 1/8 tile period per step
+        static int env_st = -2;
+        if (env_st == -2) { const char *e = getenv("PB_GEMM_STAGGER"); env_st = e ? atoi(e) : -1; }
+        const int nk = a.K / 64;
+        const int est = (3200 * nk + 24000) / 8 / 64;
+        a.stagger = env_st > 0 ? est * env_st / 100 : 0;    // measured: no gain (0.97-1.0x), so off unless requested
+    }
     if (tile == TILE_AUTO) {
         // 256x256 needs wide N and enough tiles to fill 256 CUs; the q/k/v split needs D % BN == 0
         const bool wide = a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256;

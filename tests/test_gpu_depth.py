@@ -105,3 +105,25 @@ def test_1080p_maps_to_same_network_and_runs():
     ref = O.infer(w, f[0], c.depth, c.heads)
     assert relmax(d[0], ref) < TOL_RANGE
     net.close()
+
+
+def test_1080p_batch_encode_round_trip_and_errors():
+    """Size-independent properties at BASELINE's full frame size: the heat encoding decodes back (viewer
+    contract, encode.py:36-64) to the normalised, flipped depth; min/max are exact; bad calls fail loudly."""
+    c = synth.DEPTH_CFGS["vits"]
+    w = synth.depth_anything_weights(c, seed=1234)
+    net = engine.DepthAnything(w, c, device=0, max_batch=3)
+    f = synth.frames(3, 1080, 1920, seed=8)
+    d, rgb, mn, mx = net.infer_batch(f)
+    for i in range(3):
+        assert mn[i] == d[i].min() and mx[i] == d[i].max()
+        norm = (d[i] - mn[i]) / (mx[i] - mn[i])
+        heat = O.rgb_to_heat(rgb[i])
+        assert np.abs(heat - (1.0 - norm)).max() < 0.012          # 8-bit ramp: ~3 counts of 255 over 0.65 turn
+    with pytest.raises(engine._lib.PrismaBandsError, match="bad arguments"):
+        net.infer_batch(np.zeros((0, 8, 8, 3), np.uint8))
+    net.close()
+    bad = dict(w)
+    bad.pop("pretrained.blocks.3.mlp.fc1.weight")
+    with pytest.raises(engine._lib.PrismaBandsError, match="missing weight 'pretrained.blocks.3.mlp.fc1.weight'"):
+        engine.DepthAnything(bad, c, device=0)
