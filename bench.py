@@ -166,6 +166,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # latency of BASELINE.json configs[1]: one 1280x720 frame, batch 1 (rank 0 only, outside the timed region above)
+    lat_b1 = None
+    if rank == 0:
+        f1 = torch.from_numpy(synth.frames(1, 720, 1280, seed=7)).cuda()
+        r1 = torch.empty((1, 720, 1280, 3), dtype=torch.uint8, device="cuda")
+        for i in range(8):
+            if i == 3:
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+            net.infer_dev(f1.data_ptr(), 1, 720, 1280, 0, r1.data_ptr(), d_mm[0].data_ptr(), d_mm[1].data_ptr(), True)
+            net.sync()
+        lat_b1 = (time.perf_counter() - t1) / 5 * 1e3
     net.close()
     flow = flow_leg(args, local_rank, world, rank, dist) if args.flow_pairs > 0 else None
 
@@ -192,6 +203,7 @@ def main():
                          "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5),
                          "flop_per_launch": g["flops"] / max(g["launches"], 1)},
             "model_tflops": round(fps * GFLOP_PER_FRAME / 1e3 / world, 2),
+            "latency_720p_batch1_ms": round(lat_b1, 3),
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(fam.items())},
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items()
                               if v["flops"] > 0 and v["ms"] > 0},

@@ -121,7 +121,9 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnArgs p) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) mx = fmaxf(mx, s[kt][g]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (__any(mx > mrun)) {                              // wave-uniform: rescale only when a row max grew
+        // Deferred rescale: keep the old reference max while no row max grew by more than 4 (P <= e^4 = 55, still
+        // exact to fp16's 11 bits; l and O accumulate in fp32), so most tiles skip the O rescale entirely.
+        if (__any(mx > mrun + 4.0f)) {
             const float mnew = fmaxf(mrun, mx);
             const float alpha = exp2f((mrun - mnew) * L2E);
             mrun = mnew;
