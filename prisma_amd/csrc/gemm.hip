@@ -48,15 +48,17 @@ struct EpiAux {
 };
 
 __device__ __forceinline__ float fast_gelu(float x) {
-    // x * Phi(x), erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7): one rcp, one exp, 5 fma
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    float y = fmaf(t, 1.061405429f, -1.453152027f);
-    y = fmaf(t, y, 1.421413741f);
-    y = fmaf(t, y, -0.284496736f);
-    y = fmaf(t, y, 0.254829592f);
-    const float e = 1.0f - y * t * __expf(-z * z);        // erf(|x| / sqrt2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
+    // exact-erf GELU as  max(x, 0) - |x| * Q(|x|),  Q(a) = 0.5 erfc(a / sqrt 2) = 2^P(a): a degree-5 minimax fit of
+    // log2 Q on [0, 6.5] weighted by a Q(a) (tools: numpy lstsq, max |error| of the whole expression 6.4e-7 in fp32
+    // Horner arithmetic, i.e. below fp32 round-off of the result for |x| > 4).  5 FMAs + one v_exp_f32; the A&S
+    // 7.1.26 form needed an rcp and an exp and twice the VALU work (14k of a 75k-cycle fc1 tile).
+    const float a = fminf(fabsf(x), 6.5f);
+    float p = fmaf(a, -0.00047330817324109375f, 0.007084541954100132f);
+    p = fmaf(a, p, -0.051827322691679f);
+    p = fmaf(a, p, -0.45999252796173096f);
+    p = fmaf(a, p, -1.1507878303527832f);
+    p = fmaf(a, p, -1.000037670135498f);
+    return fmaxf(x, 0.f) - a * __builtin_amdgcn_exp2f(p);
 }
 
 template <int EPI>
@@ -224,11 +226,142 @@ __device__ __forceinline__ void resid_io(const GemmArgs &p, f32x16 (&acc)[TM][TN
                 if (STORE) {
                     if (nok && m < p.M) p.resid[(int64_t)m * p.ldr + n] = acc[tm][tn][r];
                 } else {
+                    // clamped row: keeps the load addresses distinct from the epilogue's store addresses - if the
+                    // compiler CSEs the two it keeps 128 address pairs live across the main loop and spills
                     const int mc = m < p.M ? m : p.M - 1;
                     acc[tm][tn][r] = p.resid[(int64_t)mc * p.ldr + nc] + b;
                 }
             }
     }
+}
+
+// ---- interleaved output columns (fp16 epilogues, TN == 2) -----------------------------------------
+// A global store instruction is cheapest when each half wave writes ONE contiguous 128-byte line (measured:
+// ~11 cycles per instruction and CU for 2 x 128 B against ~140 for the 8 x 128 B pattern of the LDS-transposed
+// epilogue, which made a 256 x 256 fp16 tile cost 18-22k cycles).  In the MFMA layout a lane owns column `li`
+// of each 32-wide tile, so the two tiles of a wave are fed weight rows in the order  LDS row (tn*32 + j) <-
+// column 2j + tn : lane li then holds columns 2 li and 2 li + 1 of a row in acc[.][0] / acc[.][1], packs them
+// into one dword, and 32 lanes cover 64 consecutive fp16 columns = 128 bytes.  Only the DMA source rows of
+// the weight operand change; nothing moves between lanes.
+template <int EPI, int TN>
+__host__ __device__ constexpr bool epi_interleaved() {
+    return TN == 2 && (EPI == EPI_STD || EPI == EPI_QKV || EPI == EPI_PIXSHUF);
+}
+__device__ __forceinline__ int col_map(int r, bool il) {        // tile-local B row -> tile-local output column
+    return il ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;
+}
+
+template <int EPI, int TM, bool CHECK>
+__device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int n = wave_n0 + 2 * li;
+    const bool nok = n < p.N;
+    const int nc = nok ? n : 0;
+    float b0 = 0.f, b1 = 0.f;
+    if (p.bias) {
+        const int bi = EPI == EPI_PIXSHUF ? nc % p.ps_co : nc;
+        b0 = p.bias[bi]; b1 = p.bias[bi + 1];
+    }
+    // per-wave constants of the split / shuffle epilogues (a wave's 64 columns never straddle a head or a tap)
+    f16 *qk_base = nullptr;
+    float qs = 1.f;
+    int tap_dy = 0, tap_dx = 0, co = 0;
+    if constexpr (EPI == EPI_QKV) {
+        const int which = wave_n0 / p.D, hn = wave_n0 - which * p.D;
+        qk_base = (which == 0 ? p.q : p.k) + (int64_t)(hn >> 6) * p.ntp * 64 + 2 * li;
+        qs = which == 0 ? p.qscale : 1.f;
+    }
+    if constexpr (EPI == EPI_PIXSHUF) {
+        const int tap = wave_n0 / p.ps_co;
+        co = wave_n0 - tap * p.ps_co + 2 * li;
+        tap_dy = tap / p.ps_s; tap_dx = tap - tap_dy * p.ps_s;
+    }
+#pragma unroll
+    for (int th = 0; th < TM * 2; ++th) {                   // 8 accumulator registers (= 16 rows) per pass
+        const int tm = th >> 1, r0 = (th & 1) * 8;
+        int64_t off[8];
+        bool ok[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = r0 + q;
+            const int m = wave_m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            ok[q] = !CHECK || (nok && m < p.M);
+            const int mc = (!CHECK || m < p.M) ? m : p.M - 1;
+            if constexpr (EPI == EPI_QKV) {
+                const int b = mc / p.ntp, t = mc - b * p.ntp;
+                off[q] = ((int64_t)b * p.heads * p.ntp + t) * 64;
+            } else if constexpr (EPI == EPI_PIXSHUF) {
+                const int hw = p.ps_h * p.ps_w;
+                const int b = mc / hw, rem = mc - b * hw;
+                const int y = rem / p.ps_w, x = rem - y * p.ps_w;
+                off[q] = (((int64_t)b * p.ps_h * p.ps_s + (y * p.ps_s + tap_dy)) * (p.ps_w * p.ps_s) + (x * p.ps_s + tap_dx)) * p.ldo + co;
+            } else {
+                off[q] = (int64_t)mc * p.ldo + nc;
+            }
+        }
+        // every runtime switch (skip tensors, ReLU'd copy, activation) wraps a whole 8-register loop, never a
+        // single element: per-element branches on kernel arguments explode into hundreds of exec-mask branches
+        float v0[8], v1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { v0[q] = acc[tm][0][r0 + q] + b0; v1[q] = acc[tm][1][r0 + q] + b1; }
+        if constexpr (EPI == EPI_STD) {
+            if (p.pre_relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            }
+            if (p.add1) {
+                f16x2 a[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add1 + off[q]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+            }
+            if (p.add2) {
+                f16x2 a[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add2 + off[q]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+            }
+            if (p.out2) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    f16x2 o2;
+                    o2[0] = (f16)fmaxf(v0[q], 0.f); o2[1] = (f16)fmaxf(v1[q], 0.f);
+                    if (!CHECK || ok[q]) *(f16x2 *)(p.out2 + off[q]) = o2;
+                }
+            }
+            if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fast_gelu(v0[q]); v1[q] = fast_gelu(v1[q]); }
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
+            } else if (p.act == ACT_TANH) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = tanhf(v0[q]); v1[q] = tanhf(v1[q]); }
+            }
+        }
+        f16 *dst = EPI == EPI_QKV ? qk_base : p.out;
+        if (EPI != EPI_STD || p.out) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f16x2 o;
+                o[0] = (f16)(v0[q] * qs); o[1] = (f16)(v1[q] * qs);
+                if (!CHECK || ok[q]) *(f16x2 *)(dst + off[q]) = o;
+            }
+        }
+    }
+}
+
+template <int EPI, int TM>
+__device__ __forceinline__ void direct_epilogue_f16(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
+    // interior tiles (the common case) store without per-lane predicates: each predicate costs an exec-mask branch
+    if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false>(p, acc, wave_m0, wave_n0, lane);
+    else direct_epilogue_f16_impl<EPI, TM, true>(p, acc, wave_m0, wave_n0, lane);
 }
 
 // Accumulators -> per-wave LDS patch -> 8-column chunks -> fused store.  `smem` must be free of live
@@ -238,6 +371,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
                                              int wave_m0, int wave_n0, int n0) {
     constexpr int ES = TN * 32 + 4;
     constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * ES * 4;
+    constexpr bool IL = epi_interleaved<EPI, TN>();
     const int li = lane & 31, lh = lane >> 5;
     float *es = (float *)(smem + wave * EPIB);
 
@@ -246,7 +380,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
             // V third: transpose through LDS so that stores run along the token axis of Vt.
             float bb[TN];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bb[tn] = p.bias[wave_n0 + tn * 32 + li];
+            for (int tn = 0; tn < TN; ++tn) bb[tn] = p.bias[wave_n0 + (IL ? 2 * li + tn : tn * 32 + li)];
 #pragma unroll
             for (int tmi = 0; tmi < TM; ++tmi) {
 #pragma unroll
@@ -256,7 +390,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
                         f32x4 w4;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) w4[j] = acc[tmi][tn][g * 4 + j] + bb[tn];
-                        *(f32x4 *)(es + (tn * 32 + li) * 36 + 8 * g + 4 * lh) = w4;
+                        *(f32x4 *)(es + (IL ? 2 * li + tn : tn * 32 + li) * 36 + 8 * g + 4 * lh) = w4;
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -281,6 +415,13 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
         }
     }
 
+    if constexpr (IL) {
+        const bool direct = EPI != EPI_PIXSHUF || (p.ps_co & 63) == 0;
+        if (direct) {
+            direct_epilogue_f16<EPI, TM>(p, acc, wave_m0, wave_n0, lane);
+            return;
+        }
+    }
     constexpr int CPR = TN * 4;                             // 8-column chunks per patch row
     constexpr int NIT = 32 * CPR / 64;                      // rows per lane per pass
     constexpr int RSTEP = 64 / CPR;
@@ -296,7 +437,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + tn * 32 + li] = acc[tmi][tn][r];
+                es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + (IL ? 2 * li + tn : tn * 32 + li)] = acc[tmi][tn][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float v[NIT][8];
         EpiAux aux[NIT];
@@ -381,7 +522,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     }
     const f16 *b_ptr[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) b_ptr[i] = p.W + (int64_t)(n0 + srow + i * (NT / 8)) * p.K + cg * 8;
+    for (int i = 0; i < NB; ++i)
+        b_ptr[i] = p.W + (int64_t)(n0 + col_map(srow + i * (NT / 8), epi_interleaved<EPI, TN>())) * p.K + cg * 8;
 
     int c_ky = 0, c_kx = 0, c_c0 = 0;                       // conv tap state of the NEXT stage call
     const int nk = p.K >> 6;
@@ -573,7 +715,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 a_iy0[hf][u] = oy * p.cStride - p.cPad;
                 a_ix0[hf][u] = ox * p.cStride - padx;
             }
-            b_ptr[hf][u] = p.W + (int64_t)(n0 + b_row0[hf][u] + lrow) * p.K + cgu[u] * 8;
+            b_ptr[hf][u] = p.W + (int64_t)(n0 + col_map(b_row0[hf][u] + lrow, epi_interleaved<EPI, 2>())) * p.K + cgu[u] * 8;
         }
     const int nk = p.K >> 6;
     const int cpt = AMODE == A_CONV ? p.cC >> 6 : 1;     // K tiles per conv tap
@@ -715,12 +857,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     if constexpr (EPI == EPI_RESID) resid_io<4, 2, true>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
     else run_epilogue<EPI, 4, 2>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, n0);
     if (p.dbg && tid == 0) {
+        const long long t_issue = __builtin_readcyclecounter();      // all epilogue stores issued, none waited for
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long *d = p.dbg + (long long)blockIdx.x * 8;
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter(); d[4] = tr0; d[5] = wall_clock64();
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        d[6] = hw; d[7] = swz;
+        d[6] = t_issue; d[7] = swz;
     }
 }
 

@@ -10,18 +10,10 @@ for name, m, n, k, epi in [("fc1", 78336, 4096, 1024, 0), ("fc1-gelu", 78336, 40
     d = np.fromfile("/tmp/gemm_dbg.bin", dtype=np.int64).reshape(-1, 8)
     d = d[d[:, 3] != 0]
     pro, loop, epi_c, tot = d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2], d[:, 3] - d[:, 0]
+    print(f"    epilogue: issue {np.median(d[:, 6] - d[:, 2]):.0f} cycles, then drain (vmcnt 0) {np.median(d[:, 3] - d[:, 6]):.0f}; "
+          f"tile start spread (us, p10-p90 of first 256 blocks): {np.percentile((d[:256, 4] - d[:256, 4].min()) / 100.0, [10, 50, 90])}; "
+          f"end-time spread of blocks 256..511: {np.percentile((d[256:512, 5] - d[256:512, 5].min()) / 100.0, [10, 50, 90])}")
     real = (d[:, 5] - d[:, 4]) / 100.0     # us (100 MHz)
     print(f"{name}: {ms:.3f} ms/launch, blocks {len(d)}; cycles median: prologue {np.median(pro):.0f} loop {np.median(loop):.0f} "
           f"epilogue {np.median(epi_c):.0f} total {np.median(tot):.0f}; block wall median {np.median(real):.2f} us "
           f"(clock ~{np.median(tot / real) / 1e3:.2f} GHz); loop/k-tile {np.median(loop) / (k // 64):.0f} cyc")
-    # gap between consecutive blocks on the same CU
-    hw = d[:, 6]
-    cu = (hw >> 8) & 0xffffff   # everything above wave/simd id
-    gaps = []
-    for c in np.unique(cu):
-        r = d[cu == c]
-        r = r[np.argsort(r[:, 4])]
-        gaps += list((r[1:, 4] - r[:-1, 5]) / 100.0)
-    if gaps:
-        print(f"    per-CU gap between consecutive blocks: median {np.median(gaps):.2f} us, p90 {np.percentile(gaps, 90):.2f} us; "
-              f"span {(d[:, 5].max() - d[:, 4].min()) / 100.0:.1f} us")
