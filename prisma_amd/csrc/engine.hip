@@ -342,6 +342,9 @@ int DepthEngine::prepare(int B, int H, int W) {
     lh_[0] = 4 * gh_; lw_[0] = 4 * gw_; lh_[1] = 2 * gh_; lw_[1] = 2 * gw_; lh_[2] = gh_; lw_[2] = gw_;
     lh_[3] = (gh_ - 1) / 2 + 1; lw_[3] = (gw_ - 1) / 2 + 1;
     const int D = cfg_.embed_dim, F = cfg_.features, Fp = cp64(F), F2p = cp64(F / 2);
+    // GEMM row indices and per-tensor element offsets are 32-bit in the kernels
+    PB_CHECK((int64_t)B * nh_ * nw_ * F2p < (1LL << 31) && (int64_t)B * 4 * lh_[0] * lw_[0] * Fp < (1LL << 31), PB_ERR_ARG,
+             "batch %d too large for %dx%d frames (32-bit tensor offsets); lower max_batch", B, H, W);
     const int64_t rows = round_up((int64_t)B * ntp_, 256);
     const size_t slack = 32768;
     for (int pass = 0; pass < 2; ++pass) {

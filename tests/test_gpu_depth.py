@@ -127,3 +127,17 @@ def test_1080p_batch_encode_round_trip_and_errors():
     bad.pop("pretrained.blocks.3.mlp.fc1.weight")
     with pytest.raises(engine._lib.PrismaBandsError, match="missing weight 'pretrained.blocks.3.mlp.fc1.weight'"):
         engine.DepthAnything(bad, c, device=0)
+
+
+def test_odd_aspect_ratio_baseline_config1_size():
+    """934x440 (the README / BASELINE configs[0] image size) -> network 518x1106, 37x79 patches."""
+    c = synth.DEPTH_CFGS["vits"]
+    w = synth.depth_anything_weights(c, seed=1234)
+    net = engine.DepthAnything(w, c, device=0, max_batch=1)
+    f = synth.frames(1, 440, 934, seed=12)
+    assert engine.net_size(440, 934) == (518, 1106)
+    d = net.infer(f[0])
+    ref = O.infer(w, f[0], c.depth, c.heads)
+    report("934x440", d, ref)
+    assert relmax(d, ref) < TOL_RANGE and rell2(d, ref) < TOL_L2
+    net.close()
