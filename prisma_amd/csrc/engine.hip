@@ -11,8 +11,11 @@
 #include <algorithm>
 
 namespace {
-const char *kFam[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost"};
-enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_COUNT = 6 };
+// families follow the kernel symbols rocprofv3 reports: gemm8_kernel<0,0,0> (fp16-out GEMMs: fc1, DPT 1x1 / convT),
+// <0,1,0> (residual-accumulating proj / fc2), <0,2,0> (qkv), <1,0,0> (implicit-GEMM convs), attn_kernel, ...
+const char *kFam[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost", "gemm_f16_resid",
+                      "gemm_f16_qkv"};
+enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_GEMM_RESID = 6, F_GEMM_QKV = 7, F_COUNT = 8 };
 inline int cp64(int c) { return (int)round_up(c, 64); }
 }  // namespace
 
@@ -417,7 +420,7 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
     a.zero = zero_;
     const double flops = 2.0 * a.M * (double)a.N * w.Kreal;
     const double bytes = 2.0 * ((double)a.M * w.Kreal + (double)a.N * w.Kreal + (double)a.M * a.N);
-    tic(amode == A_CONV ? F_CONV : F_GEMM, flops, bytes);
+    tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes);
     if (tile == TILE_AUTO) tile = amode == A_CONV ? conv_tile : gemm_tile;
     int r = launch_gemm(stream, amode, epi, tile, a);
     toc();
