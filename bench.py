@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256, 4 simple 256")
     ap.add_argument("--conv-tile", type=int, default=0)
+    ap.add_argument("--latency", action="store_true", help="also time one 1280x720 frame at batch 1 (BASELINE configs[1])")
     ap.add_argument("--flow-pairs", type=int, default=8, help="frame pairs per GPU per step of the flow_raft leg (0 = skip)")
     args = ap.parse_args()
 
@@ -168,7 +169,7 @@ def main():
 
     # latency of BASELINE.json configs[1]: one 1280x720 frame, batch 1 (rank 0 only, outside the timed region above)
     lat_b1 = None
-    if rank == 0:
+    if rank == 0 and args.latency:
         f1 = torch.from_numpy(synth.frames(1, 720, 1280, seed=7)).cuda()
         r1 = torch.empty((1, 720, 1280, 3), dtype=torch.uint8, device="cuda")
         for i in range(8):
@@ -209,7 +210,7 @@ def main():
                          "flop_per_launch": g["flops"] / max(g["launches"], 1)},
             "gemm_family_tflops": round(mm_fl / (mm_ms * 1e-3) / 1e12, 2) if mm_ms > 0 else None,
             "model_tflops": round(fps * GFLOP_PER_FRAME / 1e3 / world, 2),
-            "latency_720p_batch1_ms": round(lat_b1, 3),
+            "latency_720p_batch1_ms": round(lat_b1, 3) if lat_b1 is not None else None,
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(fam.items())},
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items()
                               if v["flops"] > 0 and v["ms"] > 0},
