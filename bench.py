@@ -92,6 +92,20 @@ def flow_leg(args, local_rank, world, rank, dist):
     return out
 
 
+def pmc_traffic(symbol, batch):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC summary (tools/pmc_summary.py; separate
+    FETCH_SIZE / WRITE_SIZE passes over this same bench command at batch 32).  PMC passes cannot run inside the timed
+    bench, so the figure is read from profiles/ and only reported when the batch matches the one it was taken at."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01c_pmc_traffic.json")
+    if batch != 32 or not os.path.exists(path):
+        return None, None
+    want = symbol.replace(" ", "")
+    for name, v in json.load(open(path))["kernels"].items():
+        if want in name.replace(" ", ""):
+            return round(v["fetch_bytes"] + v["write_bytes"]), "profiles/r01c_pmc_traffic.json"
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +205,7 @@ def main():
                    "attention": "attn_kernel<2>"}
         dom_name, g = max(((k, v) for k, v in fam.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(symbols.get(dom_name, dom_name).split(" ")[0], B)
         mm_ms = sum(v["ms"] for k, v in fam.items() if k.startswith("gemm"))
         mm_fl = sum(v["flops"] for k, v in fam.items() if k.startswith("gemm"))
         out = {
@@ -205,7 +220,8 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s); min/max all-gather only"},
             "roofline": {"bound": "mfma", "kernel": symbols.get(dom_name, dom_name),
                          "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                          "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5),
                          "flop_per_launch": g["flops"] / max(g["launches"], 1)},
             "gemm_family_tflops": round(mm_fl / (mm_ms * 1e-3) / 1e12, 2) if mm_ms > 0 else None,
