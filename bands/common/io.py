@@ -75,14 +75,16 @@ class VideoWriter:
                 raise RuntimeError("writing .mp4 needs PyAV (reference dependency); write a .npy stack here") from e
             self._av = av.open(filename, mode="w")
             self._st = self._av.add_stream("libx264", rate=int(round(frame_rate)), options={"crf": "15"})
-            self._st.width, self._st.height, self._st.pix_fmt = width, height, "yuv420p"
+            self._w, self._h = 2 * round(width / 2), 2 * round(height / 2)
+            self._st.width, self._st.height, self._st.pix_fmt = self._w, self._h, "yuv420p"
 
     def write(self, rgb):
         if self._frames is not None:
             self._frames.append(np.ascontiguousarray(rgb))
             return
         import av
-        for pkt in self._st.encode(av.VideoFrame.from_ndarray(rgb, format="rgb24")):
+        frame = av.VideoFrame.from_ndarray(np.ascontiguousarray(rgb, np.uint8), format="rgb24")
+        for pkt in self._st.encode(frame.reformat(width=self._w, height=self._h)):     # io.py:297: frames may be scaled
             self._av.mux(pkt)
 
     def close(self):
@@ -132,3 +134,42 @@ def write_depth(path, depth, heat_rgb_fn, normalize=True, flip=False, heatmap=Tr
         rgb[0, 0] = float_to_rgb(dmin, 0.0, 1000.0)
         rgb[0, 1] = float_to_rgb(dmax, 0.0, 1000.0)
     write_rgb(path, (rgb * 255).astype(np.uint8))
+
+
+def write_flo(path, flow):
+    """Middlebury .flo (io.py:175-197): float32 magic 202021.25, int32 width, int32 height, float32 HxWx2."""
+    flow = np.ascontiguousarray(flow, np.float32)
+    with open(path, "wb") as f:
+        np.array([202021.25], np.float32).tofile(f)
+        np.array([flow.shape[1], flow.shape[0]], np.int32).tofile(f)
+        flow.tofile(f)
+
+
+def encode_flow(flow, mask):
+    """encode.py:105-110: 8.8 fixed point around 2^15 in uint16, validity in the third channel."""
+    q = np.float32(2 ** 15) + flow.astype(np.float32) * np.float32(2 ** 8)
+    ok = mask.astype(bool) & (q.max(axis=-1) < (2 ** 16 - 1)) & (0 < q.min(axis=-1))
+    return np.concatenate([q.astype(np.uint16), ok[..., None].astype(np.uint16) * (2 ** 16 - 1)], axis=-1)
+
+
+def write_png16(path, img_u16):
+    """16-bit RGB PNG, channel order as given (PIL cannot write this mode; cv2 is absent)."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(img_u16, np.uint16)
+    h, w, c = a.shape
+    assert c == 3
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), a.astype(">u2").view(np.uint8).reshape(h, w * 6)], axis=1).tobytes()
+
+    def chunk(tag, payload):
+        return struct.pack(">I", len(payload)) + tag + payload + struct.pack(">I", zlib.crc32(tag + payload) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def write_flow_png(path, flow, mask):
+    """cv2.imwrite(path, encode_flow(flow, mask)) (common/flow.py:96-99): OpenCV stores the array as B, G, R, so
+    the file's R channel is the validity mask, G is v and B is u."""
+    write_png16(path, encode_flow(flow, mask)[..., ::-1])

@@ -108,6 +108,20 @@ int pb_flow_infer_sequence(pb_ctx *ctx, const uint8_t *frames, int F, int H, int
                            float *flow_out, uint8_t *rgb_out, float *maxdisp_out);
 int pb_flow_infer_sequence_dev(pb_ctx *ctx, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
                                float *flow_out, uint8_t *rgb_out, float *maxdisp_out);
+/* Forward/backward consistency masks.  Replaces bands/common/flow.py:19-40 compute_fwdbwd_mask as
+ * called from bands/flow_raft.py:63-64: the opposite flow is sampled at p + f(p) with cv2.remap's INTER_LINEAR /
+ * BORDER_CONSTANT arithmetic, and mask = |f + f'| < alpha1 (|f| + |f'|) + alpha2 (reference defaults 0.05, 0.5).
+ *   pb_flow_infer_sequence_masks*: both directions are always computed (dirs = 2); flow_out / rgb_out / maxdisp_out
+ *     as above (any may be NULL), mask_out [F-1, 2, sh, sw] bytes of 0 / 1 (index 0 = forward mask, 1 = backward).
+ *   pb_flow_fwdbwd_mask: the mask step alone on host flows [n, 2, sh, sw, 2]. */
+int pb_flow_infer_sequence_masks(pb_ctx *ctx, const uint8_t *frames, int F, int H, int W, float scale, int iters,
+                                 float alpha1, float alpha2, float *flow_out, uint8_t *rgb_out, float *maxdisp_out,
+                                 uint8_t *mask_out);
+int pb_flow_infer_sequence_masks_dev(pb_ctx *ctx, const uint8_t *frames, int F, int H, int W, float scale, int iters,
+                                     float alpha1, float alpha2, float *flow_out, uint8_t *rgb_out, float *maxdisp_out,
+                                     uint8_t *mask_out);
+int pb_flow_fwdbwd_mask(pb_ctx *ctx, const float *flows, int n, int sh, int sw, float alpha1, float alpha2,
+                        uint8_t *mask_out);
 /* Stages of the last flow call: "fmap" [F,256,h/8,w/8], "flow_lo" [pairs*dirs, h/8*w/8, 2]. */
 int64_t pb_flow_get_stage(pb_ctx *ctx, const char *name, float *out, int64_t cap, int64_t shape_out[4]);
 

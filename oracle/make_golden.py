@@ -235,3 +235,4 @@ if __name__ == "__main__":
         full_case()
     if "raft" in which:
         raft_case()
+        raft_case(131, 181, 33, 8)      # pads to 136x184: 17 x 23 = 391 feature pixels, not a multiple of 8

@@ -242,3 +242,45 @@ def process_flow(flow: np.ndarray):
             rgb[..., c] = rgb[..., c] * rad + (1.0 - rad)
         out = (rgb * 255).astype(np.uint8)
     return out, mx
+
+
+def remap_linear_const(img: np.ndarray, map_xy: np.ndarray) -> np.ndarray:
+    """cv2.remap(img, map_xy, None, INTER_LINEAR, borderMode=BORDER_CONSTANT) for float32 img [h, w, c] and a
+    float32 absolute-coordinate map [h, w, 2] (bands/common/flow.py:19-26 warp_flow).  PARITY UNPINNED: OpenCV is
+    absent; this restates its published algorithm - coordinates quantised to 1/32 pixel by a round-half-even
+    `cvRound(x * 32)`, integer part by arithmetic shift, the 2x2 weights are products of the float32 tables
+    (1 - k/32, k/32), taps outside the image contribute the border value 0, accumulation in float32."""
+    h, w = img.shape[:2]
+    q = np.rint(map_xy.astype(np.float32) * np.float32(32.0)).astype(np.int64)
+    ix, iy = q[..., 0] >> 5, q[..., 1] >> 5
+    fx = (q[..., 0] & 31).astype(np.float32) * np.float32(1.0 / 32)
+    fy = (q[..., 1] & 31).astype(np.float32) * np.float32(1.0 / 32)
+    tx = (np.float32(1.0) - fx, fx)
+    ty = (np.float32(1.0) - fy, fy)
+    out = None
+    for k1 in range(2):
+        for k2 in range(2):
+            yy, xx = iy + k1, ix + k2
+            ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+            v = np.where(ok[..., None], img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)], np.float32(0.0))
+            term = (v * (ty[k1] * tx[k2])[..., None]).astype(np.float32)
+            out = term if out is None else (out + term).astype(np.float32)
+    return out
+
+
+def compute_fwdbwd_mask(fwd: np.ndarray, bwd: np.ndarray, alpha_1: float = 0.05, alpha_2: float = 0.5):
+    """bands/common/flow.py:28-40: warp the opposite flow by this one, keep pixels whose round trip closes to
+    within alpha_1 (|f| + |f'|) + alpha_2.  float32 throughout, as numpy evaluates the reference."""
+    def norm(a):
+        return np.sqrt((a[..., 0] * a[..., 0] + a[..., 1] * a[..., 1]).astype(np.float32)).astype(np.float32)
+
+    def one(f, other):
+        h, w = f.shape[:2]
+        grid = f.astype(np.float32).copy()
+        grid[..., 0] += np.arange(w)
+        grid[..., 1] += np.arange(h)[:, None]
+        warped = remap_linear_const(other.astype(np.float32), grid)
+        err = norm(f + warped)
+        return err < np.float32(alpha_1) * (norm(f) + norm(warped)) + np.float32(alpha_2)
+
+    return one(fwd, bwd), one(bwd, fwd)

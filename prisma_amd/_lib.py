@@ -45,6 +45,11 @@ SYMBOLS = {
     "pb_flow_out_size": (C.c_int, [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_flow_infer_sequence": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
     "pb_flow_infer_sequence_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
+    "pb_flow_infer_sequence_masks": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float,
+                                               _P, _P, _P, _P]),
+    "pb_flow_infer_sequence_masks_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
+                                                   C.c_float, _P, _P, _P, _P]),
+    "pb_flow_fwdbwd_mask": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     "pb_flow_get_stage": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "pb_dev_alloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
     "pb_dev_free": (C.c_int, [_P, _P]),

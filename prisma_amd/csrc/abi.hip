@@ -211,6 +211,53 @@ int pb_flow_infer_sequence(pb_ctx *c, const uint8_t *frames, int F, int H, int W
     return 0;
 }
 
+int pb_flow_infer_sequence_masks_dev(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters,
+                                     float alpha1, float alpha2, float *flow_out, uint8_t *rgb_out, float *maxdisp_out,
+                                     uint8_t *mask_out) {
+    PB_CHECK(c && c->raft, PB_ERR_STATE, "ctx has no flow_raft band");
+    PB_CHECK(mask_out, PB_ERR_ARG, "flow masks: mask_out is NULL");
+    return c->raft->infer(frames, F, H, W, scale, iters, 1, flow_out, rgb_out, maxdisp_out, mask_out, alpha1, alpha2);
+}
+
+int pb_flow_infer_sequence_masks(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters, float alpha1,
+                                 float alpha2, float *flow_out, uint8_t *rgb_out, float *maxdisp_out, uint8_t *mask_out) {
+    PB_CHECK(c && c->raft, PB_ERR_STATE, "ctx has no flow_raft band");
+    PB_CHECK(frames && F >= 2 && H > 0 && W > 0 && mask_out, PB_ERR_ARG, "flow masks: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    int sh, sw;
+    RaftEngine::out_size(H, W, scale, &sh, &sw);
+    const size_t nd = (size_t)(F - 1) * 2, px = (size_t)sh * sw;
+    DevMem dF, dO, dR, dM, dK;
+    PB_TRY(dF.alloc((size_t)F * H * W * 3));
+    if (flow_out) PB_TRY(dO.alloc(nd * px * 8));
+    if (rgb_out) PB_TRY(dR.alloc(nd * px * 3));
+    PB_TRY(dM.alloc(nd * 4));
+    PB_TRY(dK.alloc(nd * px));
+    PB_HIP(hipMemcpy(dF.p, frames, (size_t)F * H * W * 3, hipMemcpyHostToDevice));
+    PB_TRY(c->raft->infer(dF.as<uint8_t>(), F, H, W, scale, iters, 1, dO.as<float>(), dR.as<uint8_t>(), dM.as<float>(),
+                          dK.as<uint8_t>(), alpha1, alpha2));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    if (flow_out) PB_HIP(hipMemcpy(flow_out, dO.p, nd * px * 8, hipMemcpyDeviceToHost));
+    if (rgb_out) PB_HIP(hipMemcpy(rgb_out, dR.p, nd * px * 3, hipMemcpyDeviceToHost));
+    if (maxdisp_out) PB_HIP(hipMemcpy(maxdisp_out, dM.p, nd * 4, hipMemcpyDeviceToHost));
+    PB_HIP(hipMemcpy(mask_out, dK.p, nd * px, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pb_flow_fwdbwd_mask(pb_ctx *c, const float *flows, int n, int sh, int sw, float alpha1, float alpha2, uint8_t *mask_out) {
+    PB_CHECK(c && flows && mask_out && n > 0 && sh > 0 && sw > 0, PB_ERR_ARG, "fwdbwd_mask: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const size_t px = (size_t)n * 2 * sh * sw;
+    DevMem dO, dK;
+    PB_TRY(dO.alloc(px * 8));
+    PB_TRY(dK.alloc(px));
+    PB_HIP(hipMemcpy(dO.p, flows, px * 8, hipMemcpyHostToDevice));
+    PB_TRY(launch_fwdbwd_mask(c->stream, dO.as<float>(), n, sh, sw, alpha1, alpha2, dK.as<uint8_t>()));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(mask_out, dK.p, px, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int64_t pb_flow_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap, int64_t shape_out[4]) {
     PB_CHECK(c && c->raft && name && out && shape_out, PB_ERR_ARG, "flow get_stage: bad arguments");
     PB_HIP(hipSetDevice(c->device));

@@ -15,7 +15,8 @@ class RaftEngine {
     // frames: device uint8 [F, H, W, 3].  Outputs are device pointers (any may be null):
     //   flow_out [F-1, dirs, sh, sw, 2] fp32, rgb_out [F-1, dirs, sh, sw, 3] u8, maxdisp [F-1, dirs]
     int infer(const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward, float *flow_out,
-              uint8_t *rgb_out, float *maxdisp);
+              uint8_t *rgb_out, float *maxdisp, uint8_t *mask_out = nullptr, float alpha1 = 0.05f,
+              float alpha2 = 0.5f);
     int64_t get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]);
     int stats(pb_kernel_stat *out, int cap);
     static void out_size(int H, int W, float scale, int *sh, int *sw);
@@ -51,7 +52,7 @@ class RaftEngine {
     // plan
     int pF_ = 0, pH_ = 0, pW_ = 0, pD_ = 0;
     float pS_ = 0.f;
-    int sh_ = 0, sw_ = 0, Hp_ = 0, Wp_ = 0, padl_ = 0, padt_ = 0, h8_ = 0, w8_ = 0, P_ = 0;
+    int sh_ = 0, sw_ = 0, Hp_ = 0, Wp_ = 0, padl_ = 0, padt_ = 0, h8_ = 0, w8_ = 0, P_ = 0, P8_ = 0;
     int lh_[4] = {0, 0, 0, 0}, lw_[4] = {0, 0, 0, 0};
     char *arena_ = nullptr;
     size_t arena_bytes_ = 0, arena_off_ = 0;

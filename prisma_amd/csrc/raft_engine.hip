@@ -256,7 +256,7 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
     Hp_ = sh_ + ph; Wp_ = sw_ + pw;
     h8_ = Hp_ / 8; w8_ = Wp_ / 8; P_ = h8_ * w8_;
     PB_CHECK(h8_ >= 16 && w8_ >= 16, PB_ERR_ARG, "flow_raft: %dx%d is too small (the 4-level pyramid needs >= 128 px)", sh_, sw_);
-    PB_CHECK(P_ % 8 == 0, PB_ERR_ARG, "flow_raft: (H/8)*(W/8) = %d must be a multiple of 8", P_);
+    P8_ = (P_ + 7) / 8 * 8;       // row stride of the level-0 volume (the GEMM epilogue writes 8-column groups)
     lh_[0] = h8_; lw_[0] = w8_;
     for (int l = 1; l < 4; ++l) { lh_[l] = lh_[l - 1] / 2; lw_[l] = lw_[l - 1] / 2; }
     const int64_t ND = (int64_t)(F - 1) * dirs;
@@ -275,7 +275,7 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         for (auto &b : st_) b = (float *)carve((size_t)F * 256 * 2 * 4);
         fmap_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2 + slack);
         ctx_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2);
-        for (int l = 0; l < 4; ++l) pyr_[l] = (float *)carve((size_t)ND * P_ * lh_[l] * lw_[l] * 4 + slack);
+        for (int l = 0; l < 4; ++l) pyr_[l] = (float *)carve((size_t)ND * P_ * (l == 0 ? P8_ : lh_[l] * lw_[l]) * 4 + slack);
         const int64_t rows = round_up(ND * P_, 256);
         h32_ = (float *)carve((size_t)rows * 128 * 4); flow_ = (float *)carve((size_t)rows * 2 * 4);
         delta_ = (float *)carve((size_t)rows * 8 * 4); mask_ = (float *)carve((size_t)rows * 576 * 4);
@@ -338,8 +338,9 @@ int RaftEngine::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *o
 }
 
 int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward, float *flow_out,
-                      uint8_t *rgb_out, float *maxdisp) {
+                      uint8_t *rgb_out, float *maxdisp, uint8_t *mask_out, float alpha1, float alpha2) {
     PB_CHECK(frames && F >= 2 && H > 0 && W > 0 && iters >= 1 && scale > 0.f, PB_ERR_ARG, "flow infer: bad arguments");
+    PB_CHECK(!mask_out || backward, PB_ERR_ARG, "consistency masks need both directions (backward = 1)");
     PB_HIP(hipSetDevice(device));
     const int dirs = backward ? 2 : 1;
     int r = prepare(F, H, W, scale, dirs);
@@ -430,8 +431,8 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
             const int n = i * dirs + d;
             GemmArgs a;
             a.A = fmap_ + (int64_t)(i + d) * P_ * 256; a.lda = 256; a.M = P_;
-            a.W = fmap_ + (int64_t)(i + 1 - d) * P_ * 256; a.K = 256; a.N = P_;
-            a.out32 = pyr_[0] + (int64_t)n * P_ * P_; a.ldo = P_; a.scale = 1.f / 16.f; a.zero = zero_;
+            a.W = fmap_ + (int64_t)(i + 1 - d) * P_ * 256; a.K = 256; a.N = P8_;
+            a.out32 = pyr_[0] + (int64_t)n * P_ * P8_; a.ldo = P8_; a.scale = 1.f / 16.f; a.zero = zero_;
             tic(F_GEMM, 2.0 * P_ * (double)P_ * 256, 0);
             r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
             toc();
@@ -444,7 +445,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         }
     for (int l = 0; l < 3; ++l) {
         tic(F_ELT, 0, 0);
-        r = launch_corr_pool(stream, pyr_[l], pyr_[l + 1], rows, lh_[l], lw_[l]);
+        r = launch_corr_pool(stream, pyr_[l], pyr_[l + 1], rows, lh_[l], lw_[l], l == 0 ? P8_ : lh_[l] * lw_[l]);
         toc();
         if (r) return r;
     }
@@ -452,7 +453,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     // ---- GRU iterations (raft.py:124-144, update.py:122-136) ----
     for (int it = 0; it < iters; ++it) {
         tic(F_ELT, 0, 0);
-        r = launch_corr_lookup(stream, pyr_, lh_, lw_, flow_, P_, w8_, corr_, rows);
+        r = launch_corr_lookup(stream, pyr_, lh_, lw_, P8_, flow_, P_, w8_, corr_, rows);
         toc();
         if (r) return r;
         // BasicMotionEncoder
@@ -520,6 +521,10 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     if (r) return r;
     tic(F_PP, 0, (double)ND * sh_ * sw_ * 11);
     r = launch_flow_encode(stream, up, ND, sh_, sw_, maxd_, rgb_out, maxdisp);
+    toc();
+    if (r || !mask_out) return r;
+    tic(F_PP, 0, (double)ND * sh_ * sw_ * 17);
+    r = launch_fwdbwd_mask(stream, up, F - 1, sh_, sw_, alpha1, alpha2, mask_out);
     toc();
     return r;
 }

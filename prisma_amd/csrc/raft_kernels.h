@@ -11,9 +11,9 @@ int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, 
 int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, const float *sb, f16 *out, int B, int HW,
                     int C, int ldc);
 int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, float *flow, int64_t rows);
-int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, int h, int w);
-int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], const float *flow, int P,
-                       int w8, f16 *out, int64_t rows);
+int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, int h, int w, int src_ld);
+int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], int ld0, const float *flow,
+                       int P, int w8, f16 *out, int64_t rows);
 int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, int64_t rows);
 int launch_gru_rh(hipStream_t s, const f16 *zr, const float *h32, const f16 *hx, f16 *hx2, int64_t rows);
 int launch_gru_update(hipStream_t s, const f16 *zr, const f16 *q, float *h32, f16 *hx, int64_t rows);
@@ -22,3 +22,4 @@ int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, 
                     int sw, float *out, unsigned *maxd);
 int launch_flow_encode(hipStream_t s, const float *flow, int N, int sh, int sw, const unsigned *maxd, uint8_t *rgb,
                        float *max_out);
+int launch_fwdbwd_mask(hipStream_t s, const float *flow, int n, int h, int w, float a1, float a2, uint8_t *mask);

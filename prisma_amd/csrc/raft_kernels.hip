@@ -180,12 +180,12 @@ __global__ __launch_bounds__(256) void init_state_kernel(const f16 *__restrict__
 // correlation pyramid: level l+1 = avg_pool2d(level l, 2, 2) over the target dims (floor on odd sizes)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t NP,
-                                                         int h, int w, int oh, int ow) {
+                                                         int h, int w, int oh, int ow, int src_ld) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NP * oh * ow) return;
     const int x = (int)(i % ow), y = (int)((i / ow) % oh);
     const int64_t p = i / ((int64_t)ow * oh);
-    const float *s = src + p * h * w + (int64_t)(2 * y) * w + 2 * x;
+    const float *s = src + p * src_ld + (int64_t)(2 * y) * w + 2 * x;
     dst[i] = 0.25f * ((s[0] + s[1]) + (s[w] + s[w + 1]));
 }
 
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict_
 // y = cy/2^l + (j-4) with bilinear weights in pixel coordinates and zeros outside the level.
 // One thread per (pixel, level, i): the 9 j-samples share the x taps; output fp16 [rows][384].
 // ------------------------------------------------------------------------------------------------
-struct PyrPtrs { const float *lv[4]; int h[4], w[4]; };
+struct PyrPtrs { const float *lv[4]; int h[4], w[4], ld[4]; };
 
 __global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const float *__restrict__ flow, int P, int w8,
                                                            f16 *__restrict__ out, int64_t rows) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const floa
     const float cx = (float)(p % w8) + flow[r * 2], cy = (float)(p / w8) + flow[r * 2 + 1];
     const float inv = 1.f / (float)(1 << l);
     const int h = py.h[l], w = py.w[l];
-    const float *vol = py.lv[l] + r * (int64_t)h * w;
+    const float *vol = py.lv[l] + r * (int64_t)py.ld[l];
     // reproduce grid_sample's round trip: normalise then un-normalise (align_corners=True)
     const float x = ((2.f * (cx * inv + (float)(wi - 4)) / (float)(w - 1) - 1.f) + 1.f) * 0.5f * (float)(w - 1);
     const float x0f = floorf(x);
@@ -408,14 +408,14 @@ int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, float *f
     hipLaunchKernelGGL(init_state_kernel, dim3(nblk(rows * 32)), dim3(256), 0, s, c, h32, hx, flow, rows);
     LAUNCH_CHECK();
 }
-int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, int h, int w) {
-    hipLaunchKernelGGL(corr_pool_kernel, dim3(nblk(NP * (h / 2) * (w / 2))), dim3(256), 0, s, src, dst, NP, h, w, h / 2, w / 2);
+int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, int h, int w, int src_ld) {
+    hipLaunchKernelGGL(corr_pool_kernel, dim3(nblk(NP * (h / 2) * (w / 2))), dim3(256), 0, s, src, dst, NP, h, w, h / 2, w / 2, src_ld);
     LAUNCH_CHECK();
 }
-int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], const float *flow, int P,
-                       int w8, f16 *out, int64_t rows) {
+int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], int ld0, const float *flow,
+                       int P, int w8, f16 *out, int64_t rows) {
     PyrPtrs py;
-    for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; }
+    for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; py.ld[i] = i == 0 ? ld0 : h[i] * w[i]; }
     hipLaunchKernelGGL(corr_lookup_kernel, dim3(nblk(rows * 36)), dim3(256), 0, s, py, flow, P, w8, out, rows);
     LAUNCH_CHECK();
 }
@@ -448,4 +448,56 @@ int launch_flow_encode(hipStream_t s, const float *flow, int N, int sh, int sw, 
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(flow_encode_kernel, dim3(gx, N), dim3(256), 0, s, flow, (int64_t)sh * sw, maxd, rgb, max_out);
     LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward/backward consistency masks (bands/common/flow.py:19-40): the opposite flow is sampled at p + f(p)
+// the way cv2.remap(INTER_LINEAR, BORDER_CONSTANT) does - coordinates quantised to 1/32 px with a half-even
+// round, 2x2 weights as products of the float32 (1 - k/32, k/32) tables, zero outside - then
+// |f + f'| < a1 (|f| + |f'|) + a2.  Every step is a separately rounded fp32 operation, as numpy evaluates it.
+// flows: [n, 2, h, w, 2]; mask: [n, 2, h, w] bytes of 0 / 1.
+namespace {
+__device__ __forceinline__ float norm2_rn(float x, float y) {
+    return __fsqrt_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)));
+}
+
+__global__ __launch_bounds__(256) void fwdbwd_mask_kernel(const float2 *__restrict__ flow, int h, int w, float a1, float a2,
+                                                          uint8_t *__restrict__ mask) {
+    const int64_t hw = (int64_t)h * w;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const int nd = blockIdx.y;                                  // pair * 2 + direction
+    const float2 *self = flow + (int64_t)nd * hw, *other = flow + (int64_t)(nd ^ 1) * hw;
+    const int y = (int)(p / w), x = (int)(p - (int64_t)y * w);
+    const float2 f = self[p];
+    const int qx = __float2int_rn(__fmul_rn(__fadd_rn(f.x, (float)x), 32.f));
+    const int qy = __float2int_rn(__fmul_rn(__fadd_rn(f.y, (float)y), 32.f));
+    const int ix = qx >> 5, iy = qy >> 5;
+    const float fx = __fmul_rn((float)(qx & 31), 1.f / 32), fy = __fmul_rn((float)(qy & 31), 1.f / 32);
+    const float tx[2] = {__fsub_rn(1.f, fx), fx}, ty[2] = {__fsub_rn(1.f, fy), fy};
+    float wx = 0.f, wy = 0.f;
+#pragma unroll
+    for (int k1 = 0; k1 < 2; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int yy = iy + k1, xx = ix + k2;
+            float2 v = make_float2(0.f, 0.f);
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = other[(int64_t)yy * w + xx];
+            const float wt = __fmul_rn(ty[k1], tx[k2]);
+            const float tx_ = __fmul_rn(v.x, wt), ty_ = __fmul_rn(v.y, wt);
+            wx = (k1 | k2) ? __fadd_rn(wx, tx_) : tx_;
+            wy = (k1 | k2) ? __fadd_rn(wy, ty_) : ty_;
+        }
+    const float err = norm2_rn(__fadd_rn(f.x, wx), __fadd_rn(f.y, wy));
+    const float thr = __fadd_rn(__fmul_rn(a1, __fadd_rn(norm2_rn(f.x, f.y), norm2_rn(wx, wy))), a2);
+    mask[(int64_t)nd * hw + p] = err < thr ? 1 : 0;
+}
+}  // namespace
+
+int launch_fwdbwd_mask(hipStream_t s, const float *flow, int n, int h, int w, float a1, float a2, uint8_t *mask) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fwdbwd_mask_kernel, dim3(nblk((int64_t)h * w), 2 * n), dim3(256), 0, s, (const float2 *)flow, h, w, a1, a2,
+                       mask);
+    PB_HIP(hipGetLastError());
+    return 0;
 }

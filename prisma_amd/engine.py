@@ -262,6 +262,32 @@ class FlowRaft(_Ctx):
                                               _ptr(flow), _ptr(rgb), _ptr(mx)))
         return flow, rgb, mx
 
+    def infer_sequence_masks(self, frames: np.ndarray, scale: float = 0.75, iters: int = 12, alpha_1: float = 0.05,
+                             alpha_2: float = 0.5, want_flow: bool = True, want_rgb: bool = True):
+        """Both directions plus the forward/backward consistency masks (bands/flow_raft.py:58-64):
+        -> (flow | None, rgb | None, maxdisp [F-1,2], mask bool [F-1,2,sh,sw])."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        F, H, W, ch = frames.shape
+        assert ch == 3 and F >= 2
+        sh, sw = flow_out_size(H, W, scale)
+        flow = np.empty((F - 1, 2, sh, sw, 2), np.float32) if want_flow else None
+        rgb = np.empty((F - 1, 2, sh, sw, 3), np.uint8) if want_rgb else None
+        mx = np.empty((F - 1, 2), np.float32)
+        mask = np.empty((F - 1, 2, sh, sw), np.uint8)
+        check(self.lib.pb_flow_infer_sequence_masks(self.ctx, _ptr(frames), F, H, W, C.c_float(scale), iters,
+                                                    C.c_float(alpha_1), C.c_float(alpha_2), _ptr(flow), _ptr(rgb), _ptr(mx),
+                                                    _ptr(mask)))
+        return flow, rgb, mx, mask.view(np.bool_)
+
+    def fwdbwd_mask(self, flows: np.ndarray, alpha_1: float = 0.05, alpha_2: float = 0.5) -> np.ndarray:
+        """flows f32 [n,2,sh,sw,2] (forward, backward) -> bool [n,2,sh,sw] (bands/common/flow.py:28-40)."""
+        flows = np.ascontiguousarray(flows, np.float32)
+        n, d, sh, sw, two = flows.shape
+        assert d == 2 and two == 2
+        mask = np.empty((n, 2, sh, sw), np.uint8)
+        check(self.lib.pb_flow_fwdbwd_mask(self.ctx, _ptr(flows), n, sh, sw, C.c_float(alpha_1), C.c_float(alpha_2), _ptr(mask)))
+        return mask.view(np.bool_)
+
     def infer_sequence_dev(self, frames_ptr: int, F: int, H: int, W: int, scale: float, iters: int, backward: bool,
                            flow_ptr: int = 0, rgb_ptr: int = 0, max_ptr: int = 0):
         v = lambda p: C.c_void_p(p) if p else None

@@ -92,3 +92,57 @@ def test_flow_cli_video(tmp_path):
     assert md["bands"]["flow_raft_bwd"]["url"] == "flow_raft_bwd.npy"
     band.model.close()
     band.model = None
+
+
+def test_flow_file_writers(tmp_path):
+    """.flo layout (bands/common/io.py:175-197) and the 16-bit flow+mask PNG (encode.py:105-110 through cv2.imwrite)."""
+    from common.io import encode_flow, write_flo, write_flow_png
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    flow = (rng.standard_normal((6, 9, 2)) * 40).astype(np.float32)
+    flow[0, 0] = (200.0, 0.0)          # 2^15 + 200 * 256 overflows uint16 -> invalid
+    mask = rng.random((6, 9)) > 0.3
+    write_flo(str(tmp_path / "a.flo"), flow)
+    raw = open(tmp_path / "a.flo", "rb").read()
+    assert np.frombuffer(raw[:4], np.float32)[0] == np.float32(202021.25)
+    assert tuple(np.frombuffer(raw[4:12], np.int32)) == (9, 6)
+    assert np.array_equal(np.frombuffer(raw[12:], np.float32).reshape(6, 9, 2), flow)
+    enc = encode_flow(flow, mask)
+    assert enc.dtype == np.uint16 and enc.shape == (6, 9, 3) and enc[0, 0, 2] == 0
+    assert enc[1, 1, 0] == np.uint16(np.float32(32768) + flow[1, 1, 0] * np.float32(256))
+    assert np.array_equal(enc[..., 2] == 65535, mask & (enc[..., 2] == 65535)) and enc[..., 2][mask][1:].all()
+    write_flow_png(str(tmp_path / "a.png"), flow, mask)
+    png = np.asarray(Image.open(tmp_path / "a.png"))         # PIL reads the high bytes
+    assert np.array_equal(png, (enc[..., ::-1] >> 8).astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_flow_cli_masks_and_dumps(tmp_path):
+    import flow_raft as band
+    from prisma_amd import synth
+    folder = tmp_path / "clip"
+    folder.mkdir()
+    frames = synth.frame_pair_sequence(3, 176, 256, seed=6)
+    np.save(folder / "rgba.npy", frames)
+    (folder / "metadata.json").write_text(json.dumps({"bands": {"rgba": {"url": "rgba.npy"}}}))
+    os.environ["PRISMA_OVERWRITE"] = "1"
+    band.model = None
+    band.main(["-i", str(folder), "--iterations", "3", "--scale", "1.0", "-b", "--mask", "--subpath", "flo", "--subpath_mask", "fm"])
+    m = np.load(folder / "flow_raft_mask.npy")
+    assert m.shape == (3, 176, 256, 3) and set(np.unique(m)) <= {0, 255} and not m[-1].any()
+    assert np.load(folder / "flow_raft_mask_bwd.npy").shape == m.shape
+    assert sorted(os.listdir(folder / "flo_fwd")) == ["0000.flo", "0001.flo", "0002.flo"]
+    assert sorted(os.listdir(folder / "fm_bwd")) == ["0000.png", "0001.png", "0002.png"]
+    md = json.load(open(folder / "metadata.json"))
+    assert md["bands"]["flow_raft_mask"]["url"] == "flow_raft_mask.npy"
+    assert md["bands"]["flow_raft_mask_bwd"]["url"] == "flow_raft_mask_bwd.npy"
+    assert md["bands"]["flow_raft"]["folder"].endswith("flo")
+    # module API: infer() hands back the masks when a mask output is requested (reference :63-64)
+    import argparse
+    a = argparse.Namespace(iterations=3, output_mask="x", subpath_mask="", subpath="", backwards=False)
+    i1 = np.stack([frames[0], frames[1]]).transpose(0, 3, 1, 2).astype(np.float32)
+    i2 = i1[::-1].copy()
+    fwd, bwd, mf, mb = band.infer(a, i1, i2)
+    assert fwd.shape == (176, 256, 2) and mf.dtype == np.bool_ and mf.shape == (176, 256)
+    band.model.close()
+    band.model = None

@@ -57,6 +57,17 @@ def test_pair_against_reference_vectors(net, golden_dir):
     assert (np.abs(rgb[0, 0].astype(int) - ref_rgb.astype(int)) > 1).mean() < 1e-3     # atan2f vs numpy: off-by-one bytes only
 
 
+def test_odd_feature_grid_against_reference_vectors(net, golden_dir):
+    """131x181 pads to 136x184 -> 17 x 23 feature pixels: the level-0 volume rows are padded to a multiple of 8."""
+    z = np.load(os.path.join(golden_dir, "raft_131x181.npz"))
+    h, w = [int(v) for v in z["hw"]]
+    fr = synth.frame_pair_sequence(2, h, w, seed=int(z["frame_seed"]))
+    flow, rgb, mx = net.infer_sequence(fr, scale=1.0, iters=int(z["iters"]), backward=True)
+    for name, got, ref in (("fwd", flow[0, 0], z["fwd"]), ("bwd", flow[0, 1], z["bwd"])):
+        print("\n  %s/golden relmax %.3e relL2 %.3e  max|flow| %.2f" % (name, relmax(got, ref), rell2(got, ref), np.abs(ref).max()))
+        assert relmax(got, ref) < TOL_RANGE and rell2(got, ref) < TOL_L2
+
+
 def test_scaled_sequence_matches_oracle(net):
     fr = synth.frame_pair_sequence(3, 192, 256, seed=4)
     flow, rgb, mx = net.infer_sequence(fr, scale=0.75, iters=6, backward=False)
@@ -72,3 +83,43 @@ def test_identical_frames_give_finite_encode(net):
     fr = synth.frame_pair_sequence(1, 128, 160, seed=9)
     flow, rgb, mx = net.infer_sequence(np.concatenate([fr, fr]), scale=1.0, iters=2)
     assert np.isfinite(flow).all() and rgb.shape == (1, 1, 128, 160, 3)
+
+
+@pytest.mark.gpu
+def test_fwdbwd_mask_bit_exact():
+    """pb_flow_fwdbwd_mask == oracle restatement of compute_fwdbwd_mask (bands/common/flow.py:19-40), bit for bit,
+    on smooth near-inverse flows (mixed True / False), on noise, and with flows leaving the frame."""
+    from oracle import raft_oracle as ro
+    rng = np.random.default_rng(17)
+    h, w = 67, 93
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    fwd = np.stack([3.0 * np.sin(yy / 9.0) + 1.3, 2.0 * np.cos(xx / 7.0) - 0.4], -1).astype(np.float32)
+    bwd = (-fwd + rng.standard_normal((h, w, 2)).astype(np.float32) * 0.6).astype(np.float32)
+    noise_f = (rng.standard_normal((h, w, 2)) * 4).astype(np.float32)
+    noise_b = (rng.standard_normal((h, w, 2)) * 4).astype(np.float32)
+    far_f = np.full((h, w, 2), 70.0, np.float32)
+    flows = np.stack([np.stack([fwd, bwd]), np.stack([noise_f, noise_b]), np.stack([far_f, -far_f])])
+    net = engine.FlowRaft(synth.raft_weights(seed=4321))
+    got = net.fwdbwd_mask(flows)
+    net.close()
+    assert got.shape == (3, 2, h, w) and got.dtype == np.bool_
+    for i in range(3):
+        mf, mb = ro.compute_fwdbwd_mask(flows[i, 0], flows[i, 1])
+        assert np.array_equal(got[i, 0], mf) and np.array_equal(got[i, 1], mb)
+    assert 0.2 < got[0, 0].mean() < 0.95          # the smooth case really mixes both outcomes
+
+
+@pytest.mark.gpu
+def test_sequence_masks_match_flows():
+    """The fused path (pb_flow_infer_sequence_masks) returns the same flows as the plain backward call and masks that
+    equal the oracle's on those flows."""
+    from oracle import raft_oracle as ro
+    frames = synth.frame_pair_sequence(3, 136, 184, seed=9)
+    net = engine.FlowRaft(synth.raft_weights(seed=4321))
+    flow, rgb, mx, mask = net.infer_sequence_masks(frames, scale=1.0, iters=4)
+    flow2, rgb2, mx2 = net.infer_sequence(frames, scale=1.0, iters=4, backward=True)
+    net.close()
+    assert np.array_equal(flow, flow2) and np.array_equal(rgb, rgb2) and np.array_equal(mx, mx2)
+    for i in range(2):
+        mf, mb = ro.compute_fwdbwd_mask(flow[i, 0], flow[i, 1])
+        assert np.array_equal(mask[i, 0], mf) and np.array_equal(mask[i, 1], mb)

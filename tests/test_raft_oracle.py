@@ -4,6 +4,7 @@ import os
 import numpy as np
 
 from oracle import raft_oracle as R
+ro = R
 from prisma_amd import synth
 
 
@@ -12,8 +13,12 @@ def rel(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
-def test_raft_pair_matches_reference(golden_dir):
-    z = np.load(os.path.join(golden_dir, "raft_125x157.npz"))
+import pytest
+
+
+@pytest.mark.parametrize("case", ["raft_125x157", "raft_131x181"])
+def test_raft_pair_matches_reference(golden_dir, case):
+    z = np.load(os.path.join(golden_dir, case + ".npz"))
     h, w = [int(v) for v in z["hw"]]
     fr = synth.frame_pair_sequence(2, h, w, seed=int(z["frame_seed"]))
     wts = synth.raft_weights(seed=4321)
@@ -42,3 +47,28 @@ def test_padder_and_resize_geometry():
     assert out.shape == (30, 48, 3) and out.dtype == np.uint8
     flat = np.full((16, 16, 3), 77, np.uint8)
     assert (R.cv_resize_cubic_u8(flat, 0.75) == 77).all()          # coefficients sum to 2048 -> constants survive
+
+
+def test_fwdbwd_mask_properties():
+    """bands/common/flow.py:19-40 restatement: exactly-inverse integer flows are consistent wherever the warp stays
+    inside the image; a constant offset of more than alpha_2 breaks every pixel; sub-pixel sampling is bilinear on
+    the 1/32 grid."""
+    h, w = 24, 40
+    f = np.zeros((h, w, 2), np.float32); f[..., 0] = 3; f[..., 1] = -2
+    m_f, m_b = ro.compute_fwdbwd_mask(f, -f)
+    assert m_f.dtype == np.bool_ and m_f[2:, :w - 3].all() and not m_f[:, w - 3:].any() and not m_f[:2].any()
+    assert m_b[:h - 2, 3:].all() and not m_b[:, :3].any()
+    m_f, _ = ro.compute_fwdbwd_mask(f, -f + np.float32(1.5))
+    assert not m_f.any()
+    img = np.arange(h * w * 2, dtype=np.float32).reshape(h, w, 2)
+    grid = np.zeros((h, w, 2), np.float32)
+    grid[..., 0] = np.arange(w) + 0.25
+    grid[..., 1] = np.arange(h)[:, None] + 0.5
+    out = ro.remap_linear_const(img, grid)
+    ref = 0.5 * (0.75 * img[:-1, :-1] + 0.25 * img[:-1, 1:]) + 0.5 * (0.75 * img[1:, :-1] + 0.25 * img[1:, 1:])
+    assert np.allclose(out[:-1, :-1], ref, rtol=1e-6)
+    assert np.allclose(out[-1, :-1], 0.5 * (0.75 * img[-1, :-1] + 0.25 * img[-1, 1:]), rtol=1e-6)   # bottom taps are border 0
+    # 1/64 rounds half-to-even onto the 1/32 grid: 0.015625 * 32 = 0.5 -> 0
+    grid[..., 0] = np.arange(w) + 1.0 / 64
+    grid[..., 1] = np.arange(h)[:, None]
+    assert np.array_equal(ro.remap_linear_const(img, grid), img)
