@@ -60,6 +60,28 @@ typedef struct {
     int32_t max_batch;        /* frames per launch the arena is sized for (>= 1) */
 } pb_depth_cfg;
 
+/* SOLOv2 geometry and test_cfg for band = "mask_mmdet" (the values live in the mmdet config the reference downloads,
+ * models/solov2_r101_fpn_3x_coco.py -> _base_ solov2_r50_fpn_1x_coco.py; bands/mask_mmdet.py:26-27). */
+typedef struct {
+    int32_t blocks[4];           /* ResNet bottleneck counts: 3,4,23,3 (R-101) / 3,4,6,3 (R-50)                 */
+    int32_t scale_long;          /* test pipeline img_scale = (1333, 800), keep_ratio                            */
+    int32_t scale_short;
+    int32_t num_classes;         /* 80                                                                            */
+    int32_t feat_channels;       /* 512: kernel / class branch width                                              */
+    int32_t stacked_convs;       /* 4                                                                             */
+    int32_t num_grids[5];        /* 40, 36, 24, 16, 12                                                            */
+    int32_t strides[5];          /* 8, 8, 16, 32, 32 (area filter: mask area > stride)                            */
+    int32_t mask_feat_channels;  /* 128                                                                           */
+    int32_t mask_out_channels;   /* 256 (= dynamic kernel length)                                                 */
+    int32_t nms_pre;             /* 500                                                                           */
+    int32_t max_per_img;         /* 100                                                                           */
+    float score_thr;             /* 0.1                                                                           */
+    float mask_thr;              /* 0.5                                                                           */
+    float filter_thr;            /* 0.05                                                                          */
+    float sigma;                 /* 2.0 (gaussian Matrix NMS)                                                     */
+    int32_t max_batch;           /* frames per backbone launch the arena is sized for (>= 1)                      */
+} pb_mask_cfg;
+
 const char *pb_last_error(void);
 int pb_version(void);
 /* Number of visible HIP devices (0 on a CPU-only box; never fails). */
@@ -124,6 +146,31 @@ int pb_flow_fwdbwd_mask(pb_ctx *ctx, const float *flows, int n, int sh, int sw, 
                         uint8_t *mask_out);
 /* Stages of the last flow call: "fmap" [F,256,h/8,w/8], "flow_lo" [pairs*dirs, h/8*w/8, 2]. */
 int64_t pb_flow_get_stage(pb_ctx *ctx, const char *name, float *out, int64_t cap, int64_t shape_out[4]);
+
+/* mask_mmdet band (band = "mask_mmdet", cfg = pb_mask_cfg; weights: backbone.*, neck.*, mask_head.* in mmdet's
+ * state_dict naming).  Replaces the per-frame body of bands/mask_mmdet.py:131-154: inference_detector
+ * (mmdet/apis/inference.py:99-162: Resize keep_ratio (1333, 800) -> Normalize -> Pad 32 -> SOLOv2 forward ->
+ * get_results / Matrix NMS -> format_results) and the accumulation of :43-61,139-147.
+ *   frames      : n x H x W x 3 uint8 RGB (what decord hands the band; the reference swaps to BGR for mmdet and
+ *                 Normalize(to_rgb) swaps back, so means / stds apply in RGB order)
+ *   confidence  : --confidence; an instance is drawn when its class is kept and score > 0.5 and > confidence
+ *   keep_classes: class ids (model.CLASSES order) the band keeps, mask_mmdet.py:30; NULL keeps every class
+ *   mask_out    : n x H x W x 3 uint8: per pixel (255 * number of drawn instances covering it) mod 256 in all
+ *                 three channels - `masks.astype(np.uint8)` of the reference's float64 sum.
+ * pb_mask_get_instances: what format_results held for frame `frame` of the last call, score-descending: up to cap
+ *   scores / labels; returns the count.  masks_out (optional, [count, H, W] bytes of 0 / 1) needs
+ *   pb_set_profiling(ctx, 2) before the infer call.
+ * pb_mask_net_size: resized (nh, nw) and padded (Hp, Wp) network input for an H x W frame. */
+int pb_mask_infer_batch(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W, float confidence,
+                        const int32_t *keep_classes, int n_keep, uint8_t *mask_out);
+int pb_mask_infer_batch_dev(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W, float confidence,
+                            const int32_t *keep_classes, int n_keep, uint8_t *mask_out);
+int pb_mask_get_instances(pb_ctx *ctx, int frame, int cap, float *scores_out, int32_t *labels_out, uint8_t *masks_out,
+                          int32_t *candidates_out);
+int pb_mask_net_size(const pb_mask_cfg *cfg, int H, int W, int *nh, int *nw, int *Hp, int *Wp);
+/* Stages of the last mask call as float32 NCHW: "input", "c2".."c5", "p2".."p6", "mask_feats",
+ * "kernel_pred<l>", "cls_logit<l>" (l = 0..4). */
+int64_t pb_mask_get_stage(pb_ctx *ctx, const char *name, float *out, int64_t cap, int64_t shape_out[4]);
 
 /* Debug/parity: copy a named intermediate of the last pb_depth_infer_batch* call to the host
  * as float32 in the reference's layout ([n, C, h, w] for maps, [n, tokens, D] for tokens).

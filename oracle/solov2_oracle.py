@@ -1,0 +1,342 @@
+"""ORACLE (test infrastructure, never the product path) for the mask_mmdet band.
+
+CPU restatement in numpy + torch.nn.functional fp32 of what /root/reference/bands/mask_mmdet.py runs per frame:
+mmdet's test pipeline, ResNet + FPN, SOLOV2Head, its get_results / Matrix-NMS post-processing, format_results
+and the band's mask accumulation.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import it, as the checker.
+
+PARITY UNPINNED - the whole band.  The vendored mmdet package cannot be imported here: bands/mmdet/__init__.py:2
+needs mmcv (pinned mmcv-full==1.7.1, README.md:44), which is absent, and so are cv2, the model config
+(solov2_r101_fpn_3x_coco.py is fetched by download_models.sh:13-16) and the checkpoint.  The reference has no test
+or vector at this boundary either.  What this file follows:
+  * vendored sources, cited per function (paths relative to /root/reference/bands/mmdet/);
+  * mmcv 1.7.1 published behaviour for ConvModule (conv -> norm -> ReLU, conv bias only without a norm),
+    imrescale / rescale_size, imnormalize, impad_to_multiple;
+  * OpenCV's published 8-bit INTER_LINEAR resize (11-bit fixed-point coefficients);
+  * the upstream mmdet 2.x SOLOv2 config values (num_grids, strides, test_cfg): prisma_amd/synth.py MaskCfg.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+MEAN = (123.675, 116.28, 103.53)          # configs/_base_/datasets/coco_instance.py img_norm_cfg, RGB order
+STD = (58.395, 57.12, 57.375)
+
+
+def _t(w, k):
+    return torch.from_numpy(np.ascontiguousarray(w[k], dtype=np.float32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# test pipeline: LoadImage -> Resize(keep_ratio, (1333, 800)) -> Normalize(to_rgb) -> Pad(32)
+# datasets/pipelines/transforms.py:215-240 (_resize_img), :679-712 (Normalize), :580-655 (Pad)
+# ---------------------------------------------------------------------------------------------------
+def rescale_size(h: int, w: int, scale_long: int, scale_short: int) -> Tuple[int, int, float]:
+    """mmcv.rescale_size with a (long, short) tuple: factor = min(long / max(h, w), short / min(h, w));
+    new size = int(x * factor + 0.5).  Returns (new_h, new_w, factor)."""
+    f = min(scale_long / max(h, w), scale_short / min(h, w))
+    return int(h * float(f) + 0.5), int(w * float(f) + 0.5), f
+
+
+def linear_taps_u8(src: int, dst: int):
+    """OpenCV resize(INTER_LINEAR) tables for 8-bit images: source index pair and 11-bit coefficients."""
+    scale = 1.0 / (dst / src)
+    i0 = np.empty(dst, np.int64); i1 = np.empty(dst, np.int64)
+    c0 = np.empty(dst, np.int64); c1 = np.empty(dst, np.int64)
+    for d in range(dst):
+        fx = np.float32((d + 0.5) * scale - 0.5)
+        sx = int(np.floor(fx))
+        fx = np.float32(fx - np.float32(sx))
+        if sx < 0:
+            fx, sx = np.float32(0.0), 0
+        if sx >= src - 1:
+            fx, sx = np.float32(0.0), src - 1
+        i0[d], i1[d] = sx, min(sx + 1, src - 1)
+        c0[d] = int(np.rint(np.float32(np.float32(1.0) - fx) * np.float32(2048.0)))
+        c1[d] = int(np.rint(fx * np.float32(2048.0)))
+    return i0, i1, c0, c1
+
+
+def linear_taps_u8_rows(src: int, dst: int):
+    """Vertical tables: OpenCV keeps the fractional weight and clamps the row indices instead."""
+    scale = 1.0 / (dst / src)
+    i0 = np.empty(dst, np.int64); i1 = np.empty(dst, np.int64)
+    c0 = np.empty(dst, np.int64); c1 = np.empty(dst, np.int64)
+    for d in range(dst):
+        fy = np.float32((d + 0.5) * scale - 0.5)
+        sy = int(np.floor(fy))
+        fy = np.float32(fy - np.float32(sy))
+        i0[d], i1[d] = min(max(sy, 0), src - 1), min(max(sy + 1, 0), src - 1)
+        c0[d] = int(np.rint(np.float32(np.float32(1.0) - fy) * np.float32(2048.0)))
+        c1[d] = int(np.rint(fy * np.float32(2048.0)))
+    return i0, i1, c0, c1
+
+
+def cv_resize_linear_u8(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
+    """cv2.resize(img, (new_w, new_h), interpolation=INTER_LINEAR) on uint8 HxWxC (mmcv.imresize default backend).
+    Horizontal pass in int32 (coefficients x 2048), vertical pass
+    ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2."""
+    h, w = img.shape[:2]
+    x0, x1, a0, a1 = linear_taps_u8(w, new_w)
+    y0, y1, b0, b1 = linear_taps_u8_rows(h, new_h)
+    s = img.astype(np.int64)
+    hor = s[:, x0] * a0[None, :, None] + s[:, x1] * a1[None, :, None]                    # [h, new_w, c]
+    r0, r1 = hor[y0] >> 4, hor[y1] >> 4
+    out = (((b0[:, None, None] * r0) >> 16) + ((b1[:, None, None] * r1) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def preprocess(frame_rgb: np.ndarray, cfg) -> Tuple[np.ndarray, dict]:
+    """uint8 HxWx3 RGB frame -> float32 [1, 3, Hp, Wp] network input + meta (img_shape, ori_shape, pad_shape).
+    The band hands mmdet a BGR image and Normalize(to_rgb=True) swaps it back (mask_mmdet.py:133,
+    transforms.py:703-706), so the arithmetic is (rgb - mean_rgb) * (1 / std_rgb) in float32."""
+    H, W = frame_rgb.shape[:2]
+    nh, nw, _ = rescale_size(H, W, cfg.scale_long, cfg.scale_short)
+    img = cv_resize_linear_u8(frame_rgb, nh, nw).astype(np.float32)
+    mean = np.asarray(MEAN, np.float64).astype(np.float32)
+    stdinv = (1.0 / np.asarray(STD, np.float64)).astype(np.float32)
+    img = (img - mean) * stdinv
+    Hp, Wp = (nh + 31) // 32 * 32, (nw + 31) // 32 * 32
+    x = np.zeros((1, 3, Hp, Wp), np.float32)
+    x[0, :, :nh, :nw] = img.transpose(2, 0, 1)
+    return x, {"img_shape": (nh, nw), "ori_shape": (H, W), "pad_shape": (Hp, Wp)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# ResNet (models/backbones/resnet.py:98-302 Bottleneck style='pytorch', :612-627 forward) + FPN
+# ---------------------------------------------------------------------------------------------------
+def _bn(w, p, x):
+    return F.batch_norm(x, _t(w, p + ".running_mean"), _t(w, p + ".running_var"), _t(w, p + ".weight"), _t(w, p + ".bias"),
+                        False, 0.0, 1e-5)
+
+
+def backbone(w, cfg, x: torch.Tensor) -> List[torch.Tensor]:
+    x = F.relu(_bn(w, "backbone.bn1", F.conv2d(x, _t(w, "backbone.conv1.weight"), None, 2, 3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    outs = []
+    for li, nb in enumerate(cfg.blocks, start=1):
+        for b in range(nb):
+            p = f"backbone.layer{li}.{b}"
+            s = 2 if (b == 0 and li > 1) else 1
+            o = F.relu(_bn(w, p + ".bn1", F.conv2d(x, _t(w, p + ".conv1.weight"))))
+            o = F.relu(_bn(w, p + ".bn2", F.conv2d(o, _t(w, p + ".conv2.weight"), None, s, 1)))
+            o = _bn(w, p + ".bn3", F.conv2d(o, _t(w, p + ".conv3.weight")))
+            idt = x
+            if b == 0:
+                idt = _bn(w, p + ".downsample.1", F.conv2d(x, _t(w, p + ".downsample.0.weight"), None, s))
+            x = F.relu(o + idt)
+        outs.append(x)
+    return outs
+
+
+def fpn(w, feats: List[torch.Tensor]) -> List[torch.Tensor]:
+    """models/necks/fpn.py:150-204 with start_level 0, num_outs 5, add_extra_convs False, nearest top-down."""
+    lat = [F.conv2d(f, _t(w, f"neck.lateral_convs.{i}.conv.weight"), _t(w, f"neck.lateral_convs.{i}.conv.bias"))
+           for i, f in enumerate(feats)]
+    for i in range(3, 0, -1):
+        lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+    outs = [F.conv2d(l, _t(w, f"neck.fpn_convs.{i}.conv.weight"), _t(w, f"neck.fpn_convs.{i}.conv.bias"), 1, 1)
+            for i, l in enumerate(lat)]
+    outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+    return outs
+
+
+# ---------------------------------------------------------------------------------------------------
+# SOLOV2Head (models/dense_heads/solov2_head.py:19-292)
+# ---------------------------------------------------------------------------------------------------
+def _conv_gn_relu(w, p, x, pad):
+    x = F.conv2d(x, _t(w, p + ".conv.weight"), None, 1, pad)
+    return F.relu(F.group_norm(x, 32, _t(w, p + ".gn.weight"), _t(w, p + ".gn.bias"), 1e-5))
+
+
+def coord_feat(n, h, wd):
+    """core/utils/misc.py:190-208 generate_coordinate: channel 0 = x in [-1, 1], channel 1 = y."""
+    xr = torch.linspace(-1, 1, wd)
+    yr = torch.linspace(-1, 1, h)
+    y, x = torch.meshgrid(yr, xr, indexing="ij")
+    return torch.stack([x, y], 0)[None].expand(n, -1, -1, -1)
+
+
+def mask_features(w, feats):
+    """MaskFeatModule.forward (solov2_head.py:134-150): levels 0..3, 2x bilinear steps, coords on level 3."""
+    h = "mask_head.mask_feature_head."
+    acc = _conv_gn_relu(w, h + "convs_all_levels.0.conv0", feats[0], 1)
+    for i in range(1, 4):
+        x = feats[i]
+        if i == 3:
+            x = torch.cat([x, coord_feat(x.shape[0], x.shape[2], x.shape[3])], 1)
+        for j in range(i):
+            x = _conv_gn_relu(w, f"{h}convs_all_levels.{i}.conv{j}", x, 1)
+            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        acc = acc + x
+    return _conv_gn_relu(w, h + "conv_pred", acc, 0)
+
+
+def resize_feats(feats):
+    """solo_head.py:133-153: P2 down to P3's size, P6 up to P5's size (bilinear, align_corners False)."""
+    out = list(feats)
+    out[0] = F.interpolate(feats[0], size=feats[1].shape[-2:], mode="bilinear", align_corners=False)
+    out[-1] = F.interpolate(feats[-1], size=feats[-2].shape[-2:], mode="bilinear", align_corners=False)
+    return out
+
+
+def head(w, cfg, feats):
+    """SOLOV2Head.forward (solov2_head.py:253-292) -> (kernel_preds[5], cls_preds[5], mask_feats)."""
+    mf = mask_features(w, feats)
+    feats = resize_feats(feats)
+    kps, cps = [], []
+    for lvl in range(5):
+        x = feats[lvl]
+        x = torch.cat([x, coord_feat(x.shape[0], x.shape[2], x.shape[3])], 1)
+        x = F.interpolate(x, size=cfg.num_grids[lvl], mode="bilinear", align_corners=False)
+        k, c = x, x[:, :-2]
+        for i in range(cfg.stacked_convs):
+            k = _conv_gn_relu(w, f"mask_head.kernel_convs.{i}", k, 1)
+        for i in range(cfg.stacked_convs):
+            c = _conv_gn_relu(w, f"mask_head.cls_convs.{i}", c, 1)
+        kps.append(F.conv2d(k, _t(w, "mask_head.conv_kernel.weight"), _t(w, "mask_head.conv_kernel.bias"), 1, 1))
+        cps.append(F.conv2d(c, _t(w, "mask_head.conv_cls.weight"), _t(w, "mask_head.conv_cls.bias"), 1, 1))
+    return kps, cps, mf
+
+
+def network(w: Dict[str, np.ndarray], cfg, x: np.ndarray, return_feats: bool = False):
+    with torch.no_grad():
+        c = backbone(w, cfg, torch.from_numpy(x))
+        p = fpn(w, c)
+        kps, cps, mf = head(w, cfg, p)
+    if return_feats:
+        return kps, cps, mf, c, p
+    return kps, cps, mf
+
+
+# ---------------------------------------------------------------------------------------------------
+# post-processing (solov2_head.py:584-766, core/post_processing/matrix_nms.py:5-121)
+# ---------------------------------------------------------------------------------------------------
+def points_nms_scores(cls_pred: torch.Tensor) -> torch.Tensor:
+    """solov2_head.py:616-623: sigmoid, keep a cell only if it is the max of the 2x2 window up-left of it.
+    [n, C, g, g] -> [n, g*g, C]."""
+    s = cls_pred.sigmoid()
+    local_max = F.max_pool2d(s, 2, stride=1, padding=1)
+    s = s * (local_max[:, :, :-1, :-1] == s)
+    return s.permute(0, 2, 3, 1).reshape(s.shape[0], -1, s.shape[1])
+
+
+def matrix_nms(masks, labels, scores, mask_area, cfg):
+    """mask_matrix_nms (gaussian kernel).  -> scores, labels, keep_inds into the inputs."""
+    scores, sort_inds = torch.sort(scores, descending=True)
+    keep_inds = sort_inds
+    if cfg.nms_pre > 0 and len(sort_inds) > cfg.nms_pre:
+        sort_inds = sort_inds[:cfg.nms_pre]
+        keep_inds = keep_inds[:cfg.nms_pre]
+        scores = scores[:cfg.nms_pre]
+    masks, mask_area, labels = masks[sort_inds], mask_area[sort_inds], labels[sort_inds]
+    n = len(labels)
+    flat = masks.reshape(n, -1).float()
+    inter = torch.mm(flat, flat.t())
+    area = mask_area.expand(n, n)
+    iou = (inter / (area + area.t() - inter)).triu(diagonal=1)
+    lab = labels.expand(n, n)
+    same = (lab == lab.t()).triu(diagonal=1)
+    decay_iou = iou * same
+    comp, _ = decay_iou.max(0)
+    comp = comp.expand(n, n).t()
+    decay = torch.exp(-1 * cfg.sigma * (decay_iou ** 2)) / torch.exp(-1 * cfg.sigma * (comp ** 2))
+    coeff, _ = decay.min(0)
+    scores = scores * coeff
+    if cfg.filter_thr > 0:
+        keep = scores >= cfg.filter_thr
+        keep_inds = keep_inds[keep]
+        if not keep.any():
+            return scores.new_zeros(0), labels.new_zeros(0), labels.new_zeros(0)
+        scores, labels = scores[keep], labels[keep]
+    scores, sort_inds = torch.sort(scores, descending=True)
+    keep_inds = keep_inds[sort_inds]
+    if cfg.max_per_img > 0 and len(sort_inds) > cfg.max_per_img:
+        sort_inds = sort_inds[:cfg.max_per_img]
+        keep_inds = keep_inds[:cfg.max_per_img]
+        scores = scores[:cfg.max_per_img]
+    return scores, labels[sort_inds], keep_inds
+
+
+def get_results_single(cfg, kernel_preds, cls_scores, mask_feats, img_shape, ori_shape, return_debug=False):
+    """_get_results_single (solov2_head.py:647-766).  kernel_preds [points, 256], cls_scores [points, C] (after
+    points_nms_scores), mask_feats [1, 256, h, w].  -> scores [n], labels [n], masks bool [n, H, W]."""
+    H, W = ori_shape
+    h, w = img_shape
+    empty = (torch.zeros(0), torch.zeros(0, dtype=torch.long), torch.zeros(0, H, W, dtype=torch.bool))
+    fh, fw = mask_feats.shape[-2:]
+    up = (fh * 4, fw * 4)
+    score_mask = cls_scores > cfg.score_thr
+    cs = cls_scores[score_mask]
+    if len(cs) == 0:
+        return empty
+    inds = score_mask.nonzero()
+    labels = inds[:, 1]
+    kp = kernel_preds[inds[:, 0]]
+    edges = np.cumsum(np.asarray(cfg.num_grids) ** 2)
+    strides = torch.ones(int(edges[-1]))
+    lo = 0
+    for lvl, hi in enumerate(edges):
+        strides[lo:hi] *= cfg.strides[lvl]
+        lo = hi
+    strides = strides[inds[:, 0]]
+    mask_preds = F.conv2d(mask_feats, kp.view(kp.shape[0], -1, 1, 1), stride=1).squeeze(0).sigmoid()
+    masks = mask_preds > cfg.mask_thr
+    sum_masks = masks.sum((1, 2)).float()
+    keep = sum_masks > strides
+    if keep.sum() == 0:
+        return empty
+    masks, mask_preds, sum_masks, cs, labels = masks[keep], mask_preds[keep], sum_masks[keep], cs[keep], labels[keep]
+    mask_scores = (mask_preds * masks).sum((1, 2)) / sum_masks
+    cs = cs * mask_scores
+    scores, labels, keep_inds = matrix_nms(masks, labels, cs, sum_masks, cfg)
+    if len(scores) == 0:
+        return empty
+    mp = mask_preds[keep_inds]
+    mp = F.interpolate(mp.unsqueeze(0), size=up, mode="bilinear", align_corners=False)[:, :, :h, :w]
+    mp = F.interpolate(mp, size=(H, W), mode="bilinear", align_corners=False).squeeze(0)
+    out = (scores, labels, mp > cfg.mask_thr)
+    if return_debug:
+        return out + ({"pre_nms_scores": cs, "sum_masks": sum_masks, "keep_inds": keep_inds, "n_candidates": int(score_mask.sum())},)
+    return out
+
+
+def get_results(cfg, kps, cps, mf, img_shape, ori_shape, img_id=0, return_debug=False):
+    """get_results (solov2_head.py:584-645) for one image of the batch."""
+    with torch.no_grad():
+        cls = torch.cat([points_nms_scores(c)[img_id] for c in cps], 0)
+        ker = torch.cat([k[img_id].permute(1, 2, 0).reshape(-1, k.shape[1]) for k in kps], 0)
+        return get_results_single(cfg, ker, cls, mf[[img_id]], img_shape, ori_shape, return_debug)
+
+
+# ---------------------------------------------------------------------------------------------------
+# format_results + the band's accumulation (models/detectors/single_stage_instance_seg.py:184-250,
+# bands/mask_mmdet.py:43-61,131-154)
+# ---------------------------------------------------------------------------------------------------
+def band_mask(scores, labels, masks, class_names, keep_names, confidence: float, ori_shape) -> np.ndarray:
+    """uint8 HxWx3: every instance of a kept class with score > 0.5 (getTotalMasks' fixed default) and
+    > --confidence adds 255 to all three channels in float64; the uint8 cast wraps overlaps modulo 256."""
+    H, W = ori_shape
+    acc = np.zeros((H, W, 3), np.float64)
+    sc, lb, mk = np.asarray(scores), np.asarray(labels), np.asarray(masks)
+    for c, name in enumerate(class_names):
+        if name not in keep_names:
+            continue
+        idx = np.nonzero(lb == c)[0]                         # per-class lists keep the score-descending order
+        total = int((sc[idx] > 0.5).sum())
+        for i in idx[:total]:
+            if sc[i] > confidence:
+                acc += np.where(mk[i], 255, 0)[..., None]
+    return (acc.astype(np.int64) & 255).astype(np.uint8)
+
+
+def infer(w, cfg, frame_rgb: np.ndarray, class_names, keep_names, confidence: float = 0.5) -> np.ndarray:
+    """The band's per-frame work (mask_mmdet.py:131-147) end to end."""
+    x, meta = preprocess(frame_rgb, cfg)
+    kps, cps, mf = network(w, cfg, x)
+    scores, labels, masks = get_results(cfg, kps, cps, mf, meta["img_shape"], meta["ori_shape"])
+    return band_mask(scores, labels, masks, class_names, keep_names, confidence, meta["ori_shape"])

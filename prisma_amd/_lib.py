@@ -22,6 +22,14 @@ class pb_depth_cfg(C.Structure):
                 ("out_channels", C.c_int32 * 4), ("pos_grid", C.c_int32), ("max_batch", C.c_int32)]
 
 
+class pb_mask_cfg(C.Structure):
+    _fields_ = [("blocks", C.c_int32 * 4), ("scale_long", C.c_int32), ("scale_short", C.c_int32), ("num_classes", C.c_int32),
+                ("feat_channels", C.c_int32), ("stacked_convs", C.c_int32), ("num_grids", C.c_int32 * 5),
+                ("strides", C.c_int32 * 5), ("mask_feat_channels", C.c_int32), ("mask_out_channels", C.c_int32),
+                ("nms_pre", C.c_int32), ("max_per_img", C.c_int32), ("score_thr", C.c_float), ("mask_thr", C.c_float),
+                ("filter_thr", C.c_float), ("sigma", C.c_float), ("max_batch", C.c_int32)]
+
+
 class pb_kernel_stat(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double),
                 ("launches", C.c_int32)]
@@ -42,6 +50,12 @@ SYMBOLS = {
     "pb_sync": (C.c_int, [_P]),
     "pb_depth_net_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_depth_get_stage": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "pb_mask_infer_batch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, _P]),
+    "pb_mask_infer_batch_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, _P]),
+    "pb_mask_get_instances": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "pb_mask_net_size": (C.c_int, [C.POINTER(pb_mask_cfg), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pb_mask_get_stage": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "pb_flow_out_size": (C.c_int, [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_flow_infer_sequence": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
     "pb_flow_infer_sequence_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P]),

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "mask_engine.h"
 #include "raft_engine.h"
 
 static thread_local char g_err[1024] = "";
@@ -23,6 +24,7 @@ struct pb_ctx {
     int device = 0;
     DepthEngine *depth = nullptr;
     RaftEngine *raft = nullptr;
+    MaskEngine *mask = nullptr;
     hipStream_t stream = nullptr;   // == depth->stream when a band is loaded
     f16 *zero = nullptr;
     bool own_stream = false;
@@ -96,6 +98,21 @@ int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *we
         }
         c->stream = c->raft->stream;
         c->zero = (f16 *)c->raft->zero_page();
+    } else if (!strcmp(band, "mask_mmdet")) {
+        if (!cfg || cfg_bytes != sizeof(pb_mask_cfg) || !weights || n_weights <= 0) {
+            delete c;
+            PB_CHECK(false, PB_ERR_ARG, "mask_mmdet: needs a pb_mask_cfg (%zu bytes, got %zu) and weights", sizeof(pb_mask_cfg),
+                     cfg_bytes);
+        }
+        c->mask = new MaskEngine(device_id, *(const pb_mask_cfg *)cfg);
+        int r = c->mask->load(weights, n_weights);
+        if (r) {
+            delete c->mask;
+            delete c;
+            return r;
+        }
+        c->stream = c->mask->stream;
+        c->zero = (f16 *)c->mask->zero_page();
     } else if (!strcmp(band, "ops")) {
         // kernel-level context for the parity tests: a stream and a zero page, no model
         hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -111,7 +128,7 @@ int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *we
         c->own_stream = true;
     } else {
         delete c;
-        PB_CHECK(false, PB_ERR_ARG, "unknown band '%s' (depth_anything | flow_raft | ops)", band);
+        PB_CHECK(false, PB_ERR_ARG, "unknown band '%s' (depth_anything | flow_raft | mask_mmdet | ops)", band);
     }
     *out = c;
     return 0;
@@ -122,6 +139,7 @@ void pb_destroy(pb_ctx *c) {
     hipSetDevice(c->device);
     if (c->depth) delete c->depth;
     if (c->raft) delete c->raft;
+    if (c->mask) delete c->mask;
     if (c->own_stream) {
         hipStreamSynchronize(c->stream);
         hipFree(c->zero);
@@ -171,9 +189,10 @@ int64_t pb_depth_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap,
 }
 
 int pb_set_profiling(pb_ctx *c, int enabled) {
-    PB_CHECK(c && (c->depth || c->raft), PB_ERR_STATE, "ctx has no band");
+    PB_CHECK(c && (c->depth || c->raft || c->mask), PB_ERR_STATE, "ctx has no band");
     if (c->depth) { c->depth->timer.enabled = enabled != 0; c->depth->debug = (enabled & 2) != 0; }
     if (c->raft) { c->raft->timer.enabled = enabled != 0; c->raft->debug = (enabled & 2) != 0; }
+    if (c->mask) { c->mask->timer.enabled = (enabled & 1) != 0; c->mask->debug = (enabled & 2) != 0; }
     return 0;
 }
 
@@ -258,6 +277,58 @@ int pb_flow_fwdbwd_mask(pb_ctx *c, const float *flows, int n, int sh, int sw, fl
     return 0;
 }
 
+int pb_mask_net_size(const pb_mask_cfg *cfg, int H, int W, int *nh, int *nw, int *Hp, int *Wp) {
+    PB_CHECK(cfg && H > 0 && W > 0 && nh && nw && Hp && Wp, PB_ERR_ARG, "mask_net_size: bad arguments");
+    MaskEngine::net_size(*cfg, H, W, nh, nw, Hp, Wp);
+    return 0;
+}
+
+int pb_mask_infer_batch_dev(pb_ctx *c, const uint8_t *frames, int n, int H, int W, float confidence, const int32_t *keep,
+                            int n_keep, uint8_t *mask_out) {
+    PB_CHECK(c && c->mask, PB_ERR_STATE, "ctx has no mask_mmdet band");
+    return c->mask->infer(frames, n, H, W, confidence, keep, n_keep, mask_out);
+}
+
+int pb_mask_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, float confidence, const int32_t *keep,
+                        int n_keep, uint8_t *mask_out) {
+    PB_CHECK(c && c->mask, PB_ERR_STATE, "ctx has no mask_mmdet band");
+    PB_CHECK(frames && mask_out && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "mask infer: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * H * W * 3;
+    DevMem dF, dO;
+    PB_TRY(dF.alloc(bytes));
+    PB_TRY(dO.alloc(bytes));
+    PB_HIP(hipMemcpy(dF.p, frames, bytes, hipMemcpyHostToDevice));
+    PB_TRY(c->mask->infer(dF.as<uint8_t>(), n, H, W, confidence, keep, n_keep, dO.as<uint8_t>()));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(mask_out, dO.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pb_mask_get_instances(pb_ctx *c, int frame, int cap, float *scores_out, int32_t *labels_out, uint8_t *masks_out,
+                          int32_t *candidates_out) {
+    PB_CHECK(c && c->mask, PB_ERR_STATE, "ctx has no mask_mmdet band");
+    const auto &res = c->mask->results();
+    PB_CHECK(frame >= 0 && frame < (int)res.size(), PB_ERR_ARG, "mask instances: frame %d of %zu", frame, res.size());
+    const auto &r = res[frame];
+    const int cnt = std::min<int>(cap, (int)r.scores.size());
+    for (int i = 0; i < cnt; ++i) {
+        if (scores_out) scores_out[i] = r.scores[i];
+        if (labels_out) labels_out[i] = r.labels[i];
+    }
+    if (masks_out && cnt > 0) {
+        PB_CHECK(!r.masks.empty(), PB_ERR_STATE, "instance masks are kept only with pb_set_profiling(ctx, 2)");
+        memcpy(masks_out, r.masks.data(), r.masks.size() / r.scores.size() * cnt);
+    }
+    if (candidates_out) *candidates_out = r.candidates;
+    return (int)r.scores.size();
+}
+
+int64_t pb_mask_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap, int64_t shape_out[4]) {
+    PB_CHECK(c && c->mask && name && out && shape_out, PB_ERR_ARG, "mask get_stage: bad arguments");
+    return c->mask->get_stage(name, out, cap, shape_out);
+}
+
 int64_t pb_flow_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap, int64_t shape_out[4]) {
     PB_CHECK(c && c->raft && name && out && shape_out, PB_ERR_ARG, "flow get_stage: bad arguments");
     PB_HIP(hipSetDevice(c->device));
@@ -267,7 +338,7 @@ int64_t pb_flow_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap, 
 int pb_set_option(pb_ctx *c, const char *key, int value) {
     PB_CHECK(c && key, PB_ERR_ARG, "set_option: bad arguments");
     int *g = c->depth ? &c->depth->gemm_tile : &c->gemm_tile;
-    int *v = c->depth ? &c->depth->conv_tile : (c->raft ? &c->raft->conv_tile : &c->conv_tile);
+    int *v = c->depth ? &c->depth->conv_tile : (c->raft ? &c->raft->conv_tile : (c->mask ? &c->mask->conv_tile : &c->conv_tile));
     if (!strcmp(key, "gemm_tile")) *g = value;
     else if (!strcmp(key, "conv_tile")) *v = value;
     else PB_CHECK(false, PB_ERR_ARG, "unknown option '%s'", key);
@@ -275,8 +346,8 @@ int pb_set_option(pb_ctx *c, const char *key, int value) {
 }
 
 int pb_get_kernel_stats(pb_ctx *c, pb_kernel_stat *out, int cap) {
-    PB_CHECK(c && (c->depth || c->raft) && out, PB_ERR_STATE, "ctx has no band");
-    return c->depth ? c->depth->stats(out, cap) : c->raft->stats(out, cap);
+    PB_CHECK(c && (c->depth || c->raft || c->mask) && out, PB_ERR_STATE, "ctx has no band");
+    return c->depth ? c->depth->stats(out, cap) : (c->raft ? c->raft->stats(out, cap) : c->mask->stats(out, cap));
 }
 
 int pb_dev_alloc(pb_ctx *c, void **ptr, size_t bytes) {

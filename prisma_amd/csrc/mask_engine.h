@@ -1,0 +1,109 @@
+// mask_mmdet band engine (SOLOv2: ResNet + FPN + SOLOV2Head + Matrix NMS + the band's mask accumulation).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+#include "mask_kernels.h"
+
+class MaskEngine {
+  public:
+    MaskEngine(int device, const pb_mask_cfg &cfg) : device(device), cfg_(cfg) {}
+    ~MaskEngine();
+    int load(const pb_tensor *w, int n);
+    // frames: device uint8 [n, H, W, 3] RGB.  mask_out: device uint8 [n, H, W, 3] (the band's "mask ids" image).
+    int infer(const uint8_t *frames, int n, int H, int W, float confidence, const int32_t *keep, int n_keep, uint8_t *mask_out);
+    int64_t get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]);
+    int stats(pb_kernel_stat *out, int cap);
+    static void net_size(const pb_mask_cfg &cfg, int H, int W, int *nh, int *nw, int *Hp, int *Wp);
+
+    // results of the last infer(): per frame, score-descending (what format_results would hand to the band)
+    struct Instances {
+        std::vector<float> scores;
+        std::vector<int32_t> labels;
+        std::vector<uint8_t> masks;      // [count, H, W] bytes of 0 / 1, filled only when `debug` is set
+        int candidates = 0;              // grid cells over score_thr (before the area filter)
+    };
+    const std::vector<Instances> &results() const { return results_; }
+
+    hipStream_t stream = nullptr;
+    int device = 0;
+    bool debug = false;
+    KernelTimer timer;
+    int conv_tile = TILE_AUTO;
+    const f16 *zero_page() const { return zero_; }
+
+  private:
+    struct GN { float *g = nullptr, *b = nullptr; int C = 0; };
+    struct ConvGN { PackedW w; GN gn; };
+    struct Bneck { PackedW c1, c2, c3, ds; bool has_ds = false; int stride = 1, planes = 0, inpl = 0; };
+
+    int prepare(int n, int H, int W);
+    int run_chunk(const uint8_t *frames, int n, int first, float confidence, const std::vector<uint8_t> &keep_class,
+                  uint8_t *mask_out);
+    int backbone(int n);
+    int neck(int n);
+    int head(int n);
+    int post_frame(int b, int frame_index, float confidence, const std::vector<uint8_t> &keep_class, uint8_t *mask_out);
+    int ensure_post(size_t cands);
+
+    int conv(const f16 *in, int cC, int cLd, int n, int H, int W, int k, int stride, const PackedW &w, f16 *out, int ldo, int act,
+             const f16 *add1 = nullptr);
+    int conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, const PackedW &w, float *out, int ldo);
+    int dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1 = nullptr);
+    int conv_gn_relu(const f16 *in, int cC, int cLd, int n, int H, int W, int k, const ConvGN &c, f16 *tmp, f16 *out, int ldo);
+    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias);
+    int pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out);
+    int fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift);
+    int load_gn(const std::string &name, int C, GN &out);
+    int load_conv_gn(const std::string &name, ConvGN &out);
+    void *carve(size_t bytes);
+    void tic(int fam, double flops, double bytes);
+    void toc();
+
+    pb_mask_cfg cfg_;
+    std::map<std::string, const pb_tensor *> tmap_;
+    std::vector<void *> owned_;
+    f16 *zero_ = nullptr;
+
+    // weights
+    PackedW stem_;
+    std::vector<Bneck> blocks_[4];
+    PackedW lat_[4], fpnc_[4];
+    ConvGN mfc_[4][3], mfpred_;
+    std::vector<ConvGN> kconv_, cconv_;
+    PackedW conv_cls_, conv_kernel_;
+
+    // plan
+    int pB_ = 0, pH_ = 0, pW_ = 0;
+    int nh_ = 0, nw_ = 0, Hp_ = 0, Wp_ = 0;
+    int lh_[6] = {}, lw_[6] = {};            // feature sizes at strides 4, 8, 16, 32, 64 (index 0..4); [5] = stride 2
+    int pts_ = 0, goff_[6] = {};
+    char *arena_ = nullptr;
+    size_t arena_bytes_ = 0, arena_off_ = 0;
+    bool planning_ = false;
+    int *xt_ = nullptr, *yt_ = nullptr;
+    f16 *img_ = nullptr, *colA_ = nullptr, *stem_out_ = nullptr, *pool_ = nullptr;
+    float *chw_ = nullptr;
+    f16 *sx_[4][2] = {}, *st1_[4] = {}, *st2_[4] = {}, *sds_[4] = {};
+    const f16 *c_[4] = {};
+    f16 *latb_[4] = {}, *p_[5] = {};
+    f16 *mt_[2] = {}, *mg_[2] = {}, *macc_ = nullptr, *mf_ = nullptr, *p5cc_ = nullptr;
+    f16 *fcc_ = nullptr, *rs_ = nullptr, *grid_ = nullptr, *hk_[3] = {};
+    float *kp_ = nullptr, *cl_ = nullptr, *cs_ = nullptr;
+    float *gst_ = nullptr, *gaff_ = nullptr;
+
+    // post-processing scratch (grown on demand, outside the arena)
+    size_t post_cap_ = 0;
+    f16 *pk_ = nullptr, *bin_ = nullptr;
+    float *plog_ = nullptr, *pstat_ = nullptr, *inter_ = nullptr, *sig_ = nullptr, *nmsf_ = nullptr;
+    int *pidx_ = nullptr, *nmsi_ = nullptr;
+    uint8_t *use_ = nullptr, *inst_ = nullptr;
+    size_t inst_bytes_ = 0;
+    std::vector<float> h_scores_;
+
+    std::vector<Instances> results_;
+    int last_n_ = 0;
+    std::map<std::string, Stage> stages_;
+};

@@ -1,0 +1,742 @@
+// MaskEngine: the mask_mmdet band (SOLOv2 R-101 FPN) on one MI355X.
+// Reference call stack being replaced: bands/mask_mmdet.py:131-154 (per-frame loop) -> mmdet/apis/inference.py:99-162
+// (test pipeline + model(return_loss=False)) -> models/detectors/single_stage_instance_seg.py:150-250 ->
+// models/backbones/resnet.py, models/necks/fpn.py, models/dense_heads/solov2_head.py (forward, get_results),
+// core/post_processing/matrix_nms.py -> format_results -> bands/mask_mmdet.py:43-61,139-147 (accumulation).
+//
+// Schedule: frames go through backbone / neck / head in batches (the reference runs one frame at a time); every
+// convolution is an MFMA GEMM launch (1x1 as dense GEMM, 3x3 as implicit GEMM) with eval-mode BatchNorm folded and
+// ReLU / residual add in the epilogue; GroupNorm needs run-time statistics and stays a stats + apply pair.  The
+// data-dependent part of get_results (which grid cells pass score_thr, the area filter, two sorts) is control
+// logic on the host over a few KB of scores, exactly the decisions torch makes on the reference's host; every
+// numeric step (sigmoid / points-NMS, dynamic convolution, mask areas and maskness, pairwise intersections,
+// Matrix-NMS decay, the two bilinear resizes, thresholds and the accumulation) is a kernel.
+#include "mask_engine.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "raft_kernels.h"
+
+namespace {
+enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_COUNT = 6 };
+const char *kFamM[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost"};
+inline int cp64(int c) { return (int)round_up(c, 64); }
+
+// OpenCV resize(INTER_LINEAR) tables for 8-bit images: {i0, i1, c0, c1} per destination index.  Columns zero the
+// fraction at the borders, rows clamp the indices instead (imgproc resize.cpp, the linear branch).
+void linear_taps_u8(int src, int dst, bool rows, std::vector<int> &t) {
+    t.resize((size_t)dst * 4);
+    const double scale = 1.0 / ((double)dst / (double)src);
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        int i0, i1;
+        if (rows) {
+            i0 = std::min(std::max(s, 0), src - 1);
+            i1 = std::min(std::max(s + 1, 0), src - 1);
+        } else {
+            if (s < 0) { f = 0.f; s = 0; }
+            if (s >= src - 1) { f = 0.f; s = src - 1; }
+            i0 = s;
+            i1 = std::min(s + 1, src - 1);
+        }
+        t[(size_t)d * 4 + 0] = i0;
+        t[(size_t)d * 4 + 1] = i1;
+        t[(size_t)d * 4 + 2] = (int)nearbyintf((1.f - f) * 2048.f);
+        t[(size_t)d * 4 + 3] = (int)nearbyintf(f * 2048.f);
+    }
+}
+}  // namespace
+
+void MaskEngine::net_size(const pb_mask_cfg &cfg, int H, int W, int *nh, int *nw, int *Hp, int *Wp) {
+    // mmcv.rescale_size((long, short)): factor = min(long / max(h, w), short / min(h, w)); int(x * factor + 0.5)
+    const double f = std::min((double)cfg.scale_long / std::max(H, W), (double)cfg.scale_short / std::min(H, W));
+    *nh = (int)(H * f + 0.5);
+    *nw = (int)(W * f + 0.5);
+    *Hp = (*nh + 31) / 32 * 32;
+    *Wp = (*nw + 31) / 32 * 32;
+}
+
+void MaskEngine::tic(int fam, double flops, double bytes) {
+    if (!timer.enabled) return;
+    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes};
+    hipEventRecord(r.a, stream);
+    timer.recs.push_back(r);
+}
+void MaskEngine::toc() {
+    if (!timer.enabled) return;
+    hipEventRecord(timer.recs.back().b, stream);
+}
+int MaskEngine::stats(pb_kernel_stat *out, int cap) {
+    if (hipStreamSynchronize(stream) != hipSuccess) return -2;
+    pb_kernel_stat acc[F_COUNT];
+    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFamM[i], 0, 0, 0, 0};
+    for (auto &r : timer.recs) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        acc[r.fam].ms += ms; acc[r.fam].flops += r.flops; acc[r.fam].bytes += r.bytes; acc[r.fam].launches++;
+    }
+    int n = 0;
+    for (int i = 0; i < F_COUNT && n < cap; ++i)
+        if (acc[i].launches) out[n++] = acc[i];
+    return n;
+}
+
+MaskEngine::~MaskEngine() {
+    hipSetDevice(device);
+    if (stream) hipStreamSynchronize(stream);
+    for (auto p : owned_) hipFree(p);
+    void *post[] = {pk_, bin_, plog_, pstat_, inter_, sig_, nmsf_, pidx_, nmsi_, use_, inst_};
+    for (auto p : post)
+        if (p) hipFree(p);
+    if (arena_) hipFree(arena_);
+    if (stream) hipStreamDestroy(stream);
+}
+
+int MaskEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias) {
+    const int64_t Np = round_up(N, 256);
+    std::vector<f16> h((size_t)Np * Kpad, (f16)0.f);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) h[(size_t)n * Kpad + k] = (f16)src[(size_t)n * K + k];
+    void *p = nullptr;
+    PB_HIP(hipMalloc(&p, h.size() * 2));
+    owned_.push_back(p);
+    PB_HIP(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    out.w = (f16 *)p; out.N = (int)round_up(N, 8); out.K = Kpad; out.Kreal = K; out.bias = nullptr;
+    if (bias) {
+        void *b = nullptr;
+        PB_HIP(hipMalloc(&b, std::max<size_t>((size_t)Np * 4, 256)));
+        owned_.push_back(b);
+        PB_HIP(hipMemset(b, 0, (size_t)Np * 4));
+        PB_HIP(hipMemcpy(b, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        out.bias = (float *)b;
+    }
+    return 0;
+}
+
+int MaskEngine::fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift) {
+    const char *sfx[4] = {".weight", ".bias", ".running_mean", ".running_var"};
+    const float *t[4];
+    for (int i = 0; i < 4; ++i) {
+        auto it = tmap_.find(bn + sfx[i]);
+        PB_CHECK(it != tmap_.end() && it->second->shape[0] == C, PB_ERR_ARG, "missing weight '%s%s' [%d]", bn.c_str(), sfx[i], C);
+        t[i] = (const float *)it->second->data;
+    }
+    scale.resize(C); shift.resize(C);
+    for (int c = 0; c < C; ++c) {
+        const float s = t[0][c] / sqrtf(t[3][c] + 1e-5f);       // BatchNorm2d eval, eps 1e-5 (mmcv build_norm_layer default)
+        scale[c] = s;
+        shift[c] = t[1][c] - t[2][c] * s;
+    }
+    return 0;
+}
+
+// conv weight [co, ci, kh, kw] (+ optional bias) -> [co, (ky*kw + kx) * cp64(ci) + c] with a per-output affine (folded BN)
+int MaskEngine::pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out) {
+    auto iw = tmap_.find(name + ".weight");
+    PB_CHECK(iw != tmap_.end() && iw->second->ndim == 4, PB_ERR_ARG, "missing conv '%s'", name.c_str());
+    const float *b = nullptr;
+    if (has_bias) {
+        auto ib = tmap_.find(name + ".bias");
+        PB_CHECK(ib != tmap_.end(), PB_ERR_ARG, "missing bias of '%s'", name.c_str());
+        b = (const float *)ib->second->data;
+    }
+    const pb_tensor *t = iw->second;
+    const int co = (int)t->shape[0], ci = (int)t->shape[1], kh = (int)t->shape[2], kw = (int)t->shape[3];
+    const float *w = (const float *)t->data;
+    const int cip = cp64(ci), K = kh * kw * cip;
+    std::vector<float> g((size_t)co * K, 0.f), bb(co);
+    for (int o = 0; o < co; ++o) {
+        const float s = scale ? scale[o] : 1.f;
+        for (int c = 0; c < ci; ++c)
+            for (int tp = 0; tp < kh * kw; ++tp) g[(size_t)o * K + tp * cip + c] = w[((size_t)o * ci + c) * kh * kw + tp] * s;
+        bb[o] = (b ? b[o] : 0.f) * s + (shift ? shift[o] : 0.f);
+    }
+    int r = pack(g.data(), co, K, K, out, bb.data());
+    out.Kreal = kh * kw * ci;
+    return r;
+}
+
+int MaskEngine::load_gn(const std::string &name, int C, GN &out) {
+    auto ig = tmap_.find(name + ".weight"), ib = tmap_.find(name + ".bias");
+    PB_CHECK(ig != tmap_.end() && ib != tmap_.end() && ig->second->shape[0] == C, PB_ERR_ARG, "missing group norm '%s' [%d]",
+             name.c_str(), C);
+    void *p = nullptr;
+    PB_HIP(hipMalloc(&p, (size_t)C * 8));
+    owned_.push_back(p);
+    PB_HIP(hipMemcpy(p, ig->second->data, (size_t)C * 4, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy((float *)p + C, ib->second->data, (size_t)C * 4, hipMemcpyHostToDevice));
+    out.g = (float *)p; out.b = (float *)p + C; out.C = C;
+    return 0;
+}
+
+// mmcv ConvModule with a norm: conv without bias -> GroupNorm(32) -> ReLU; submodules `conv` and `gn`
+int MaskEngine::load_conv_gn(const std::string &name, ConvGN &out) {
+    int r = pack_conv(name + ".conv", false, nullptr, nullptr, out.w);
+    if (r) return r;
+    return load_gn(name + ".gn", (int)tmap_[name + ".conv.weight"]->shape[0], out.gn);
+}
+
+int MaskEngine::load(const pb_tensor *w, int n) {
+    PB_HIP(hipSetDevice(device));
+    PB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    PB_CHECK(cfg_.num_classes > 0 && cfg_.feat_channels % 32 == 0 && cfg_.mask_feat_channels % 32 == 0 &&
+                 cfg_.mask_out_channels == 256 && cfg_.stacked_convs >= 1 && cfg_.nms_pre > 0 && cfg_.nms_pre <= 512 &&
+                 cfg_.max_per_img > 0 && cfg_.max_batch >= 1,
+             PB_ERR_ARG, "mask_mmdet: unsupported configuration");
+    for (int i = 0; i < n; ++i) {
+        PB_CHECK(w[i].data && w[i].name, PB_ERR_ARG, "weight %d: null", i);
+        if (w[i].dtype == PB_F32) tmap_[w[i].name] = &w[i];
+    }
+    {
+        void *z = nullptr;
+        PB_HIP(hipMalloc(&z, 4096));
+        PB_HIP(hipMemset(z, 0, 4096));
+        owned_.push_back(z);
+        zero_ = (f16 *)z;
+    }
+    int r;
+    std::vector<float> sc, sf;
+    {   // stem 7x7/s2 (resnet.py:560-580, no bias) + bn1: im2col order k = tap*3 + c, K 147 -> 192
+        auto iw = tmap_.find("backbone.conv1.weight");
+        PB_CHECK(iw != tmap_.end(), PB_ERR_ARG, "missing backbone.conv1.weight");
+        if ((r = fold_bn("backbone.bn1", 64, sc, sf))) return r;
+        const float *wt = (const float *)iw->second->data;
+        std::vector<float> g((size_t)64 * 147);
+        for (int o = 0; o < 64; ++o)
+            for (int c = 0; c < 3; ++c)
+                for (int tp = 0; tp < 49; ++tp) g[(size_t)o * 147 + tp * 3 + c] = wt[((size_t)o * 3 + c) * 49 + tp] * sc[o];
+        if ((r = pack(g.data(), 64, 147, 192, stem_, sf.data()))) return r;
+    }
+    int inpl = 64;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = 64 << li;
+        blocks_[li].resize(cfg_.blocks[li]);
+        for (int b = 0; b < cfg_.blocks[li]; ++b) {
+            Bneck &B = blocks_[li][b];
+            const std::string p = "backbone.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            B.planes = planes; B.inpl = inpl;
+            B.stride = (b == 0 && li > 0) ? 2 : 1;              // style 'pytorch': the 3x3 carries the stride
+            if ((r = fold_bn(p + ".bn1", planes, sc, sf)) || (r = pack_conv(p + ".conv1", false, sc.data(), sf.data(), B.c1))) return r;
+            if ((r = fold_bn(p + ".bn2", planes, sc, sf)) || (r = pack_conv(p + ".conv2", false, sc.data(), sf.data(), B.c2))) return r;
+            if ((r = fold_bn(p + ".bn3", planes * 4, sc, sf)) || (r = pack_conv(p + ".conv3", false, sc.data(), sf.data(), B.c3))) return r;
+            B.has_ds = b == 0;
+            if (B.has_ds) {
+                if ((r = fold_bn(p + ".downsample.1", planes * 4, sc, sf)) ||
+                    (r = pack_conv(p + ".downsample.0", false, sc.data(), sf.data(), B.ds)))
+                    return r;
+            }
+            inpl = planes * 4;
+        }
+    }
+    for (int i = 0; i < 4; ++i) {
+        if ((r = pack_conv("neck.lateral_convs." + std::to_string(i) + ".conv", true, nullptr, nullptr, lat_[i]))) return r;
+        if ((r = pack_conv("neck.fpn_convs." + std::to_string(i) + ".conv", true, nullptr, nullptr, fpnc_[i]))) return r;
+    }
+    const std::string h = "mask_head.mask_feature_head.";
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < std::max(i, 1); ++j)
+            if ((r = load_conv_gn(h + "convs_all_levels." + std::to_string(i) + ".conv" + std::to_string(j), mfc_[i][j]))) return r;
+    if ((r = load_conv_gn(h + "conv_pred", mfpred_))) return r;
+    kconv_.resize(cfg_.stacked_convs);
+    cconv_.resize(cfg_.stacked_convs);
+    for (int i = 0; i < cfg_.stacked_convs; ++i) {
+        if ((r = load_conv_gn("mask_head.kernel_convs." + std::to_string(i), kconv_[i]))) return r;
+        if ((r = load_conv_gn("mask_head.cls_convs." + std::to_string(i), cconv_[i]))) return r;
+    }
+    if ((r = pack_conv("mask_head.conv_cls", true, nullptr, nullptr, conv_cls_))) return r;
+    if ((r = pack_conv("mask_head.conv_kernel", true, nullptr, nullptr, conv_kernel_))) return r;
+    PB_CHECK(conv_kernel_.N == cfg_.mask_out_channels && mfpred_.w.N == cfg_.mask_out_channels, PB_ERR_ARG,
+             "mask_mmdet: kernel / mask feature widths do not match the configuration");
+    tmap_.clear();
+    PB_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+void *MaskEngine::carve(size_t bytes) {
+    const size_t off = arena_off_;
+    arena_off_ += round_up((int64_t)bytes, 256);
+    return planning_ ? nullptr : (void *)(arena_ + off);
+}
+
+int MaskEngine::prepare(int n, int H, int W) {
+    const int B = std::min(n, cfg_.max_batch);
+    if (B <= pB_ && H == pH_ && W == pW_) return 0;
+    PB_HIP(hipStreamSynchronize(stream));
+    net_size(cfg_, H, W, &nh_, &nw_, &Hp_, &Wp_);
+    PB_CHECK(Hp_ >= 64 && Wp_ >= 64, PB_ERR_ARG, "mask_mmdet: network input %dx%d is too small", Hp_, Wp_);
+    lh_[5] = Hp_ / 2; lw_[5] = Wp_ / 2;
+    for (int i = 0; i < 4; ++i) { lh_[i] = Hp_ / (4 << i); lw_[i] = Wp_ / (4 << i); }
+    lh_[4] = (lh_[3] - 1) / 2 + 1; lw_[4] = (lw_[3] - 1) / 2 + 1;
+    pts_ = 0;
+    int gmax = 0;
+    for (int l = 0; l < 5; ++l) { goff_[l] = pts_; pts_ += cfg_.num_grids[l] * cfg_.num_grids[l]; gmax = std::max(gmax, cfg_.num_grids[l]); }
+    goff_[5] = pts_;
+    const int fc = cfg_.feat_channels, mfc = cfg_.mask_feat_channels, Cp = conv_cls_.N;
+    const size_t slack = 1 << 20;
+    auto rows = [&](int i) { return (size_t)round_up((int64_t)B * lh_[i] * lw_[i], 256); };
+    for (int pass = 0; pass < 2; ++pass) {
+        planning_ = pass == 0;
+        arena_off_ = 0;
+        xt_ = (int *)carve((size_t)nw_ * 16); yt_ = (int *)carve((size_t)nh_ * 16);
+        img_ = (f16 *)carve((size_t)B * Hp_ * Wp_ * 8 + slack);
+        chw_ = debug ? (float *)carve((size_t)B * 3 * Hp_ * Wp_ * 4) : nullptr;
+        colA_ = (f16 *)carve(rows(5) * 192 * 2);
+        stem_out_ = (f16 *)carve(rows(5) * 64 * 2);
+        pool_ = (f16 *)carve(rows(0) * 64 * 2 + slack);
+        for (int s = 0; s < 4; ++s) {
+            const int p = 64 << s, in = s == 0 ? 0 : s - 1;
+            sx_[s][0] = (f16 *)carve(rows(s) * p * 4 * 2 + slack);
+            sx_[s][1] = (f16 *)carve(rows(s) * p * 4 * 2 + slack);
+            st1_[s] = (f16 *)carve(rows(in) * p * 2 + slack);
+            st2_[s] = (f16 *)carve(rows(s) * p * 2 + slack);
+            sds_[s] = (f16 *)carve(rows(s) * p * 4 * 2 + slack);
+        }
+        for (int i = 0; i < 4; ++i) { latb_[i] = (f16 *)carve(rows(i) * 256 * 2 + slack); p_[i] = (f16 *)carve(rows(i) * 256 * 2 + slack); }
+        p_[4] = (f16 *)carve(rows(4) * 256 * 2 + slack);
+        mt_[0] = (f16 *)carve(rows(0) * 256 * 2 + slack);
+        mg_[0] = (f16 *)carve(rows(0) * mfc * 2 + slack); mg_[1] = (f16 *)carve(rows(0) * mfc * 2 + slack);
+        macc_ = (f16 *)carve(rows(0) * mfc * 2 + slack);
+        mf_ = (f16 *)carve(rows(0) * 256 * 2 + slack);
+        p5cc_ = (f16 *)carve(rows(3) * 320 * 2 + slack);
+        fcc_ = (f16 *)carve(rows(1) * 320 * 2 + slack);
+        rs_ = (f16 *)carve(rows(1) * 256 * 2 + slack);
+        const size_t grows = (size_t)round_up((int64_t)B * gmax * gmax, 256);
+        grid_ = (f16 *)carve(grows * 320 * 2 + slack);
+        for (auto &b : hk_) b = (f16 *)carve(grows * fc * 2 + slack);
+        kp_ = (float *)carve((size_t)B * pts_ * 256 * 4 + slack);
+        cl_ = (float *)carve((size_t)B * pts_ * Cp * 4 + slack);
+        cs_ = (float *)carve((size_t)B * pts_ * Cp * 4 + slack);
+        gst_ = (float *)carve((size_t)B * 512 * 2 * 4); gaff_ = (float *)carve((size_t)B * 512 * 2 * 4);
+        if (pass == 0) {
+            if (arena_off_ > arena_bytes_) {
+                if (arena_) PB_HIP(hipFree(arena_));
+                arena_ = nullptr; arena_bytes_ = 0;
+                hipError_t e = hipMalloc((void **)&arena_, arena_off_);
+                PB_CHECK(e == hipSuccess, PB_ERR_MEMORY, "mask arena of %zu bytes: %s", arena_off_, hipGetErrorString(e));
+                arena_bytes_ = arena_off_;
+            }
+            PB_HIP(hipMemsetAsync(arena_, 0, arena_bytes_, stream));
+        }
+    }
+    std::vector<int> xt, yt;
+    linear_taps_u8(W, nw_, false, xt);
+    linear_taps_u8(H, nh_, true, yt);
+    PB_HIP(hipMemcpyAsync(xt_, xt.data(), xt.size() * 4, hipMemcpyHostToDevice, stream));
+    PB_HIP(hipMemcpyAsync(yt_, yt.data(), yt.size() * 4, hipMemcpyHostToDevice, stream));
+    PB_HIP(hipStreamSynchronize(stream));
+    pB_ = B; pH_ = H; pW_ = W;
+    return 0;
+}
+
+int MaskEngine::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int k, int stride, const PackedW &w, f16 *out, int ldo,
+                     int act, const f16 *add1) {
+    GemmArgs a;
+    a.A = in; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_;
+    a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = k; a.cStride = stride; a.cPad = k / 2; a.cPadX = k / 2;
+    a.cOH = (H + 2 * (k / 2) - k) / stride + 1; a.cOW = (W + 2 * (k / 2) - k) / stride + 1;
+    a.M = n * a.cOH * a.cOW;
+    a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
+    PB_CHECK(w.K == k * k * cC, PB_ERR_STATE, "conv: packed K %d != %d*%d*%d", w.K, k, k, cC);
+    tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
+    int r = launch_gemm(stream, A_CONV, EPI_STD, conv_tile, a);
+    toc();
+    return r;
+}
+
+int MaskEngine::conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, const PackedW &w, float *out, int ldo) {
+    GemmArgs a;
+    a.A = in; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_;
+    a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1; a.cOH = H; a.cOW = W;
+    a.M = n * H * W;
+    a.out32 = out; a.ldo = ldo; a.scale = 1.f;
+    PB_CHECK(w.K == 9 * cC, PB_ERR_STATE, "conv_f32: packed K %d != 9*%d", w.K, cC);
+    tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
+    int r = launch_gemm(stream, A_CONV, EPI_F32, TILE_128, a);
+    toc();
+    return r;
+}
+
+int MaskEngine::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1) {
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_; a.M = (int)M;
+    a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
+    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 0);
+    int r = launch_gemm(stream, A_DENSE, EPI_STD, TILE_AUTO, a);
+    toc();
+    return r;
+}
+
+int MaskEngine::conv_gn_relu(const f16 *in, int cC, int cLd, int n, int H, int W, int k, const ConvGN &c, f16 *tmp, f16 *out,
+                             int ldo) {
+    int r = k == 1 ? dense(in, cLd, (int64_t)n * H * W, c.w, tmp, c.w.N, ACT_NONE) : conv(in, cC, cLd, n, H, W, k, 1, c.w, tmp, c.w.N, ACT_NONE);
+    if (r) return r;
+    tic(F_ELT, 0, (double)n * H * W * c.w.N * 6);
+    r = launch_gn_relu(stream, tmp, out, n, H * W, c.gn.C, c.w.N, ldo, 32, c.gn.g, c.gn.b, gst_, gaff_);
+    toc();
+    return r;
+}
+
+int MaskEngine::backbone(int n) {
+    int r;
+    const int H2 = lh_[5], W2 = lw_[5];
+    tic(F_ELT, 0, 0);
+    r = launch_im2col7_img(stream, img_, n, Hp_, Wp_, H2, W2, colA_, 192);
+    toc();
+    if (r) return r;
+    if ((r = dense(colA_, 192, (int64_t)n * H2 * W2, stem_, stem_out_, 64, ACT_RELU))) return r;
+    tic(F_ELT, 0, 0);
+    r = launch_maxpool3x3s2(stream, stem_out_, pool_, n, H2, W2, 64);
+    toc();
+    if (r) return r;
+    const f16 *x = pool_;
+    int hi = lh_[0], wi = lw_[0];
+    for (int s = 0; s < 4; ++s) {
+        for (size_t b = 0; b < blocks_[s].size(); ++b) {
+            const Bneck &B = blocks_[s][b];
+            const int ho = (hi - 1) / B.stride + 1, wo = (wi - 1) / B.stride + 1, p = B.planes;
+            if ((r = dense(x, B.inpl, (int64_t)n * hi * wi, B.c1, st1_[s], p, ACT_RELU))) return r;
+            if ((r = conv(st1_[s], p, p, n, hi, wi, 3, B.stride, B.c2, st2_[s], p, ACT_RELU))) return r;
+            const f16 *idt = x;
+            if (B.has_ds) {
+                if (B.stride == 1) r = dense(x, B.inpl, (int64_t)n * hi * wi, B.ds, sds_[s], 4 * p, ACT_NONE);
+                else r = conv(x, B.inpl, B.inpl, n, hi, wi, 1, B.stride, B.ds, sds_[s], 4 * p, ACT_NONE);
+                if (r) return r;
+                idt = sds_[s];
+            }
+            f16 *out = sx_[s][b & 1];
+            if ((r = dense(st2_[s], p, (int64_t)n * ho * wo, B.c3, out, 4 * p, ACT_RELU, idt))) return r;
+            x = out; hi = ho; wi = wo;
+        }
+        PB_CHECK(hi == lh_[s] && wi == lw_[s], PB_ERR_STATE, "backbone: stage %d size %dx%d != %dx%d", s, hi, wi, lh_[s], lw_[s]);
+        c_[s] = x;
+        stages_["c" + std::to_string(s + 2)] = Stage{x, 1, 0, 256 << s, lh_[s], lw_[s], 256 << s, 0};
+    }
+    return 0;
+}
+
+int MaskEngine::neck(int n) {
+    int r;
+    for (int i = 0; i < 4; ++i)
+        if ((r = dense(c_[i], 256 << i, (int64_t)n * lh_[i] * lw_[i], lat_[i], latb_[i], 256, ACT_NONE))) return r;
+    for (int i = 3; i > 0; --i) {
+        tic(F_ELT, 0, 0);
+        r = launch_nearest_add(stream, latb_[i - 1], latb_[i], n, lh_[i - 1], lw_[i - 1], lh_[i], lw_[i], 256);
+        toc();
+        if (r) return r;
+    }
+    for (int i = 0; i < 4; ++i)
+        if ((r = conv(latb_[i], 256, 256, n, lh_[i], lw_[i], 3, 1, fpnc_[i], p_[i], 256, ACT_NONE))) return r;
+    tic(F_ELT, 0, 0);
+    r = launch_subsample2(stream, p_[3], p_[4], n, lh_[3], lw_[3], 256);
+    toc();
+    for (int i = 0; i < 5; ++i) stages_["p" + std::to_string(i + 2)] = Stage{p_[i], 1, 0, 256, lh_[i], lw_[i], 256, 0};
+    return r;
+}
+
+int MaskEngine::head(int n) {
+    int r;
+    const int mfc = cfg_.mask_feat_channels, fc = cfg_.feat_channels, Cp = conv_cls_.N;
+    // ---- MaskFeatModule.forward (solov2_head.py:134-150) ----
+    if ((r = conv_gn_relu(p_[0], 256, 256, n, lh_[0], lw_[0], 3, mfc_[0][0], mt_[0], macc_, mfc))) return r;
+    for (int i = 1; i < 4; ++i) {
+        const f16 *x = p_[i];
+        int cC = 256, h = lh_[i], w = lw_[i];
+        if (i == 3) {
+            tic(F_ELT, 0, 0);
+            r = launch_coord_concat(stream, p_[3], p5cc_, n, h, w, 256, 256);
+            toc();
+            if (r) return r;
+            x = p5cc_; cC = 320;
+        }
+        for (int j = 0; j < i; ++j) {
+            if ((r = conv_gn_relu(x, cC, cC, n, h, w, 3, mfc_[i][j], mt_[0], mg_[0], mfc))) return r;
+            const bool last = j == i - 1;
+            tic(F_ELT, 0, 0);
+            r = launch_bilinear(stream, mg_[0], last ? macc_ : mg_[1], n, h, w, 2 * h, 2 * w, mfc, mfc, mfc, last ? 1 : 0);
+            toc();
+            if (r) return r;
+            x = mg_[1]; cC = mfc; h *= 2; w *= 2;
+        }
+        PB_CHECK(h == lh_[0] && w == lw_[0], PB_ERR_STATE, "mask feature level %d ends at %dx%d", i, h, w);
+    }
+    if ((r = conv_gn_relu(macc_, mfc, mfc, n, lh_[0], lw_[0], 1, mfpred_, mt_[0], mf_, 256))) return r;
+    stages_["mask_feats"] = Stage{mf_, 1, 0, 256, lh_[0], lw_[0], 256, 0};
+
+    // ---- resize_feats + the two prediction branches per level (solov2_head.py:253-292) ----
+    for (int lvl = 0; lvl < 5; ++lvl) {
+        const int g = cfg_.num_grids[lvl];
+        const f16 *src = p_[lvl];
+        int fh = lh_[lvl], fw = lw_[lvl];
+        if (lvl == 0 || lvl == 4) {
+            const int th = lvl == 0 ? lh_[1] : lh_[3], tw = lvl == 0 ? lw_[1] : lw_[3];
+            tic(F_ELT, 0, 0);
+            r = launch_bilinear(stream, src, rs_, n, fh, fw, th, tw, 256, 256, 256, 0);
+            toc();
+            if (r) return r;
+            src = rs_; fh = th; fw = tw;
+        }
+        tic(F_ELT, 0, 0);
+        r = launch_coord_concat(stream, src, fcc_, n, fh, fw, 256, 256);
+        if (!r) r = launch_bilinear(stream, fcc_, grid_, n, fh, fw, g, g, 320, 320, 320, 0);
+        toc();
+        if (r) return r;
+        const f16 *x = grid_;
+        int cC = 320, cLd = 320;
+        for (int i = 0; i < cfg_.stacked_convs; ++i) {
+            f16 *o = hk_[1 + (i & 1)];
+            if ((r = conv_gn_relu(x, cC, cLd, n, g, g, 3, kconv_[i], hk_[0], o, fc))) return r;
+            x = o; cC = cLd = fc;
+        }
+        float *kp = kp_ + (int64_t)n * goff_[lvl] * 256;
+        if ((r = conv_f32(x, fc, fc, n, g, g, conv_kernel_, kp, 256))) return r;
+        x = grid_; cC = 256; cLd = 320;                                   // cate_feat = kernel_feat[:, :-2]
+        for (int i = 0; i < cfg_.stacked_convs; ++i) {
+            f16 *o = hk_[1 + (i & 1)];
+            if ((r = conv_gn_relu(x, cC, cLd, n, g, g, 3, cconv_[i], hk_[0], o, fc))) return r;
+            x = o; cC = cLd = fc;
+        }
+        float *cl = cl_ + (int64_t)n * goff_[lvl] * Cp;
+        if ((r = conv_f32(x, fc, fc, n, g, g, conv_cls_, cl, Cp))) return r;
+        tic(F_PP, 0, (double)n * g * g * Cp * 8);
+        r = launch_cls_points_nms(stream, cl, cs_, n, pts_, goff_[lvl], g, Cp);
+        toc();
+        if (r) return r;
+        stages_["kernel_pred" + std::to_string(lvl)] = Stage{kp, 3, 0, 256, g, g, 256, 0};
+        stages_["cls_logit" + std::to_string(lvl)] = Stage{cl, 3, 0, cfg_.num_classes, g, g, Cp, 0};
+    }
+    return 0;
+}
+
+int MaskEngine::ensure_post(size_t cands) {
+    const size_t HW4 = (size_t)lh_[0] * lw_[0];
+    const size_t need = round_up((int64_t)std::max<size_t>(cands, 256), 256);
+    if (need <= post_cap_) return 0;
+    PB_CHECK(need <= (1u << 16), PB_ERR_MEMORY, "mask_mmdet: %zu candidate cells over score_thr in one frame", cands);
+    PB_HIP(hipStreamSynchronize(stream));
+    void **bufs[] = {(void **)&pk_, (void **)&plog_, (void **)&pstat_, (void **)&pidx_};
+    for (auto b : bufs)
+        if (*b) { PB_HIP(hipFree(*b)); *b = nullptr; }
+    PB_HIP(hipMalloc((void **)&pk_, need * 256 * 2));
+    PB_HIP(hipMalloc((void **)&plog_, need * HW4 * 4));
+    PB_HIP(hipMalloc((void **)&pstat_, need * 2 * 4));
+    PB_HIP(hipMalloc((void **)&pidx_, need * 4));
+    post_cap_ = need;
+    return 0;
+}
+
+// _get_results_single (solov2_head.py:647-766) + format_results + the band's accumulation for frame b of the chunk
+int MaskEngine::post_frame(int b, int frame_index, float confidence, const std::vector<uint8_t> &keep_class, uint8_t *mask_out) {
+    const int C = cfg_.num_classes, Cp = conv_cls_.N, n = last_n_;
+    const int fh = lh_[0], fw = lw_[0], HW4 = fh * fw;
+    const int64_t opix = (int64_t)pH_ * pW_;
+    Instances &res = results_[frame_index];
+    res = Instances();
+    uint8_t *out = mask_out + (int64_t)frame_index * opix * 3;
+    auto empty = [&]() -> int {
+        PB_HIP(hipMemsetAsync(out, 0, (size_t)opix * 3, stream));
+        return 0;
+    };
+    // candidates in nonzero() order: cell-major, class-minor
+    struct Cand { int cell, label; float score; };
+    std::vector<Cand> cand;
+    const float *sc = h_scores_.data() + (int64_t)b * pts_ * Cp;
+    for (int p = 0; p < pts_; ++p)
+        for (int c = 0; c < C; ++c)
+            if (sc[(int64_t)p * Cp + c] > cfg_.score_thr) cand.push_back({p, c, sc[(int64_t)p * Cp + c]});
+    res.candidates = (int)cand.size();
+    if (cand.empty()) return empty();
+    int r;
+    if ((r = ensure_post(cand.size()))) return r;
+    const int K = (int)cand.size();
+    std::vector<int> rows(K);
+    std::vector<float> stride_of(K);
+    for (int i = 0; i < K; ++i) {
+        int lvl = 0;
+        while (cand[i].cell >= goff_[lvl + 1]) ++lvl;
+        rows[i] = n * goff_[lvl] + b * (goff_[lvl + 1] - goff_[lvl]) + (cand[i].cell - goff_[lvl]);     // level-major kernel rows
+        stride_of[i] = (float)cfg_.strides[lvl];
+    }
+    PB_HIP(hipMemcpyAsync(pidx_, rows.data(), (size_t)K * 4, hipMemcpyHostToDevice, stream));
+    tic(F_PP, 0, (double)K * 256 * 6);
+    r = launch_gather_rows_f16(stream, kp_, pidx_, pk_, K, (int)round_up(K, 256), 256);
+    toc();
+    if (r) return r;
+    {   // dynamic convolution: logits[k][pixel] = <kernel_k, mask_feats[pixel]>
+        GemmArgs a;
+        a.A = pk_; a.lda = 256; a.M = K; a.W = mf_ + (int64_t)b * HW4 * 256; a.K = 256; a.N = HW4;
+        a.out32 = plog_; a.ldo = HW4; a.scale = 1.f; a.zero = zero_;
+        tic(F_GEMM, 2.0 * K * (double)HW4 * 256, 0);
+        r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
+        toc();
+        if (r) return r;
+    }
+    tic(F_PP, 0, (double)K * HW4 * 4);
+    r = launch_mask_stats(stream, plog_, K, HW4, HW4, cfg_.mask_thr, pstat_);
+    toc();
+    if (r) return r;
+    std::vector<float> st((size_t)K * 2);
+    PB_HIP(hipMemcpyAsync(st.data(), pstat_, (size_t)K * 8, hipMemcpyDeviceToHost, stream));
+    PB_HIP(hipStreamSynchronize(stream));
+    // keep = sum_masks > strides; cls_scores *= maskness
+    struct Kept { int row, label; float score, area; };
+    std::vector<Kept> kept;
+    for (int i = 0; i < K; ++i)
+        if (st[(size_t)i * 2] > stride_of[i]) kept.push_back({i, cand[i].label, cand[i].score * (st[(size_t)i * 2 + 1] / st[(size_t)i * 2]), st[(size_t)i * 2]});
+    if (kept.empty()) return empty();
+    std::stable_sort(kept.begin(), kept.end(), [](const Kept &x, const Kept &y) { return x.score > y.score; });
+    if ((int)kept.size() > cfg_.nms_pre) kept.resize(cfg_.nms_pre);
+    const int n2 = (int)kept.size(), n2p = (int)round_up(n2, 8);
+    if (!bin_) {
+        PB_HIP(hipMalloc((void **)&bin_, (size_t)768 * HW4 * 2));
+        PB_HIP(hipMemsetAsync(bin_, 0, (size_t)768 * HW4 * 2, stream));
+        PB_HIP(hipMalloc((void **)&inter_, (size_t)512 * 512 * 4));
+        PB_HIP(hipMalloc((void **)&nmsf_, 4 * 512 * 4));
+        PB_HIP(hipMalloc((void **)&nmsi_, 2 * 512 * 4));
+        PB_HIP(hipMalloc((void **)&sig_, (size_t)cfg_.max_per_img * HW4 * 4));
+        PB_HIP(hipMalloc((void **)&use_, 512));
+    }
+    std::vector<int> li(1024);
+    std::vector<float> lf(1024);
+    for (int i = 0; i < n2; ++i) { li[i] = kept[i].row; li[512 + i] = kept[i].label; lf[i] = kept[i].area; lf[512 + i] = kept[i].score; }
+    PB_HIP(hipMemcpyAsync(nmsi_, li.data(), 1024 * 4, hipMemcpyHostToDevice, stream));
+    PB_HIP(hipMemcpyAsync(nmsf_, lf.data(), 1024 * 4, hipMemcpyHostToDevice, stream));
+    tic(F_PP, 0, (double)n2 * HW4 * 6);
+    r = launch_binarize_rows(stream, plog_, HW4, nmsi_, n2, n2p, HW4, cfg_.mask_thr, bin_);
+    toc();
+    if (r) return r;
+    {   // pairwise intersections of the binary masks (matrix_nms.py:66-67): exact in fp32
+        GemmArgs a;
+        a.A = bin_; a.lda = HW4; a.M = n2; a.W = bin_; a.K = HW4; a.N = n2p;
+        a.out32 = inter_; a.ldo = 512; a.scale = 1.f; a.zero = zero_;
+        tic(F_GEMM, 2.0 * n2 * (double)n2p * HW4, 0);
+        r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
+        toc();
+        if (r) return r;
+    }
+    tic(F_PP, 0, (double)n2 * n2 * 4);
+    r = launch_matrix_nms(stream, inter_, 512, nmsf_, nmsi_ + 512, nmsf_ + 512, n2, cfg_.sigma, nmsf_ + 1024);
+    toc();
+    if (r) return r;
+    std::vector<float> ns(n2);
+    PB_HIP(hipMemcpyAsync(ns.data(), nmsf_ + 1024, (size_t)n2 * 4, hipMemcpyDeviceToHost, stream));
+    PB_HIP(hipStreamSynchronize(stream));
+    struct Fin { int row, label; float score; };
+    std::vector<Fin> fin;
+    for (int i = 0; i < n2; ++i)
+        if (!(cfg_.filter_thr > 0.f) || ns[i] >= cfg_.filter_thr) fin.push_back({kept[i].row, kept[i].label, ns[i]});
+    if (fin.empty()) return empty();
+    std::stable_sort(fin.begin(), fin.end(), [](const Fin &x, const Fin &y) { return x.score > y.score; });
+    if ((int)fin.size() > cfg_.max_per_img) fin.resize(cfg_.max_per_img);
+    const int n3 = (int)fin.size();
+    // the band (mask_mmdet.py:43-49,139-147): classes in the keep list, score > 0.5 (getTotalMasks' default) and > --confidence
+    std::vector<uint8_t> use(n3);
+    std::vector<int> frow(n3);
+    for (int i = 0; i < n3; ++i) {
+        frow[i] = fin[i].row;
+        use[i] = keep_class[fin[i].label] && fin[i].score > 0.5f && fin[i].score > confidence;
+        res.scores.push_back(fin[i].score);
+        res.labels.push_back(fin[i].label);
+    }
+    PB_HIP(hipMemcpyAsync(nmsi_, frow.data(), (size_t)n3 * 4, hipMemcpyHostToDevice, stream));
+    PB_HIP(hipMemcpyAsync(use_, use.data(), (size_t)n3, hipMemcpyHostToDevice, stream));
+    tic(F_PP, 0, (double)n3 * HW4 * 8);
+    r = launch_sigmoid_rows(stream, plog_, HW4, nmsi_, n3, HW4, sig_);
+    toc();
+    if (r) return r;
+    uint8_t *inst = nullptr;
+    if (debug) {
+        const size_t need = (size_t)n3 * opix;
+        if (need > inst_bytes_) {
+            if (inst_) PB_HIP(hipFree(inst_));
+            PB_HIP(hipMalloc((void **)&inst_, need));
+            inst_bytes_ = need;
+        }
+        inst = inst_;
+    }
+    tic(F_PP, 0, (double)opix * (3 + 64.0 * n3));
+    r = launch_band_accumulate(stream, sig_, n3, fh, fw, nh_, nw_, pH_, pW_, cfg_.mask_thr, use_, out, inst);
+    toc();
+    if (r) return r;
+    if (debug) {
+        res.masks.resize((size_t)n3 * opix);
+        PB_HIP(hipMemcpyAsync(res.masks.data(), inst_, (size_t)n3 * opix, hipMemcpyDeviceToHost, stream));
+    }
+    PB_HIP(hipStreamSynchronize(stream));       // host vectors (rows / use) go out of scope here
+    return 0;
+}
+
+int MaskEngine::run_chunk(const uint8_t *frames, int n, int first, float confidence, const std::vector<uint8_t> &keep_class,
+                          uint8_t *mask_out) {
+    int r;
+    last_n_ = n;
+    tic(F_PP, 0, (double)n * ((double)pH_ * pW_ * 3 + (double)Hp_ * Wp_ * 8));
+    r = launch_mask_prep(stream, frames, n, pH_, pW_, nh_, nw_, Hp_, Wp_, xt_, yt_, img_, chw_);
+    toc();
+    if (r) return r;
+    if (chw_) stages_["input"] = Stage{chw_, 2, 0, 3, Hp_, Wp_, 0, 0};
+    if ((r = backbone(n)) || (r = neck(n)) || (r = head(n))) return r;
+    const int Cp = conv_cls_.N;
+    h_scores_.resize((size_t)n * pts_ * Cp);
+    PB_HIP(hipMemcpyAsync(h_scores_.data(), cs_, h_scores_.size() * 4, hipMemcpyDeviceToHost, stream));
+    PB_HIP(hipStreamSynchronize(stream));
+    for (int b = 0; b < n; ++b)
+        if ((r = post_frame(b, first + b, confidence, keep_class, mask_out))) return r;
+    return 0;
+}
+
+int MaskEngine::infer(const uint8_t *frames, int n, int H, int W, float confidence, const int32_t *keep, int n_keep,
+                      uint8_t *mask_out) {
+    PB_CHECK(frames && mask_out && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "mask infer: bad arguments");
+    PB_HIP(hipSetDevice(device));
+    std::vector<uint8_t> keep_class(cfg_.num_classes, keep ? 0 : 1);
+    for (int i = 0; i < n_keep && keep; ++i) {
+        PB_CHECK(keep[i] >= 0 && keep[i] < cfg_.num_classes, PB_ERR_ARG, "mask infer: class id %d out of range", keep[i]);
+        keep_class[keep[i]] = 1;
+    }
+    int r = prepare(n, H, W);
+    if (r) return r;
+    timer.reset();
+    stages_.clear();
+    results_.assign(n, Instances());
+    for (int s = 0; s < n; s += pB_) {
+        const int m = std::min(pB_, n - s);
+        if ((r = run_chunk(frames + (int64_t)s * H * W * 3, m, s, confidence, keep_class, mask_out))) return r;
+    }
+    return 0;
+}
+
+int64_t MaskEngine::get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]) {
+    auto it = stages_.find(name);
+    PB_CHECK(it != stages_.end(), PB_ERR_ARG, "unknown stage '%s'", name);
+    const Stage &s = it->second;
+    PB_HIP(hipStreamSynchronize(stream));
+    const int n = last_n_;
+    const int64_t total = (int64_t)n * s.c * s.h * s.w;
+    shape[0] = n; shape[1] = s.c; shape[2] = s.h; shape[3] = s.w;
+    PB_CHECK(total <= cap, PB_ERR_ARG, "stage buffer too small");
+    if (s.kind == 2) {          // fp32 NCHW already
+        PB_HIP(hipMemcpy(out, s.ptr, total * 4, hipMemcpyDeviceToHost));
+        return total;
+    }
+    if (s.kind == 3) {          // fp32 rows [n*h*w][ld] -> NCHW on the host
+        std::vector<float> tmp((size_t)n * s.h * s.w * s.ld);
+        PB_HIP(hipMemcpy(tmp.data(), s.ptr, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < n; ++b)
+            for (int64_t c = 0; c < s.c; ++c)
+                for (int64_t p = 0; p < s.h * s.w; ++p) out[((int64_t)b * s.c + c) * s.h * s.w + p] = tmp[((int64_t)b * s.h * s.w + p) * s.ld + c];
+        return total;
+    }
+    float *tmp = nullptr;
+    PB_HIP(hipMalloc((void **)&tmp, total * 4));
+    int r = launch_nhwc_f16_to_nchw_f32(stream, (const f16 *)s.ptr, tmp, n, (int)s.c, (int)s.h, (int)s.w, (int)s.ld);
+    if (r) return r;
+    PB_HIP(hipStreamSynchronize(stream));
+    PB_HIP(hipMemcpy(out, tmp, total * 4, hipMemcpyDeviceToHost));
+    PB_HIP(hipFree(tmp));
+    return total;
+}

@@ -1,0 +1,26 @@
+// Launchers of the mask_mmdet band's non-GEMM kernels (mask_kernels.hip).
+#pragma once
+#include "common.h"
+
+// xt / yt: per destination column / row {i0, i1, c0, c1} (OpenCV INTER_LINEAR 11-bit tables); chw (optional): the
+// normalised fp32 network input [n][3][Hp][Wp] for parity dumps.
+int launch_mask_prep(hipStream_t s, const uint8_t *frames, int n, int H, int W, int nh, int nw, int Hp, int Wp, const int *xt,
+                     const int *yt, f16 *out, float *chw);
+int launch_maxpool3x3s2(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C);
+int launch_nearest_add(hipStream_t s, f16 *dst, const f16 *src, int n, int h, int w, int sh, int sw, int C);
+int launch_subsample2(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C);
+int launch_coord_concat(hipStream_t s, const f16 *x, f16 *y, int n, int h, int w, int C, int ldi);
+int launch_bilinear(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int OH, int OW, int C, int ldi, int ldo,
+                    int accumulate);
+int launch_gn_relu(hipStream_t s, const f16 *x, f16 *y, int n, int HW, int C, int ldc, int ldo, int groups, const float *gamma,
+                   const float *beta, float *stats, float *aff);
+int launch_cls_points_nms(hipStream_t s, const float *logit, float *score, int n, int pts_total, int off, int g, int C);
+int launch_gather_rows_f16(hipStream_t s, const float *src, const int *idx, f16 *dst, int count, int rows_pad, int cols);
+int launch_mask_stats(hipStream_t s, const float *logit, int rows, int HW, int64_t ld, float thr, float *out);
+int launch_binarize_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int rows_pad, int HW, float thr,
+                         f16 *bin);
+int launch_matrix_nms(hipStream_t s, const float *inter, int ld, const float *area, const int *label, const float *score, int n,
+                      float sigma, float *out);
+int launch_sigmoid_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int HW, float *sig);
+int launch_band_accumulate(hipStream_t s, const float *sig, int k, int fh, int fw, int h, int w, int H, int W, float thr,
+                           const uint8_t *use, uint8_t *out, uint8_t *inst);

@@ -1,0 +1,499 @@
+// HBM-bound kernels of the mask_mmdet band (SOLOv2) for gfx950.
+// Reference being replaced (paths under bands/mmdet/ of the reference):
+//   datasets/pipelines/transforms.py:215-240,679-712,580-655  Resize(keep_ratio) / Normalize / Pad  -> mask_prep
+//   models/backbones/resnet.py:612-627                        stem max-pool                          -> maxpool3x3s2
+//   models/necks/fpn.py:161-188                               nearest top-down add, stride-2 extra level
+//   core/utils/misc.py:190-208                                generate_coordinate                    -> coord_concat
+//   models/dense_heads/solov2_head.py:134-150,253-292         bilinear resizes, GroupNorm + ReLU
+//   models/dense_heads/solov2_head.py:616-623                 sigmoid + points NMS                   -> cls_points_nms
+//   models/dense_heads/solov2_head.py:718-735                 mask threshold / area / maskness       -> mask_stats
+//   core/post_processing/matrix_nms.py:62-98                  Matrix NMS decay                       -> matrix_nms
+//   solov2_head.py:748-759 + bands/mask_mmdet.py:43-61,139-147  upsample x4, crop, resize, threshold, accumulate
+#include "mask_kernels.h"
+
+namespace {
+
+inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+#define LAUNCH_CHECK()            \
+    PB_HIP(hipGetLastError()); \
+    return 0
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// torch upsample_bilinear2d source index (align_corners = False): src = max(scale * (dst + 0.5) - 0.5, 0)
+__device__ __forceinline__ void lerp_src(int dst, float scale, int in, int &i0, int &i1, float &l1) {
+    const float src = fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame prep: uint8 RGB [n][H][W][3] -> OpenCV 8-bit INTER_LINEAR resize to (nh, nw) (11-bit fixed-point
+// coefficients, tables from the host) -> (v - mean) * (1 / std) in fp32 -> zero pad to (Hp, Wp) ->
+// fp16 [n][Hp][Wp][4] (channel 3 = 0).  One thread per padded pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_prep_kernel(const uint8_t *__restrict__ frames, int n, int H, int W, int nh, int nw,
+                                                        int Hp, int Wp, const int4 *__restrict__ xt,
+                                                        const int4 *__restrict__ yt, f16 *__restrict__ out,
+                                                        float *__restrict__ chw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * Hp * Wp) return;
+    const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), f = (int)(i / ((int64_t)Wp * Hp));
+    f16x4 o;
+    o[0] = o[1] = o[2] = o[3] = (f16)0.f;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (y < nh && x < nw) {
+        const int4 tx = xt[x], ty = yt[y];
+        const uint8_t *r0 = frames + ((int64_t)f * H + ty.x) * W * 3, *r1 = frames + ((int64_t)f * H + ty.y) * W * 3;
+        const float mean[3] = {123.675f, 116.28f, 103.53f};
+        const float istd[3] = {(float)(1.0 / 58.395), (float)(1.0 / 57.12), (float)(1.0 / 57.375)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = r0[tx.x * 3 + c] * tx.z + r0[tx.y * 3 + c] * tx.w;
+            const int h1 = r1[tx.x * 3 + c] * tx.z + r1[tx.y * 3 + c] * tx.w;
+            int q = (((ty.z * (h0 >> 4)) >> 16) + ((ty.w * (h1 >> 4)) >> 16) + 2) >> 2;
+            q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            v[c] = __fmul_rn(__fsub_rn((float)q, mean[c]), istd[c]);
+            o[c] = (f16)v[c];
+        }
+    }
+    *(f16x4 *)(out + i * 4) = o;
+    if (chw)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) chw[(((int64_t)f * 3 + c) * Hp + y) * Wp + x] = v[c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// max_pool2d(3, stride 2, padding 1), NHWC fp16, 8 channels per thread
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int n, int H, int W,
+                                                           int OH, int OW, int C8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * OH * OW * C8) return;
+    const int c = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const f16x8 v = *(const f16x8 *)(x + (((int64_t)b * H + iy) * W + ix) * C8 * 8 + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)v[j]);
+        }
+    }
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)m[j];
+    *(f16x8 *)(y + i * 8) = o;
+}
+
+// dst[n][h][w][C] += src[n][sh][sw][C] at the torch 'nearest' source pixel min(floor(d * sh / h), sh - 1)
+__global__ __launch_bounds__(256) void nearest_add_kernel(f16 *__restrict__ dst, const f16 *__restrict__ src, int n, int h, int w,
+                                                          int sh, int sw, int C8, float fy, float fx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * h * w * C8) return;
+    const int c = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((int64_t)w * h));
+    const int sy = min((int)floorf((float)y * fy), sh - 1), sx = min((int)floorf((float)x * fx), sw - 1);
+    const f16x8 a = *(const f16x8 *)(dst + i * 8);
+    const f16x8 s = *(const f16x8 *)(src + (((int64_t)b * sh + sy) * sw + sx) * C8 * 8 + c * 8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)((float)a[j] + (float)s[j]);
+    *(f16x8 *)(dst + i * 8) = o;
+}
+
+// max_pool2d(kernel 1, stride 2): out[y][x] = in[2y][2x]
+__global__ __launch_bounds__(256) void subsample2_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int n, int H, int W, int OH,
+                                                         int OW, int C8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * OH * OW * C8) return;
+    const int c = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    *(f16x8 *)(y + i * 8) = *(const f16x8 *)(x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C8 * 8 + c * 8);
+}
+
+// torch.linspace(-1, 1, steps)[i] in float32
+__device__ __forceinline__ float linspace_pm1(int i, int steps) {
+    if (steps <= 1) return -1.f;
+    const float step = 2.f / (float)(steps - 1);
+    return i < steps / 2 ? -1.f + step * (float)i : 1.f - step * (float)(steps - 1 - i);
+}
+
+// [n][h][w][C] (ld ldi) -> [n][h][w][C + 64]: channels C, C+1 = (x, y) coordinates in [-1, 1], rest 0
+__global__ __launch_bounds__(256) void coord_concat_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int n, int h, int w,
+                                                           int C8, int ldi) {
+    const int O8 = C8 + 8;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * h * w * O8) return;
+    const int c = (int)(i % O8);
+    const int64_t pix = i / O8;
+    f16x8 o;
+    if (c < C8) {
+        o = *(const f16x8 *)(x + pix * ldi + c * 8);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+        if (c == C8) {
+            const int px = (int)(pix % w), py = (int)((pix / w) % h);
+            o[0] = (f16)linspace_pm1(px, w);
+            o[1] = (f16)linspace_pm1(py, h);
+        }
+    }
+    *(f16x8 *)(y + pix * (int64_t)(O8 * 8) + c * 8) = o;
+}
+
+// NHWC fp16 bilinear resize, align_corners = False, separate pixel strides, optional accumulate into y
+__global__ __launch_bounds__(256) void bilinear_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int n, int H, int W, int OH,
+                                                       int OW, int C8, int ldi, int ldo, float sy, float sx, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * OH * OW * C8) return;
+    const int c = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    lerp_src(oy, sy, H, y0, y1, ly);
+    lerp_src(ox, sx, W, x0, x1, lx);
+    const f16 *base = x + (int64_t)b * H * W * ldi + c * 8;
+    const f16x8 v00 = *(const f16x8 *)(base + ((int64_t)y0 * W + x0) * ldi);
+    const f16x8 v01 = *(const f16x8 *)(base + ((int64_t)y0 * W + x1) * ldi);
+    const f16x8 v10 = *(const f16x8 *)(base + ((int64_t)y1 * W + x0) * ldi);
+    const f16x8 v11 = *(const f16x8 *)(base + ((int64_t)y1 * W + x1) * ldi);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    f16 *dst = y + pix * ldo + c * 8;
+    f16x8 o;
+    if (accumulate) o = *(const f16x8 *)dst;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = hy * (hx * (float)v00[j] + lx * (float)v01[j]) + ly * (hx * (float)v10[j] + lx * (float)v11[j]);
+        o[j] = (f16)(accumulate ? (float)o[j] + v : v);
+    }
+    *(f16x8 *)dst = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(32 groups, eps 1e-5) + ReLU: per-(sample, channel) sums (atomics) -> per-(sample, channel) affine
+// -> one fused apply pass.  x: [n][HW][ldc] fp16.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16 *__restrict__ x, int HW, int C8, int ldc, float *__restrict__ stats,
+                                                       int chunk) {
+    __shared__ float red[256 * 16];
+    const int b = blockIdx.y;
+    const int c8 = threadIdx.x % C8, pl = threadIdx.x / C8, npl = blockDim.x / C8;
+    const int p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, HW);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (pl < npl) {
+        for (int p = p0 + pl; p < p1; p += npl) {
+            const f16x8 v = *(const f16x8 *)(x + ((int64_t)b * HW + p) * ldc + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s[j]; red[threadIdx.x * 16 + 8 + j] = q[j]; }
+    __syncthreads();
+    if (pl == 0) {
+        for (int o = 1; o < npl; ++o)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) red[c8 * 16 + j] += red[(o * C8 + c8) * 16 + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&stats[((int64_t)b * C8 * 8 + c8 * 8 + j) * 2 + 0], red[c8 * 16 + j]);
+            atomicAdd(&stats[((int64_t)b * C8 * 8 + c8 * 8 + j) * 2 + 1], red[c8 * 16 + 8 + j]);
+        }
+    }
+}
+
+// stats [n][C][2] -> affine [n][C][2] = (rstd_g * gamma_c, beta_c - mean_g * rstd_g * gamma_c)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float *__restrict__ aff, int n, int C,
+                                                          int cpg, float inv_cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * C) return;
+    const int c = i % C, b = i / C, g0 = c / cpg * cpg;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < cpg; ++k) {
+        s += stats[((int64_t)b * C + g0 + k) * 2];
+        q += stats[((int64_t)b * C + g0 + k) * 2 + 1];
+    }
+    const float mean = s * inv_cnt;
+    const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
+    const float r = rsqrtf(var + 1e-5f) * gamma[c];
+    aff[(int64_t)i * 2] = r;
+    aff[(int64_t)i * 2 + 1] = beta[c] - mean * r;
+}
+
+__global__ __launch_bounds__(256) void gn_apply_relu_kernel(const f16 *__restrict__ x, const float *__restrict__ aff,
+                                                            f16 *__restrict__ y, int n, int HW, int C8, int ldc, int ldo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * HW * C8) return;
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int b = (int)(pix / HW);
+    const f16x8 v = *(const f16x8 *)(x + pix * ldc + c8 * 8);
+    const float *a = aff + ((int64_t)b * C8 * 8 + c8 * 8) * 2;
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)fmaxf((float)v[j] * a[j * 2] + a[j * 2 + 1], 0.f);
+    *(f16x8 *)(y + pix * ldo + c8 * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// class scores: sigmoid, then keep a cell only if it equals the max of the 2x2 window whose lower-right corner
+// it is (max_pool2d(2, stride 1, padding 1)[:-1, :-1] == s).  logit: this level's [n][g*g][C]; score: all levels
+// concatenated per frame [n][pts_total][C], this level's cells start at row `off`.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cls_points_nms_kernel(const float *__restrict__ logit, float *__restrict__ score, int n,
+                                                             int pts_total, int off, int g, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * g * g * C) return;
+    const int c = (int)(i % C);
+    const int cell = (int)((i / C) % (g * g)), b = (int)(i / ((int64_t)C * g * g));
+    const int y = cell / g, x = cell - y * g;
+    const float *base = logit + (int64_t)b * g * g * C + c;                    // this level's logits: [n][g*g][C]
+    const float s = sigmoidf_(base[(int64_t)cell * C]);
+    float m = s;
+    if (x > 0) m = fmaxf(m, sigmoidf_(base[(int64_t)(cell - 1) * C]));
+    if (y > 0) m = fmaxf(m, sigmoidf_(base[(int64_t)(cell - g) * C]));
+    if (x > 0 && y > 0) m = fmaxf(m, sigmoidf_(base[(int64_t)(cell - g - 1) * C]));
+    score[((int64_t)b * pts_total + off + cell) * C + c] = m == s ? s : 0.f;
+}
+
+// dst[k][cols] (fp16) = src[idx[k]][cols] (fp32); rows k >= count are zero
+__global__ __launch_bounds__(256) void gather_rows_f16_kernel(const float *__restrict__ src, const int *__restrict__ idx,
+                                                              f16 *__restrict__ dst, int count, int rows_pad, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows_pad * cols) return;
+    const int c = (int)(i % cols), k = (int)(i / cols);
+    dst[i] = k < count ? (f16)src[(int64_t)idx[k] * cols + c] : (f16)0.f;
+}
+
+// per candidate row of dynamic-conv logits [k][ld]: area = #(sigmoid > thr), soft = sum of sigmoid over those
+__global__ __launch_bounds__(256) void mask_stats_kernel(const float *__restrict__ logit, int HW, int64_t ld, float thr,
+                                                         float *__restrict__ out) {
+    const float *row = logit + (int64_t)blockIdx.x * ld;
+    float cnt = 0.f, soft = 0.f;
+    for (int p = threadIdx.x * 4; p < HW; p += 1024) {
+        const f32x4 v = *(const f32x4 *)(row + p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = sigmoidf_(v[j]);
+            if (s > thr) { cnt += 1.f; soft += s; }
+        }
+    }
+    cnt = wave_sum(cnt);
+    soft = wave_sum(soft);
+    __shared__ float red[8];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = cnt; red[4 + (threadIdx.x >> 6)] = soft; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 2] = red[0] + red[1] + red[2] + red[3];
+        out[blockIdx.x * 2 + 1] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
+// bin[k][HW] (fp16 0 / 1) = sigmoid(logit[idx[k]]) > thr; rows k >= count are zero
+__global__ __launch_bounds__(256) void binarize_rows_kernel(const float *__restrict__ logit, int64_t ld, const int *__restrict__ idx,
+                                                            int count, int HW, float thr, f16 *__restrict__ bin) {
+    const int k = blockIdx.y;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (p >= HW) return;
+    f16x8 o;
+    if (k < count) {
+        const float *row = logit + (int64_t)idx[k] * ld + p;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = sigmoidf_(row[j]) > thr ? (f16)1.f : (f16)0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+    }
+    *(f16x8 *)(bin + (int64_t)k * HW + p) = o;
+}
+
+// Matrix NMS, gaussian kernel (matrix_nms.py:62-98).  inter [n][ld] = pairwise intersections of the score-sorted
+// masks; one block, thread j owns column j.
+__global__ __launch_bounds__(512) void matrix_nms_kernel(const float *__restrict__ inter, int ld, const float *__restrict__ area,
+                                                         const int *__restrict__ label, const float *__restrict__ score, int n,
+                                                         float sigma, float *__restrict__ out) {
+    __shared__ float comp[512];
+    const int j = threadIdx.x;
+    float cj = 0.f;
+    if (j < n)
+        for (int i = 0; i < j; ++i)
+            if (label[i] == label[j]) {
+                const float in = inter[(int64_t)i * ld + j];
+                cj = fmaxf(cj, in / (area[i] + area[j] - in));
+            }
+    comp[j] = cj;
+    __syncthreads();
+    if (j >= n) return;
+    float coeff = INFINITY;
+    for (int i = 0; i < n; ++i) {
+        float d = 0.f;
+        if (i < j && label[i] == label[j]) {
+            const float in = inter[(int64_t)i * ld + j];
+            d = in / (area[i] + area[j] - in);
+        }
+        const float c = comp[i];
+        coeff = fminf(coeff, expf(-1.f * sigma * (d * d)) / expf(-1.f * sigma * (c * c)));
+    }
+    out[j] = score[j] * coeff;
+}
+
+// sig[k][HW] = sigmoid(logit[idx[k]][:HW])
+__global__ __launch_bounds__(256) void sigmoid_rows_kernel(const float *__restrict__ logit, int64_t ld, const int *__restrict__ idx,
+                                                           int HW, float *__restrict__ sig) {
+    const int k = blockIdx.y;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= HW) return;
+    const f32x4 v = *(const f32x4 *)(logit + (int64_t)idx[k] * ld + p);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = sigmoidf_(v[j]);
+    *(f32x4 *)(sig + (int64_t)k * HW + p) = o;
+}
+
+// Final masks: F.interpolate(sig, x4)[:h, :w] -> F.interpolate(size = (H, W)) -> > thr, both bilinear with
+// align_corners = False, evaluated per output pixel (4 x 4 taps).  use[k] != 0 marks the instances the band
+// accumulates (kept class, score > 0.5 and > --confidence): out pixel = (255 * count) mod 256 in all three
+// channels.  inst (optional): the per-instance boolean masks [k][H][W].
+__global__ __launch_bounds__(256) void band_accumulate_kernel(const float *__restrict__ sig, int k, int fh, int fw, int h, int w,
+                                                              int H, int W, float sy2, float sx2, float thr,
+                                                              const uint8_t *__restrict__ use, uint8_t *__restrict__ out,
+                                                              uint8_t *__restrict__ inst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int X = (int)(i % W), Y = (int)(i / W);
+    int ya, yb, xa, xb;
+    float ly2, lx2;
+    lerp_src(Y, sy2, h, ya, yb, ly2);
+    lerp_src(X, sx2, w, xa, xb, lx2);
+    int ry[2][2], rx[2][2];
+    float fy[2], fx[2];
+    lerp_src(ya, 0.25f, fh, ry[0][0], ry[0][1], fy[0]);
+    lerp_src(yb, 0.25f, fh, ry[1][0], ry[1][1], fy[1]);
+    lerp_src(xa, 0.25f, fw, rx[0][0], rx[0][1], fx[0]);
+    lerp_src(xb, 0.25f, fw, rx[1][0], rx[1][1], fx[1]);
+    int count = 0;
+    for (int m = 0; m < k; ++m) {
+        if (!inst && !use[m]) continue;
+        const float *s = sig + (int64_t)m * fh * fw;
+        float up[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float hy = 1.f - fy[a], hx = 1.f - fx[b];
+                up[a][b] = hy * (hx * s[ry[a][0] * fw + rx[b][0]] + fx[b] * s[ry[a][0] * fw + rx[b][1]]) +
+                           fy[a] * (hx * s[ry[a][1] * fw + rx[b][0]] + fx[b] * s[ry[a][1] * fw + rx[b][1]]);
+            }
+        const float v = (1.f - ly2) * ((1.f - lx2) * up[0][0] + lx2 * up[0][1]) + ly2 * ((1.f - lx2) * up[1][0] + lx2 * up[1][1]);
+        const bool on = v > thr;
+        if (inst) inst[(int64_t)m * H * W + i] = on ? 1 : 0;
+        if (on && use[m]) ++count;
+    }
+    if (out) {
+        const uint8_t b = (uint8_t)((255 * count) & 255);
+        out[i * 3] = b; out[i * 3 + 1] = b; out[i * 3 + 2] = b;
+    }
+}
+
+}  // namespace
+
+int launch_mask_prep(hipStream_t s, const uint8_t *frames, int n, int H, int W, int nh, int nw, int Hp, int Wp, const int *xt,
+                     const int *yt, f16 *out, float *chw) {
+    hipLaunchKernelGGL(mask_prep_kernel, dim3(nblk((int64_t)n * Hp * Wp)), dim3(256), 0, s, frames, n, H, W, nh, nw, Hp, Wp,
+                       (const int4 *)xt, (const int4 *)yt, out, chw);
+    LAUNCH_CHECK();
+}
+int launch_maxpool3x3s2(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C) {
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(nblk((int64_t)n * OH * OW * (C / 8))), dim3(256), 0, s, x, y, n, H, W, OH, OW, C / 8);
+    LAUNCH_CHECK();
+}
+int launch_nearest_add(hipStream_t s, f16 *dst, const f16 *src, int n, int h, int w, int sh, int sw, int C) {
+    hipLaunchKernelGGL(nearest_add_kernel, dim3(nblk((int64_t)n * h * w * (C / 8))), dim3(256), 0, s, dst, src, n, h, w, sh, sw, C / 8,
+                       (float)sh / (float)h, (float)sw / (float)w);
+    LAUNCH_CHECK();
+}
+int launch_subsample2(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C) {
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(subsample2_kernel, dim3(nblk((int64_t)n * OH * OW * (C / 8))), dim3(256), 0, s, x, y, n, H, W, OH, OW, C / 8);
+    LAUNCH_CHECK();
+}
+int launch_coord_concat(hipStream_t s, const f16 *x, f16 *y, int n, int h, int w, int C, int ldi) {
+    hipLaunchKernelGGL(coord_concat_kernel, dim3(nblk((int64_t)n * h * w * (C / 8 + 8))), dim3(256), 0, s, x, y, n, h, w, C / 8, ldi);
+    LAUNCH_CHECK();
+}
+int launch_bilinear(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int OH, int OW, int C, int ldi, int ldo,
+                    int accumulate) {
+    PB_CHECK(C % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0, -1, "bilinear: C=%d ldi=%d ldo=%d must be multiples of 8", C, ldi, ldo);
+    hipLaunchKernelGGL(bilinear_kernel, dim3(nblk((int64_t)n * OH * OW * (C / 8))), dim3(256), 0, s, x, y, n, H, W, OH, OW, C / 8, ldi,
+                       ldo, (float)H / (float)OH, (float)W / (float)OW, accumulate);
+    LAUNCH_CHECK();
+}
+int launch_gn_relu(hipStream_t s, const f16 *x, f16 *y, int n, int HW, int C, int ldc, int ldo, int groups, const float *gamma,
+                   const float *beta, float *stats, float *aff) {
+    const int C8 = C / 8;
+    PB_CHECK(C % 8 == 0 && C8 <= 256 && 256 % C8 == 0 && C % groups == 0, -1, "group norm: C=%d groups=%d unsupported", C, groups);
+    PB_HIP(hipMemsetAsync(stats, 0, (size_t)n * C * 2 * 4, s));
+    const int chunk = 2048;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((HW + chunk - 1) / chunk, n), dim3(256), 0, s, x, HW, C8, ldc, stats, chunk);
+    const int cpg = C / groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nblk((int64_t)n * C)), dim3(256), 0, s, stats, gamma, beta, aff, n, C, cpg,
+                       1.f / ((float)HW * (float)cpg));
+    hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(nblk((int64_t)n * HW * C8)), dim3(256), 0, s, x, aff, y, n, HW, C8, ldc, ldo);
+    LAUNCH_CHECK();
+}
+int launch_cls_points_nms(hipStream_t s, const float *logit, float *score, int n, int pts_total, int off, int g, int C) {
+    hipLaunchKernelGGL(cls_points_nms_kernel, dim3(nblk((int64_t)n * g * g * C)), dim3(256), 0, s, logit, score, n, pts_total, off, g, C);
+    LAUNCH_CHECK();
+}
+int launch_gather_rows_f16(hipStream_t s, const float *src, const int *idx, f16 *dst, int count, int rows_pad, int cols) {
+    hipLaunchKernelGGL(gather_rows_f16_kernel, dim3(nblk((int64_t)rows_pad * cols)), dim3(256), 0, s, src, idx, dst, count, rows_pad, cols);
+    LAUNCH_CHECK();
+}
+int launch_mask_stats(hipStream_t s, const float *logit, int rows, int HW, int64_t ld, float thr, float *out) {
+    PB_CHECK(HW % 4 == 0 && ld % 4 == 0, -1, "mask_stats: HW=%d must be a multiple of 4", HW);
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(mask_stats_kernel, dim3(rows), dim3(256), 0, s, logit, HW, ld, thr, out);
+    LAUNCH_CHECK();
+}
+int launch_binarize_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int rows_pad, int HW, float thr,
+                         f16 *bin) {
+    PB_CHECK(HW % 8 == 0, -1, "binarize: HW=%d must be a multiple of 8", HW);
+    hipLaunchKernelGGL(binarize_rows_kernel, dim3(nblk(HW / 8), rows_pad), dim3(256), 0, s, logit, ld, idx, count, HW, thr, bin);
+    LAUNCH_CHECK();
+}
+int launch_matrix_nms(hipStream_t s, const float *inter, int ld, const float *area, const int *label, const float *score, int n,
+                      float sigma, float *out) {
+    PB_CHECK(n > 0 && n <= 512, -1, "matrix_nms: n=%d (1..512)", n);
+    hipLaunchKernelGGL(matrix_nms_kernel, dim3(1), dim3(512), 0, s, inter, ld, area, label, score, n, sigma, out);
+    LAUNCH_CHECK();
+}
+int launch_sigmoid_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int HW, float *sig) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(sigmoid_rows_kernel, dim3(nblk(HW / 4), count), dim3(256), 0, s, logit, ld, idx, HW, sig);
+    LAUNCH_CHECK();
+}
+int launch_band_accumulate(hipStream_t s, const float *sig, int k, int fh, int fw, int h, int w, int H, int W, float thr,
+                           const uint8_t *use, uint8_t *out, uint8_t *inst) {
+    hipLaunchKernelGGL(band_accumulate_kernel, dim3(nblk((int64_t)H * W)), dim3(256), 0, s, sig, k, fh, fw, h, w, H, W,
+                       (float)h / (float)H, (float)w / (float)W, thr, use, out, inst);
+    LAUNCH_CHECK();
+}

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import check
-from .synth import DEPTH_CFGS, DepthCfg
+from .synth import DEPTH_CFGS, MASK_CFGS, DepthCfg, MaskCfg
 
 
 def _ptr(a: Optional[np.ndarray]):
@@ -311,3 +311,86 @@ class FlowRaft(_Ctx):
         while len(dims) > 1 and dims[-1] == 1:
             dims.pop()
         return out[:n].reshape(dims).copy()
+
+
+def _mask_cfg(cfg: MaskCfg, max_batch: int) -> "_lib.pb_mask_cfg":
+    return _lib.pb_mask_cfg((C.c_int32 * 4)(*cfg.blocks), cfg.scale_long, cfg.scale_short, cfg.num_classes, cfg.feat_channels,
+                            cfg.stacked_convs, (C.c_int32 * 5)(*cfg.num_grids), (C.c_int32 * 5)(*cfg.strides),
+                            cfg.mask_feat_channels, cfg.mask_out_channels, cfg.nms_pre, cfg.max_per_img, cfg.score_thr,
+                            cfg.mask_thr, cfg.filter_thr, cfg.sigma, max_batch)
+
+
+def mask_net_size(cfg: MaskCfg | str, H: int, W: int) -> Tuple[int, int, int, int]:
+    """(nh, nw, Hp, Wp): keep-ratio rescale to (scale_long, scale_short), then pad to a multiple of 32."""
+    cfg = MASK_CFGS[cfg] if isinstance(cfg, str) else cfg
+    c = _mask_cfg(cfg, 1)
+    v = [C.c_int() for _ in range(4)]
+    check(_lib.load().pb_mask_net_size(C.byref(c), H, W, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+class MaskMMDet(_Ctx):
+    """SOLOv2 instance-mask band on one GPU (bands/mask_mmdet.py:36-39 init_model, :131-154 per-frame body).
+
+    weights: mmdet state_dict naming (backbone.*, neck.*, mask_head.*) -> float32 ndarray.
+    """
+
+    def __init__(self, weights: Dict[str, np.ndarray], cfg: MaskCfg | str = "r101", device: int = 0, max_batch: int = 4):
+        super().__init__()
+        self.cfg = MASK_CFGS[cfg] if isinstance(cfg, str) else cfg
+        c = _mask_cfg(self.cfg, max_batch)
+        keep = {k: _f32(v) for k, v in weights.items() if np.asarray(v).dtype.kind == "f"}
+        arr = (_lib.pb_tensor * len(keep))()
+        for i, (name, w) in enumerate(keep.items()):
+            arr[i].name = name.encode()
+            arr[i].dtype = 0
+            arr[i].ndim = w.ndim
+            for j, s in enumerate(w.shape):
+                arr[i].shape[j] = s
+            arr[i].data = w.ctypes.data
+        check(self.lib.pb_create(C.byref(self.ctx), device, b"mask_mmdet", arr, len(keep), C.byref(c), C.sizeof(c)))
+        self._hw = None
+
+    def infer_batch(self, frames: np.ndarray, confidence: float = 0.5, keep_classes=None) -> np.ndarray:
+        """frames uint8 [n,H,W,3] RGB -> uint8 [n,H,W,3] accumulated masks of the kept classes."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, H, W, ch = frames.shape
+        assert ch == 3
+        out = np.empty_like(frames)
+        ids = None if keep_classes is None else np.ascontiguousarray(keep_classes, np.int32)
+        check(self.lib.pb_mask_infer_batch(self.ctx, _ptr(frames), n, H, W, C.c_float(confidence), _ptr(ids),
+                                           0 if ids is None else len(ids), _ptr(out)))
+        self._hw = (H, W)
+        return out
+
+    def infer_batch_dev(self, frames_ptr: int, n: int, H: int, W: int, confidence: float, keep_classes, out_ptr: int):
+        ids = None if keep_classes is None else np.ascontiguousarray(keep_classes, np.int32)
+        check(self.lib.pb_mask_infer_batch_dev(self.ctx, C.c_void_p(frames_ptr), n, H, W, C.c_float(confidence), _ptr(ids),
+                                               0 if ids is None else len(ids), C.c_void_p(out_ptr)))
+        self._hw = (H, W)
+
+    def instances(self, frame: int, with_masks: bool = False):
+        """(scores, labels, masks bool [k,H,W] | None, candidate_count) of frame `frame` of the last call."""
+        cap = self.cfg.max_per_img
+        sc, lb, cand = np.empty(cap, np.float32), np.empty(cap, np.int32), C.c_int32()
+        masks = None
+        if with_masks:
+            H, W = self._hw
+            masks = np.empty((cap, H, W), np.uint8)
+        k = check(self.lib.pb_mask_get_instances(self.ctx, frame, cap, _ptr(sc), _ptr(lb), _ptr(masks), C.byref(cand)))
+        return sc[:k].copy(), lb[:k].copy(), (masks[:k].view(np.bool_) if with_masks else None), cand.value
+
+    def set_profiling(self, timing: bool = True, debug_stages: bool = False):
+        check(self.lib.pb_set_profiling(self.ctx, (1 if timing else 0) | (2 if debug_stages else 0)))
+
+    def kernel_stats(self) -> List[dict]:
+        arr = (_lib.pb_kernel_stat * 16)()
+        n = check(self.lib.pb_get_kernel_stats(self.ctx, arr, 16))
+        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes,
+                     launches=arr[i].launches) for i in range(n)]
+
+    def stage(self, name: str, cap: int = 1 << 27) -> np.ndarray:
+        out = np.empty(cap, np.float32)
+        shape = (C.c_int64 * 4)()
+        n = check(self.lib.pb_mask_get_stage(self.ctx, name.encode(), _ptr(out), cap, shape))
+        return out[:n].reshape([int(s) for s in shape]).copy()

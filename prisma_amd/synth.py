@@ -284,3 +284,155 @@ def frame_pair_sequence(n: int, height: int, width: int, seed: int = 0, shift: T
         for c in range(3):
             out[i, ..., c] = np.clip(map_coordinates(tex[..., c], [ys, xs], order=1) * 255.0, 0, 255).astype(np.uint8)
     return out
+
+
+# ----------------------------------------------------------------------------
+# SOLOv2 (ResNet + FPN + SOLOV2Head), mmdet 2.x state_dict naming as loaded by
+# /root/reference/bands/mask_mmdet.py:36-39 (init_detector): backbone.* (models/backbones/resnet.py:306-659),
+# neck.* (models/necks/fpn.py:11-204), mask_head.* (models/dense_heads/solov2_head.py:19-292).
+# ----------------------------------------------------------------------------
+@dataclass(frozen=True)
+class MaskCfg:
+    blocks: Tuple[int, int, int, int] = (3, 4, 23, 3)        # ResNet-101
+    scale_long: int = 1333                                   # test pipeline img_scale=(1333, 800), keep_ratio
+    scale_short: int = 800
+    num_classes: int = 80
+    feat_channels: int = 512                                 # head stacked convs
+    stacked_convs: int = 4
+    num_grids: Tuple[int, ...] = (40, 36, 24, 16, 12)
+    strides: Tuple[int, ...] = (8, 8, 16, 32, 32)
+    mask_feat_channels: int = 128
+    mask_out_channels: int = 256
+    nms_pre: int = 500
+    score_thr: float = 0.1
+    mask_thr: float = 0.5
+    filter_thr: float = 0.05
+    sigma: float = 2.0
+    max_per_img: int = 100
+
+
+MASK_CFGS = {
+    "r101": MaskCfg(),
+    "r50": MaskCfg(blocks=(3, 4, 6, 3)),
+    # small configurations for CPU-sized parity cases (same code paths, fewer blocks / pixels)
+    "tiny": MaskCfg(blocks=(1, 1, 1, 1), scale_long=320, scale_short=192, feat_channels=128,
+                    num_grids=(12, 10, 8, 6, 4)),
+    "r18ish": MaskCfg(blocks=(2, 2, 2, 2), scale_long=448, scale_short=256, feat_channels=256,
+                      num_grids=(20, 18, 12, 8, 6)),
+}
+
+# COCO class order used by mmdet (model.CLASSES); the band keeps the 11 animate classes (mask_mmdet.py:30)
+COCO_CLASSES = ('person', 'bicycle', 'car', 'motorcycle', 'airplane', 'bus', 'train', 'truck', 'boat', 'traffic light',
+                'fire hydrant', 'stop sign', 'parking meter', 'bench', 'bird', 'cat', 'dog', 'horse', 'sheep', 'cow',
+                'elephant', 'bear', 'zebra', 'giraffe', 'backpack', 'umbrella', 'handbag', 'tie', 'suitcase', 'frisbee',
+                'skis', 'snowboard', 'sports ball', 'kite', 'baseball bat', 'baseball glove', 'skateboard', 'surfboard',
+                'tennis racket', 'bottle', 'wine glass', 'cup', 'fork', 'knife', 'spoon', 'bowl', 'banana', 'apple',
+                'sandwich', 'orange', 'broccoli', 'carrot', 'hot dog', 'pizza', 'donut', 'cake', 'chair', 'couch',
+                'potted plant', 'bed', 'dining table', 'toilet', 'tv', 'laptop', 'mouse', 'remote', 'keyboard',
+                'cell phone', 'microwave', 'oven', 'toaster', 'sink', 'refrigerator', 'book', 'clock', 'vase',
+                'scissors', 'teddy bear', 'hair drier', 'toothbrush')
+BAND_CLASSES = ('person', 'bird', 'cat', 'dog', 'horse', 'sheep', 'cow', 'elephant', 'bear', 'zebra', 'giraffe')
+
+
+def solov2_param_shapes(cfg: MaskCfg) -> List[Tuple[str, Tuple[int, ...]]]:
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def bn(name, c):
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            out.append((f"{name}.{s}", (c,)))
+        out.append((name + ".num_batches_tracked", ()))
+
+    def gn(name, c):
+        out.append((name + ".weight", (c,)))
+        out.append((name + ".bias", (c,)))
+
+    out.append(("backbone.conv1.weight", (64, 3, 7, 7)))
+    bn("backbone.bn1", 64)
+    inpl = 64
+    for li, nb in enumerate(cfg.blocks, start=1):
+        planes = 64 << (li - 1)
+        for b in range(nb):
+            p = f"backbone.layer{li}.{b}"
+            out.append((p + ".conv1.weight", (planes, inpl, 1, 1)))
+            bn(p + ".bn1", planes)
+            out.append((p + ".conv2.weight", (planes, planes, 3, 3)))
+            bn(p + ".bn2", planes)
+            out.append((p + ".conv3.weight", (planes * 4, planes, 1, 1)))
+            bn(p + ".bn3", planes * 4)
+            if b == 0:
+                out.append((p + ".downsample.0.weight", (planes * 4, inpl, 1, 1)))
+                bn(p + ".downsample.1", planes * 4)
+            inpl = planes * 4
+    for i, c in enumerate((256, 512, 1024, 2048)):
+        out.append((f"neck.lateral_convs.{i}.conv.weight", (256, c, 1, 1)))
+        out.append((f"neck.lateral_convs.{i}.conv.bias", (256,)))
+        out.append((f"neck.fpn_convs.{i}.conv.weight", (256, 256, 3, 3)))
+        out.append((f"neck.fpn_convs.{i}.conv.bias", (256,)))
+    mf, fc = cfg.mask_feat_channels, cfg.feat_channels
+    h = "mask_head.mask_feature_head."
+    for i in range(4):                                      # start_level 0 .. end_level 3
+        for j in range(max(i, 1)):
+            cin = 256 if j == 0 else mf
+            if i == 3 and j == 0:
+                cin = 258                                   # + (x, y) coordinate channels on the coarsest level
+            out.append((f"{h}convs_all_levels.{i}.conv{j}.conv.weight", (mf, cin, 3, 3)))
+            gn(f"{h}convs_all_levels.{i}.conv{j}.gn", mf)
+    out.append((h + "conv_pred.conv.weight", (cfg.mask_out_channels, mf, 1, 1)))
+    gn(h + "conv_pred.gn", cfg.mask_out_channels)
+    for i in range(cfg.stacked_convs):
+        out.append((f"mask_head.kernel_convs.{i}.conv.weight", (fc, 258 if i == 0 else fc, 3, 3)))
+        gn(f"mask_head.kernel_convs.{i}.gn", fc)
+        out.append((f"mask_head.cls_convs.{i}.conv.weight", (fc, 256 if i == 0 else fc, 3, 3)))
+        gn(f"mask_head.cls_convs.{i}.gn", fc)
+    out.append(("mask_head.conv_cls.weight", (cfg.num_classes, fc, 3, 3)))
+    out.append(("mask_head.conv_cls.bias", (cfg.num_classes,)))
+    out.append(("mask_head.conv_kernel.weight", (cfg.mask_out_channels, fc, 3, 3)))
+    out.append(("mask_head.conv_kernel.bias", (cfg.mask_out_channels,)))
+    return out
+
+
+def solov2_weights(cfg: MaskCfg, seed: int = 777) -> Dict[str, np.ndarray]:
+    """Seeded weights that keep every stage at unit scale and give a usable detector statistic: class logits with
+    a negative bias so a few hundred grid cells clear score_thr, a handful of them in the band's classes above 0.5,
+    and dynamic-conv logits with enough contrast that masks are clean blobs rather than threshold noise."""
+    w: Dict[str, np.ndarray] = {}
+    band_ids = [COCO_CLASSES.index(c) for c in BAND_CLASSES]
+    for name, shape in solov2_param_shapes(cfg):
+        g = _rng(seed, name)
+        if name.endswith("num_batches_tracked"):
+            w[name] = np.array(1, np.int64)
+        elif name.endswith("running_var"):
+            w[name] = (0.5 + g.random(shape, dtype=np.float32)).astype(np.float32)
+        elif name.endswith("running_mean"):
+            w[name] = g.standard_normal(shape, dtype=np.float32) * np.float32(0.1)
+        elif len(shape) == 1 and (".bn" in name or ".downsample.1." in name or ".gn." in name):
+            if name.endswith("weight"):
+                base = 0.4 if name.endswith(".bn3.weight") else 1.0      # keep the residual sum from growing per block
+                w[name] = (base * (1.0 + 0.1 * g.standard_normal(shape, dtype=np.float32))).astype(np.float32)
+            else:
+                w[name] = (0.1 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        elif name == "mask_head.conv_cls.bias":
+            # class logits come out ~N(bias, 1.6^2): aim for ~300 cells over score_thr among the other classes and
+            # ~8 cells of the band's classes over 0.5 whatever the number of grid cells
+            from scipy.stats import norm
+            pts = float(sum(g_ * g_ for g_ in cfg.num_grids))
+            n_band = sum(1 for i in band_ids if i < shape[0])
+            b_other = float(np.log(cfg.score_thr / (1 - cfg.score_thr))) - 1.6 * norm.isf(min(0.4, 300.0 / (pts * max(shape[0] - n_band, 1))))
+            b_band = 0.2 - 1.6 * norm.isf(min(0.4, 8.0 / (pts * max(n_band, 1))))
+            b = np.full(shape, b_other, np.float32)
+            b[[i for i in band_ids if i < shape[0]]] = b_band
+            w[name] = b
+        elif name.endswith("bias"):
+            w[name] = (0.05 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+            gain = 1.4
+            if name == "mask_head.conv_cls.weight":
+                gain = 2.2
+            elif name == "mask_head.conv_kernel.weight":
+                gain = 1.0
+            elif ".downsample.0." in name or ".conv3." in name or "lateral_convs" in name or "fpn_convs" in name \
+                    or "conv_pred" in name:
+                gain = 1.0
+            w[name] = g.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(fan_in))
+    return w
