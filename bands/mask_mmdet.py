@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""mask (mmdet / SOLOv2) band - drop-in for /root/reference/bands/mask_mmdet.py on MI355X.
+
+Same CLI (reference :164-199), same outputs (mask.png | mask.mp4 with the accumulated instance masks of the 11
+animate COCO classes, optional COLMAP black/white frames in --subpath, optional SDF in the green channel,
+metadata entry `bands.mask = {url, ids}` :113-115,158-161), same module-level names (BAND, CLASSES, init_model()).
+mmdet's init_detector / inference_detector are replaced by libprisma_bands.so through prisma_amd.engine; frames
+are pushed in batches instead of one by one.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_rgb  # noqa: E402
+from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
+from prisma_amd import engine, synth  # noqa: E402
+
+BAND = "mask"
+MODEL = "models/solov2_r101_fpn_3x_coco_20220511_095119-c559a076.pth"
+CLASSES = list(synth.BAND_CLASSES)
+CONFIDENCE_THRESHOLD = 0.5
+BATCH = int(os.environ.get("PRISMA_BATCH", "8"))
+
+model = None
+data = None
+
+
+def load_weights(path, cfg):
+    """mmdet checkpoints keep the tensors under 'state_dict'."""
+    if path and os.path.exists(path):
+        if path.endswith(".npz"):
+            z = np.load(path)
+            return {k: z[k] for k in z.files}
+        import torch
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        return {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "numpy")}
+    print(f"[{BAND}] checkpoint {path!r} not found; using seeded synthetic weights", file=sys.stderr)
+    return synth.solov2_weights(cfg)
+
+
+def init_model(arch="r101", weights=MODEL, device=0, max_batch=BATCH):
+    global model
+    cfg = synth.MASK_CFGS[arch]
+    model = engine.MaskMMDet(load_weights(weights, cfg), cfg, device=device, max_batch=max_batch)
+    model.CLASSES = synth.COCO_CLASSES
+    return model
+
+
+def keep_ids():
+    return [synth.COCO_CLASSES.index(c) for c in CLASSES]
+
+
+def get_sdf(masks_u8):
+    """reference :64-69 (snowy.generate_sdf on luminance != 0, remapped and clamped).  snowy 0.0.9 is absent:
+    signed Euclidean distance = distance to the mask outside it, minus distance to the background inside it."""
+    from scipy.ndimage import distance_transform_edt
+    inside = masks_u8[..., :3].astype(np.float64).mean(-1) != 0.0
+    sdf = distance_transform_edt(~inside) - distance_transform_edt(inside)
+    sdf = ((sdf + 127.0) / 255.0 - 0.25) * 2.0
+    return 1.0 - np.clip(sdf, 0.0, 1.0)
+
+
+def _finish(masks_u8, args):
+    if args.sdf:
+        out = masks_u8.astype(np.float64)
+        out[..., 1] = get_sdf(masks_u8) * 255
+        return out.astype(np.uint8)
+    return masks_u8
+
+
+def process_image(args):
+    img = open_rgb(args.input)
+    masks = model.infer_batch(img[None], args.confidence, keep_ids())[0]
+    write_rgb(args.output, _finish(masks, args))
+    data["bands"][BAND] = {"url": os.path.basename(args.output), "ids": CLASSES}
+
+
+def process_video(args):
+    src = FrameReader(args.input)
+    n = len(src)
+    h, w = src[0].shape[:2]
+    out = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output)
+    if args.subpath:
+        args.subpath = os.path.join(os.path.dirname(args.output), args.subpath)
+        create_folder(args.subpath)
+    for s in range(0, n, BATCH):
+        frames = np.stack([src[i] for i in range(s, min(n, s + BATCH))])
+        masks = model.infer_batch(frames, args.confidence, keep_ids())
+        for j in range(len(frames)):
+            if args.subpath:        # COLMAP wants black objects on white (reference :149-150)
+                write_rgb(os.path.join(args.subpath, "{:05d}.png".format(s + j)), 255 - masks[j])
+            out.write(_finish(masks[j], args))
+    out.close()
+    # the reference replaces the whole entry here, which also drops the `folder` key it set earlier (:127-129,158-161)
+    data["bands"][BAND] = {"url": os.path.basename(args.output), "ids": CLASSES}
+
+
+def main(argv=None):
+    global data
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--input", "-i", help="input", type=str, required=True)
+    ap.add_argument("--output", "-o", help="output", type=str, default="")
+    ap.add_argument("--confidence", "-c", help="confidence threshold", type=float, default=CONFIDENCE_THRESHOLD)
+    ap.add_argument("--sdf", "-s", help="Encode SDF on GREEN channel", action="store_true")
+    ap.add_argument("--subpath", help="Mask Subpath to frames", type=str, default="")
+    ap.add_argument("--arch", help="backbone / geometry preset (prisma_amd.synth.MASK_CFGS)", default="r101")
+    ap.add_argument("--weights", help="mmdet checkpoint (.pth) or .npz state dict", default=MODEL)
+    args = ap.parse_args(argv)
+    data = load_metadata(args.input)
+    meta_path = args.input
+    if data:
+        print("PRISMA metadata found and loaded")
+        args.input = get_url(meta_path, data, "rgba")
+        args.output = get_target(args.input, data, band=BAND, target=args.output, force_extension="png")
+    else:
+        data = {"bands": {}}
+        if not args.output:
+            ext = os.path.basename(args.input).rsplit(".", 1)[1]
+            args.output = os.path.join(os.path.dirname(args.input), BAND + "." + (ext if is_video(args.input) else "png"))
+    check_overwrite(args.output)
+    init_model(args.arch, args.weights)
+    if is_video(args.output):
+        process_video(args)
+    else:
+        process_image(args)
+    if os.path.isdir(meta_path):
+        write_metadata(meta_path, data)
+
+
+if __name__ == "__main__":
+    main()

@@ -92,6 +92,62 @@ def flow_leg(args, local_rank, world, rank, dist):
     return out
 
 
+def mask_leg(args, local_rank, world, rank, dist):
+    """Third line: the mask band (SOLOv2 R-101 FPN) on 1920x1080 frames, args.mask_frames per GPU per step, resident in
+    HBM (BASELINE.json configs[4] runs it beside depth and flow).  FLOP count: the convolution / GEMM launches'
+    own multiply-adds (the dynamic convolution depends on how many grid cells fire)."""
+    from prisma_amd import engine, synth
+    H, W, B = 1080, 1920, args.mask_frames
+    cfg = synth.MASK_CFGS["r101"]
+    wts = synth.solov2_weights(cfg)
+    net = engine.MaskMMDet(wts, cfg, device=local_rank, max_batch=min(B, 8))
+    frames = synth.frames(B, H, W, seed=70 + rank)
+    d_frames = torch.from_numpy(frames).cuda()
+    d_out = torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda")
+    keep = [synth.COCO_CLASSES.index(c) for c in synth.BAND_CLASSES]
+    torch.cuda.synchronize()
+
+    def step():
+        net.infer_batch_dev(d_frames.data_ptr(), B, H, W, 0.5, keep, d_out.data_ptr())
+        net.sync()
+
+    step()
+    net.set_profiling(timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fam = {}
+    steps = max(1, args.steps // 2)
+    for _ in range(steps):
+        step()
+        for s in net.kernel_stats():
+            f = fam.setdefault(s["name"], dict(ms=0.0, flops=0.0))
+            f["ms"] += s["ms"]; f["flops"] += s["flops"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    drawn = int((d_out[:, :, :, 0] != 0).any(dim=2).any(dim=1).sum().item())
+    inst = [len(net.instances(b)[0]) for b in range(B)]
+    cand = [net.instances(b)[3] for b in range(B)]
+    out = {"metric": "frames/sec (mask_mmdet SOLOv2 R-101, 1080p)", "value": round(world * B * steps / dt, 3), "unit": "frames/s",
+           "ms_per_step": round(dt / steps * 1e3, 3), "frames_per_step_per_gpu": B,
+           "gflop_per_frame": round(sum(v["flops"] for v in fam.values()) / (steps * B) / 1e9, 1),
+           "frames_with_masks": drawn, "mean_candidates": round(float(np.mean(cand)), 1), "mean_instances": round(float(np.mean(inst)), 1),
+           "kernel_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in sorted(fam.items())},
+           "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items() if v["flops"] > 0 and v["ms"] > 0}}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import solov2_oracle as SO
+        cores = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(cores)
+        t0 = time.time()
+        SO.infer(wts, cfg, frames[0], synth.COCO_CLASSES, synth.BAND_CLASSES, 0.5)
+        dt = time.time() - t0
+        out["cpu_baseline"] = {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": f"1 frame 1920x1080, oracle/solov2_oracle.py, {dt:.1f} s wall"}
+    net.close()
+    return out
+
+
 def pmc_traffic(symbol, batch):
     """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC summary (tools/pmc_summary.py; separate
     FETCH_SIZE / WRITE_SIZE passes over this same bench command at batch 32).  PMC passes cannot run inside the timed
@@ -119,6 +175,7 @@ def main():
     ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256, 4 simple 256")
     ap.add_argument("--conv-tile", type=int, default=0)
     ap.add_argument("--latency", action="store_true", help="also time one 1280x720 frame at batch 1 (BASELINE configs[1])")
+    ap.add_argument("--mask-frames", type=int, default=8, help="frames per step of the mask_mmdet leg (0 = skip that leg)")
     ap.add_argument("--flow-pairs", type=int, default=8, help="frame pairs per GPU per step of the flow_raft leg (0 = skip)")
     args = ap.parse_args()
 
@@ -194,6 +251,7 @@ def main():
         lat_b1 = (time.perf_counter() - t1) / 5 * 1e3
     net.close()
     flow = flow_leg(args, local_rank, world, rank, dist) if args.flow_pairs > 0 else None
+    mask = mask_leg(args, local_rank, world, rank, dist) if args.mask_frames > 0 else None
 
     if rank == 0:
         fps = world * B * args.steps / dt
@@ -235,6 +293,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(weights, cfg, H, W)
         if flow:
             out["flow_raft"] = flow
+        if mask:
+            out["mask_mmdet"] = mask
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -222,9 +222,27 @@ def raft_case(hgt=125, wid=157, seed=21, iters=12):
                         flow_it0=st["flow_it0"])
 
 
+def mask_case(seed=5):
+    """Self-vector of oracle/solov2_oracle.py (the mask band's reference cannot be imported: mmcv is absent)."""
+    from oracle import solov2_oracle as SO
+    cfg = synth.MASK_CFGS["tiny"]
+    w = synth.solov2_weights(cfg)
+    fr = synth.frames(1, 180, 300, seed=seed)[0]
+    x, meta = SO.preprocess(fr, cfg)
+    kps, cps, mf = SO.network(w, cfg, x)
+    sc, lb, mk = SO.get_results(cfg, kps, cps, mf, meta["img_shape"], meta["ori_shape"])
+    img = SO.band_mask(sc, lb, mk, synth.COCO_CLASSES, synth.BAND_CLASSES, 0.5, meta["ori_shape"])
+    print(f"[solov2 tiny] {len(sc)} instances, {int((sc > 0.5).sum())} over 0.5, image values {np.unique(img)}")
+    np.savez_compressed(os.path.join(GOLD, "solov2_tiny_180x300.npz"), frame_seed=np.array(seed), cls_logit4=cps[4].numpy(),
+                        mask_feats_sub=mf.numpy()[0, ::16, ::4, ::4].copy(), scores=sc.numpy(), labels=lb.numpy(), mask_image=img)
+
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full", "raft"]
+    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full", "raft", "mask"]
+    if "mask" in which:
+        mask_case()
     if "encode" in which:
         encode_case()
     if "vits" in which:

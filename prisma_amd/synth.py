@@ -412,13 +412,16 @@ def solov2_weights(cfg: MaskCfg, seed: int = 777) -> Dict[str, np.ndarray]:
             else:
                 w[name] = (0.1 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
         elif name == "mask_head.conv_cls.bias":
-            # class logits come out ~N(bias, 1.6^2): aim for ~300 cells over score_thr among the other classes and
-            # ~8 cells of the band's classes over 0.5 whatever the number of grid cells
+            # class logits come out ~N(bias, 1.55^2) (twice that spread for the band's classes, whose conv_cls rows are
+            # doubled below): ~300 cells of the other classes clear score_thr, and the band's classes get a long tail -
+            # few cells over score_thr, the best of them (about 4 sigma out) well over 0.5
             from scipy.stats import norm
             pts = float(sum(g_ * g_ for g_ in cfg.num_grids))
             n_band = sum(1 for i in band_ids if i < shape[0])
-            b_other = float(np.log(cfg.score_thr / (1 - cfg.score_thr))) - 1.6 * norm.isf(min(0.4, 300.0 / (pts * max(shape[0] - n_band, 1))))
-            b_band = 0.2 - 1.6 * norm.isf(min(0.4, 8.0 / (pts * max(n_band, 1))))
+            b_other = float(np.log(cfg.score_thr / (1 - cfg.score_thr))) - 1.55 * norm.isf(min(0.4, 300.0 / (pts * max(shape[0] - n_band, 1))))
+            # measured: wide heads (feat_channels 512) give smoother, lighter-tailed logit fields - their maximum sits
+            # ~2.7 sigma out instead of ~4 - so they get a larger row gain and a matching bias
+            b_band = 2.5 - (2.7 * 5.3 if cfg.feat_channels >= 512 else 4.0 * 3.1)
             b = np.full(shape, b_other, np.float32)
             b[[i for i in band_ids if i < shape[0]]] = b_band
             w[name] = b
@@ -430,9 +433,11 @@ def solov2_weights(cfg: MaskCfg, seed: int = 777) -> Dict[str, np.ndarray]:
             if name == "mask_head.conv_cls.weight":
                 gain = 2.2
             elif name == "mask_head.conv_kernel.weight":
-                gain = 1.0
+                gain = 3.0                               # high-contrast dynamic-conv logits: crisp masks, maskness near 1
             elif ".downsample.0." in name or ".conv3." in name or "lateral_convs" in name or "fpn_convs" in name \
                     or "conv_pred" in name:
                 gain = 1.0
             w[name] = g.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(fan_in))
+            if name == "mask_head.conv_cls.weight":
+                w[name][[i for i in band_ids if i < shape[0]]] *= np.float32(3.0 if cfg.feat_channels >= 512 else 2.0)
     return w

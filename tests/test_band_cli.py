@@ -146,3 +146,33 @@ def test_flow_cli_masks_and_dumps(tmp_path):
     assert fwd.shape == (176, 256, 2) and mf.dtype == np.bool_ and mf.shape == (176, 256)
     band.model.close()
     band.model = None
+
+
+@pytest.mark.gpu
+def test_mask_cli_video_and_image(tmp_path):
+    import mask_mmdet as band
+    from prisma_amd import synth
+    from PIL import Image
+    folder = tmp_path / "clip"
+    folder.mkdir()
+    frames = synth.frames(3, 180, 300, seed=5)
+    np.save(folder / "rgba.npy", frames)
+    (folder / "metadata.json").write_text(json.dumps({"bands": {"rgba": {"url": "rgba.npy"}}}))
+    os.environ["PRISMA_OVERWRITE"] = "1"
+    band.model = None
+    band.main(["-i", str(folder), "--arch", "tiny", "--subpath", "mask_frames", "--sdf"])
+    out = np.load(folder / "mask.npy")
+    assert out.shape == frames.shape and out.dtype == np.uint8
+    assert np.array_equal(out[..., 0], out[..., 2]) and out[..., 0].any()       # R == B = accumulated masks, G = SDF
+    assert not np.array_equal(out[..., 0], out[..., 1])
+    colmap = np.asarray(Image.open(folder / "mask_frames" / "00001.png"))
+    assert np.array_equal(colmap[..., 0], 255 - out[1, ..., 0])
+    md = json.load(open(folder / "metadata.json"))
+    assert md["bands"]["mask"] == {"url": "mask.npy", "ids": band.CLASSES}
+    # still image, no metadata folder
+    Image.fromarray(frames[0]).save(tmp_path / "img.png")
+    band.main(["-i", str(tmp_path / "img.png"), "--arch", "tiny"])
+    png = np.asarray(Image.open(tmp_path / "mask.png"))
+    assert png.shape == (180, 300, 3) and np.array_equal(png[..., 0], out[0, ..., 0])
+    band.model.close()
+    band.model = None

@@ -113,3 +113,34 @@ def test_keep_classes_and_confidence(tiny):
     assert (allc != 0).sum() >= (base != 0).sum()
     with pytest.raises(engine._lib.PrismaBandsError):
         net.infer_batch(frames, 0.5, [80])
+
+
+def test_r101_720p_against_oracle():
+    """BASELINE-size case: ResNet-101, one 1280x720 frame -> 1333x750 -> 768x1344 network input."""
+    cfg = synth.MASK_CFGS["r101"]
+    w = synth.solov2_weights(cfg)
+    net = engine.MaskMMDet(w, cfg, max_batch=2)
+    net.set_profiling(True, True)
+    frames = synth.frames(2, 720, 1280, seed=2)
+    out = net.infer_batch(frames, 0.5, KEEP)
+    assert engine.mask_net_size(cfg, 720, 1280) == (750, 1333, 768, 1344)
+    x, meta = SO.preprocess(frames[1], cfg)
+    assert np.array_equal(net.stage("input")[1], x[0])
+    kps, cps, mf, c, p = SO.network(w, cfg, x, return_feats=True)
+    for name, ref in (("c5", c[3]), ("p2", p[0]), ("mask_feats", mf), ("kernel_pred0", kps[0]), ("cls_logit0", cps[0]),
+                      ("cls_logit4", cps[4])):
+        got = net.stage(name)[1:2]
+        a, b = relmax(got, ref.numpy()), rell2(got, ref.numpy())
+        print("  %-13s relmax %.3e relL2 %.3e" % (name, a, b))
+        assert a < 2 * TOL_RANGE and b < 2 * TOL_L2, name
+    sc, lb, mk, dbg = _oracle_post_from_engine(cfg, net, 2, meta, 1)
+    g_sc, g_lb, g_mk, g_cand = net.instances(1, with_masks=True)
+    print("  %d candidates, %d instances, %d over 0.5" % (g_cand, len(g_sc), int((g_sc > 0.5).sum())))
+    assert g_cand == dbg["n_candidates"] and np.array_equal(g_lb, lb.numpy())
+    assert np.allclose(g_sc, sc.numpy(), rtol=2e-5, atol=1e-7)
+    assert (g_mk != mk.numpy()).mean() < 2e-4
+    ref_img = SO.band_mask(sc, lb, mk, synth.COCO_CLASSES, synth.BAND_CLASSES, 0.5, meta["ori_shape"])
+    assert (out[1] != ref_img).mean() < 5e-4 and out[1].any()
+    st = {s["name"]: s for s in net.kernel_stats()}
+    print("  kernel ms (2 frames):", {k: round(v["ms"], 2) for k, v in st.items()})
+    net.close()
