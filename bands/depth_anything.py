@@ -19,7 +19,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_depth  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
-from prisma_amd import engine, synth  # noqa: E402
+from prisma_amd import engine, shard, synth  # noqa: E402
 
 BAND = "depth_anything"
 BATCH = int(os.environ.get("PRISMA_BATCH", "32"))
@@ -27,6 +27,7 @@ BATCH = int(os.environ.get("PRISMA_BATCH", "32"))
 model = None
 data = None
 args = None
+ranks = None          # shard.Ranks(): one process per GPU under torchrun, world 1 otherwise
 
 
 def heat_to_rgb(heat):
@@ -83,10 +84,13 @@ def process_image(a):
 
 
 def process_video(a):
+    """Frames shard by rank: every rank encodes its contiguous block on its own GPU; the encoded frames and
+    the per-frame (min, max) are gathered so rank 0 writes the video, the CSVs and the metadata in frame order."""
+    rk = ranks or shard.Ranks()
     src = FrameReader(a.input)
     n = len(src)
     h, w = src[0].shape[:2]
-    out = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=a.output)
+    out = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=a.output) if rk.main else None
     out_folder = os.path.dirname(a.output)
     if a.subpath:
         if data:
@@ -94,14 +98,18 @@ def process_video(a):
         a.subpath = os.path.join(out_folder, a.subpath)
         create_folder(a.subpath)
     if model is None:
-        init_model()
-    lo, hi = [], []
-    for s in range(0, n, BATCH):
-        frames = np.stack([src[i] for i in range(s, min(n, s + BATCH))])
+        init_model(device=rk.device)
+    first, last = rk.frames(n)
+    lo, hi, held = [], [], []
+    for s in range(first, last, BATCH):
+        frames = np.stack([src[i] for i in range(s, min(last, s + BATCH))])
         want_depth = bool(a.npy or a.subpath)
         depth, rgb, mn, mx = model.infer_batch(frames, want_depth=want_depth, want_rgb=True, flip=True)
         for j in range(len(frames)):
-            out.write(rgb[j])
+            if rk.world == 1:
+                out.write(rgb[j])
+            else:
+                held.append(rgb[j])
             if a.npy and a.subpath:
                 np.save(os.path.join(a.subpath, "{:05d}.npy".format(s + j)), depth[j])
             if a.subpath:
@@ -109,6 +117,15 @@ def process_video(a):
                             normalize=True, flip=True, heatmap=True, encode_range=True)
         lo += [float(v) for v in mn]
         hi += [float(v) for v in mx]
+    if rk.world > 1:
+        every = rk.gather(np.stack(held) if held else np.zeros((0, h, w, 3), np.uint8), n)
+        mm = rk.gather(np.asarray([lo, hi], np.float32).T.reshape(-1, 2), n)
+        if rk.main:
+            for f in every:
+                out.write(f)
+            lo, hi = [float(v) for v in mm[:, 0]], [float(v) for v in mm[:, 1]]
+    if not rk.main:
+        return
     out.close()
     with open(os.path.join(out_folder, BAND + "_min.csv"), "w") as f:
         f.writelines("{}\n".format(v) for v in lo)
@@ -120,7 +137,7 @@ def process_video(a):
 
 
 def main(argv=None):
-    global args, data
+    global args, data, ranks
     ap = argparse.ArgumentParser()
     ap.add_argument("--input", "-i", help="Input image/video", type=str, required=True)
     ap.add_argument("--output", "-o", help="Output image/video", type=str, default="")
@@ -145,13 +162,17 @@ def main(argv=None):
         if not args.output:
             ext = os.path.basename(args.input).rsplit(".", 1)[1]
             args.output = os.path.join(os.path.dirname(args.input), BAND + "." + (ext if is_video(args.input) else "png"))
-    check_overwrite(args.output)
-    init_model(args.encoder, args.weights)
+    ranks = shard.Ranks()
+    if ranks.main:
+        check_overwrite(args.output)
+    init_model(args.encoder, args.weights, device=ranks.device)
     if is_video(args.output):
         process_video(args)
-    else:
+    elif ranks.main:
         process_image(args)
-    write_metadata(meta_path, data)
+    if ranks.main:
+        write_metadata(meta_path, data)
+    ranks.close()
 
 
 if __name__ == "__main__":

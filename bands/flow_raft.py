@@ -19,7 +19,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 from common.io import FrameReader, VideoWriter, check_overwrite, write_flo, write_flow_png  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
-from prisma_amd import engine, synth  # noqa: E402
+from prisma_amd import engine, shard, synth  # noqa: E402
 
 BAND = "flow_raft"
 MODEL = "models/raft-things.pth"
@@ -28,6 +28,7 @@ CHUNK = int(os.environ.get("PRISMA_BATCH", "16"))
 
 model = None
 data = None
+ranks = None          # shard.Ranks(): one process per GPU under torchrun, world 1 otherwise
 
 
 def load_weights(path):
@@ -72,6 +73,9 @@ def _mask_rgb(mask):
 
 
 def process_video(args):
+    """Pairs (i, i+1) shard by rank in contiguous blocks with a one-frame halo; the encoded frames, masks
+    and max displacements are gathered so rank 0 writes every output in frame order."""
+    rk = ranks or shard.Ranks()
     src = FrameReader(args.input)
     n = len(src)
     h, w = src[0].shape[:2]
@@ -79,6 +83,47 @@ def process_video(args):
     ext = args.output.rsplit(".", 1)[1]
     want_mask = bool(args.output_mask or args.subpath_mask)
     both = args.backwards or want_mask or bool(args.subpath)
+    want_flow = bool(args.subpath or args.subpath_mask)
+    if model is None:
+        init_model(args, device=rk.device)
+    sh, sw = engine.flow_out_size(h, w, args.scale)
+    first, last = rk.frames(n - 1)                       # pair indices owned by this rank
+    cols = {"rgb_f": [], "rgb_b": [], "mask_f": [], "mask_b": [], "mx": []}
+    for s in range(first, last, CHUNK):
+        e = min(last, s + CHUNK)
+        frames = np.stack([src[i] for i in range(s, e + 1)])                          # 1-frame halo
+        mask = None
+        if want_mask:
+            flow, rgb, mx, mask = model.infer_sequence_masks(frames, scale=args.scale, iters=args.iterations,
+                                                             want_flow=want_flow, want_rgb=True)
+        else:
+            flow, rgb, mx = model.infer_sequence(frames, scale=args.scale, iters=args.iterations, backward=both,
+                                                 want_flow=want_flow, want_rgb=True)
+        for j in range(e - s):
+            cols["rgb_f"].append(rgb[j, 0])
+            cols["mx"].append(np.float32(mx[j, 0]))
+            if both:
+                cols["rgb_b"].append(rgb[j, 1])
+            if want_mask:
+                cols["mask_f"].append(mask[j, 0])
+                cols["mask_b"].append(mask[j, 1])
+            if args.subpath:    # the reference crashes here (common/flow.py:91 shadows io.write_flow); write the .flo it meant to
+                write_flo(os.path.join(args.subpath + "_fwd", "%04d.flo" % (s + j)), flow[j, 0])
+                if args.backwards:
+                    write_flo(os.path.join(args.subpath + "_bwd", "%04d.flo" % (s + j)), flow[j, 1])
+            if args.subpath_mask:
+                write_flow_png(os.path.join(args.subpath_mask + "_fwd", "%04d.png" % (s + j)), flow[j, 0], mask[j, 0])
+                if args.backwards:
+                    write_flow_png(os.path.join(args.subpath_mask + "_bwd", "%04d.png" % (s + j)), flow[j, 1], mask[j, 1])
+    shapes = {"rgb_f": (sh, sw, 3), "rgb_b": (sh, sw, 3), "mask_f": (sh, sw), "mask_b": (sh, sw), "mx": ()}
+    dtypes = {"rgb_f": np.uint8, "rgb_b": np.uint8, "mask_f": np.uint8, "mask_b": np.uint8, "mx": np.float32}
+    used = ["rgb_f", "mx"] + (["rgb_b"] if both else []) + (["mask_f", "mask_b"] if want_mask else [])
+    got = {}
+    for k in used:
+        local = np.asarray(cols[k], dtypes[k]).reshape((len(cols[k]),) + shapes[k])
+        got[k] = rk.gather(local, n - 1) if rk.world > 1 else local
+    if not rk.main:
+        return
     fwd_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output)
     bwd_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=base + "_bwd." + ext) if args.backwards else None
     fwd_mask_video = bwd_mask_video = None
@@ -87,48 +132,27 @@ def process_video(args):
         fwd_mask_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output_mask)
         if args.backwards:
             bwd_mask_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=mbase + "_bwd." + mext)
-    if model is None:
-        init_model(args)
-    max_disps = []
-    sh, sw = engine.flow_out_size(h, w, args.scale)
-    want_flow = bool(args.subpath or args.subpath_mask)
-
-    def emit(idx, rgb_f, rgb_b, mx, flow_f, flow_b, mask_f, mask_b):
-        fwd_video.write(rgb_f)
-        max_disps.append(mx)
-        if fwd_mask_video:
-            fwd_mask_video.write(_mask_rgb(mask_f))
-        if bwd_mask_video:
-            bwd_mask_video.write(_mask_rgb(mask_b))
-        if bwd_video:
-            bwd_video.write(rgb_b)
-        if args.subpath:        # the reference crashes here (common/flow.py:91 shadows io.write_flow); write the .flo it meant to
-            write_flo(os.path.join(args.subpath + "_fwd", "%04d.flo" % idx), flow_f)
-            if args.backwards:
-                write_flo(os.path.join(args.subpath + "_bwd", "%04d.flo" % idx), flow_b)
-        if args.subpath_mask:
-            write_flow_png(os.path.join(args.subpath_mask + "_fwd", "%04d.png" % idx), flow_f, mask_f)
-            if args.backwards:
-                write_flow_png(os.path.join(args.subpath_mask + "_bwd", "%04d.png" % idx), flow_b, mask_b)
-
-    for s in range(0, n - 1, CHUNK):
-        frames = np.stack([src[i] for i in range(s, min(n, s + CHUNK + 1))])      # 1-frame halo
-        mask = None
-        if want_mask:
-            flow, rgb, mx, mask = model.infer_sequence_masks(frames, scale=args.scale, iters=args.iterations,
-                                                             want_flow=want_flow, want_rgb=True)
-        else:
-            flow, rgb, mx = model.infer_sequence(frames, scale=args.scale, iters=args.iterations, backward=both,
-                                                 want_flow=want_flow, want_rgb=True)
-        for j in range(len(frames) - 1):
-            emit(s + j, rgb[j, 0], rgb[j, 1] if both else None, float(mx[j, 0]),
-                 flow[j, 0] if want_flow else None, flow[j, 1] if want_flow and both else None,
-                 mask[j, 0] if want_mask else None, mask[j, 1] if want_mask else None)
-    # last frame: zero flow -> 0/0 -> NaN -> uint8 0, max displacement 0.0, all-False masks (reference :116-131)
     zero = np.zeros((sh, sw, 3), np.uint8)
+    for i in range(n):      # last frame: zero flow -> 0/0 -> NaN -> uint8 0, max displacement 0.0, all-False masks (reference :116-131)
+        tail = i == n - 1
+        fwd_video.write(zero if tail else got["rgb_f"][i])
+        if bwd_video:
+            bwd_video.write(zero if tail else got["rgb_b"][i])
+        if fwd_mask_video:
+            fwd_mask_video.write(zero if tail else _mask_rgb(got["mask_f"][i]))
+        if bwd_mask_video:
+            bwd_mask_video.write(zero if tail else _mask_rgb(got["mask_b"][i]))
+    max_disps = [float(v) for v in got["mx"].reshape(-1)] + [0.0]
     zf = np.zeros((sh, sw, 2), np.float32)
-    zm = np.zeros((sh, sw), bool)
-    emit(n - 1, zero, zero, 0.0, zf, zf, zm, zm)
+    if args.subpath:
+        write_flo(os.path.join(args.subpath + "_fwd", "%04d.flo" % (n - 1)), zf)
+        if args.backwards:
+            write_flo(os.path.join(args.subpath + "_bwd", "%04d.flo" % (n - 1)), zf)
+    if args.subpath_mask:
+        zm = np.zeros((sh, sw), bool)
+        write_flow_png(os.path.join(args.subpath_mask + "_fwd", "%04d.png" % (n - 1)), zf, zm)
+        if args.backwards:
+            write_flow_png(os.path.join(args.subpath_mask + "_bwd", "%04d.png" % (n - 1)), zf, zm)
     for v in (fwd_video, bwd_video, fwd_mask_video, bwd_mask_video):
         if v:
             v.close()
@@ -149,7 +173,7 @@ def process_video(args):
 
 
 def main(argv=None):
-    global data
+    global data, ranks
     ap = argparse.ArgumentParser()
     ap.add_argument("-input", "-i", "--input", dest="input", help="input", type=str, required=True)
     ap.add_argument("-output", "-o", "--output", dest="output", help="output", type=str, default="")
@@ -179,7 +203,9 @@ def main(argv=None):
             args.output = os.path.join(os.path.dirname(args.input), BAND + "." + os.path.basename(args.input).rsplit(".", 1)[1])
     if not is_video(args.output):
         raise SystemExit(f"[{BAND}] needs a video input")
-    check_overwrite(args.output)
+    ranks = shard.Ranks()
+    if ranks.main:
+        check_overwrite(args.output)
     input_folder = os.path.dirname(args.input)
     for attr in ("subpath", "subpath_mask"):
         if getattr(args, attr):
@@ -187,9 +213,11 @@ def main(argv=None):
             os.makedirs(getattr(args, attr) + "_fwd", exist_ok=True)
             if args.backwards:
                 os.makedirs(getattr(args, attr) + "_bwd", exist_ok=True)
-    init_model(args)
+    init_model(args, device=ranks.device)
     process_video(args)
-    write_metadata(meta_path, data)
+    if ranks.main:
+        write_metadata(meta_path, data)
+    ranks.close()
 
 
 if __name__ == "__main__":

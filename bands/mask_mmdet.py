@@ -20,7 +20,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_rgb  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
-from prisma_amd import engine, synth  # noqa: E402
+from prisma_amd import engine, shard, synth  # noqa: E402
 
 BAND = "mask"
 MODEL = "models/solov2_r101_fpn_3x_coco_20220511_095119-c559a076.pth"
@@ -30,6 +30,7 @@ BATCH = int(os.environ.get("PRISMA_BATCH", "8"))
 
 model = None
 data = None
+ranks = None          # shard.Ranks(): one process per GPU under torchrun, world 1 otherwise
 
 
 def load_weights(path, cfg):
@@ -84,27 +85,37 @@ def process_image(args):
 
 
 def process_video(args):
+    """Frames shard by rank (no cross-frame state, reference :131-154); rank 0 gathers and writes the video."""
+    rk = ranks or shard.Ranks()
     src = FrameReader(args.input)
     n = len(src)
     h, w = src[0].shape[:2]
-    out = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output)
     if args.subpath:
         args.subpath = os.path.join(os.path.dirname(args.output), args.subpath)
         create_folder(args.subpath)
-    for s in range(0, n, BATCH):
-        frames = np.stack([src[i] for i in range(s, min(n, s + BATCH))])
+    first, last = rk.frames(n)
+    held = []
+    for s in range(first, last, BATCH):
+        frames = np.stack([src[i] for i in range(s, min(last, s + BATCH))])
         masks = model.infer_batch(frames, args.confidence, keep_ids())
         for j in range(len(frames)):
             if args.subpath:        # COLMAP wants black objects on white (reference :149-150)
                 write_rgb(os.path.join(args.subpath, "{:05d}.png".format(s + j)), 255 - masks[j])
-            out.write(_finish(masks[j], args))
+            held.append(_finish(masks[j], args))
+    local = np.stack(held) if held else np.zeros((0, h, w, 3), np.uint8)
+    every = rk.gather(local, n) if rk.world > 1 else local
+    if not rk.main:
+        return
+    out = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output)
+    for f in every:
+        out.write(f)
     out.close()
     # the reference replaces the whole entry here, which also drops the `folder` key it set earlier (:127-129,158-161)
     data["bands"][BAND] = {"url": os.path.basename(args.output), "ids": CLASSES}
 
 
 def main(argv=None):
-    global data
+    global data, ranks
     ap = argparse.ArgumentParser()
     ap.add_argument("--input", "-i", help="input", type=str, required=True)
     ap.add_argument("--output", "-o", help="output", type=str, default="")
@@ -125,14 +136,17 @@ def main(argv=None):
         if not args.output:
             ext = os.path.basename(args.input).rsplit(".", 1)[1]
             args.output = os.path.join(os.path.dirname(args.input), BAND + "." + (ext if is_video(args.input) else "png"))
-    check_overwrite(args.output)
-    init_model(args.arch, args.weights)
+    ranks = shard.Ranks()
+    if ranks.main:
+        check_overwrite(args.output)
+    init_model(args.arch, args.weights, device=ranks.device)
     if is_video(args.output):
         process_video(args)
-    else:
+    elif ranks.main:
         process_image(args)
-    if os.path.isdir(meta_path):
+    if ranks.main:
         write_metadata(meta_path, data)
+    ranks.close()
 
 
 if __name__ == "__main__":

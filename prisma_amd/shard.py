@@ -28,26 +28,28 @@ def shard_range(n_frames: int, rank: int, world: int, halo: int = 0) -> Tuple[in
     return max(0, start - halo) if stop > start else start, stop
 
 
-def gather_frame_scalars(local: np.ndarray, n_frames: int, device=None) -> np.ndarray | None:
-    """All-gather per-frame scalar rows ([n_local, k] float32) into frame order; rank 0 gets [n_frames, k].
+def gather_rows(local: np.ndarray, n_frames: int, device=None) -> np.ndarray | None:
+    """All-gather per-frame rows ([n_local, ...], any dtype torch knows) into frame order; rank 0 gets [n_frames, ...].
 
-    Shards have ceil(n/world) frames except the tail; every rank pads to that length so one
-    fixed-size all_gather_into_tensor suffices.
+    Used for the per-frame scalars (float32 min / max / max-displacement, 4-8 bytes per frame) and, by the band scripts,
+    for the encoded uint8 frames rank 0 muxes into the output video (6.2 MB per 1080p frame over xGMI).  Shards have
+    ceil(n/world) frames except the tail; every rank pads to that length so one fixed-size all_gather_into_tensor
+    suffices.
     """
     import torch
     import torch.distributed as dist
-    local = np.ascontiguousarray(local, np.float32)
+    local = np.ascontiguousarray(local)
     if local.ndim == 1:
         local = local[:, None]
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local[:n_frames]
     world, rank = dist.get_world_size(), dist.get_rank()
     per = -(-n_frames // world)
-    k = local.shape[1]
+    tail = local.shape[1:]
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    buf = torch.zeros((per, k), dtype=torch.float32, device=dev)
+    buf = torch.zeros((per,) + tail, dtype=torch.from_numpy(local[:0]).dtype, device=dev)
     buf[: local.shape[0]] = torch.from_numpy(local).to(dev)
-    out = torch.empty((world * per, k), dtype=torch.float32, device=dev)
+    out = torch.empty((world * per,) + tail, dtype=buf.dtype, device=dev)
     dist.all_gather_into_tensor(out, buf)
     if rank != 0:
         return None
@@ -57,3 +59,51 @@ def gather_frame_scalars(local: np.ndarray, n_frames: int, device=None) -> np.nd
         s, e = shard_range(n_frames, r, world)
         rows.append(o[r * per: r * per + (e - s)])
     return np.concatenate(rows, 0)
+
+
+def gather_frame_scalars(local: np.ndarray, n_frames: int, device=None) -> np.ndarray | None:
+    """float32 rows ([n_local, k]): the (min, max) / max-displacement columns of the CSV files."""
+    return gather_rows(np.asarray(local, np.float32), n_frames, device)
+
+
+class Ranks:
+    """One process per GPU under `torchrun` / `python -m torch.distributed.run` (RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_ADDR=127.0.0.1); a plain `python bands/<band>.py` is world 1 and touches neither torch nor a process group."""
+
+    def __init__(self):
+        import os
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            self.backend = os.environ.get("PRISMA_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+            if not dist.is_initialized():
+                if self.backend == "nccl":
+                    torch.cuda.set_device(self.device)
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+
+    @property
+    def device(self) -> int:
+        import os
+        g = int(os.environ.get("PRISMA_GPUS_PER_NODE", "0"))       # set to 1 to let several ranks share one GPU (tests)
+        return self.local_rank % g if g > 0 else self.local_rank
+
+    @property
+    def main(self) -> bool:
+        return self.rank == 0
+
+    def frames(self, n: int, halo: int = 0) -> Tuple[int, int]:
+        return shard_range(n, self.rank, self.world, halo)
+
+    def gather(self, local: np.ndarray, n: int):
+        return gather_rows(local, n)
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
