@@ -96,7 +96,8 @@ class MaskEngine {
 
     // post-processing scratch (grown on demand, outside the arena)
     size_t post_cap_ = 0;
-    f16 *pk_ = nullptr, *bin_ = nullptr;
+    f16 *pk_ = nullptr;
+    unsigned long long *bits_ = nullptr;
     float *plog_ = nullptr, *pstat_ = nullptr, *inter_ = nullptr, *sig_ = nullptr, *nmsf_ = nullptr;
     int *pidx_ = nullptr, *nmsi_ = nullptr;
     uint8_t *use_ = nullptr, *inst_ = nullptr;

@@ -90,7 +90,7 @@ MaskEngine::~MaskEngine() {
     hipSetDevice(device);
     if (stream) hipStreamSynchronize(stream);
     for (auto p : owned_) hipFree(p);
-    void *post[] = {pk_, bin_, plog_, pstat_, inter_, sig_, nmsf_, pidx_, nmsi_, use_, inst_};
+    void *post[] = {pk_, bits_, plog_, pstat_, inter_, sig_, nmsf_, pidx_, nmsi_, use_, inst_};
     for (auto p : post)
         if (p) hipFree(p);
     if (arena_) hipFree(arena_);
@@ -267,6 +267,13 @@ int MaskEngine::prepare(int n, int H, int W) {
     const int B = std::min(n, cfg_.max_batch);
     if (B <= pB_ && H == pH_ && W == pW_) return 0;
     PB_HIP(hipStreamSynchronize(stream));
+    {   // the post-processing scratch is sized by the mask-feature resolution: drop it when the geometry changes
+        void **post[] = {(void **)&pk_, (void **)&bits_, (void **)&plog_, (void **)&pstat_, (void **)&inter_, (void **)&sig_,
+                         (void **)&nmsf_, (void **)&pidx_, (void **)&nmsi_, (void **)&use_};
+        for (auto b : post)
+            if (*b) { PB_HIP(hipFree(*b)); *b = nullptr; }
+        post_cap_ = 0;
+    }
     net_size(cfg_, H, W, &nh_, &nw_, &Hp_, &Wp_);
     PB_CHECK(Hp_ >= 64 && Wp_ >= 64, PB_ERR_ARG, "mask_mmdet: network input %dx%d is too small", Hp_, Wp_);
     lh_[5] = Hp_ / 2; lw_[5] = Wp_ / 2;
@@ -590,12 +597,11 @@ int MaskEngine::post_frame(int b, int frame_index, float confidence, const std::
     if (kept.empty()) return empty();
     std::stable_sort(kept.begin(), kept.end(), [](const Kept &x, const Kept &y) { return x.score > y.score; });
     if ((int)kept.size() > cfg_.nms_pre) kept.resize(cfg_.nms_pre);
-    const int n2 = (int)kept.size(), n2p = (int)round_up(n2, 8);
-    if (!bin_) {
-        PB_HIP(hipMalloc((void **)&bin_, (size_t)768 * HW4 * 2));
-        PB_HIP(hipMemsetAsync(bin_, 0, (size_t)768 * HW4 * 2, stream));
+    const int n2 = (int)kept.size();
+    if (!bits_) {
+        PB_HIP(hipMalloc((void **)&bits_, (size_t)512 * (HW4 / 64) * 8));
         PB_HIP(hipMalloc((void **)&inter_, (size_t)512 * 512 * 4));
-        PB_HIP(hipMalloc((void **)&nmsf_, 4 * 512 * 4));
+        PB_HIP(hipMalloc((void **)&nmsf_, 5 * 512 * 4));
         PB_HIP(hipMalloc((void **)&nmsi_, 2 * 512 * 4));
         PB_HIP(hipMalloc((void **)&sig_, (size_t)cfg_.max_per_img * HW4 * 4));
         PB_HIP(hipMalloc((void **)&use_, 512));
@@ -605,21 +611,11 @@ int MaskEngine::post_frame(int b, int frame_index, float confidence, const std::
     for (int i = 0; i < n2; ++i) { li[i] = kept[i].row; li[512 + i] = kept[i].label; lf[i] = kept[i].area; lf[512 + i] = kept[i].score; }
     PB_HIP(hipMemcpyAsync(nmsi_, li.data(), 1024 * 4, hipMemcpyHostToDevice, stream));
     PB_HIP(hipMemcpyAsync(nmsf_, lf.data(), 1024 * 4, hipMemcpyHostToDevice, stream));
-    tic(F_PP, 0, (double)n2 * HW4 * 6);
-    r = launch_binarize_rows(stream, plog_, HW4, nmsi_, n2, n2p, HW4, cfg_.mask_thr, bin_);
-    toc();
-    if (r) return r;
-    {   // pairwise intersections of the binary masks (matrix_nms.py:66-67): exact in fp32
-        GemmArgs a;
-        a.A = bin_; a.lda = HW4; a.M = n2; a.W = bin_; a.K = HW4; a.N = n2p;
-        a.out32 = inter_; a.ldo = 512; a.scale = 1.f; a.zero = zero_;
-        tic(F_GEMM, 2.0 * n2 * (double)n2p * HW4, 0);
-        r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
-        toc();
-        if (r) return r;
-    }
-    tic(F_PP, 0, (double)n2 * n2 * 4);
-    r = launch_matrix_nms(stream, inter_, 512, nmsf_, nmsi_ + 512, nmsf_ + 512, n2, cfg_.sigma, nmsf_ + 1024);
+    // binary masks as bit rows; pairwise intersections by popcount (matrix_nms.py:66-67), then the decay
+    tic(F_PP, 0, (double)n2 * HW4 * 4 + (double)n2 * n2 * (HW4 / 8));
+    r = launch_bitpack_rows(stream, plog_, HW4, nmsi_, n2, HW4, cfg_.mask_thr, bits_);
+    if (!r) r = launch_mask_intersections(stream, bits_, n2, HW4 / 64, inter_, 512);
+    if (!r) r = launch_matrix_nms(stream, inter_, 512, nmsf_, nmsi_ + 512, nmsf_ + 512, n2, cfg_.sigma, nmsf_ + 1536, nmsf_ + 1024);
     toc();
     if (r) return r;
     std::vector<float> ns(n2);

@@ -17,10 +17,11 @@ int launch_gn_relu(hipStream_t s, const f16 *x, f16 *y, int n, int HW, int C, in
 int launch_cls_points_nms(hipStream_t s, const float *logit, float *score, int n, int pts_total, int off, int g, int C);
 int launch_gather_rows_f16(hipStream_t s, const float *src, const int *idx, f16 *dst, int count, int rows_pad, int cols);
 int launch_mask_stats(hipStream_t s, const float *logit, int rows, int HW, int64_t ld, float thr, float *out);
-int launch_binarize_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int rows_pad, int HW, float thr,
-                         f16 *bin);
+int launch_bitpack_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int HW, float thr,
+                        unsigned long long *bits);
+int launch_mask_intersections(hipStream_t s, const unsigned long long *bits, int n, int words, float *inter, int ld);
 int launch_matrix_nms(hipStream_t s, const float *inter, int ld, const float *area, const int *label, const float *score, int n,
-                      float sigma, float *out);
+                      float sigma, float *comp, float *out);
 int launch_sigmoid_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int HW, float *sig);
 int launch_band_accumulate(hipStream_t s, const float *sig, int k, int fh, int fw, int h, int w, int H, int W, float thr,
                            const uint8_t *use, uint8_t *out, uint8_t *inst);

@@ -307,52 +307,75 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const float *__restrict
     }
 }
 
-// bin[k][HW] (fp16 0 / 1) = sigmoid(logit[idx[k]]) > thr; rows k >= count are zero
-__global__ __launch_bounds__(256) void binarize_rows_kernel(const float *__restrict__ logit, int64_t ld, const int *__restrict__ idx,
-                                                            int count, int HW, float thr, f16 *__restrict__ bin) {
+// bits[k][HW / 64]: bit p of row k = sigmoid(logit[idx[k]][p]) > thr (one ballot per wave = one 64-bit word)
+__global__ __launch_bounds__(256) void bitpack_rows_kernel(const float *__restrict__ logit, int64_t ld, const int *__restrict__ idx,
+                                                           int HW, float thr, unsigned long long *__restrict__ bits) {
     const int k = blockIdx.y;
-    const int p = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (p >= HW) return;
-    f16x8 o;
-    if (k < count) {
-        const float *row = logit + (int64_t)idx[k] * ld + p;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = sigmoidf_(row[j]) > thr ? (f16)1.f : (f16)0.f;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
-    }
-    *(f16x8 *)(bin + (int64_t)k * HW + p) = o;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool on = p < HW && sigmoidf_(logit[(int64_t)idx[k] * ld + p]) > thr;
+    const unsigned long long m = __ballot(on);
+    if ((threadIdx.x & 63) == 0 && p < HW) bits[(int64_t)k * (HW / 64) + (p >> 6)] = m;
 }
 
-// Matrix NMS, gaussian kernel (matrix_nms.py:62-98).  inter [n][ld] = pairwise intersections of the score-sorted
-// masks; one block, thread j owns column j.
-__global__ __launch_bounds__(512) void matrix_nms_kernel(const float *__restrict__ inter, int ld, const float *__restrict__ area,
-                                                         const int *__restrict__ label, const float *__restrict__ score, int n,
-                                                         float sigma, float *__restrict__ out) {
-    __shared__ float comp[512];
-    const int j = threadIdx.x;
-    float cj = 0.f;
-    if (j < n)
-        for (int i = 0; i < j; ++i)
-            if (label[i] == label[j]) {
+// inter[i][j] = |mask_i & mask_j| for i <= j (matrix_nms.py:66-67 computes it as a float matmul of the 0/1 masks;
+// the popcount is the same integer).  16 x 16 pairs per block, 64-word chunks of both row groups staged in LDS.
+__global__ __launch_bounds__(256) void mask_intersections_kernel(const unsigned long long *__restrict__ bits, int n, int words,
+                                                                 float *__restrict__ inter, int ld) {
+    if (blockIdx.y > blockIdx.x) return;                       // only the upper triangle is ever read
+    __shared__ unsigned long long a[16][65], b[16][65];
+    const int tj = threadIdx.x & 15, ti = threadIdx.x >> 4;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    int acc = 0;
+    for (int w0 = 0; w0 < words; w0 += 64) {
+        for (int t = threadIdx.x; t < 16 * 64; t += 256) {
+            const int r = t >> 6, w = t & 63;
+            const bool okw = w0 + w < words;
+            a[r][w] = (okw && i0 + r < n) ? bits[(int64_t)(i0 + r) * words + w0 + w] : 0ull;
+            b[r][w] = (okw && j0 + r < n) ? bits[(int64_t)(j0 + r) * words + w0 + w] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int w = 0; w < 64; ++w) acc += __popcll(a[ti][w] & b[tj][w]);
+        __syncthreads();
+    }
+    if (i0 + ti < n && j0 + tj < n) inter[(int64_t)(i0 + ti) * ld + j0 + tj] = (float)acc;
+}
+
+// Matrix NMS, gaussian kernel (matrix_nms.py:62-98) on the score-sorted masks.  One wave per column j, lanes over i.
+//   pass 0: comp[j] = max_{i < j, label_i == label_j} iou_ij                 (compensate_iou)
+//   pass 1: out[j] = score[j] * min_i exp(-sigma d_ij^2) / exp(-sigma comp_i^2), d_ij = iou_ij for i < j with equal
+//           labels and 0 otherwise                                            (decay_coefficient)
+__global__ __launch_bounds__(64) void matrix_nms_kernel(const float *__restrict__ inter, int ld, const float *__restrict__ area,
+                                                        const int *__restrict__ label, const float *__restrict__ score, int n,
+                                                        float sigma, float *__restrict__ comp, float *__restrict__ out, int pass) {
+    const int j = blockIdx.x;
+    const int lj = label[j];
+    const float aj = area[j];
+    if (pass == 0) {
+        float c = 0.f;
+        for (int i = threadIdx.x; i < j; i += 64)
+            if (label[i] == lj) {
                 const float in = inter[(int64_t)i * ld + j];
-                cj = fmaxf(cj, in / (area[i] + area[j] - in));
+                c = fmaxf(c, in / (area[i] + aj - in));
             }
-    comp[j] = cj;
-    __syncthreads();
-    if (j >= n) return;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c = fmaxf(c, __shfl_xor(c, o));
+        if (threadIdx.x == 0) comp[j] = c;
+        return;
+    }
     float coeff = INFINITY;
-    for (int i = 0; i < n; ++i) {
+    for (int i = threadIdx.x; i < n; i += 64) {
         float d = 0.f;
-        if (i < j && label[i] == label[j]) {
+        if (i < j && label[i] == lj) {
             const float in = inter[(int64_t)i * ld + j];
-            d = in / (area[i] + area[j] - in);
+            d = in / (area[i] + aj - in);
         }
         const float c = comp[i];
         coeff = fminf(coeff, expf(-1.f * sigma * (d * d)) / expf(-1.f * sigma * (c * c)));
     }
-    out[j] = score[j] * coeff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) coeff = fminf(coeff, __shfl_xor(coeff, o));
+    if (threadIdx.x == 0) out[j] = score[j] * coeff;
 }
 
 // sig[k][HW] = sigmoid(logit[idx[k]][:HW])
@@ -474,16 +497,23 @@ int launch_mask_stats(hipStream_t s, const float *logit, int rows, int HW, int64
     hipLaunchKernelGGL(mask_stats_kernel, dim3(rows), dim3(256), 0, s, logit, HW, ld, thr, out);
     LAUNCH_CHECK();
 }
-int launch_binarize_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int rows_pad, int HW, float thr,
-                         f16 *bin) {
-    PB_CHECK(HW % 8 == 0, -1, "binarize: HW=%d must be a multiple of 8", HW);
-    hipLaunchKernelGGL(binarize_rows_kernel, dim3(nblk(HW / 8), rows_pad), dim3(256), 0, s, logit, ld, idx, count, HW, thr, bin);
+int launch_bitpack_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int HW, float thr,
+                        unsigned long long *bits) {
+    PB_CHECK(HW % 64 == 0, -1, "bitpack: HW=%d must be a multiple of 64", HW);
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(bitpack_rows_kernel, dim3(nblk(HW), count), dim3(256), 0, s, logit, ld, idx, HW, thr, bits);
+    LAUNCH_CHECK();
+}
+int launch_mask_intersections(hipStream_t s, const unsigned long long *bits, int n, int words, float *inter, int ld) {
+    const unsigned t = (unsigned)((n + 15) / 16);
+    hipLaunchKernelGGL(mask_intersections_kernel, dim3(t, t), dim3(256), 0, s, bits, n, words, inter, ld);
     LAUNCH_CHECK();
 }
 int launch_matrix_nms(hipStream_t s, const float *inter, int ld, const float *area, const int *label, const float *score, int n,
-                      float sigma, float *out) {
-    PB_CHECK(n > 0 && n <= 512, -1, "matrix_nms: n=%d (1..512)", n);
-    hipLaunchKernelGGL(matrix_nms_kernel, dim3(1), dim3(512), 0, s, inter, ld, area, label, score, n, sigma, out);
+                      float sigma, float *comp, float *out) {
+    PB_CHECK(n > 0, -1, "matrix_nms: n=%d", n);
+    hipLaunchKernelGGL(matrix_nms_kernel, dim3(n), dim3(64), 0, s, inter, ld, area, label, score, n, sigma, comp, out, 0);
+    hipLaunchKernelGGL(matrix_nms_kernel, dim3(n), dim3(64), 0, s, inter, ld, area, label, score, n, sigma, comp, out, 1);
     LAUNCH_CHECK();
 }
 int launch_sigmoid_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int HW, float *sig) {
