@@ -45,6 +45,7 @@ class MaskEngine {
     int backbone(int n);
     int neck(int n);
     int head(int n);
+    int head_level(int n, int lvl);
     int post_frame(int b, int frame_index, float confidence, const std::vector<uint8_t> &keep_class, uint8_t *mask_out);
     int ensure_post(size_t cands);
 
@@ -90,9 +91,15 @@ class MaskEngine {
     const f16 *c_[4] = {};
     f16 *latb_[4] = {}, *p_[5] = {};
     f16 *mt_[2] = {}, *mg_[2] = {}, *macc_ = nullptr, *mf_ = nullptr, *p5cc_ = nullptr;
-    f16 *fcc_ = nullptr, *rs_ = nullptr, *grid_ = nullptr, *hk_[3] = {};
+    f16 *fcc_[5] = {}, *rs_[5] = {}, *grid_[5] = {}, *hk_[5][3] = {};
+    float *gstl_[5] = {}, *gaffl_[5] = {};
     float *kp_ = nullptr, *cl_ = nullptr, *cs_ = nullptr;
     float *gst_ = nullptr, *gaff_ = nullptr;
+    // streams: helpers launch on cur_ (main stream, or one of the per-level streams while the head is forked)
+    hipStream_t cur_ = nullptr, ls_[5] = {};
+    hipEvent_t ev_fork_ = nullptr, ev_join_[5] = {};
+    float *gst_cur_ = nullptr, *gaff_cur_ = nullptr;
+    std::vector<size_t> open_;
 
     // post-processing scratch (grown on demand, outside the arena)
     size_t post_cap_ = 0;

@@ -64,12 +64,14 @@ void MaskEngine::net_size(const pb_mask_cfg &cfg, int H, int W, int *nh, int *nw
 void MaskEngine::tic(int fam, double flops, double bytes) {
     if (!timer.enabled) return;
     KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes};
-    hipEventRecord(r.a, stream);
+    hipEventRecord(r.a, cur_);
     timer.recs.push_back(r);
+    open_.push_back(timer.recs.size() - 1);
 }
 void MaskEngine::toc() {
     if (!timer.enabled) return;
-    hipEventRecord(timer.recs.back().b, stream);
+    hipEventRecord(timer.recs[open_.back()].b, cur_);
+    open_.pop_back();
 }
 int MaskEngine::stats(pb_kernel_stat *out, int cap) {
     if (hipStreamSynchronize(stream) != hipSuccess) return -2;
@@ -94,6 +96,11 @@ MaskEngine::~MaskEngine() {
     for (auto p : post)
         if (p) hipFree(p);
     if (arena_) hipFree(arena_);
+    for (int l = 0; l < 5; ++l) {
+        if (ls_[l]) { hipStreamSynchronize(ls_[l]); hipStreamDestroy(ls_[l]); }
+        if (ev_join_[l]) hipEventDestroy(ev_join_[l]);
+    }
+    if (ev_fork_) hipEventDestroy(ev_fork_);
     if (stream) hipStreamDestroy(stream);
 }
 
@@ -184,6 +191,12 @@ int MaskEngine::load_conv_gn(const std::string &name, ConvGN &out) {
 int MaskEngine::load(const pb_tensor *w, int n) {
     PB_HIP(hipSetDevice(device));
     PB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    cur_ = stream;
+    for (int l = 0; l < 5; ++l) {
+        PB_HIP(hipStreamCreateWithFlags(&ls_[l], hipStreamNonBlocking));
+        PB_HIP(hipEventCreateWithFlags(&ev_join_[l], hipEventDisableTiming));
+    }
+    PB_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     PB_CHECK(cfg_.num_classes > 0 && cfg_.feat_channels % 32 == 0 && cfg_.mask_feat_channels % 32 == 0 &&
                  cfg_.mask_out_channels == 256 && cfg_.stacked_convs >= 1 && cfg_.nms_pre > 0 && cfg_.nms_pre <= 512 &&
                  cfg_.max_per_img > 0 && cfg_.max_batch >= 1,
@@ -310,11 +323,15 @@ int MaskEngine::prepare(int n, int H, int W) {
         macc_ = (f16 *)carve(rows(0) * mfc * 2 + slack);
         mf_ = (f16 *)carve(rows(0) * 256 * 2 + slack);
         p5cc_ = (f16 *)carve(rows(3) * 320 * 2 + slack);
-        fcc_ = (f16 *)carve(rows(1) * 320 * 2 + slack);
-        rs_ = (f16 *)carve(rows(1) * 256 * 2 + slack);
-        const size_t grows = (size_t)round_up((int64_t)B * gmax * gmax, 256);
-        grid_ = (f16 *)carve(grows * 320 * 2 + slack);
-        for (auto &b : hk_) b = (f16 *)carve(grows * fc * 2 + slack);
+        for (int l = 0; l < 5; ++l) {                        // each level's two branches run on their own stream
+            const int fl = l == 0 ? 1 : (l == 4 ? 3 : l);     // resolution after resize_feats
+            const size_t grows = (size_t)round_up((int64_t)B * cfg_.num_grids[l] * cfg_.num_grids[l], 256);
+            fcc_[l] = (f16 *)carve(rows(fl) * 320 * 2 + slack);
+            rs_[l] = (l == 0 || l == 4) ? (f16 *)carve(rows(fl) * 256 * 2 + slack) : nullptr;
+            grid_[l] = (f16 *)carve(grows * 320 * 2 + slack);
+            for (auto &b : hk_[l]) b = (f16 *)carve(grows * fc * 2 + slack);
+            gstl_[l] = (float *)carve((size_t)B * 512 * 2 * 4); gaffl_[l] = (float *)carve((size_t)B * 512 * 2 * 4);
+        }
         kp_ = (float *)carve((size_t)B * pts_ * 256 * 4 + slack);
         cl_ = (float *)carve((size_t)B * pts_ * Cp * 4 + slack);
         cs_ = (float *)carve((size_t)B * pts_ * Cp * 4 + slack);
@@ -350,7 +367,7 @@ int MaskEngine::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int k,
     a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
     PB_CHECK(w.K == k * k * cC, PB_ERR_STATE, "conv: packed K %d != %d*%d*%d", w.K, k, k, cC);
     tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
-    int r = launch_gemm(stream, A_CONV, EPI_STD, conv_tile, a);
+    int r = launch_gemm(cur_, A_CONV, EPI_STD, conv_tile, a);
     toc();
     return r;
 }
@@ -363,7 +380,7 @@ int MaskEngine::conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, co
     a.out32 = out; a.ldo = ldo; a.scale = 1.f;
     PB_CHECK(w.K == 9 * cC, PB_ERR_STATE, "conv_f32: packed K %d != 9*%d", w.K, cC);
     tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
-    int r = launch_gemm(stream, A_CONV, EPI_F32, TILE_128, a);
+    int r = launch_gemm(cur_, A_CONV, EPI_F32, TILE_128, a);
     toc();
     return r;
 }
@@ -373,7 +390,7 @@ int MaskEngine::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *o
     a.A = A; a.lda = lda; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_; a.M = (int)M;
     a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
     tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 0);
-    int r = launch_gemm(stream, A_DENSE, EPI_STD, TILE_AUTO, a);
+    int r = launch_gemm(cur_, A_DENSE, EPI_STD, TILE_AUTO, a);
     toc();
     return r;
 }
@@ -383,7 +400,7 @@ int MaskEngine::conv_gn_relu(const f16 *in, int cC, int cLd, int n, int H, int W
     int r = k == 1 ? dense(in, cLd, (int64_t)n * H * W, c.w, tmp, c.w.N, ACT_NONE) : conv(in, cC, cLd, n, H, W, k, 1, c.w, tmp, c.w.N, ACT_NONE);
     if (r) return r;
     tic(F_ELT, 0, (double)n * H * W * c.w.N * 6);
-    r = launch_gn_relu(stream, tmp, out, n, H * W, c.gn.C, c.w.N, ldo, 32, c.gn.g, c.gn.b, gst_, gaff_);
+    r = launch_gn_relu(cur_, tmp, out, n, H * W, c.gn.C, c.w.N, ldo, 32, c.gn.g, c.gn.b, gst_cur_, gaff_cur_);
     toc();
     return r;
 }
@@ -447,7 +464,7 @@ int MaskEngine::neck(int n) {
 
 int MaskEngine::head(int n) {
     int r;
-    const int mfc = cfg_.mask_feat_channels, fc = cfg_.feat_channels, Cp = conv_cls_.N;
+    const int mfc = cfg_.mask_feat_channels;
     // ---- MaskFeatModule.forward (solov2_head.py:134-150) ----
     if ((r = conv_gn_relu(p_[0], 256, 256, n, lh_[0], lw_[0], 3, mfc_[0][0], mt_[0], macc_, mfc))) return r;
     for (int i = 1; i < 4; ++i) {
@@ -474,48 +491,53 @@ int MaskEngine::head(int n) {
     if ((r = conv_gn_relu(macc_, mfc, mfc, n, lh_[0], lw_[0], 1, mfpred_, mt_[0], mf_, 256))) return r;
     stages_["mask_feats"] = Stage{mf_, 1, 0, 256, lh_[0], lw_[0], 256, 0};
 
-    // ---- resize_feats + the two prediction branches per level (solov2_head.py:253-292) ----
-    for (int lvl = 0; lvl < 5; ++lvl) {
-        const int g = cfg_.num_grids[lvl];
-        const f16 *src = p_[lvl];
-        int fh = lh_[lvl], fw = lw_[lvl];
-        if (lvl == 0 || lvl == 4) {
-            const int th = lvl == 0 ? lh_[1] : lh_[3], tw = lvl == 0 ? lw_[1] : lw_[3];
-            tic(F_ELT, 0, 0);
-            r = launch_bilinear(stream, src, rs_, n, fh, fw, th, tw, 256, 256, 256, 0);
-            toc();
-            if (r) return r;
-            src = rs_; fh = th; fw = tw;
-        }
+    return 0;
+}
+
+// resize_feats + the two prediction branches of one level (solov2_head.py:253-292), on that level's stream
+int MaskEngine::head_level(int n, int lvl) {
+    int r;
+    const int fc = cfg_.feat_channels, Cp = conv_cls_.N;
+    const int g = cfg_.num_grids[lvl];
+    f16 *fcc = fcc_[lvl], *rs = rs_[lvl], *grid = grid_[lvl], **hk = hk_[lvl];
+    const f16 *src = p_[lvl];
+    int fh = lh_[lvl], fw = lw_[lvl];
+    if (lvl == 0 || lvl == 4) {
+        const int th = lvl == 0 ? lh_[1] : lh_[3], tw = lvl == 0 ? lw_[1] : lw_[3];
         tic(F_ELT, 0, 0);
-        r = launch_coord_concat(stream, src, fcc_, n, fh, fw, 256, 256);
-        if (!r) r = launch_bilinear(stream, fcc_, grid_, n, fh, fw, g, g, 320, 320, 320, 0);
+        r = launch_bilinear(cur_, src, rs, n, fh, fw, th, tw, 256, 256, 256, 0);
         toc();
         if (r) return r;
-        const f16 *x = grid_;
-        int cC = 320, cLd = 320;
-        for (int i = 0; i < cfg_.stacked_convs; ++i) {
-            f16 *o = hk_[1 + (i & 1)];
-            if ((r = conv_gn_relu(x, cC, cLd, n, g, g, 3, kconv_[i], hk_[0], o, fc))) return r;
-            x = o; cC = cLd = fc;
-        }
-        float *kp = kp_ + (int64_t)n * goff_[lvl] * 256;
-        if ((r = conv_f32(x, fc, fc, n, g, g, conv_kernel_, kp, 256))) return r;
-        x = grid_; cC = 256; cLd = 320;                                   // cate_feat = kernel_feat[:, :-2]
-        for (int i = 0; i < cfg_.stacked_convs; ++i) {
-            f16 *o = hk_[1 + (i & 1)];
-            if ((r = conv_gn_relu(x, cC, cLd, n, g, g, 3, cconv_[i], hk_[0], o, fc))) return r;
-            x = o; cC = cLd = fc;
-        }
-        float *cl = cl_ + (int64_t)n * goff_[lvl] * Cp;
-        if ((r = conv_f32(x, fc, fc, n, g, g, conv_cls_, cl, Cp))) return r;
-        tic(F_PP, 0, (double)n * g * g * Cp * 8);
-        r = launch_cls_points_nms(stream, cl, cs_, n, pts_, goff_[lvl], g, Cp);
-        toc();
-        if (r) return r;
-        stages_["kernel_pred" + std::to_string(lvl)] = Stage{kp, 3, 0, 256, g, g, 256, 0};
-        stages_["cls_logit" + std::to_string(lvl)] = Stage{cl, 3, 0, cfg_.num_classes, g, g, Cp, 0};
+        src = rs; fh = th; fw = tw;
     }
+    tic(F_ELT, 0, 0);
+    r = launch_coord_concat(cur_, src, fcc, n, fh, fw, 256, 256);
+    if (!r) r = launch_bilinear(cur_, fcc, grid, n, fh, fw, g, g, 320, 320, 320, 0);
+    toc();
+    if (r) return r;
+    const f16 *x = grid;
+    int cC = 320, cLd = 320;
+    for (int i = 0; i < cfg_.stacked_convs; ++i) {
+        f16 *o = hk[1 + (i & 1)];
+        if ((r = conv_gn_relu(x, cC, cLd, n, g, g, 3, kconv_[i], hk[0], o, fc))) return r;
+        x = o; cC = cLd = fc;
+    }
+    float *kp = kp_ + (int64_t)n * goff_[lvl] * 256;
+    if ((r = conv_f32(x, fc, fc, n, g, g, conv_kernel_, kp, 256))) return r;
+    x = grid; cC = 256; cLd = 320;                                   // cate_feat = kernel_feat[:, :-2]
+    for (int i = 0; i < cfg_.stacked_convs; ++i) {
+        f16 *o = hk[1 + (i & 1)];
+        if ((r = conv_gn_relu(x, cC, cLd, n, g, g, 3, cconv_[i], hk[0], o, fc))) return r;
+        x = o; cC = cLd = fc;
+    }
+    float *cl = cl_ + (int64_t)n * goff_[lvl] * Cp;
+    if ((r = conv_f32(x, fc, fc, n, g, g, conv_cls_, cl, Cp))) return r;
+    tic(F_PP, 0, (double)n * g * g * Cp * 8);
+    r = launch_cls_points_nms(cur_, cl, cs_, n, pts_, goff_[lvl], g, Cp);
+    toc();
+    if (r) return r;
+    stages_["kernel_pred" + std::to_string(lvl)] = Stage{kp, 3, 0, 256, g, g, 256, 0};
+    stages_["cls_logit" + std::to_string(lvl)] = Stage{cl, 3, 0, cfg_.num_classes, g, g, Cp, 0};
     return 0;
 }
 
@@ -675,7 +697,20 @@ int MaskEngine::run_chunk(const uint8_t *frames, int n, int first, float confide
     toc();
     if (r) return r;
     if (chw_) stages_["input"] = Stage{chw_, 2, 0, 3, Hp_, Wp_, 0, 0};
-    if ((r = backbone(n)) || (r = neck(n)) || (r = head(n))) return r;
+    if ((r = backbone(n)) || (r = neck(n))) return r;
+    // fork: the five levels' prediction branches only read the FPN outputs and are small (n * g^2 rows each), so they
+    // run on their own streams beside the mask-feature branch on the main stream
+    PB_HIP(hipEventRecord(ev_fork_, stream));
+    for (int l = 0; l < 5 && !r; ++l) {
+        PB_HIP(hipStreamWaitEvent(ls_[l], ev_fork_, 0));
+        cur_ = ls_[l]; gst_cur_ = gstl_[l]; gaff_cur_ = gaffl_[l];
+        r = head_level(n, l);
+        cur_ = stream; gst_cur_ = gst_; gaff_cur_ = gaff_;
+        if (!r) PB_HIP(hipEventRecord(ev_join_[l], ls_[l]));
+    }
+    if (r) return r;
+    if ((r = head(n))) return r;
+    for (int l = 0; l < 5; ++l) PB_HIP(hipStreamWaitEvent(stream, ev_join_[l], 0));
     const int Cp = conv_cls_.N;
     h_scores_.resize((size_t)n * pts_ * Cp);
     PB_HIP(hipMemcpyAsync(h_scores_.data(), cs_, h_scores_.size() * 4, hipMemcpyDeviceToHost, stream));
@@ -696,7 +731,9 @@ int MaskEngine::infer(const uint8_t *frames, int n, int H, int W, float confiden
     }
     int r = prepare(n, H, W);
     if (r) return r;
+    cur_ = stream; gst_cur_ = gst_; gaff_cur_ = gaff_;
     timer.reset();
+    open_.clear();
     stages_.clear();
     results_.assign(n, Instances());
     for (int s = 0; s < n; s += pB_) {

@@ -11,6 +11,8 @@
 //   solov2_head.py:748-759 + bands/mask_mmdet.py:43-61,139-147  upsample x4, crop, resize, threshold, accumulate
 #include "mask_kernels.h"
 
+#include <algorithm>
+
 namespace {
 
 inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
@@ -475,7 +477,8 @@ int launch_gn_relu(hipStream_t s, const f16 *x, f16 *y, int n, int HW, int C, in
     const int C8 = C / 8;
     PB_CHECK(C % 8 == 0 && C8 <= 256 && 256 % C8 == 0 && C % groups == 0, -1, "group norm: C=%d groups=%d unsupported", C, groups);
     PB_HIP(hipMemsetAsync(stats, 0, (size_t)n * C * 2 * 4, s));
-    const int chunk = 2048;
+    // ~2048 blocks over the batch: big maps get short chunks (more parallelism), small maps one block per sample
+    const int chunk = (int)std::min<int64_t>(2048, std::max<int64_t>(64, ((int64_t)HW * n + 2047) / 2048));
     hipLaunchKernelGGL(gn_stats_kernel, dim3((HW + chunk - 1) / chunk, n), dim3(256), 0, s, x, HW, C8, ldc, stats, chunk);
     const int cpg = C / groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(nblk((int64_t)n * C)), dim3(256), 0, s, stats, gamma, beta, aff, n, C, cpg,
