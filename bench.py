@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256, 4 simple 256")
     ap.add_argument("--conv-tile", type=int, default=0)
     ap.add_argument("--latency", action="store_true", help="also time one 1280x720 frame at batch 1 (BASELINE configs[1])")
+    ap.add_argument("--host-chunks", type=int, default=4, help="batches pushed through the host-pointer API for the PCIe-inclusive rate (0 = skip)")
     ap.add_argument("--mask-frames", type=int, default=8, help="frames per step of the mask_mmdet leg (0 = skip that leg)")
     ap.add_argument("--flow-pairs", type=int, default=8, help="frame pairs per GPU per step of the flow_raft leg (0 = skip)")
     args = ap.parse_args()
@@ -249,6 +250,18 @@ def main():
             net.infer_dev(f1.data_ptr(), 1, 720, 1280, 0, r1.data_ptr(), d_mm[0].data_ptr(), d_mm[1].data_ptr(), True)
             net.sync()
         lat_b1 = (time.perf_counter() - t1) / 5 * 1e3
+    # PCIe-inclusive rate (never `value`): the host-pointer entry point over 4 chunks from pageable numpy memory -
+    # pinned staging + H2D / compute / D2H on three streams (abi.hip pb_depth_infer_batch)
+    host_fps = None
+    if rank == 0 and args.host_chunks > 0:
+        hf = np.concatenate([frames] * args.host_chunks)
+        net.set_profiling(timing=False)
+        net.infer_batch(hf[:B], want_depth=False, want_rgb=True, flip=True)
+        t1 = time.perf_counter()
+        _, h_rgb, h_mn, h_mx = net.infer_batch(hf, want_depth=False, want_rgb=True, flip=True)
+        host_fps = len(hf) / (time.perf_counter() - t1)
+        assert h_rgb.shape == hf.shape and np.isfinite(h_mn).all()
+        del hf, h_rgb
     net.close()
     flow = flow_leg(args, local_rank, world, rank, dist) if args.flow_pairs > 0 else None
     mask = mask_leg(args, local_rank, world, rank, dist) if args.mask_frames > 0 else None
@@ -284,6 +297,7 @@ def main():
                          "flop_per_launch": g["flops"] / max(g["launches"], 1)},
             "gemm_family_tflops": round(mm_fl / (mm_ms * 1e-3) / 1e12, 2) if mm_ms > 0 else None,
             "model_tflops": round(fps * GFLOP_PER_FRAME / 1e3 / world, 2),
+            "pcie_inclusive_fps": round(host_fps, 2) if host_fps else None,
             "latency_720p_batch1_ms": round(lat_b1, 3) if lat_b1 is not None else None,
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(fam.items())},
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items()

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "engine.h"
@@ -20,6 +21,58 @@ void pb_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// pinned staging + device slots of the host-pointer entry points (pb_depth_infer_batch)
+struct HostPipe {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_h2d[2] = {}, ev_comp[2] = {}, ev_d2h[2] = {};
+    void *h_in[2] = {}, *h_depth[2] = {}, *h_rgb[2] = {}, *h_mm[2] = {};
+    void *d_in[2] = {}, *d_depth[2] = {}, *d_rgb[2] = {}, *d_mm[2] = {};
+    size_t cap_in = 0, cap_d = 0, cap_r = 0, cap_m = 0;
+    int grow(void **h, void **d, size_t &cap, size_t need) {
+        if (need <= cap) return 0;
+        for (int i = 0; i < 2; ++i) {
+            if (h[i]) PB_HIP(hipHostFree(h[i]));
+            if (d[i]) PB_HIP(hipFree(d[i]));
+            h[i] = d[i] = nullptr;
+            PB_HIP(hipHostMalloc(&h[i], need, hipHostMallocDefault));
+            PB_HIP(hipMalloc(&d[i], need));
+        }
+        cap = need;
+        return 0;
+    }
+    int ensure(size_t in_b, size_t d_b, size_t r_b, size_t m_b) {
+        if (!s_in) {
+            PB_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+            PB_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                PB_HIP(hipEventCreateWithFlags(&ev_h2d[i], hipEventDisableTiming));
+                PB_HIP(hipEventCreateWithFlags(&ev_comp[i], hipEventDisableTiming));
+                PB_HIP(hipEventCreateWithFlags(&ev_d2h[i], hipEventDisableTiming));
+            }
+        }
+        int r;
+        if ((r = grow(h_in, d_in, cap_in, in_b)) || (r = grow(h_depth, d_depth, cap_d, d_b)) || (r = grow(h_rgb, d_rgb, cap_r, r_b)) ||
+            (r = grow(h_mm, d_mm, cap_m, m_b)))
+            return r;
+        return 0;
+    }
+    void release() {
+        if (s_in) { hipStreamSynchronize(s_in); hipStreamSynchronize(s_out); }
+        void **hs[] = {h_in, h_depth, h_rgb, h_mm}, **ds[] = {d_in, d_depth, d_rgb, d_mm};
+        for (int k = 0; k < 4; ++k)
+            for (int i = 0; i < 2; ++i) {
+                if (hs[k][i]) hipHostFree(hs[k][i]);
+                if (ds[k][i]) hipFree(ds[k][i]);
+            }
+        for (int i = 0; i < 2; ++i) {
+            if (ev_h2d[i]) hipEventDestroy(ev_h2d[i]);
+            if (ev_comp[i]) hipEventDestroy(ev_comp[i]);
+            if (ev_d2h[i]) hipEventDestroy(ev_d2h[i]);
+        }
+        if (s_in) { hipStreamDestroy(s_in); hipStreamDestroy(s_out); }
+    }
+};
+
 struct pb_ctx {
     int device = 0;
     DepthEngine *depth = nullptr;
@@ -29,6 +82,7 @@ struct pb_ctx {
     f16 *zero = nullptr;
     bool own_stream = false;
     int gemm_tile = TILE_AUTO, conv_tile = TILE_AUTO;
+    HostPipe pipe;
 };
 
 namespace {
@@ -137,6 +191,7 @@ int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *we
 void pb_destroy(pb_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    c->pipe.release();
     if (c->depth) delete c->depth;
     if (c->raft) delete c->raft;
     if (c->mask) delete c->mask;
@@ -160,25 +215,50 @@ int pb_depth_infer_batch_dev(pb_ctx *c, const uint8_t *frames, int n, int H, int
     return c->depth->infer(frames, n, H, W, depth_out, rgb_out, min_out, max_out, flip);
 }
 
+// Host-pointer variant: a three-stage pipeline over chunks of max_batch frames.  Stage 1 copies the caller's frames
+// into a pinned staging buffer and DMAs them to HBM on a copy stream, stage 2 is the band on the ctx stream, stage 3
+// DMAs the results into pinned memory on a second copy stream and hands them to the caller's arrays.  Two slots per
+// stage, ordered by events, so the PCIe traffic of chunks i+1 and i-1 overlaps the compute of chunk i.
 int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, float *depth_out, uint8_t *rgb_out,
                          float *min_out, float *max_out, int flip) {
     PB_CHECK(c && c->depth, PB_ERR_STATE, "ctx has no depth_anything band");
     PB_CHECK(frames && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "infer: bad arguments");
     PB_HIP(hipSetDevice(c->device));
     const size_t px = (size_t)H * W;
-    DevMem dF, dD, dR, dM;
-    PB_TRY(dF.alloc(n * px * 3));
-    if (depth_out) PB_TRY(dD.alloc(n * px * 4));
-    if (rgb_out) PB_TRY(dR.alloc(n * px * 3));
-    PB_TRY(dM.alloc((size_t)n * 8));
-    PB_HIP(hipMemcpy(dF.p, frames, n * px * 3, hipMemcpyHostToDevice));
-    float *mn = dM.as<float>(), *mx = mn + n;
-    PB_TRY(c->depth->infer(dF.as<uint8_t>(), n, H, W, dD.as<float>(), dR.as<uint8_t>(), mn, mx, flip));
-    PB_HIP(hipStreamSynchronize(c->stream));
-    if (depth_out) PB_HIP(hipMemcpy(depth_out, dD.p, n * px * 4, hipMemcpyDeviceToHost));
-    if (rgb_out) PB_HIP(hipMemcpy(rgb_out, dR.p, n * px * 3, hipMemcpyDeviceToHost));
-    if (min_out) PB_HIP(hipMemcpy(min_out, mn, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (max_out) PB_HIP(hipMemcpy(max_out, mx, (size_t)n * 4, hipMemcpyDeviceToHost));
+    const int cap = std::min(n, c->depth->max_batch());
+    HostPipe &hp = c->pipe;
+    const size_t in_b = (size_t)cap * px * 3, d_b = depth_out ? (size_t)cap * px * 4 : 0, r_b = rgb_out ? in_b : 0,
+                 m_b = (size_t)cap * 8;
+    PB_TRY(hp.ensure(in_b, d_b, r_b, m_b));
+    const int chunks = (n + cap - 1) / cap;
+    auto finish = [&](int i) -> int {           // results of chunk i: pinned -> caller
+        const int slot = i & 1, s0 = i * cap, m = std::min(cap, n - s0);
+        PB_HIP(hipEventSynchronize(hp.ev_d2h[slot]));
+        if (depth_out) memcpy(depth_out + (size_t)s0 * px, hp.h_depth[slot], (size_t)m * px * 4);
+        if (rgb_out) memcpy(rgb_out + (size_t)s0 * px * 3, hp.h_rgb[slot], (size_t)m * px * 3);
+        const float *mm = (const float *)hp.h_mm[slot];
+        if (min_out) memcpy(min_out + s0, mm, (size_t)m * 4);
+        if (max_out) memcpy(max_out + s0, mm + cap, (size_t)m * 4);
+        return 0;
+    };
+    for (int i = 0; i < chunks; ++i) {
+        const int slot = i & 1, s0 = i * cap, m = std::min(cap, n - s0);
+        if (i >= 2) PB_TRY(finish(i - 2));       // frees this slot's pinned output and (through ev_d2h) its device buffers
+        memcpy(hp.h_in[slot], frames + (size_t)s0 * px * 3, (size_t)m * px * 3);
+        PB_HIP(hipMemcpyAsync(hp.d_in[slot], hp.h_in[slot], (size_t)m * px * 3, hipMemcpyHostToDevice, hp.s_in));
+        PB_HIP(hipEventRecord(hp.ev_h2d[slot], hp.s_in));
+        PB_HIP(hipStreamWaitEvent(c->stream, hp.ev_h2d[slot], 0));
+        float *mn = (float *)hp.d_mm[slot], *mx = mn + cap;
+        PB_TRY(c->depth->infer((const uint8_t *)hp.d_in[slot], m, H, W, (float *)(d_b ? hp.d_depth[slot] : nullptr),
+                               (uint8_t *)(r_b ? hp.d_rgb[slot] : nullptr), mn, mx, flip));
+        PB_HIP(hipEventRecord(hp.ev_comp[slot], c->stream));
+        PB_HIP(hipStreamWaitEvent(hp.s_out, hp.ev_comp[slot], 0));
+        if (d_b) PB_HIP(hipMemcpyAsync(hp.h_depth[slot], hp.d_depth[slot], (size_t)m * px * 4, hipMemcpyDeviceToHost, hp.s_out));
+        if (r_b) PB_HIP(hipMemcpyAsync(hp.h_rgb[slot], hp.d_rgb[slot], (size_t)m * px * 3, hipMemcpyDeviceToHost, hp.s_out));
+        PB_HIP(hipMemcpyAsync(hp.h_mm[slot], hp.d_mm[slot], m_b, hipMemcpyDeviceToHost, hp.s_out));
+        PB_HIP(hipEventRecord(hp.ev_d2h[slot], hp.s_out));
+    }
+    for (int i = std::max(0, chunks - 2); i < chunks; ++i) PB_TRY(finish(i));
     return 0;
 }
 

@@ -51,6 +51,7 @@ class DepthEngine {
     // scratch for op-level tests
     int dev_alloc(void **p, size_t bytes);
     const f16 *zero_page() const { return zero_; }
+    int max_batch() const { return cfg_.max_batch > 0 ? cfg_.max_batch : 1; }
 
   private:
     int prepare(int B, int H, int W);
