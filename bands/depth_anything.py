@@ -58,10 +58,33 @@ def load_weights(encoder, path=""):
 def init_model(encoder=None, weights="", device=0, max_batch=BATCH):
     global model
     encoder = encoder or (args.encoder if args else "vitl")
-    if args is not None and getattr(args, "metric", "none") != "none":
-        raise NotImplementedError("--metric indoor|outdoor (ZoeDepth head) is not built yet: SURVEY.md section 8(f)")
-    model = engine.DepthAnything(load_weights(encoder, weights), encoder, device=device, max_batch=max_batch)
+    metric = getattr(args, "metric", "none") if args is not None else "none"
+    if metric != "none":
+        # reference :52-57: ZoeDepth (eval config) over the ViT-L core, checkpoints models/depth_anything_metric_depth_{indoor,outdoor}.pt
+        path = weights or os.path.join("models", f"depth_anything_metric_depth_{metric}.pt")
+        model = engine.DepthAnything(load_metric_weights(path), "vitl", device=device, max_batch=max_batch, metric=True)
+    else:
+        model = engine.DepthAnything(load_weights(encoder, weights), encoder, device=device, max_batch=max_batch)
     return model
+
+
+def load_metric_weights(path):
+    """ZoeDepth state dict (`core.core.*` + the metric head); `model_io.load_state_from_resource` keeps it under 'model'."""
+    if path and os.path.exists(path):
+        if path.endswith(".npz"):
+            z = np.load(path)
+            return {k: z[k].astype(np.float32) for k in z.files}
+        import torch
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("model", sd)
+        return {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "numpy")}
+    print(f"[{BAND}] metric checkpoint {path!r} not found; using seeded synthetic weights", file=sys.stderr)
+    return synth.zoe_weights()
+
+
+def _flip():
+    """The relative model encodes near = hot (flip), the metric models do not (reference :150,188)."""
+    return getattr(args, "metric", "none") == "none" if args is not None else True
 
 
 def infer(img, normalize=False):
@@ -80,7 +103,7 @@ def process_image(a):
                                          "max": {"value": float(pred.max()), "type": "float"}}
     if a.npy:
         np.save(os.path.join(out_folder, BAND + ".npy"), pred)
-    write_depth(a.output, pred, heat_to_rgb, normalize=True, heatmap=True, encode_range=True, flip=True)
+    write_depth(a.output, pred, heat_to_rgb, normalize=True, heatmap=True, encode_range=True, flip=_flip())
 
 
 def process_video(a):
@@ -104,7 +127,7 @@ def process_video(a):
     for s in range(first, last, BATCH):
         frames = np.stack([src[i] for i in range(s, min(last, s + BATCH))])
         want_depth = bool(a.npy or a.subpath)
-        depth, rgb, mn, mx = model.infer_batch(frames, want_depth=want_depth, want_rgb=True, flip=True)
+        depth, rgb, mn, mx = model.infer_batch(frames, want_depth=want_depth, want_rgb=True, flip=_flip())
         for j in range(len(frames)):
             if rk.world == 1:
                 out.write(rgb[j])
@@ -114,7 +137,7 @@ def process_video(a):
                 np.save(os.path.join(a.subpath, "{:05d}.npy".format(s + j)), depth[j])
             if a.subpath:
                 write_depth(os.path.join(a.subpath, "{:05d}.png".format(s + j)), depth[j], heat_to_rgb,
-                            normalize=True, flip=True, heatmap=True, encode_range=True)
+                            normalize=True, flip=_flip(), heatmap=True, encode_range=True)
         lo += [float(v) for v in mn]
         hi += [float(v) for v in mx]
     if rk.world > 1:

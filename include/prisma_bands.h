@@ -58,6 +58,10 @@ typedef struct {
     int32_t out_channels[4];  /* DPT reassemble widths                  */
     int32_t pos_grid;         /* 37 (pos_embed rows = 1 + 37*37)        */
     int32_t max_batch;        /* frames per launch the arena is sized for (>= 1) */
+    int32_t metric;           /* 1: ZoeDepth metric head on top (`--metric indoor|outdoor`, ViT-L only): weights also
+                               * carry conv2.*, seed_bin_regressor.*, seed_projector.*, projectors.*, attractors.*,
+                               * conditional_log_binomial.mlp.* (ZoeDepth state dict, `core.core.` prefix stripped);
+                               * the network input is 392 x 518, depth_out is metric depth, use flip = 0 */
 } pb_depth_cfg;
 
 /* SOLOv2 geometry and test_cfg for band = "mask_mmdet" (the values live in the mmdet config the reference downloads,

@@ -238,11 +238,65 @@ def mask_case(seed=5):
 
 
 
+def zoe_layers_case(seed=31):
+    """The metric head's layers against the reference's own modules (they import torch only), same seeded weights."""
+    import importlib.util
+    from oracle import zoe_oracle as Z
+
+    def load(name):
+        path = os.path.join(REF, "bands", "patchfusion", "zoedepth", "models", "layers", name + ".py")
+        spec = importlib.util.spec_from_file_location("ref_zoe_" + name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    att, dist, loc = load("attractor"), load("dist_layers"), load("localbins_layers")
+    w = {k: v for k, v in synth.zoe_weights().items() if not k.startswith("core.")}
+    tw = lambda pre: {k[len(pre):]: torch.from_numpy(v) for k, v in w.items() if k.startswith(pre)}
+    g = np.random.default_rng(seed)
+    rnd = lambda *s: torch.from_numpy(g.standard_normal(s).astype(np.float32))
+    out = {}
+    with torch.no_grad():
+        x = rnd(1, 256, 5, 6)
+        seed_m = loc.SeedBinRegressorUnnormed(256, n_bins=64)
+        seed_m.load_state_dict(tw("seed_bin_regressor."))
+        b0 = seed_m(x)[1]
+        assert torch.equal(b0, Z.seed_bin_regressor(w, x))
+        pr = loc.Projector(256, 128)
+        pr.load_state_dict(tw("seed_projector."))
+        e0 = pr(x)
+        assert torch.equal(e0, Z.projector(w, "seed_projector", x))
+        xb = rnd(1, 128, 10, 12)
+        a0 = att.AttractorLayerUnnormed(128, 64, n_attractors=16, alpha=1000, gamma=2, kind="mean", attractor_type="inv")
+        a0.load_state_dict(tw("attractors.0."))
+        bn, bc = a0(xb, b0, e0, interpolate=True)
+        mine = Z.attractor(w, "attractors.0", xb, b0, e0)
+        assert torch.equal(bn, mine) and torch.equal(bc, mine)
+        a3 = att.AttractorLayerUnnormed(128, 64, n_attractors=1, alpha=1000, gamma=2, kind="mean", attractor_type="inv")
+        a3.load_state_dict(tw("attractors.3."))
+        xb3 = rnd(1, 128, 12, 14)
+        b3 = a3(xb3, bn, xb, interpolate=True)[0]
+        assert torch.equal(b3, Z.attractor(w, "attractors.3", xb3, bn, xb))
+        clb = dist.ConditionalLogBinomial(33, 128, n_classes=64, min_temp=0.0212, max_temp=50.0)
+        clb.load_state_dict({**tw("conditional_log_binomial."), "log_binomial_transform.k_idx": torch.arange(0, 64).view(1, -1, 1, 1),
+                             "log_binomial_transform.K_minus_1": torch.Tensor([63]).view(1, -1, 1, 1)})
+        last, cond = rnd(1, 33, 12, 14).abs(), rnd(1, 128, 12, 14)
+        pz = clb(last, cond)
+        mine = Z.conditional_log_binomial(w, last, cond)
+        assert torch.equal(pz, mine), (pz - mine).abs().max()
+        out.update(x=x.numpy(), seed_bins=b0.numpy(), seed_emb=e0.numpy(), xb=xb.numpy(), bins0=bn.numpy(), xb3=xb3.numpy(),
+                   bins3=b3.numpy(), last=last.numpy(), cond=cond.numpy(), prob=pz.numpy())
+    print("[zoe layers] SeedBinRegressorUnnormed, Projector, AttractorLayerUnnormed x2, ConditionalLogBinomial: oracle == reference (exact)")
+    np.savez_compressed(os.path.join(GOLD, "zoe_layers.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full", "raft", "mask"]
+    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full", "raft", "mask", "zoe"]
     if "mask" in which:
         mask_case()
+    if "zoe" in which:
+        zoe_layers_case()
     if "encode" in which:
         encode_case()
     if "vits" in which:

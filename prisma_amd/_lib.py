@@ -19,7 +19,7 @@ class pb_tensor(C.Structure):
 
 class pb_depth_cfg(C.Structure):
     _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32), ("features", C.c_int32),
-                ("out_channels", C.c_int32 * 4), ("pos_grid", C.c_int32), ("max_batch", C.c_int32)]
+                ("out_channels", C.c_int32 * 4), ("pos_grid", C.c_int32), ("max_batch", C.c_int32), ("metric", C.c_int32)]
 
 
 class pb_mask_cfg(C.Structure):

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "kernels.h"
+#include "zoe_kernels.h"
 
 struct PackedW {
     f16 *w = nullptr;        // [Npad, K] fp16, K % 64 == 0
@@ -58,6 +59,11 @@ class DepthEngine {
     int run_chunk(const uint8_t *frames, int n, float *depth_out, uint8_t *rgb_out, float *mn, float *mx, int flip);
     int vit(int n);
     int head(int n);
+    // ZoeDepth metric head (engine_zoe.hip)
+    int load_metric();
+    int plan_metric(int B, int H, int W);
+    int metric_tables(int H, int W);
+    int metric_head(int n);
     int gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int tile = TILE_AUTO);
     int conv3(const f16 *in, int inC, int n, int H, int W, const PackedW &w, f16 *out, f16 *out2, const f16 *add1,
               const f16 *add2, int act, int stride, int outC);
@@ -104,4 +110,13 @@ class DepthEngine {
     unsigned *mm_ = nullptr;
     std::map<std::string, Stage> stages_;
     std::map<std::string, float *> snaps_;
+    // metric head: weights, buffers (arena), Pillow resize tables
+    struct Mlp2 { PackedW a, b; };
+    PackedW zconv2_;
+    Mlp2 zseed_, zsproj_, zproj_[4], zattr_[4], zclb_;
+    f16 *act32_ = nullptr, *zx0_ = nullptr, *zh_ = nullptr, *zemb_[2] = {}, *zxa_ = nullptr, *zcat_ = nullptr, *zmid_ = nullptr;
+    float *zA_ = nullptr, *zbins_[2] = {}, *zpt_ = nullptr, *md_ = nullptr, *ptmp_ = nullptr;
+    int *pxb_ = nullptr, *pyb_ = nullptr;
+    double *pxk_ = nullptr, *pyk_ = nullptr;
+    int pxks_ = 0, pyks_ = 0;
 };

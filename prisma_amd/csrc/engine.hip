@@ -236,6 +236,10 @@ int DepthEngine::load(const pb_tensor *w, int n) {
     { NEED(b2, Hh + "scratch.output_conv2.2.bias", 1); b2_ = b2[0]; }
 #undef NEED
 #undef UP
+    if (cfg_.metric) {
+        int rm = load_metric();
+        if (rm) return rm;
+    }
     tmap_.clear();            // host tensors are not referenced after pb_create returns
     PB_HIP(hipDeviceSynchronize());   // null-stream memsets / copies done before the ctx stream is used
     return 0;
@@ -275,6 +279,23 @@ void cubic_taps(int src, int dst, std::vector<int> &idx, std::vector<float> &wt)
 
 inline float cc1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 inline float cc2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+// torch F.interpolate(mode="bilinear", align_corners=True) as a 4-tap table (two zero weights): the metric model's
+// input resize (patchfusion/zoedepth/models/base_models/depth_anything.py:172-174)
+void bilinear_ac_taps(int src, int dst, std::vector<int> &idx, std::vector<float> &wt) {
+    idx.assign((size_t)dst * 4, 0);
+    wt.assign((size_t)dst * 4, 0.f);
+    const float scale = dst > 1 ? (float)(src - 1) / (float)(dst - 1) : 0.f;
+    for (int d = 0; d < dst; ++d) {
+        const float s = scale * (float)d;
+        int i0 = (int)s;
+        if (i0 > src - 1) i0 = src - 1;
+        const int i1 = i0 + (i0 < src - 1 ? 1 : 0);
+        const float l = s - (float)i0;
+        idx[(size_t)d * 4 + 0] = i0; idx[(size_t)d * 4 + 1] = i1; idx[(size_t)d * 4 + 2] = i1; idx[(size_t)d * 4 + 3] = i1;
+        wt[(size_t)d * 4 + 0] = 1.f - l; wt[(size_t)d * 4 + 1] = l;
+    }
+}
 
 // torch F.interpolate(mode="bicubic", scale_factor=(sy, sx)) of the [g, g, D] position grid to [gh, gw, D]
 // (vision_transformer.py:179-210; numeric semantics verified in SURVEY.md section 8 a-4).
@@ -341,6 +362,7 @@ int DepthEngine::prepare(int B, int H, int W) {
     PB_HIP(hipStreamSynchronize(stream));
     int r = pb_depth_net_size(H, W, &nh_, &nw_);
     if (r) return r;
+    if (cfg_.metric) { nh_ = 392; nw_ = 518; }      // DepthAnythingCore.prep: img_size [392, 518], aspect ratio not kept
     gh_ = nh_ / 14; gw_ = nw_ / 14; P_ = gh_ * gw_; ntok_ = P_ + 1; ntp_ = (int)round_up(ntok_, 16);
     lh_[0] = 4 * gh_; lw_[0] = 4 * gw_; lh_[1] = 2 * gh_; lw_[1] = 2 * gw_; lh_[2] = gh_; lw_[2] = gw_;
     lh_[3] = (gh_ - 1) / 2 + 1; lw_[3] = (gw_ - 1) / 2 + 1;
@@ -381,6 +403,7 @@ int DepthEngine::prepare(int B, int H, int W) {
         netd_ = (float *)carve((size_t)B * nh_ * nw_ * 4);
         full_ = (float *)carve((size_t)B * H * W * 4);
         mm_ = (unsigned *)carve((size_t)B * 8);
+        if (cfg_.metric && (r = plan_metric(B, H, W))) return r;
         if (pass == 0) {
             if (arena_off_ > arena_bytes_) {
                 if (arena_) PB_HIP(hipFree(arena_));
@@ -396,8 +419,14 @@ int DepthEngine::prepare(int B, int H, int W) {
     }
     std::vector<int> xi, yi;
     std::vector<float> xw, yw, pos;
-    cubic_taps(W, nw_, xi, xw);
-    cubic_taps(H, nh_, yi, yw);
+    if (cfg_.metric) {
+        bilinear_ac_taps(W, nw_, xi, xw);
+        bilinear_ac_taps(H, nh_, yi, yw);
+        if ((r = metric_tables(H, W))) return r;
+    } else {
+        cubic_taps(W, nw_, xi, xw);
+        cubic_taps(H, nh_, yi, yw);
+    }
     interp_pos(pos_host_, cfg_.pos_grid, D, gh_, gw_, 0.1f, pos);
     PB_HIP(hipMemcpyAsync(xi_, xi.data(), xi.size() * 4, hipMemcpyHostToDevice, stream));
     PB_HIP(hipMemcpyAsync(xw_, xw.data(), xw.size() * 4, hipMemcpyHostToDevice, stream));
@@ -569,7 +598,18 @@ int DepthEngine::head(int n) {
     if ((r = conv3(path_[0], Fp, n, h1, w1, oc1_, o1_, nullptr, nullptr, nullptr, ACT_NONE, 1, F2p))) return r;
     nhwc("output_conv1", o1_, F2, h1, w1, F2p);
     if ((r = bil(o1_, up_, h1, w1, nh_, nw_, F2, F2p))) return r;
-    {   // output_conv2: 3x3 -> ReLU -> 1x1 -> ReLU fused in one implicit-GEMM launch
+    if (cfg_.metric) {   // the metric head needs the 32-channel activation ("out_conv" hook): 3x3 + ReLU, then the 1x1 + ReLU
+        GemmArgs a;
+        a.A = up_;
+        a.cH = nh_; a.cW = nw_; a.cC = F2p; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cOH = nh_; a.cOW = nw_;
+        a.M = n * nh_ * nw_; a.N = 32; a.out = act32_; a.ldo = 32; a.act = ACT_RELU;
+        if ((r = gemm(A_CONV, EPI_STD, a, oc2_))) return r;
+        tic(F_ELT, 0, (double)a.M * 68);
+        r = launch_dot32_relu(stream, act32_, 32, w2_, b2_, netd_, a.M);
+        toc();
+        if (r) return r;
+        nhwc("output_conv2_0", act32_, 32, nh_, nw_, 32);
+    } else {   // output_conv2: 3x3 -> ReLU -> 1x1 -> ReLU fused in one implicit-GEMM launch
         GemmArgs a;
         a.A = up_;
         a.cH = nh_; a.cW = nw_; a.cC = F2p; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cOH = nh_; a.cOW = nw_;
@@ -594,6 +634,19 @@ int DepthEngine::run_chunk(const uint8_t *frames, int n, float *depth_out, uint8
     if ((r = head(n))) return r;
     // dpt.py:163-164 (bilinear to the same size with align_corners=True, ReLU) is the identity on netd_.
     float *full = depth_out ? depth_out : full_;
+    if (cfg_.metric) {      // ZoeDepth head -> Pillow resize to the frame -> per-frame min / max -> heat encode
+        if ((r = metric_head(n))) return r;
+        tic(F_PP, 0, (double)n * ((double)nh_ * nw_ * 4 + (double)pH_ * pW_ * 8));
+        r = launch_pil_resize(stream, md_, ptmp_, full, n, nh_, nw_, pH_, pW_, pxb_, pxk_, pxks_, pyb_, pyk_, pyks_);
+        if (!r) r = launch_init_minmax(stream, mm_, n);
+        if (!r) r = launch_minmax_only(stream, full, n, (int64_t)pH_ * pW_, mm_);
+        toc();
+        if (r) return r;
+        tic(F_PP, 0, (double)n * (double)pH_ * pW_ * 7);
+        r = launch_heat_encode(stream, full, n, pH_, pW_, mm_, flip, rgb_out, mn, mx);
+        toc();
+        return r;
+    }
     tic(F_PP, 0, (double)n * ((double)nh_ * nw_ * 4 + (double)pH_ * pW_ * 4));
     if ((r = launch_init_minmax(stream, mm_, n))) return r;
     r = launch_depth_resize_minmax(stream, netd_, n, nh_, nw_, full, pH_, pW_, mm_);

@@ -155,11 +155,14 @@ class DepthAnything(_Ctx):
     """
 
     def __init__(self, weights: Dict[str, np.ndarray], cfg: DepthCfg | str = "vitl", device: int = 0,
-                 max_batch: int = 1):
+                 max_batch: int = 1, metric: bool = False):
         super().__init__()
         self.cfg = DEPTH_CFGS[cfg] if isinstance(cfg, str) else cfg
+        self.metric = bool(metric)
+        if self.metric:      # ZoeDepth state dict: the core's tensors sit under `core.core.`
+            weights = {(k[len("core.core."):] if k.startswith("core.core.") else k): v for k, v in weights.items()}
         c = _lib.pb_depth_cfg(self.cfg.embed_dim, self.cfg.depth, self.cfg.heads, self.cfg.features,
-                              (C.c_int32 * 4)(*self.cfg.out_channels), self.cfg.pos_grid, max_batch)
+                              (C.c_int32 * 4)(*self.cfg.out_channels), self.cfg.pos_grid, max_batch, int(self.metric))
         keep: List[np.ndarray] = []
         arr = (_lib.pb_tensor * len(weights))()
         for i, (name, w) in enumerate(weights.items()):

@@ -441,3 +441,61 @@ def solov2_weights(cfg: MaskCfg, seed: int = 777) -> Dict[str, np.ndarray]:
             if name == "mask_head.conv_cls.weight":
                 w[name][[i for i in band_ids if i < shape[0]]] *= np.float32(3.0 if cfg.feat_channels >= 512 else 2.0)
     return w
+
+
+# ----------------------------------------------------------------------------
+# ZoeDepth metric head over the Depth-Anything ViT-L + DPT core (`depth_anything --metric indoor|outdoor`):
+# /root/reference/bands/patchfusion/zoedepth/models/zoedepth/zoedepth_v1.py:39-137, config_zoedepth.json
+# (n_bins 64, bin_embedding_dim 128, softplus bin centres, n_attractors [16, 8, 4, 1], alpha 1000 in the config but 300
+# in effect - the layer calls inv_attractor with its defaults -, gamma 2, kind mean, type inv, min_temp 0.0212, max_temp 50, img_size [392, 518]).  state_dict naming of ZoeDepth: the core's
+# tensors sit under `core.core.` (DepthAnythingCore.core = DPT_DINOv2).
+# ----------------------------------------------------------------------------
+ZOE = dict(n_bins=64, bin_dim=128, n_attractors=(16, 8, 4, 1), alpha=300.0, gamma=2, min_temp=0.0212, max_temp=50.0,
+           img_size=(392, 518), features=256, last_in=33)
+
+
+def zoe_head_param_shapes() -> List[Tuple[str, Tuple[int, ...]]]:
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def conv(name, co, ci):
+        out.append((name + ".weight", (co, ci, 1, 1)))
+        out.append((name + ".bias", (co,)))
+
+    F_, nb, bd = ZOE["features"], ZOE["n_bins"], ZOE["bin_dim"]
+    conv("conv2", F_, F_)
+    conv("seed_bin_regressor._net.0", 256, F_)
+    conv("seed_bin_regressor._net.2", nb, 256)
+    conv("seed_projector._net.0", 128, F_)
+    conv("seed_projector._net.2", bd, 128)
+    for i, na in enumerate(ZOE["n_attractors"]):
+        conv(f"projectors.{i}._net.0", 128, F_)
+        conv(f"projectors.{i}._net.2", bd, 128)
+        conv(f"attractors.{i}._net.0", 128, bd)
+        conv(f"attractors.{i}._net.2", na, 128)
+    bott = (ZOE["last_in"] + bd) // 2
+    conv("conditional_log_binomial.mlp.0", bott, ZOE["last_in"] + bd)
+    conv("conditional_log_binomial.mlp.2", 4, bott)
+    return out
+
+
+def zoe_weights(seed: int = 2468) -> Dict[str, np.ndarray]:
+    """ZoeDepth state dict on the seeded ViT-L core: `core.core.<depth-anything name>` + the metric head.  The seed
+    regressor's bias spreads the 64 softplus bin centres over ~0.5 .. 8 (metres), attractor outputs land in the same
+    range, so the attractors move bins and the log-binomial picks among distinct depths."""
+    core = depth_anything_weights("vitl", seed=1234)
+    w: Dict[str, np.ndarray] = {"core.core." + k: v for k, v in core.items()}
+    for name, shape in zoe_head_param_shapes():
+        g = _rng(seed, name)
+        if name.endswith(".bias"):
+            b = (0.1 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+            if name == "seed_bin_regressor._net.2.bias":
+                b = np.linspace(0.5, 8.0, shape[0]).astype(np.float32)
+            elif name.startswith("attractors.") and name.endswith("_net.2.bias"):
+                b = np.linspace(1.0, 7.0, shape[0]).astype(np.float32) if shape[0] > 1 else np.array([3.0], np.float32)
+            w[name] = b
+        else:
+            gain = 1.4 if name.endswith("_net.0.weight") or name.endswith("mlp.0.weight") else 1.0
+            if name == "seed_bin_regressor._net.2.weight" or (name.startswith("attractors.") and name.endswith("_net.2.weight")):
+                gain = 0.5
+            w[name] = g.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(shape[1]))
+    return w

@@ -173,6 +173,34 @@ def test_mask_cli_video_and_image(tmp_path):
     Image.fromarray(frames[0]).save(tmp_path / "img.png")
     band.main(["-i", str(tmp_path / "img.png"), "--arch", "tiny"])
     png = np.asarray(Image.open(tmp_path / "mask.png"))
-    assert png.shape == (180, 300, 3) and np.array_equal(png[..., 0], out[0, ..., 0])
+    # batch of 3 vs batch of 1: GroupNorm statistics are fp32 atomics and tile shapes differ, so threshold-edge pixels may flip
+    assert png.shape == (180, 300, 3) and (png[..., 0] != out[0, ..., 0]).mean() < 0.01
     band.model.close()
     band.model = None
+
+
+@pytest.mark.gpu
+def test_cli_metric_depth(tmp_path):
+    """`--metric indoor`: ZoeDepth head, not flipped (reference bands/depth_anything.py:52-57,106-119,150,188)."""
+    import depth_anything as band
+    from prisma_amd import synth
+    folder = tmp_path / "clip"
+    folder.mkdir()
+    frames = synth.frames(2, 120, 200, seed=3)
+    np.save(folder / "rgba.npy", frames)
+    (folder / "metadata.json").write_text(json.dumps({"bands": {"rgba": {"url": "rgba.npy"}}}))
+    os.environ["PRISMA_OVERWRITE"] = "1"
+    band.model = None
+    band.main(["-i", str(folder), "--metric", "indoor"])
+    out = np.load(folder / "depth_anything.npy")
+    assert out.shape == frames.shape
+    lo = [float(x) for x in open(folder / "depth_anything_min.csv")]
+    hi = [float(x) for x in open(folder / "depth_anything_max.csv")]
+    assert all(0.1 < a < b < 20.0 for a, b in zip(lo, hi))            # metres, not the relative model's arbitrary scale
+    d = band.infer(frames[1])
+    assert d.shape == (120, 200) and abs(d.min() - lo[1]) < 1e-6 and abs(d.max() - hi[1]) < 1e-6
+    far = np.unravel_index(d.argmax(), d.shape)
+    assert tuple(out[1][far]) == (255, 0, 0)                            # farthest = heat 1 = red: not flipped
+    band.model.close()
+    band.model = None
+    band.args = None
