@@ -56,6 +56,10 @@ def test_two_ranks_equal_one(tmp_path, script, extra, outputs):
                 # the two launches: encoded flow may move by one grey level, masks flip only on the threshold's edge
                 d = np.abs(x.astype(int) - y.astype(int))
                 assert (d > 1).mean() < 2e-3 if "mask" not in name else (d > 0).mean() < 2e-3, name
+            elif script.startswith("mask"):
+                # GroupNorm statistics are fp32 atomics too, and batch composition changes the GEMM tiling: pixels on a
+                # mask's 0.5 edge may flip
+                assert (x != y).mean() < 0.01, name
             else:
                 assert np.array_equal(x, y), name
         elif script.startswith("flow"):
