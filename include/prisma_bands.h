@@ -199,7 +199,8 @@ typedef struct {
 } pb_kernel_stat;
 int pb_set_profiling(pb_ctx *ctx, int enabled);
 /* Tuning / A-B switches: "gemm_tile", "conv_tile" = 0 auto, 1 128x128, 2 256x256 ping-pong,
- * 4 256x256 single-barrier. */
+ * 4 256x256 single-barrier; "gemm_breg" = 1: weights of the 256x256 GEMMs go straight to registers in MFMA
+ * fragment order instead of through the LDS (experiment, measured slower; default 0). */
 int pb_set_option(pb_ctx *ctx, const char *key, int value);
 int pb_get_kernel_stats(pb_ctx *ctx, pb_kernel_stat *out, int cap);
 

@@ -421,6 +421,7 @@ int pb_set_option(pb_ctx *c, const char *key, int value) {
     int *v = c->depth ? &c->depth->conv_tile : (c->raft ? &c->raft->conv_tile : (c->mask ? &c->mask->conv_tile : &c->conv_tile));
     if (!strcmp(key, "gemm_tile")) *g = value;
     else if (!strcmp(key, "conv_tile")) *v = value;
+    else if (!strcmp(key, "gemm_breg") && c->depth) c->depth->breg = value;
     else PB_CHECK(false, PB_ERR_ARG, "unknown option '%s'", key);
     return 0;
 }

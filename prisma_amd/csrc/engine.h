@@ -14,6 +14,7 @@ struct PackedW {
     f16 *w = nullptr;        // [Npad, K] fp16, K % 64 == 0
     float *bias = nullptr;   // [N] fp32 or null
     int N = 0, K = 0, Kreal = 0;
+    mutable f16 *wf[2] = {nullptr, nullptr};   // fragment-order copies (plain / interleaved columns), built on first use
 };
 
 struct Stage {
@@ -47,6 +48,8 @@ class DepthEngine {
     int device = 0;
     bool debug = false;
     int gemm_tile = TILE_AUTO, conv_tile = TILE_AUTO;
+    int breg = 0;            // 1: 256x256 GEMMs read the weights in fragment order straight into registers (gemm8b_kernel);
+                             // measured 3-8 % slower than the LDS path (both wave rows fetch B from L2), so off by default
     KernelTimer timer;
 
     // scratch for op-level tests

@@ -451,6 +451,18 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
     const double bytes = 2.0 * ((double)a.M * w.Kreal + (double)a.N * w.Kreal + (double)a.M * a.N);
     tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes);
     if (tile == TILE_AUTO) tile = amode == A_CONV ? conv_tile : gemm_tile;
+    if (breg && w.N % 256 == 0 && (tile == TILE_AUTO || tile == TILE_256) && epi != EPI_HEAD) {
+        const int il = (epi == EPI_STD || epi == EPI_QKV || epi == EPI_PIXSHUF) ? 1 : 0;
+        if (!w.wf[il]) {
+            void *q = nullptr;
+            PB_HIP(hipMalloc(&q, (size_t)round_up(w.N, 256) * w.K * 2));
+            owned_.push_back(q);
+            int rp = launch_frag_pack(stream, w.w, (f16 *)q, (int)round_up(w.N, 256), w.K, il);
+            if (rp) return rp;
+            w.wf[il] = (f16 *)q;
+        }
+        a.Wf = w.wf[il];
+    }
     int r = launch_gemm(stream, amode, epi, tile, a);
     toc();
     return r;

@@ -12,6 +12,7 @@ struct GemmArgs {
     const f16 *A = nullptr;
     int64_t lda = 0;
     const f16 *W = nullptr;
+    const f16 *Wf = nullptr;              // optional: W in MFMA fragment order (pack_fragments); selects the register-B 256x256 kernel
     int K = 0, M = 0, N = 0;              // N = columns actually written (multiple of 8)
     // implicit-GEMM convolution: input [B, cH, cW, cC] (cC % 64 == 0), K = KH*KW*cC, rows = (b, oy, ox)
     // kernel KH x cKW (tap = ky * cKW + kx), padding (cPadY, cPadX); cLd = pixel stride in elements (0 = cC), so a
@@ -51,3 +52,6 @@ struct GemmArgs {
 
 // Launches the kernel on `stream`.  tile: TILE_AUTO picks from the shape.
 int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a);
+// Packed weights [Npad % 256 == 0][K] -> MFMA fragment order for GemmArgs::Wf; `interleaved` must match the epilogue
+// the weight is used with (EPI_STD, EPI_QKV, EPI_PIXSHUF store interleaved column pairs).
+int launch_frag_pack(hipStream_t s, const f16 *W, f16 *Wf, int Npad, int K, int interleaved);

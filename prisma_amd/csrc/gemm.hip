@@ -865,10 +865,240 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     }
 }
 
+// Same tile walk and A staging as gemm8_kernel, but the B operand (packed weights) never touches the LDS: p.Wf holds
+// the weights pre-swizzled into MFMA fragment order - [tile_n][k tile][wave column][j][ks][lane][8 halves] - so a wave's
+// eight B fragments of a K tile are one contiguous 8 KB block read with eight coalesced 16-byte global loads straight
+// into registers, one K tile ahead.  That halves the LDS traffic (no B DMA writes, no B fragment reads); the price is
+// that both wave rows fetch the same B block from L2.  VMEM ops per thread and K tile, in issue order:
+//     p0: B_j0(t+1) x4 | p1: A_1(t+1) x2 | p2: B_j1(t+1) x4, A_0(t+2) x2 | p3: -
+// with `s_waitcnt vmcnt(8)` in p1 (B_j1(t), A_1(t) landed) and p3 (A_0(t+1), B_j0(t+1) landed); loads past the last
+// K tile re-read the last one (harmless: their LDS slots / registers are dead) so the count never changes.
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(512) void gemm8b_kernel(const GemmArgs p) {
+    constexpr int VAR = 0;
+    constexpr int BM = 256, BN = 256;
+    constexpr int BUF = 65536, BOFF = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wr = wave >> 2, wc = wave & 3;
+    long long ts0 = 0, ts1 = 0, ts2 = 0, tr0 = 0;
+    stagger_start(p.stagger, 256);
+    if (p.dbg) { ts0 = __builtin_readcyclecounter(); tr0 = wall_clock64(); }
+
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    // Within an XCD's contiguous range, walk 8 (M) x GN (N) super-tiles so that the ~32 tiles in flight on
+    // the XCD share few A and W panels (fewer L2 misses -> less MALL/HBM traffic; loop time is unchanged).
+    int tile_m, tile_n;
+    {
+        const int GN = tilesN < 4 ? tilesN : 4;
+        const int per_band = 8 * tilesN;                 // tiles in a band of 8 M-panels
+        const int band = swz / per_band, rem = swz - band * per_band;
+        const int tilesM = nwg / tilesN;
+        const int bh = (tilesM - band * 8) < 8 ? (tilesM - band * 8) : 8;   // M-panels in this band
+        const int grp = rem / (bh * GN), r2 = rem - grp * bh * GN;
+        const int gw = (tilesN - grp * GN) < GN ? (tilesN - grp * GN) : GN; // N-panels in this group
+        tile_m = band * 8 + r2 / gw;
+        tile_n = grp * GN + r2 % gw;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging geometry: half tile h in {A_0, A_1, B_0, B_1}, two DMAs (u = 0, 1) per thread ----
+    // DMA (wave, u) covers the 8 LDS rows starting at row0; lane -> row0 + (lane >> 3), chunk lane & 7.
+    const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
+    const int lrow = lane >> 3;
+    int a_row0[2][2];                                // [half][u], tile-local row of the DMA's first row
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = wave * 2 + u;
+            a_row0[hf][u] = (g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8;
+        }
+    // swizzled global chunk of this lane's LDS slot: row0 is a multiple of 8 with (row0 >> 3) & 1 == u
+    int cgu[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) cgu[u] = (lane & 7) ^ ((4 * u + (lane >> 4)) & 7);
+
+    const f16 *a_ptr[2][2];
+    int a_iy0[2][2], a_ix0[2][2];
+    bool a_ok[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int m = m0 + a_row0[hf][u] + lrow;
+            if constexpr (AMODE == A_DENSE) {
+                const int mc = m < p.M ? m : p.M - 1;
+                a_ptr[hf][u] = p.A + (int64_t)mc * p.lda + cgu[u] * 8;
+                a_ok[hf][u] = true;
+                a_iy0[hf][u] = a_ix0[hf][u] = 0;
+            } else {
+                const int ohw = p.cOH * p.cOW;
+                const int b = m / ohw, rem = m - b * ohw;
+                const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+                a_ok[hf][u] = m < p.M;
+                a_ptr[hf][u] = p.A + (int64_t)b * p.cH * p.cW * cld + cgu[u] * 8;
+                a_iy0[hf][u] = oy * p.cStride - p.cPad;
+                a_ix0[hf][u] = ox * p.cStride - padx;
+            }
+        }
+    const int nk = p.K >> 6;
+    const int cpt = AMODE == A_CONV ? p.cC >> 6 : 1;     // K tiles per conv tap
+
+    auto stage_a_to = [&](int hf, int kt, int slot) {
+        char *base = smem + slot * BUF;
+        int ky = 0, kx = 0, c0 = 0;
+        if constexpr (AMODE == A_CONV) {
+            const int tap = kt / cpt;
+            c0 = (kt - tap * cpt) << 6;
+            ky = tap / p.cKW;
+            kx = tap - ky * p.cKW;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f16 *src;
+            if constexpr (AMODE == A_DENSE) {
+                src = a_ptr[hf][u] + kt * 64;
+            } else {
+                const int iy = a_iy0[hf][u] + ky, ix = a_ix0[hf][u] + kx;
+                const bool ok = a_ok[hf][u] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+                src = ok ? a_ptr[hf][u] + ((iy * p.cW + ix) * cld + c0) : p.zero;
+            }
+            const int g = wave * 2 + u;
+            glds16(src, base + ((g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8) * 128);
+        }
+    };
+    // this wave's fragment blocks: 8 KB per K tile, block (j, ks) at + (j * 4 + ks) * 1 KB, lane l at + l * 16 B
+    const f16 *bf = p.Wf + (((int64_t)tile_n * nk * 4 + wc) * 8) * 512 + lane * 8;
+    auto load_b = [&](f16x8 (&dst)[4], int j, int kt) {
+        const int kc = kt < nk ? kt : nk - 1;
+        const f16 *src = bf + (int64_t)kc * (4 * 8 * 512) + j * 4 * 512;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const f16x8 *)(src + ks * 512);
+    };
+    // ---- fragment addressing: chunk(ks) = (lh ^ fsw) ^ 2 ks  ->  byte offset = c0 ^ (32 ks) ----
+    const int li = lane & 31, lh = lane >> 5;
+    const int c0 = (lh ^ ((li >> 1) & 7)) * 16;
+    const int a_base = (wr * 128 + li) * 128;            // + i*8192 + rt*4096
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (EPI == EPI_RESID) resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+    f16x8 fa[2][4], fb0[4], fb1[4], fbn0[4], fbn1[4];
+
+    // prologue: B_j0(0) A_0(0) B_j1(0) | A_1(0) A_0(1); the first three must have landed before the loop
+    load_b(fb0, 0, 0); stage_a_to(0, 0, 0); load_b(fb1, 1, 0); stage_a_to(1, 0, 0); stage_a_to(0, 1 < nk ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    PB_BAR();
+    if (wr == 1) PB_BAR();                               // stagger the second wave group by one barrier
+    if (p.dbg) ts1 = __builtin_readcyclecounter();
+
+    for (int t = 0; t < nk; ++t) {
+        const char *sb = smem + (t & 1) * BUF;
+        const int ta = t + 1 < nk ? t + 1 : nk - 1, tb = t + 2 < nk ? t + 2 : nk - 1;
+        // ================= p0 =================
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const f16x8 *)(sb + a_base + rt * 4096 + (c0 ^ (ks * 32)));
+        load_b(fbn0, 0, t + 1);
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[rt][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
+        // ================= p1 =================
+        stage_a_to(1, ta, (t + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // B_j1(t) in registers, A_1(t) in the LDS
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[rt][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
+        // ================= p2 =================
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                fa[rt][ks] = *(const f16x8 *)(sb + a_base + 8192 + rt * 4096 + (c0 ^ (ks * 32)));
+        load_b(fbn1, 1, t + 1);
+        stage_a_to(0, tb, t & 1);
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[2 + rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[2 + rt][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
+        // ================= p3 =================
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A_0(t+1) in the LDS, B_j0(t+1) in registers
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[2 + rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[2 + rt][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { fb0[ks] = fbn0[ks]; fb1[ks] = fbn1[ks]; }
+        PB_BAR();
+    }
+    if (wr == 0) PB_BAR();                               // re-align the two wave groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.dbg) ts2 = __builtin_readcyclecounter();
+    if constexpr (EPI == EPI_RESID) resid_io<4, 2, true>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+    else run_epilogue<EPI, 4, 2>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, n0);
+    if (p.dbg && tid == 0) {
+        const long long t_issue = __builtin_readcyclecounter();      // all epilogue stores issued, none waited for
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long *d = p.dbg + (long long)blockIdx.x * 8;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter(); d[4] = tr0; d[5] = wall_clock64();
+        d[6] = t_issue; d[7] = swz;
+    }
+}
+
 template <int AMODE, int EPI, int VAR = 0>
 int launch_g8(hipStream_t stream, const GemmArgs &a) {
     constexpr int SMEM = 131072;
     auto kern = gemm8_kernel<AMODE, EPI, VAR>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), SMEM, stream, a);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int AMODE, int EPI>
+int launch_g8b(hipStream_t stream, const GemmArgs &a) {
+    constexpr int SMEM = 131072;
+    auto kern = gemm8b_kernel<AMODE, EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -904,13 +1134,39 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
     if constexpr (EPI == EPI_HEAD) {
         return launch_t<256, 32, 4, 1, AMODE, EPI>(s, a);
     } else {
-        if (tile == TILE_256) return launch_g8<AMODE, EPI>(s, a);
+        if (tile == TILE_256) return a.Wf ? launch_g8b<AMODE, EPI>(s, a) : launch_g8<AMODE, EPI>(s, a);
         if (tile == TILE_256_SIMPLE) return launch_t<256, 256, 2, 4, AMODE, EPI>(s, a);
         return launch_t<128, 128, 2, 2, AMODE, EPI>(s, a);
     }
 }
 
 }  // namespace
+
+namespace {
+// W [Npad][K] row-major -> fragment order [tile_n][k tile][wave column][j][ks][lane][8] (see gemm8b_kernel)
+__global__ __launch_bounds__(256) void frag_pack_kernel(const f16 *__restrict__ W, f16 *__restrict__ Wf, int nk, int K, int il,
+                                                        int64_t chunks) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= chunks) return;
+    const int lane = (int)(i & 63);
+    const int ks = (int)((i >> 6) & 3), j = (int)((i >> 8) & 1), wc = (int)((i >> 9) & 3);
+    const int64_t tk = i >> 11;                                   // tile_n * nk + kt
+    const int kt = (int)(tk % nk);
+    const int64_t tn = tk / nk;
+    const int li = lane & 31, lh = lane >> 5;
+    const int r = wc * 64 + j * 32 + li;
+    const int col = il ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;
+    *(f16x8 *)(Wf + i * 8) = *(const f16x8 *)(W + (tn * 256 + col) * K + kt * 64 + ks * 16 + lh * 8);
+}
+}  // namespace
+
+int launch_frag_pack(hipStream_t s, const f16 *W, f16 *Wf, int Npad, int K, int interleaved) {
+    PB_CHECK(Npad % 256 == 0 && K % 64 == 0, -1, "frag_pack: Npad=%d K=%d", Npad, K);
+    const int64_t chunks = (int64_t)Npad * K / 8;
+    hipLaunchKernelGGL(frag_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, W, Wf, K / 64, K, interleaved, chunks);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
 
 int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a_in) {
     GemmArgs a = a_in;
