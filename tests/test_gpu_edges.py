@@ -1,0 +1,77 @@
+"""GPU: edge cases of the three bands through the C ABI - smallest / odd / large frames, batches that are not a multiple
+of max_batch, argument errors.  The reference has no tests of its own; these pin the behaviour the band scripts rely on."""
+import numpy as np
+import pytest
+
+from prisma_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+Err = engine._lib.PrismaBandsError
+
+
+@pytest.fixture(scope="module")
+def depth():
+    net = engine.DepthAnything(synth.depth_anything_weights("vits", seed=1234), "vits", max_batch=3)
+    yield net
+    net.close()
+
+
+def test_depth_tiny_odd_and_4k_frames(depth):
+    for h, w in ((1, 1), (7, 13), (33, 517), (2160, 3840)):
+        fr = synth.frames(1, h, w, seed=h + w)
+        d, rgb, mn, mx = depth.infer_batch(fr)
+        assert d.shape == (1, h, w) and rgb.shape == (1, h, w, 3) and np.isfinite(d).all()
+        assert mn[0] == d.min() and mx[0] == d.max()
+        if mx[0] > mn[0]:
+            hot = np.unravel_index(d[0].argmax(), d[0].shape)
+            assert tuple(rgb[0][hot]) == (0, 25, 255)         # flipped relative depth: the nearest (largest) value is heat 0
+        else:                                                 # constant map: 0/0 -> NaN -> byte 0 everywhere (encode.py:13-33)
+            assert not rgb.any()
+
+
+def test_depth_batch_not_multiple_of_max_batch(depth):
+    fr = synth.frames(7, 60, 100, seed=9)                     # max_batch 3 -> chunks of 3, 3, 1
+    d, rgb, mn, mx = depth.infer_batch(fr)
+    one, rgb1, mn1, mx1 = depth.infer_batch(fr[6:7])
+    assert np.allclose(d[6], one[0], rtol=0, atol=2e-3 * float(one.max())) and abs(mn[6] - mn1[0]) <= 2e-3 * mx1[0]
+    assert (np.abs(rgb[6].astype(int) - rgb1[0].astype(int)) > 2).mean() < 1e-2
+
+
+def test_depth_argument_errors(depth):
+    with pytest.raises(Err):
+        depth.infer_batch(np.zeros((0, 8, 8, 3), np.uint8))
+    with pytest.raises(AssertionError):
+        depth.infer_batch(np.zeros((1, 8, 8, 4), np.uint8))
+    with pytest.raises(Err):
+        engine.DepthAnything({"pretrained.cls_token": np.zeros((1, 1, 384), np.float32)}, "vits")     # missing weights
+
+
+def test_flow_minimum_sequence_and_too_small_frames():
+    net = engine.FlowRaft(synth.raft_weights(seed=4321))
+    fr = synth.frame_pair_sequence(2, 128, 128, seed=1)       # smallest legal: the 4-level pyramid needs 16 x 16 at 1/8
+    flow, rgb, mx = net.infer_sequence(fr, scale=1.0, iters=1)
+    assert flow.shape == (1, 1, 128, 128, 2) and np.isfinite(flow).all()
+    with pytest.raises(Err, match="too small"):               # the reference returns NaN here (level-3 map of height 1)
+        net.infer_sequence(synth.frame_pair_sequence(2, 96, 160, seed=1), scale=1.0, iters=1)
+    with pytest.raises(AssertionError):
+        net.infer_sequence(fr[:1], scale=1.0, iters=1)
+    with pytest.raises(Err):
+        net.infer_sequence_masks(fr, scale=1.0, iters=0)
+    # a sequence longer than anything planned before re-plans the arena
+    fr9 = synth.frame_pair_sequence(9, 128, 136, seed=2)
+    flow, _, mx = net.infer_sequence(fr9, scale=1.0, iters=2, backward=True, want_rgb=False)
+    assert flow.shape == (8, 2, 128, 136, 2) and (mx > 0).all()
+    net.close()
+
+
+def test_mask_small_frame_and_no_detection():
+    cfg = synth.MASK_CFGS["tiny"]
+    net = engine.MaskMMDet(synth.solov2_weights(cfg), cfg, max_batch=2)
+    keep = [synth.COCO_CLASSES.index(c) for c in synth.BAND_CLASSES]
+    out = net.infer_batch(synth.frames(3, 37, 53, seed=4), 0.5, keep)          # upscaled to the 320 x 192 test scale
+    assert out.shape == (3, 37, 53, 3)
+    none = net.infer_batch(np.zeros((1, 64, 64, 3), np.uint8), 1.1, keep)      # nothing can pass confidence 1.1
+    assert not none.any() and len(net.instances(0)[0]) >= 0
+    with pytest.raises(Err):
+        net.infer_batch(np.zeros((0, 8, 8, 3), np.uint8))
+    net.close()
