@@ -148,6 +148,48 @@ def mask_leg(args, local_rank, world, rank, dist):
     return out
 
 
+def pipeline_leg(args, local_rank, world, rank, dist):
+    """BASELINE.json configs[4]: every frame of a 1080p clip goes through depth_anything, flow_raft (forward pairs, the band's
+    default --scale 0.75, 12 iterations) and mask_mmdet, fused pre / post-processing, frames resident in HBM.  One step =
+    args.pipeline_frames frames through the three bands back to back on this rank's GPU."""
+    from prisma_amd import engine, synth
+    H, W, B = 1080, 1920, args.pipeline_frames
+    dn = engine.DepthAnything(synth.depth_anything_weights("vitl", seed=1234), "vitl", device=local_rank, max_batch=B)
+    fn = engine.FlowRaft(synth.raft_weights(seed=4321), device=local_rank)
+    mcfg = synth.MASK_CFGS["r101"]
+    mn = engine.MaskMMDet(synth.solov2_weights(mcfg), mcfg, device=local_rank, max_batch=min(B, 8))
+    frames = torch.from_numpy(synth.frame_pair_sequence(B, H, W, seed=90 + rank)).cuda()
+    d_rgb = torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda")
+    d_mm = torch.empty((2, B), dtype=torch.float32, device="cuda")
+    sh, sw = engine.flow_out_size(H, W, 0.75)
+    f_rgb = torch.empty((B - 1, sh, sw, 3), dtype=torch.uint8, device="cuda")
+    f_mx = torch.empty((B - 1,), dtype=torch.float32, device="cuda")
+    m_out = torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda")
+    keep = [synth.COCO_CLASSES.index(c) for c in synth.BAND_CLASSES]
+
+    def step():
+        dn.infer_dev(frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), d_mm[0].data_ptr(), d_mm[1].data_ptr(), True)
+        fn.infer_sequence_dev(frames.data_ptr(), B, H, W, 0.75, 12, False, 0, f_rgb.data_ptr(), f_mx.data_ptr())
+        mn.infer_batch_dev(frames.data_ptr(), B, H, W, 0.5, keep, m_out.data_ptr())
+        dn.sync(); fn.sync(); mn.sync()
+
+    step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    steps = max(1, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for n_ in (dn, fn, mn):
+        n_.close()
+    return {"metric": "frames/sec (depth_anything + flow_raft + mask_mmdet on every 1080p frame)", "value": round(world * B * steps / dt, 3),
+            "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "frames_per_step_per_gpu": B,
+            "note": "the three bands run back to back on one stream each; flow at --scale 0.75 (816 x 1440), forward pairs only"}
+
+
 def pmc_traffic(symbol, batch):
     """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC summary (tools/pmc_summary.py; separate
     FETCH_SIZE / WRITE_SIZE passes over this same bench command at batch 32).  PMC passes cannot run inside the timed
@@ -176,6 +218,7 @@ def main():
     ap.add_argument("--conv-tile", type=int, default=0)
     ap.add_argument("--latency", action="store_true", help="also time one 1280x720 frame at batch 1 (BASELINE configs[1])")
     ap.add_argument("--host-chunks", type=int, default=4, help="batches pushed through the host-pointer API for the PCIe-inclusive rate (0 = skip)")
+    ap.add_argument("--pipeline-frames", type=int, default=16, help="frames per step of the three-band pipeline leg (0 = skip)")
     ap.add_argument("--mask-frames", type=int, default=8, help="frames per step of the mask_mmdet leg (0 = skip that leg)")
     ap.add_argument("--flow-pairs", type=int, default=8, help="frame pairs per GPU per step of the flow_raft leg (0 = skip)")
     args = ap.parse_args()
@@ -265,6 +308,7 @@ def main():
     net.close()
     flow = flow_leg(args, local_rank, world, rank, dist) if args.flow_pairs > 0 else None
     mask = mask_leg(args, local_rank, world, rank, dist) if args.mask_frames > 0 else None
+    pipe = pipeline_leg(args, local_rank, world, rank, dist) if args.pipeline_frames > 1 else None
 
     if rank == 0:
         fps = world * B * args.steps / dt
@@ -309,6 +353,8 @@ def main():
             out["flow_raft"] = flow
         if mask:
             out["mask_mmdet"] = mask
+        if pipe:
+            out["pipeline"] = pipe
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
