@@ -275,7 +275,11 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         for (auto &b : st_) b = (float *)carve((size_t)F * 256 * 2 * 4);
         fmap_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2 + slack);
         ctx_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2);
-        for (int l = 0; l < 4; ++l) pyr_[l] = (float *)carve((size_t)ND * P_ * (l == 0 ? P8_ : lh_[l] * lw_[l]) * 4 + slack);
+        for (int l = 0; l < 4; ++l) {
+            pld_[l] = (int)round_up(lh_[l] * lw_[l], 8);      // row stride of level l (the GEMM epilogue writes 8-column groups)
+            pyr_[l] = (float *)carve((size_t)ND * P_ * pld_[l] * 4 + slack);
+            fpool_[l] = l == 0 ? nullptr : (f16 *)carve((size_t)round_up((int64_t)F * lh_[l] * lw_[l], 256) * 256 * 2 + slack);
+        }
         const int64_t rows = round_up(ND * P_, 256);
         h32_ = (float *)carve((size_t)rows * 128 * 4); flow_ = (float *)carve((size_t)rows * 2 * 4);
         delta_ = (float *)carve((size_t)rows * 8 * 4); mask_ = (float *)carve((size_t)rows * 576 * 4);
@@ -425,35 +429,41 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     }
     stages_["fmap"] = Stage{fmap_, 1, 0, 256, h8_, w8_, 256, 0};
 
-    // ---- all-pairs correlation volume + pyramid, recurrent state ----
+    // ---- all-pairs correlation pyramid, recurrent state ----
+    // corr.py:22-27 pools the volume over the target dims; pooling is linear, so level l is the correlation of fmap1 with the
+    // l-times avg-pooled target features: three small pooling passes over [F, P, 256] instead of three over the 4 P^2-byte volume
+    for (int l = 1; l < 4; ++l) {
+        tic(F_ELT, 0, 0);
+        r = launch_avgpool2_nhwc(stream, l == 1 ? fmap_ : fpool_[l - 1], fpool_[l], F, lh_[l - 1], lw_[l - 1], 256);
+        toc();
+        if (r) return r;
+    }
     for (int i = 0; i < F - 1; ++i)
         for (int d = 0; d < dirs; ++d) {
             const int n = i * dirs + d;
-            GemmArgs a;
-            a.A = fmap_ + (int64_t)(i + d) * P_ * 256; a.lda = 256; a.M = P_;
-            a.W = fmap_ + (int64_t)(i + 1 - d) * P_ * 256; a.K = 256; a.N = P8_;
-            a.out32 = pyr_[0] + (int64_t)n * P_ * P8_; a.ldo = P8_; a.scale = 1.f / 16.f; a.zero = zero_;
-            tic(F_GEMM, 2.0 * P_ * (double)P_ * 256, 0);
-            r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
-            toc();
-            if (r) return r;
+            for (int l = 0; l < 4; ++l) {
+                const int Pl = lh_[l] * lw_[l];
+                GemmArgs a;
+                a.A = fmap_ + (int64_t)(i + d) * P_ * 256; a.lda = 256; a.M = P_;
+                a.W = (l == 0 ? fmap_ + (int64_t)(i + 1 - d) * P_ * 256 : fpool_[l] + (int64_t)(i + 1 - d) * Pl * 256);
+                a.K = 256; a.N = pld_[l];
+                a.out32 = pyr_[l] + (int64_t)n * P_ * pld_[l]; a.ldo = pld_[l]; a.scale = 1.f / 16.f; a.zero = zero_;
+                tic(F_GEMM, 2.0 * P_ * (double)Pl * 256, 0);
+                r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
+                toc();
+                if (r) return r;
+            }
             tic(F_ELT, 0, 0);
             r = launch_init_state(stream, ctx_ + (int64_t)(i + d) * P_ * 256, h32_ + (int64_t)n * P_ * 128,
                                   hx_ + (int64_t)n * P_ * 384, flow_ + (int64_t)n * P_ * 2, P_);
             toc();
             if (r) return r;
         }
-    for (int l = 0; l < 3; ++l) {
-        tic(F_ELT, 0, 0);
-        r = launch_corr_pool(stream, pyr_[l], pyr_[l + 1], rows, lh_[l], lw_[l], l == 0 ? P8_ : lh_[l] * lw_[l]);
-        toc();
-        if (r) return r;
-    }
 
     // ---- GRU iterations (raft.py:124-144, update.py:122-136) ----
     for (int it = 0; it < iters; ++it) {
         tic(F_ELT, 0, 0);
-        r = launch_corr_lookup(stream, pyr_, lh_, lw_, P8_, flow_, P_, w8_, corr_, rows);
+        r = launch_corr_lookup(stream, pyr_, lh_, lw_, pld_, flow_, P_, w8_, corr_, rows);
         toc();
         if (r) return r;
         // BasicMotionEncoder

@@ -12,7 +12,8 @@ int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, 
                     int C, int ldc);
 int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, float *flow, int64_t rows);
 int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, int h, int w, int src_ld);
-int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], int ld0, const float *flow,
+int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C);
+int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], const int ld[4], const float *flow,
                        int P, int w8, f16 *out, int64_t rows);
 int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, int64_t rows);
 int launch_gru_rh(hipStream_t s, const f16 *zr, const float *h32, const f16 *hx, f16 *hx2, int64_t rows);

@@ -4,6 +4,8 @@
 // bands/raft/raft.py:73-84 (convex upsample), bands/common/encode.py:98-126 (process_flow).
 #include "raft_kernels.h"
 
+#include <algorithm>
+
 namespace {
 
 inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
@@ -194,6 +196,24 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict_
 // y = cy/2^l + (j-4) with bilinear weights in pixel coordinates and zeros outside the level.
 // One thread per (pixel, level, i): the 9 j-samples share the x taps; output fp16 [rows][384].
 // ------------------------------------------------------------------------------------------------
+// avg_pool2d(2, 2) with floor on odd sizes, NHWC fp16, 8 channels per thread: the pooled target feature maps whose
+// correlation with fmap1 IS the pooled correlation volume (corr.py:22-27; the pooling is linear)
+__global__ __launch_bounds__(256) void avgpool2_nhwc_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int n, int H, int W, int OH,
+                                                            int OW, int C8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * OH * OW * C8) return;
+    const int c = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    const f16 *base = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C8 * 8 + c * 8;
+    const f16x8 v00 = *(const f16x8 *)base, v01 = *(const f16x8 *)(base + C8 * 8);
+    const f16x8 v10 = *(const f16x8 *)(base + (int64_t)W * C8 * 8), v11 = *(const f16x8 *)(base + (int64_t)(W + 1) * C8 * 8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)(0.25f * (((float)v00[j] + (float)v01[j]) + ((float)v10[j] + (float)v11[j])));
+    *(f16x8 *)(y + i * 8) = o;
+}
+
 struct PyrPtrs { const float *lv[4]; int h[4], w[4], ld[4]; };
 
 __global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const float *__restrict__ flow, int P, int w8,
@@ -287,25 +307,25 @@ __global__ void flow_update_kernel(float *__restrict__ flow, const float *__rest
 
 // ------------------------------------------------------------------------------------------------
 // convex upsample (raft.py:73-84) fused with the unpad and the per-flow max displacement:
-// one thread per full-resolution pixel of the padded frame; mask fp32 [rows][576] (already * 0.25).
+// mask fp32 [rows][576] (already * 0.25).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned f2ord_(float f) {
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// one wave per 1/8-resolution pixel, lane = sub-pixel (sy * 8 + sx): the nine 64-wide mask groups are coalesced reads
 __global__ __launch_bounds__(256) void upsample_kernel(const float *__restrict__ flow, const float *__restrict__ mask, int h8,
                                                         int w8, int pad_l, int pad_t, int sh, int sw,
                                                         float *__restrict__ out, unsigned *__restrict__ maxd) {
     const int n = blockIdx.y;
     const int P = h8 * w8;
     float dmax = 0.f;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (int64_t)sh * sw) {
-        const int ox = (int)(i % sw), oy = (int)(i / sw);
-        const int X = ox + pad_l, Y = oy + pad_t;
-        const int px = X >> 3, py = Y >> 3, sub = (Y & 7) * 8 + (X & 7);
-        const float *m = mask + ((int64_t)n * P + py * w8 + px) * 576 + sub;
+    const int sub = threadIdx.x & 63;
+    // grid-stride over the low-res pixels so that a wave issues ONE atomicMax at the end (same-address atomics serialise)
+    for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += gridDim.x * 4) {
+        const int py = p / w8, px = p - py * w8;
+        const float *m = mask + ((int64_t)n * P + p) * 576 + sub;
         float e[9], mx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { e[k] = m[k * 64]; mx = fmaxf(mx, e[k]); }
@@ -323,9 +343,12 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float *__restrict__
                 v += wgt * (8.f * f[1]);
             }
         }
-        float *o = out + ((int64_t)n * sh * sw + i) * 2;
-        o[0] = u; o[1] = v;
-        dmax = __fsqrt_rn(__fadd_rn(__fmul_rn(u, u), __fmul_rn(v, v)));
+        const int oy = py * 8 + (sub >> 3) - pad_t, ox = px * 8 + (sub & 7) - pad_l;
+        if ((unsigned)oy < (unsigned)sh && (unsigned)ox < (unsigned)sw) {
+            float *o = out + (((int64_t)n * sh + oy) * sw + ox) * 2;
+            o[0] = u; o[1] = v;
+            dmax = fmaxf(dmax, __fsqrt_rn(__fadd_rn(__fmul_rn(u, u), __fmul_rn(v, v))));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
@@ -412,10 +435,15 @@ int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, in
     hipLaunchKernelGGL(corr_pool_kernel, dim3(nblk(NP * (h / 2) * (w / 2))), dim3(256), 0, s, src, dst, NP, h, w, h / 2, w / 2, src_ld);
     LAUNCH_CHECK();
 }
-int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], int ld0, const float *flow,
+int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2;
+    hipLaunchKernelGGL(avgpool2_nhwc_kernel, dim3(nblk((int64_t)n * OH * OW * (C / 8))), dim3(256), 0, s, x, y, n, H, W, OH, OW, C / 8);
+    LAUNCH_CHECK();
+}
+int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], const int ld[4], const float *flow,
                        int P, int w8, f16 *out, int64_t rows) {
     PyrPtrs py;
-    for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; py.ld[i] = i == 0 ? ld0 : h[i] * w[i]; }
+    for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; py.ld[i] = ld[i]; }
     hipLaunchKernelGGL(corr_lookup_kernel, dim3(nblk(rows * 36)), dim3(256), 0, s, py, flow, P, w8, out, rows);
     LAUNCH_CHECK();
 }
@@ -438,7 +466,7 @@ int launch_flow_update(hipStream_t s, float *flow, const float *delta, int64_t r
 int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, int h8, int w8, int pad_l, int pad_t, int sh,
                     int sw, float *out, unsigned *maxd) {
     hipLaunchKernelGGL(fill_u32_kernel, dim3(nblk(N)), dim3(256), 0, s, maxd, 0u, N);
-    hipLaunchKernelGGL(upsample_kernel, dim3(nblk((int64_t)sh * sw), N), dim3(256), 0, s, flow, mask, h8, w8, pad_l, pad_t, sh,
+    hipLaunchKernelGGL(upsample_kernel, dim3(std::min(nblk((int64_t)h8 * w8, 4), 256u), N), dim3(256), 0, s, flow, mask, h8, w8, pad_l, pad_t, sh,
                        sw, out, maxd);
     LAUNCH_CHECK();
 }
