@@ -1136,6 +1136,7 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
     } else {
         if (tile == TILE_256) return a.Wf ? launch_g8b<AMODE, EPI>(s, a) : launch_g8<AMODE, EPI>(s, a);
         if (tile == TILE_256_SIMPLE) return launch_t<256, 256, 2, 4, AMODE, EPI>(s, a);
+        if (tile == TILE_256x128) return launch_t<256, 128, 4, 2, AMODE, EPI>(s, a);
         return launch_t<128, 128, 2, 2, AMODE, EPI>(s, a);
     }
 }
