@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--conv-tile", type=int, default=0)
     ap.add_argument("--latency", action="store_true", help="also time one 1280x720 frame at batch 1 (BASELINE configs[1])")
     ap.add_argument("--host-chunks", type=int, default=4, help="batches pushed through the host-pointer API for the PCIe-inclusive rate (0 = skip)")
-    ap.add_argument("--pipeline-frames", type=int, default=16, help="frames per step of the three-band pipeline leg (0 = skip)")
+    ap.add_argument("--pipeline-frames", type=int, default=32, help="frames per step of the three-band pipeline leg (0 = skip)")
     ap.add_argument("--mask-frames", type=int, default=8, help="frames per step of the mask_mmdet leg (0 = skip that leg)")
     ap.add_argument("--flow-pairs", type=int, default=8, help="frame pairs per GPU per step of the flow_raft leg (0 = skip)")
     args = ap.parse_args()
