@@ -197,6 +197,9 @@ typedef struct {
     double bytes;         /* algorithmic HBM bytes (compulsory traffic) of those launches */
     int32_t launches;
 } pb_kernel_stat;
+/* enabled: bit 0 = time every kernel launch with HIP events on the ctx stream, bit 1 = keep debug stages / instance
+ * masks, bit 2 = accumulate the timings over successive infer calls (pb_get_kernel_stats then reports the sums since
+ * this call) instead of restarting at every infer call. */
 int pb_set_profiling(pb_ctx *ctx, int enabled);
 /* Tuning / A-B switches: "gemm_tile", "conv_tile" = 0 auto, 1 128x128, 2 256x256 ping-pong,
  * 4 256x256 single-barrier; "gemm_breg" = 1: weights of the 256x256 GEMMs go straight to registers in MFMA

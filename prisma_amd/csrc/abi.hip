@@ -270,9 +270,13 @@ int64_t pb_depth_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap,
 
 int pb_set_profiling(pb_ctx *c, int enabled) {
     PB_CHECK(c && (c->depth || c->raft || c->mask), PB_ERR_STATE, "ctx has no band");
-    if (c->depth) { c->depth->timer.enabled = enabled != 0; c->depth->debug = (enabled & 2) != 0; }
-    if (c->raft) { c->raft->timer.enabled = enabled != 0; c->raft->debug = (enabled & 2) != 0; }
-    if (c->mask) { c->mask->timer.enabled = (enabled & 1) != 0; c->mask->debug = (enabled & 2) != 0; }
+    KernelTimer *t = c->depth ? &c->depth->timer : (c->raft ? &c->raft->timer : &c->mask->timer);
+    t->enabled = (enabled & 1) != 0;
+    t->accumulate = (enabled & 4) != 0;
+    t->clear();
+    if (c->depth) c->depth->debug = (enabled & 2) != 0;
+    if (c->raft) c->raft->debug = (enabled & 2) != 0;
+    if (c->mask) c->mask->debug = (enabled & 2) != 0;
     return 0;
 }
 

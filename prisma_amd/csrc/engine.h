@@ -29,8 +29,10 @@ struct KernelTimer {
     std::vector<hipEvent_t> pool;
     size_t used = 0;
     bool enabled = false;
+    bool accumulate = false;      // keep the records of earlier infer calls (one query after a timed loop)
     hipEvent_t get();
-    void reset() { recs.clear(); used = 0; }
+    void reset() { if (accumulate) return; recs.clear(); used = 0; }
+    void clear() { recs.clear(); used = 0; }
     ~KernelTimer();
 };
 

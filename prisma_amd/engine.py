@@ -206,8 +206,8 @@ class DepthAnything(_Ctx):
         check(self.lib.pb_depth_infer_batch_dev(self.ctx, v(frames_ptr), n, H, W, v(depth_ptr), v(rgb_ptr),
                                                 v(min_ptr), v(max_ptr), int(flip)))
 
-    def set_profiling(self, timing: bool = True, debug_stages: bool = False):
-        check(self.lib.pb_set_profiling(self.ctx, (1 if timing else 0) | (2 if debug_stages else 0)))
+    def set_profiling(self, timing: bool = True, debug_stages: bool = False, accumulate: bool = False):
+        check(self.lib.pb_set_profiling(self.ctx, (1 if timing else 0) | (2 if debug_stages else 0) | (4 if accumulate else 0)))
 
     def kernel_stats(self) -> List[dict]:
         arr = (_lib.pb_kernel_stat * 16)()
