@@ -1,0 +1,55 @@
+// Shared plumbing of the convolutional band engines (flow_raft, mask_mmdet): the named-weight map, fp16 GEMM packing with
+// folded BatchNorm, a two-pass arena, per-family kernel timing, and the implicit-GEMM / dense GEMM launch helpers.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+class EngineBase {
+  public:
+    explicit EngineBase(int device) : device(device) {}
+    virtual ~EngineBase();
+    int stats(pb_kernel_stat *out, int cap);
+
+    hipStream_t stream = nullptr;
+    int device = 0;
+    bool debug = false;
+    KernelTimer timer;
+    int conv_tile = TILE_AUTO;
+    const f16 *zero_page() const { return zero_; }
+
+  protected:
+    enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_COUNT = 6 };
+
+    // create the ctx stream, index the float32 tensors by name, allocate the zero page
+    int begin_load(const pb_tensor *w, int n);
+    const pb_tensor *find(const std::string &name) const;
+    // src: host fp32 [N, K] in GEMM order -> device fp16 [round_up(N, 256), Kpad] (+ fp32 bias, zero padded)
+    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias);
+    // eval-mode BatchNorm2d (eps 1e-5) as a per-channel (scale, shift)
+    int fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift);
+    // conv weight [co, ci, kh, kw] (+ bias) -> rows [co][(ky * kw + kx) * round_up(ci, 64) + c], optional per-output affine
+    int pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out);
+
+    void *carve(size_t bytes);
+    // grow the arena to the planned size (after the planning pass) and zero it
+    int commit_arena(const char *what);
+
+    // helpers launch on cur_ (the ctx stream unless a derived engine forks work onto side streams)
+    void tic(int fam, double flops, double bytes);
+    void toc();
+    int conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w, f16 *out, int ldo,
+             int act, int pre_relu = 0, const f16 *add1 = nullptr);
+    int dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1 = nullptr);
+
+    std::map<std::string, const pb_tensor *> tmap_;
+    std::vector<void *> owned_;                 // permanent device allocations (weights), freed by the destructor
+    f16 *zero_ = nullptr;
+    char *arena_ = nullptr;
+    size_t arena_bytes_ = 0, arena_off_ = 0;
+    bool planning_ = false;
+    hipStream_t cur_ = nullptr;
+    std::vector<size_t> open_;                  // tic / toc nesting across streams
+};

@@ -1,0 +1,173 @@
+#include "engine_base.h"
+
+#include <math.h>
+
+#include <algorithm>
+
+namespace {
+const char *kFam[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost"};
+inline int cp64(int c) { return (int)round_up(c, 64); }
+}  // namespace
+
+EngineBase::~EngineBase() {
+    hipSetDevice(device);
+    if (stream) hipStreamSynchronize(stream);
+    for (auto p : owned_) hipFree(p);
+    if (arena_) hipFree(arena_);
+    if (stream) hipStreamDestroy(stream);
+}
+
+void EngineBase::tic(int fam, double flops, double bytes) {
+    if (!timer.enabled) return;
+    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes};
+    hipEventRecord(r.a, cur_);
+    timer.recs.push_back(r);
+    open_.push_back(timer.recs.size() - 1);
+}
+void EngineBase::toc() {
+    if (!timer.enabled) return;
+    hipEventRecord(timer.recs[open_.back()].b, cur_);
+    open_.pop_back();
+}
+
+int EngineBase::stats(pb_kernel_stat *out, int cap) {
+    if (hipStreamSynchronize(stream) != hipSuccess) return -2;
+    pb_kernel_stat acc[F_COUNT];
+    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFam[i], 0, 0, 0, 0};
+    for (auto &r : timer.recs) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        acc[r.fam].ms += ms; acc[r.fam].flops += r.flops; acc[r.fam].bytes += r.bytes; acc[r.fam].launches++;
+    }
+    int n = 0;
+    for (int i = 0; i < F_COUNT && n < cap; ++i)
+        if (acc[i].launches) out[n++] = acc[i];
+    return n;
+}
+
+int EngineBase::begin_load(const pb_tensor *w, int n) {
+    PB_HIP(hipSetDevice(device));
+    PB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    cur_ = stream;
+    for (int i = 0; i < n; ++i) {
+        PB_CHECK(w[i].data && w[i].name, PB_ERR_ARG, "weight %d: null", i);
+        if (w[i].dtype == PB_F32) tmap_[w[i].name] = &w[i];      // integer buffers (num_batches_tracked) are not needed
+    }
+    void *z = nullptr;
+    PB_HIP(hipMalloc(&z, 4096));
+    PB_HIP(hipMemset(z, 0, 4096));
+    owned_.push_back(z);
+    zero_ = (f16 *)z;
+    return 0;
+}
+
+const pb_tensor *EngineBase::find(const std::string &name) const {
+    auto it = tmap_.find(name);
+    return it == tmap_.end() ? nullptr : it->second;
+}
+
+int EngineBase::pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias) {
+    const int64_t Np = round_up(N, 256);
+    std::vector<f16> h((size_t)Np * Kpad, (f16)0.f);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) h[(size_t)n * Kpad + k] = (f16)src[(size_t)n * K + k];
+    void *p = nullptr;
+    PB_HIP(hipMalloc(&p, h.size() * 2));
+    owned_.push_back(p);
+    PB_HIP(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    out.w = (f16 *)p; out.N = N; out.K = Kpad; out.Kreal = K; out.bias = nullptr;
+    if (bias) {
+        void *b = nullptr;
+        PB_HIP(hipMalloc(&b, std::max<size_t>((size_t)Np * 4, 256)));
+        owned_.push_back(b);
+        PB_HIP(hipMemset(b, 0, (size_t)Np * 4));
+        PB_HIP(hipMemcpy(b, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        out.bias = (float *)b;
+    }
+    return 0;
+}
+
+int EngineBase::fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift) {
+    const char *sfx[4] = {".weight", ".bias", ".running_mean", ".running_var"};
+    const float *t[4];
+    for (int i = 0; i < 4; ++i) {
+        const pb_tensor *x = find(bn + sfx[i]);
+        PB_CHECK(x && x->shape[0] == C, PB_ERR_ARG, "missing weight '%s%s' [%d]", bn.c_str(), sfx[i], C);
+        t[i] = (const float *)x->data;
+    }
+    scale.resize(C); shift.resize(C);
+    for (int c = 0; c < C; ++c) {
+        const float s = t[0][c] / sqrtf(t[3][c] + 1e-5f);       // nn.BatchNorm2d eval, eps 1e-5
+        scale[c] = s;
+        shift[c] = t[1][c] - t[2][c] * s;
+    }
+    return 0;
+}
+
+int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out) {
+    const pb_tensor *t = find(name + ".weight");
+    PB_CHECK(t && t->ndim == 4, PB_ERR_ARG, "missing conv '%s'", name.c_str());
+    const float *b = nullptr;
+    if (has_bias) {
+        const pb_tensor *tb = find(name + ".bias");
+        PB_CHECK(tb, PB_ERR_ARG, "missing bias of '%s'", name.c_str());
+        b = (const float *)tb->data;
+    }
+    const int co = (int)t->shape[0], ci = (int)t->shape[1], kh = (int)t->shape[2], kw = (int)t->shape[3];
+    const float *w = (const float *)t->data;
+    const int cip = cp64(ci), K = kh * kw * cip;
+    std::vector<float> g((size_t)co * K, 0.f), bb(co);
+    for (int o = 0; o < co; ++o) {
+        const float s = scale ? scale[o] : 1.f;
+        for (int c = 0; c < ci; ++c)
+            for (int tp = 0; tp < kh * kw; ++tp) g[(size_t)o * K + tp * cip + c] = w[((size_t)o * ci + c) * kh * kw + tp] * s;
+        bb[o] = (b ? b[o] : 0.f) * s + (shift ? shift[o] : 0.f);
+    }
+    int r = pack(g.data(), co, K, K, out, bb.data());
+    out.Kreal = kh * kw * ci;
+    return r;
+}
+
+void *EngineBase::carve(size_t bytes) {
+    const size_t off = arena_off_;
+    arena_off_ += round_up((int64_t)bytes, 256);
+    return planning_ ? nullptr : (void *)(arena_ + off);
+}
+
+int EngineBase::commit_arena(const char *what) {
+    if (arena_off_ > arena_bytes_) {
+        if (arena_) PB_HIP(hipFree(arena_));
+        arena_ = nullptr; arena_bytes_ = 0;
+        hipError_t e = hipMalloc((void **)&arena_, arena_off_);
+        PB_CHECK(e == hipSuccess, PB_ERR_MEMORY, "%s arena of %zu bytes: %s", what, arena_off_, hipGetErrorString(e));
+        arena_bytes_ = arena_off_;
+    }
+    // stale bit patterns must never be read as fp16 NaN / Inf by padded tiles
+    PB_HIP(hipMemsetAsync(arena_, 0, arena_bytes_, stream));
+    return 0;
+}
+
+int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w, f16 *out,
+                     int ldo, int act, int pre_relu, const f16 *add1) {
+    GemmArgs a;
+    a.A = in; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_;
+    a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = kw; a.cStride = stride; a.cPad = kh / 2; a.cPadX = kw / 2;
+    a.cOH = (H + 2 * (kh / 2) - kh) / stride + 1; a.cOW = (W + 2 * (kw / 2) - kw) / stride + 1;
+    a.M = n * a.cOH * a.cOW;
+    a.out = out; a.ldo = ldo; a.act = act; a.pre_relu = pre_relu; a.add1 = add1;
+    PB_CHECK(w.K == kh * kw * cC, PB_ERR_STATE, "conv: packed K %d != %d*%d*%d", w.K, kh, kw, cC);
+    tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
+    int r = launch_gemm(cur_, A_CONV, EPI_STD, conv_tile, a);
+    toc();
+    return r;
+}
+
+int EngineBase::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1) {
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_; a.M = (int)M;
+    a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
+    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 0);
+    int r = launch_gemm(cur_, A_DENSE, EPI_STD, TILE_AUTO, a);
+    toc();
+    return r;
+}

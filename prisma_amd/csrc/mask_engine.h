@@ -4,18 +4,17 @@
 #include <string>
 #include <vector>
 
-#include "engine.h"
+#include "engine_base.h"
 #include "mask_kernels.h"
 
-class MaskEngine {
+class MaskEngine : public EngineBase {
   public:
-    MaskEngine(int device, const pb_mask_cfg &cfg) : device(device), cfg_(cfg) {}
-    ~MaskEngine();
+    MaskEngine(int device, const pb_mask_cfg &cfg) : EngineBase(device), cfg_(cfg) {}
+    ~MaskEngine() override;
     int load(const pb_tensor *w, int n);
     // frames: device uint8 [n, H, W, 3] RGB.  mask_out: device uint8 [n, H, W, 3] (the band's "mask ids" image).
     int infer(const uint8_t *frames, int n, int H, int W, float confidence, const int32_t *keep, int n_keep, uint8_t *mask_out);
     int64_t get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]);
-    int stats(pb_kernel_stat *out, int cap);
     static void net_size(const pb_mask_cfg &cfg, int H, int W, int *nh, int *nw, int *Hp, int *Wp);
 
     // results of the last infer(): per frame, score-descending (what format_results would hand to the band)
@@ -26,13 +25,6 @@ class MaskEngine {
         int candidates = 0;              // grid cells over score_thr (before the area filter)
     };
     const std::vector<Instances> &results() const { return results_; }
-
-    hipStream_t stream = nullptr;
-    int device = 0;
-    bool debug = false;
-    KernelTimer timer;
-    int conv_tile = TILE_AUTO;
-    const f16 *zero_page() const { return zero_; }
 
   private:
     struct GN { float *g = nullptr, *b = nullptr; int C = 0; };
@@ -49,24 +41,12 @@ class MaskEngine {
     int post_frame(int b, int frame_index, float confidence, const std::vector<uint8_t> &keep_class, uint8_t *mask_out);
     int ensure_post(size_t cands);
 
-    int conv(const f16 *in, int cC, int cLd, int n, int H, int W, int k, int stride, const PackedW &w, f16 *out, int ldo, int act,
-             const f16 *add1 = nullptr);
     int conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, const PackedW &w, float *out, int ldo);
-    int dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1 = nullptr);
     int conv_gn_relu(const f16 *in, int cC, int cLd, int n, int H, int W, int k, const ConvGN &c, f16 *tmp, f16 *out, int ldo);
-    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias);
-    int pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out);
-    int fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift);
     int load_gn(const std::string &name, int C, GN &out);
     int load_conv_gn(const std::string &name, ConvGN &out);
-    void *carve(size_t bytes);
-    void tic(int fam, double flops, double bytes);
-    void toc();
 
     pb_mask_cfg cfg_;
-    std::map<std::string, const pb_tensor *> tmap_;
-    std::vector<void *> owned_;
-    f16 *zero_ = nullptr;
 
     // weights
     PackedW stem_;
@@ -81,9 +61,6 @@ class MaskEngine {
     int nh_ = 0, nw_ = 0, Hp_ = 0, Wp_ = 0;
     int lh_[6] = {}, lw_[6] = {};            // feature sizes at strides 4, 8, 16, 32, 64 (index 0..4); [5] = stride 2
     int pts_ = 0, goff_[6] = {};
-    char *arena_ = nullptr;
-    size_t arena_bytes_ = 0, arena_off_ = 0;
-    bool planning_ = false;
     int *xt_ = nullptr, *yt_ = nullptr;
     f16 *img_ = nullptr, *colA_ = nullptr, *stem_out_ = nullptr, *pool_ = nullptr;
     float *chw_ = nullptr;
@@ -96,10 +73,9 @@ class MaskEngine {
     float *kp_ = nullptr, *cl_ = nullptr, *cs_ = nullptr;
     float *gst_ = nullptr, *gaff_ = nullptr;
     // streams: helpers launch on cur_ (main stream, or one of the per-level streams while the head is forked)
-    hipStream_t cur_ = nullptr, ls_[5] = {};
+    hipStream_t ls_[5] = {};
     hipEvent_t ev_fork_ = nullptr, ev_join_[5] = {};
     float *gst_cur_ = nullptr, *gaff_cur_ = nullptr;
-    std::vector<size_t> open_;
 
     // post-processing scratch (grown on demand, outside the arena)
     size_t post_cap_ = 0;

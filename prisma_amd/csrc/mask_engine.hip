@@ -21,8 +21,6 @@
 #include "raft_kernels.h"
 
 namespace {
-enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_COUNT = 6 };
-const char *kFamM[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost"};
 inline int cp64(int c) { return (int)round_up(c, 64); }
 
 // OpenCV resize(INTER_LINEAR) tables for 8-bit images: {i0, i1, c0, c1} per destination index.  Columns zero the
@@ -61,111 +59,17 @@ void MaskEngine::net_size(const pb_mask_cfg &cfg, int H, int W, int *nh, int *nw
     *Wp = (*nw + 31) / 32 * 32;
 }
 
-void MaskEngine::tic(int fam, double flops, double bytes) {
-    if (!timer.enabled) return;
-    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes};
-    hipEventRecord(r.a, cur_);
-    timer.recs.push_back(r);
-    open_.push_back(timer.recs.size() - 1);
-}
-void MaskEngine::toc() {
-    if (!timer.enabled) return;
-    hipEventRecord(timer.recs[open_.back()].b, cur_);
-    open_.pop_back();
-}
-int MaskEngine::stats(pb_kernel_stat *out, int cap) {
-    if (hipStreamSynchronize(stream) != hipSuccess) return -2;
-    pb_kernel_stat acc[F_COUNT];
-    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFamM[i], 0, 0, 0, 0};
-    for (auto &r : timer.recs) {
-        float ms = 0;
-        hipEventElapsedTime(&ms, r.a, r.b);
-        acc[r.fam].ms += ms; acc[r.fam].flops += r.flops; acc[r.fam].bytes += r.bytes; acc[r.fam].launches++;
-    }
-    int n = 0;
-    for (int i = 0; i < F_COUNT && n < cap; ++i)
-        if (acc[i].launches) out[n++] = acc[i];
-    return n;
-}
-
 MaskEngine::~MaskEngine() {
     hipSetDevice(device);
     if (stream) hipStreamSynchronize(stream);
-    for (auto p : owned_) hipFree(p);
     void *post[] = {pk_, bits_, plog_, pstat_, inter_, sig_, nmsf_, pidx_, nmsi_, use_, inst_};
     for (auto p : post)
         if (p) hipFree(p);
-    if (arena_) hipFree(arena_);
     for (int l = 0; l < 5; ++l) {
         if (ls_[l]) { hipStreamSynchronize(ls_[l]); hipStreamDestroy(ls_[l]); }
         if (ev_join_[l]) hipEventDestroy(ev_join_[l]);
     }
     if (ev_fork_) hipEventDestroy(ev_fork_);
-    if (stream) hipStreamDestroy(stream);
-}
-
-int MaskEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias) {
-    const int64_t Np = round_up(N, 256);
-    std::vector<f16> h((size_t)Np * Kpad, (f16)0.f);
-    for (int n = 0; n < N; ++n)
-        for (int k = 0; k < K; ++k) h[(size_t)n * Kpad + k] = (f16)src[(size_t)n * K + k];
-    void *p = nullptr;
-    PB_HIP(hipMalloc(&p, h.size() * 2));
-    owned_.push_back(p);
-    PB_HIP(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-    out.w = (f16 *)p; out.N = (int)round_up(N, 8); out.K = Kpad; out.Kreal = K; out.bias = nullptr;
-    if (bias) {
-        void *b = nullptr;
-        PB_HIP(hipMalloc(&b, std::max<size_t>((size_t)Np * 4, 256)));
-        owned_.push_back(b);
-        PB_HIP(hipMemset(b, 0, (size_t)Np * 4));
-        PB_HIP(hipMemcpy(b, bias, (size_t)N * 4, hipMemcpyHostToDevice));
-        out.bias = (float *)b;
-    }
-    return 0;
-}
-
-int MaskEngine::fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift) {
-    const char *sfx[4] = {".weight", ".bias", ".running_mean", ".running_var"};
-    const float *t[4];
-    for (int i = 0; i < 4; ++i) {
-        auto it = tmap_.find(bn + sfx[i]);
-        PB_CHECK(it != tmap_.end() && it->second->shape[0] == C, PB_ERR_ARG, "missing weight '%s%s' [%d]", bn.c_str(), sfx[i], C);
-        t[i] = (const float *)it->second->data;
-    }
-    scale.resize(C); shift.resize(C);
-    for (int c = 0; c < C; ++c) {
-        const float s = t[0][c] / sqrtf(t[3][c] + 1e-5f);       // BatchNorm2d eval, eps 1e-5 (mmcv build_norm_layer default)
-        scale[c] = s;
-        shift[c] = t[1][c] - t[2][c] * s;
-    }
-    return 0;
-}
-
-// conv weight [co, ci, kh, kw] (+ optional bias) -> [co, (ky*kw + kx) * cp64(ci) + c] with a per-output affine (folded BN)
-int MaskEngine::pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out) {
-    auto iw = tmap_.find(name + ".weight");
-    PB_CHECK(iw != tmap_.end() && iw->second->ndim == 4, PB_ERR_ARG, "missing conv '%s'", name.c_str());
-    const float *b = nullptr;
-    if (has_bias) {
-        auto ib = tmap_.find(name + ".bias");
-        PB_CHECK(ib != tmap_.end(), PB_ERR_ARG, "missing bias of '%s'", name.c_str());
-        b = (const float *)ib->second->data;
-    }
-    const pb_tensor *t = iw->second;
-    const int co = (int)t->shape[0], ci = (int)t->shape[1], kh = (int)t->shape[2], kw = (int)t->shape[3];
-    const float *w = (const float *)t->data;
-    const int cip = cp64(ci), K = kh * kw * cip;
-    std::vector<float> g((size_t)co * K, 0.f), bb(co);
-    for (int o = 0; o < co; ++o) {
-        const float s = scale ? scale[o] : 1.f;
-        for (int c = 0; c < ci; ++c)
-            for (int tp = 0; tp < kh * kw; ++tp) g[(size_t)o * K + tp * cip + c] = w[((size_t)o * ci + c) * kh * kw + tp] * s;
-        bb[o] = (b ? b[o] : 0.f) * s + (shift ? shift[o] : 0.f);
-    }
-    int r = pack(g.data(), co, K, K, out, bb.data());
-    out.Kreal = kh * kw * ci;
-    return r;
 }
 
 int MaskEngine::load_gn(const std::string &name, int C, GN &out) {
@@ -189,29 +93,17 @@ int MaskEngine::load_conv_gn(const std::string &name, ConvGN &out) {
 }
 
 int MaskEngine::load(const pb_tensor *w, int n) {
-    PB_HIP(hipSetDevice(device));
-    PB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    cur_ = stream;
+    PB_CHECK(cfg_.num_classes > 0 && cfg_.feat_channels % 32 == 0 && cfg_.mask_feat_channels % 32 == 0 &&
+                 cfg_.mask_out_channels == 256 && cfg_.stacked_convs >= 1 && cfg_.nms_pre > 0 && cfg_.nms_pre <= 512 &&
+                 cfg_.max_per_img > 0 && cfg_.max_batch >= 1,
+             PB_ERR_ARG, "mask_mmdet: unsupported configuration");
+    int r0 = begin_load(w, n);
+    if (r0) return r0;
     for (int l = 0; l < 5; ++l) {
         PB_HIP(hipStreamCreateWithFlags(&ls_[l], hipStreamNonBlocking));
         PB_HIP(hipEventCreateWithFlags(&ev_join_[l], hipEventDisableTiming));
     }
     PB_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-    PB_CHECK(cfg_.num_classes > 0 && cfg_.feat_channels % 32 == 0 && cfg_.mask_feat_channels % 32 == 0 &&
-                 cfg_.mask_out_channels == 256 && cfg_.stacked_convs >= 1 && cfg_.nms_pre > 0 && cfg_.nms_pre <= 512 &&
-                 cfg_.max_per_img > 0 && cfg_.max_batch >= 1,
-             PB_ERR_ARG, "mask_mmdet: unsupported configuration");
-    for (int i = 0; i < n; ++i) {
-        PB_CHECK(w[i].data && w[i].name, PB_ERR_ARG, "weight %d: null", i);
-        if (w[i].dtype == PB_F32) tmap_[w[i].name] = &w[i];
-    }
-    {
-        void *z = nullptr;
-        PB_HIP(hipMalloc(&z, 4096));
-        PB_HIP(hipMemset(z, 0, 4096));
-        owned_.push_back(z);
-        zero_ = (f16 *)z;
-    }
     int r;
     std::vector<float> sc, sf;
     {   // stem 7x7/s2 (resnet.py:560-580, no bias) + bn1: im2col order k = tap*3 + c, K 147 -> 192
@@ -262,18 +154,13 @@ int MaskEngine::load(const pb_tensor *w, int n) {
         if ((r = load_conv_gn("mask_head.cls_convs." + std::to_string(i), cconv_[i]))) return r;
     }
     if ((r = pack_conv("mask_head.conv_cls", true, nullptr, nullptr, conv_cls_))) return r;
+    conv_cls_.N = (int)round_up(conv_cls_.N, 8);             // the GEMM writes 8-column groups; the pad rows are zero
     if ((r = pack_conv("mask_head.conv_kernel", true, nullptr, nullptr, conv_kernel_))) return r;
     PB_CHECK(conv_kernel_.N == cfg_.mask_out_channels && mfpred_.w.N == cfg_.mask_out_channels, PB_ERR_ARG,
              "mask_mmdet: kernel / mask feature widths do not match the configuration");
     tmap_.clear();
     PB_HIP(hipDeviceSynchronize());
     return 0;
-}
-
-void *MaskEngine::carve(size_t bytes) {
-    const size_t off = arena_off_;
-    arena_off_ += round_up((int64_t)bytes, 256);
-    return planning_ ? nullptr : (void *)(arena_ + off);
 }
 
 int MaskEngine::prepare(int n, int H, int W) {
@@ -337,14 +224,8 @@ int MaskEngine::prepare(int n, int H, int W) {
         cs_ = (float *)carve((size_t)B * pts_ * Cp * 4 + slack);
         gst_ = (float *)carve((size_t)B * 512 * 2 * 4); gaff_ = (float *)carve((size_t)B * 512 * 2 * 4);
         if (pass == 0) {
-            if (arena_off_ > arena_bytes_) {
-                if (arena_) PB_HIP(hipFree(arena_));
-                arena_ = nullptr; arena_bytes_ = 0;
-                hipError_t e = hipMalloc((void **)&arena_, arena_off_);
-                PB_CHECK(e == hipSuccess, PB_ERR_MEMORY, "mask arena of %zu bytes: %s", arena_off_, hipGetErrorString(e));
-                arena_bytes_ = arena_off_;
-            }
-            PB_HIP(hipMemsetAsync(arena_, 0, arena_bytes_, stream));
+            const int rc = commit_arena("mask");
+            if (rc) return rc;
         }
     }
     std::vector<int> xt, yt;
@@ -355,21 +236,6 @@ int MaskEngine::prepare(int n, int H, int W) {
     PB_HIP(hipStreamSynchronize(stream));
     pB_ = B; pH_ = H; pW_ = W;
     return 0;
-}
-
-int MaskEngine::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int k, int stride, const PackedW &w, f16 *out, int ldo,
-                     int act, const f16 *add1) {
-    GemmArgs a;
-    a.A = in; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_;
-    a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = k; a.cStride = stride; a.cPad = k / 2; a.cPadX = k / 2;
-    a.cOH = (H + 2 * (k / 2) - k) / stride + 1; a.cOW = (W + 2 * (k / 2) - k) / stride + 1;
-    a.M = n * a.cOH * a.cOW;
-    a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
-    PB_CHECK(w.K == k * k * cC, PB_ERR_STATE, "conv: packed K %d != %d*%d*%d", w.K, k, k, cC);
-    tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
-    int r = launch_gemm(cur_, A_CONV, EPI_STD, conv_tile, a);
-    toc();
-    return r;
 }
 
 int MaskEngine::conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, const PackedW &w, float *out, int ldo) {
@@ -385,19 +251,9 @@ int MaskEngine::conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, co
     return r;
 }
 
-int MaskEngine::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1) {
-    GemmArgs a;
-    a.A = A; a.lda = lda; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_; a.M = (int)M;
-    a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
-    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 0);
-    int r = launch_gemm(cur_, A_DENSE, EPI_STD, TILE_AUTO, a);
-    toc();
-    return r;
-}
-
 int MaskEngine::conv_gn_relu(const f16 *in, int cC, int cLd, int n, int H, int W, int k, const ConvGN &c, f16 *tmp, f16 *out,
                              int ldo) {
-    int r = k == 1 ? dense(in, cLd, (int64_t)n * H * W, c.w, tmp, c.w.N, ACT_NONE) : conv(in, cC, cLd, n, H, W, k, 1, c.w, tmp, c.w.N, ACT_NONE);
+    int r = k == 1 ? dense(in, cLd, (int64_t)n * H * W, c.w, tmp, c.w.N, ACT_NONE) : conv(in, cC, cLd, n, H, W, k, k, 1, c.w, tmp, c.w.N, ACT_NONE);
     if (r) return r;
     tic(F_ELT, 0, (double)n * H * W * c.w.N * 6);
     r = launch_gn_relu(cur_, tmp, out, n, H * W, c.gn.C, c.w.N, ldo, 32, c.gn.g, c.gn.b, gst_cur_, gaff_cur_);
@@ -424,11 +280,11 @@ int MaskEngine::backbone(int n) {
             const Bneck &B = blocks_[s][b];
             const int ho = (hi - 1) / B.stride + 1, wo = (wi - 1) / B.stride + 1, p = B.planes;
             if ((r = dense(x, B.inpl, (int64_t)n * hi * wi, B.c1, st1_[s], p, ACT_RELU))) return r;
-            if ((r = conv(st1_[s], p, p, n, hi, wi, 3, B.stride, B.c2, st2_[s], p, ACT_RELU))) return r;
+            if ((r = conv(st1_[s], p, p, n, hi, wi, 3, 3, B.stride, B.c2, st2_[s], p, ACT_RELU))) return r;
             const f16 *idt = x;
             if (B.has_ds) {
                 if (B.stride == 1) r = dense(x, B.inpl, (int64_t)n * hi * wi, B.ds, sds_[s], 4 * p, ACT_NONE);
-                else r = conv(x, B.inpl, B.inpl, n, hi, wi, 1, B.stride, B.ds, sds_[s], 4 * p, ACT_NONE);
+                else r = conv(x, B.inpl, B.inpl, n, hi, wi, 1, 1, B.stride, B.ds, sds_[s], 4 * p, ACT_NONE);
                 if (r) return r;
                 idt = sds_[s];
             }
@@ -454,7 +310,7 @@ int MaskEngine::neck(int n) {
         if (r) return r;
     }
     for (int i = 0; i < 4; ++i)
-        if ((r = conv(latb_[i], 256, 256, n, lh_[i], lw_[i], 3, 1, fpnc_[i], p_[i], 256, ACT_NONE))) return r;
+        if ((r = conv(latb_[i], 256, 256, n, lh_[i], lw_[i], 3, 3, 1, fpnc_[i], p_[i], 256, ACT_NONE))) return r;
     tic(F_ELT, 0, 0);
     r = launch_subsample2(stream, p_[3], p_[4], n, lh_[3], lw_[3], 256);
     toc();

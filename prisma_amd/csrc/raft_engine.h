@@ -4,13 +4,12 @@
 #include <string>
 #include <vector>
 
-#include "engine.h"
+#include "engine_base.h"
 #include "raft_kernels.h"
 
-class RaftEngine {
+class RaftEngine : public EngineBase {
   public:
-    explicit RaftEngine(int device) : device(device) {}
-    ~RaftEngine();
+    explicit RaftEngine(int device) : EngineBase(device) {}
     int load(const pb_tensor *w, int n);
     // frames: device uint8 [F, H, W, 3].  Outputs are device pointers (any may be null):
     //   flow_out [F-1, dirs, sh, sw, 2] fp32, rgb_out [F-1, dirs, sh, sw, 3] u8, maxdisp [F-1, dirs]
@@ -18,45 +17,21 @@ class RaftEngine {
               uint8_t *rgb_out, float *maxdisp, uint8_t *mask_out = nullptr, float alpha1 = 0.05f,
               float alpha2 = 0.5f);
     int64_t get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]);
-    int stats(pb_kernel_stat *out, int cap);
     static void out_size(int H, int W, float scale, int *sh, int *sw);
-
-    hipStream_t stream = nullptr;
-    int device = 0;
-    bool debug = false;
-    KernelTimer timer;
-    int conv_tile = TILE_AUTO;
-    const f16 *zero_page() const { return zero_; }
 
   private:
     struct Enc {                    // BasicEncoder weights (BN folded for cnet)
         PackedW stem, l[3][2][2], ds[3], out;
     };
     int prepare(int F, int H, int W, float scale, int dirs);
-    int conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w, f16 *out,
-             int ldo, int act, int pre_relu = 0, const f16 *add1 = nullptr);
-    int dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act);
-    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias);
-    int pack_conv(const std::string &name, const float *scale, const float *shift, PackedW &out);
-    int fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift);
-    void *carve(size_t bytes);
-    void tic(int fam, double flops, double bytes);
-    void toc();
-
-    std::map<std::string, const pb_tensor *> tmap_;
-    std::vector<void *> owned_;
     Enc fnet_, cnet_;
     PackedW convc1_, convc2_, convf1_, convf2_, convm_, zr_[2], q_[2], fh1_, fh2_, mk0_, mk2_;
-    f16 *zero_ = nullptr;
 
     // plan
     int pF_ = 0, pH_ = 0, pW_ = 0, pD_ = 0;
     float pS_ = 0.f;
     int sh_ = 0, sw_ = 0, Hp_ = 0, Wp_ = 0, padl_ = 0, padt_ = 0, h8_ = 0, w8_ = 0, P_ = 0, P8_ = 0;
     int lh_[4] = {0, 0, 0, 0}, lw_[4] = {0, 0, 0, 0};
-    char *arena_ = nullptr;
-    size_t arena_bytes_ = 0, arena_off_ = 0;
-    bool planning_ = false;
     int *xi_ = nullptr, *xc_ = nullptr, *yi_ = nullptr, *yc_ = nullptr;
     f16 *img_ = nullptr, *colA_ = nullptr;
     f16 *r1_[7] = {}, *r2_[7] = {}, *r3_[7] = {};     // scratch maps at 1/2, 1/4, 1/8 resolution: t1 t2 t3 outA outB stem stem_n

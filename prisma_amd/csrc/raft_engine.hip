@@ -18,8 +18,6 @@
 #include <algorithm>
 
 namespace {
-enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_COUNT = 6 };
-const char *kFamR[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost"};
 inline int cp64(int c) { return (int)round_up(c, 64); }
 
 void cubic_taps_u8(int src, int dst, double scale, std::vector<int> &idx, std::vector<int> &co) {
@@ -50,111 +48,9 @@ void RaftEngine::out_size(int H, int W, float scale, int *sh, int *sw) {
     *sw = (int)nearbyint((double)W * scale);
 }
 
-void RaftEngine::tic(int fam, double flops, double bytes) {
-    if (!timer.enabled) return;
-    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes};
-    hipEventRecord(r.a, stream);
-    timer.recs.push_back(r);
-}
-void RaftEngine::toc() {
-    if (!timer.enabled) return;
-    hipEventRecord(timer.recs.back().b, stream);
-}
-int RaftEngine::stats(pb_kernel_stat *out, int cap) {
-    if (hipStreamSynchronize(stream) != hipSuccess) return -2;
-    pb_kernel_stat acc[F_COUNT];
-    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFamR[i], 0, 0, 0, 0};
-    for (auto &r : timer.recs) {
-        float ms = 0;
-        hipEventElapsedTime(&ms, r.a, r.b);
-        acc[r.fam].ms += ms; acc[r.fam].flops += r.flops; acc[r.fam].bytes += r.bytes; acc[r.fam].launches++;
-    }
-    int n = 0;
-    for (int i = 0; i < F_COUNT && n < cap; ++i)
-        if (acc[i].launches) out[n++] = acc[i];
-    return n;
-}
-
-RaftEngine::~RaftEngine() {
-    hipSetDevice(device);
-    if (stream) hipStreamSynchronize(stream);
-    for (auto p : owned_) hipFree(p);
-    if (arena_) hipFree(arena_);
-    if (stream) hipStreamDestroy(stream);
-}
-
-int RaftEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias) {
-    const int64_t Np = round_up(N, 256);
-    std::vector<f16> h((size_t)Np * Kpad, (f16)0.f);
-    for (int n = 0; n < N; ++n)
-        for (int k = 0; k < K; ++k) h[(size_t)n * Kpad + k] = (f16)src[(size_t)n * K + k];
-    void *p = nullptr;
-    PB_HIP(hipMalloc(&p, h.size() * 2));
-    owned_.push_back(p);
-    PB_HIP(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-    out.w = (f16 *)p; out.N = N; out.K = Kpad; out.Kreal = K; out.bias = nullptr;
-    if (bias) {
-        void *b = nullptr;
-        PB_HIP(hipMalloc(&b, std::max<size_t>((size_t)Np * 4, 256)));
-        owned_.push_back(b);
-        PB_HIP(hipMemset(b, 0, (size_t)Np * 4));
-        PB_HIP(hipMemcpy(b, bias, (size_t)N * 4, hipMemcpyHostToDevice));
-        out.bias = (float *)b;
-    }
-    return 0;
-}
-
-int RaftEngine::fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift) {
-    const char *sfx[4] = {".weight", ".bias", ".running_mean", ".running_var"};
-    const float *t[4];
-    for (int i = 0; i < 4; ++i) {
-        auto it = tmap_.find(bn + sfx[i]);
-        PB_CHECK(it != tmap_.end(), PB_ERR_ARG, "missing weight '%s%s'", bn.c_str(), sfx[i]);
-        t[i] = (const float *)it->second->data;
-    }
-    scale.resize(C); shift.resize(C);
-    for (int c = 0; c < C; ++c) {
-        const float s = t[0][c] / sqrtf(t[3][c] + 1e-5f);       // nn.BatchNorm2d eval, eps 1e-5 (extractor.py:24-28)
-        scale[c] = s;
-        shift[c] = t[1][c] - t[2][c] * s;
-    }
-    return 0;
-}
-
-// conv weight [co, ci, kh, kw] (+ bias) -> [co, (ky*kw + kx) * cp64(ci) + c], optional per-output affine (folded BN)
-int RaftEngine::pack_conv(const std::string &name, const float *scale, const float *shift, PackedW &out) {
-    auto iw = tmap_.find(name + ".weight"), ib = tmap_.find(name + ".bias");
-    PB_CHECK(iw != tmap_.end() && ib != tmap_.end() && iw->second->ndim == 4, PB_ERR_ARG, "missing conv '%s'", name.c_str());
-    const pb_tensor *t = iw->second;
-    const int co = (int)t->shape[0], ci = (int)t->shape[1], kh = (int)t->shape[2], kw = (int)t->shape[3];
-    const float *w = (const float *)t->data, *b = (const float *)ib->second->data;
-    const int cip = cp64(ci), K = kh * kw * cip;
-    std::vector<float> g((size_t)co * K, 0.f), bb(co);
-    for (int o = 0; o < co; ++o) {
-        const float s = scale ? scale[o] : 1.f;
-        for (int c = 0; c < ci; ++c)
-            for (int tp = 0; tp < kh * kw; ++tp) g[(size_t)o * K + tp * cip + c] = w[((size_t)o * ci + c) * kh * kw + tp] * s;
-        bb[o] = b[o] * s + (shift ? shift[o] : 0.f);
-    }
-    int r = pack(g.data(), co, K, K, out, bb.data());
-    out.Kreal = kh * kw * ci;
-    return r;
-}
-
 int RaftEngine::load(const pb_tensor *w, int n) {
-    PB_HIP(hipSetDevice(device));
-    PB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    for (int i = 0; i < n; ++i) {
-        PB_CHECK(w[i].data && w[i].name, PB_ERR_ARG, "weight %d: null", i);
-        if (w[i].dtype == PB_F32) tmap_[w[i].name] = &w[i];      // num_batches_tracked (int64) is not needed
-    }
-    {
-        void *z = nullptr;
-        PB_HIP(hipMalloc(&z, 4096));
-        PB_HIP(hipMemset(z, 0, 4096));
-        owned_.push_back(z);
-        zero_ = (f16 *)z;
-    }
+    int r0 = begin_load(w, n);
+    if (r0) return r0;
     int r;
     const int dims[3] = {64, 96, 128};
     for (int e = 0; e < 2; ++e) {
@@ -181,22 +77,22 @@ int RaftEngine::load(const pb_tensor *w, int n) {
                 const std::string p = en + ".layer" + std::to_string(li + 1) + "." + std::to_string(bi);
                 for (int c = 0; c < 2; ++c) {
                     if (bnf && (r = fold_bn(p + ".norm" + std::to_string(c + 1), dims[li], sc, sf))) return r;
-                    if ((r = pack_conv(p + ".conv" + std::to_string(c + 1), bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr,
+                    if ((r = pack_conv(p + ".conv" + std::to_string(c + 1), true, bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr,
                                        E.l[li][bi][c])))
                         return r;
                 }
                 if (bi == 0 && li > 0) {
                     if (bnf && (r = fold_bn(p + ".norm3", dims[li], sc, sf))) return r;
-                    if ((r = pack_conv(p + ".downsample.0", bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr, E.ds[li]))) return r;
+                    if ((r = pack_conv(p + ".downsample.0", true, bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr, E.ds[li]))) return r;
                 }
             }
-        if ((r = pack_conv(en + ".conv2", nullptr, nullptr, E.out))) return r;
+        if ((r = pack_conv(en + ".conv2", true, nullptr, nullptr, E.out))) return r;
     }
     const std::string u = "update_block.";
-    if ((r = pack_conv(u + "encoder.convc1", nullptr, nullptr, convc1_))) return r;
-    if ((r = pack_conv(u + "encoder.convc2", nullptr, nullptr, convc2_))) return r;
-    if ((r = pack_conv(u + "encoder.convf2", nullptr, nullptr, convf2_))) return r;
-    if ((r = pack_conv(u + "encoder.conv", nullptr, nullptr, convm_))) return r;
+    if ((r = pack_conv(u + "encoder.convc1", true, nullptr, nullptr, convc1_))) return r;
+    if ((r = pack_conv(u + "encoder.convc2", true, nullptr, nullptr, convc2_))) return r;
+    if ((r = pack_conv(u + "encoder.convf2", true, nullptr, nullptr, convf2_))) return r;
+    if ((r = pack_conv(u + "encoder.conv", true, nullptr, nullptr, convm_))) return r;
     convm_.N = 128;                                         // 126 real outputs + 2 zero rows (N must be a multiple of 8)
     {   // convf1 7x7 on the 2-channel flow: im2col order k = tap*2 + c, K 98 -> 128
         auto iw = tmap_.find(u + "encoder.convf1.weight"), ib = tmap_.find(u + "encoder.convf1.bias");
@@ -229,22 +125,16 @@ int RaftEngine::load(const pb_tensor *w, int n) {
             }
         }
         if ((r = pack(g.data(), 256, K, K, zr_[half], bb.data()))) return r;
-        if ((r = pack_conv(u + "gru.convq" + sfx, nullptr, nullptr, q_[half]))) return r;
+        if ((r = pack_conv(u + "gru.convq" + sfx, true, nullptr, nullptr, q_[half]))) return r;
     }
-    if ((r = pack_conv(u + "flow_head.conv1", nullptr, nullptr, fh1_))) return r;
-    if ((r = pack_conv(u + "flow_head.conv2", nullptr, nullptr, fh2_))) return r;
+    if ((r = pack_conv(u + "flow_head.conv1", true, nullptr, nullptr, fh1_))) return r;
+    if ((r = pack_conv(u + "flow_head.conv2", true, nullptr, nullptr, fh2_))) return r;
     fh2_.N = 8;                                             // 2 real outputs, rows 2..7 are zero
-    if ((r = pack_conv(u + "mask.0", nullptr, nullptr, mk0_))) return r;
-    if ((r = pack_conv(u + "mask.2", nullptr, nullptr, mk2_))) return r;
+    if ((r = pack_conv(u + "mask.0", true, nullptr, nullptr, mk0_))) return r;
+    if ((r = pack_conv(u + "mask.2", true, nullptr, nullptr, mk2_))) return r;
     tmap_.clear();
     PB_HIP(hipDeviceSynchronize());
     return 0;
-}
-
-void *RaftEngine::carve(size_t bytes) {
-    const size_t off = arena_off_;
-    arena_off_ += round_up((int64_t)bytes, 256);
-    return planning_ ? nullptr : (void *)(arena_ + off);
 }
 
 int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
@@ -292,14 +182,8 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         up_ = (float *)carve((size_t)ND * sh_ * sw_ * 2 * 4);
         maxd_ = (unsigned *)carve((size_t)ND * 4);
         if (pass == 0) {
-            if (arena_off_ > arena_bytes_) {
-                if (arena_) PB_HIP(hipFree(arena_));
-                arena_ = nullptr; arena_bytes_ = 0;
-                hipError_t e = hipMalloc((void **)&arena_, arena_off_);
-                PB_CHECK(e == hipSuccess, PB_ERR_MEMORY, "flow arena of %zu bytes: %s", arena_off_, hipGetErrorString(e));
-                arena_bytes_ = arena_off_;
-            }
-            PB_HIP(hipMemsetAsync(arena_, 0, arena_bytes_, stream));
+            const int rc = commit_arena("flow");
+            if (rc) return rc;
         }
     }
     if (scale != 1.f) {
@@ -314,31 +198,6 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
     PB_HIP(hipStreamSynchronize(stream));
     pF_ = F; pH_ = H; pW_ = W; pS_ = scale; pD_ = dirs;
     return 0;
-}
-
-int RaftEngine::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w,
-                     f16 *out, int ldo, int act, int pre_relu, const f16 *add1) {
-    GemmArgs a;
-    a.A = in; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_;
-    a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = kw; a.cStride = stride; a.cPad = kh / 2; a.cPadX = kw / 2;
-    a.cOH = (H + 2 * (kh / 2) - kh) / stride + 1; a.cOW = (W + 2 * (kw / 2) - kw) / stride + 1;
-    a.M = n * a.cOH * a.cOW;
-    a.out = out; a.ldo = ldo; a.act = act; a.pre_relu = pre_relu; a.add1 = add1;
-    PB_CHECK(w.K == kh * kw * cC, PB_ERR_STATE, "conv: packed K %d != %d*%d*%d", w.K, kh, kw, cC);
-    tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
-    int r = launch_gemm(stream, A_CONV, EPI_STD, conv_tile, a);
-    toc();
-    return r;
-}
-
-int RaftEngine::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act) {
-    GemmArgs a;
-    a.A = A; a.lda = lda; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_; a.M = (int)M;
-    a.out = out; a.ldo = ldo; a.act = act;
-    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 0);
-    int r = launch_gemm(stream, A_DENSE, EPI_STD, TILE_AUTO, a);
-    toc();
-    return r;
 }
 
 int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward, float *flow_out,

@@ -28,7 +28,8 @@ def test_header_symbols_exported(lib):
 
 
 def test_struct_layout_matches_header():
-    assert C.sizeof(_lib.pb_depth_cfg) == 10 * 4
+    assert C.sizeof(_lib.pb_depth_cfg) == 11 * 4            # ... max_batch, metric
+    assert C.sizeof(_lib.pb_mask_cfg) == 28 * 4             # 23 int32 + 4 float + max_batch
     assert C.sizeof(_lib.pb_tensor) == 8 + 4 + 4 + 6 * 8 + 8
     assert C.sizeof(_lib.pb_kernel_stat) == 8 + 3 * 8 + 8
 
