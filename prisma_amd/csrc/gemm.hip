@@ -720,8 +720,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     const int nk = p.K >> 6;
     const int cpt = AMODE == A_CONV ? p.cC >> 6 : 1;     // K tiles per conv tap
 
-    auto stage_a = [&](int hf, int kt) {
-        char *base = smem + (kt & 1) * BUF;
+    // staging past the last K tile re-reads the last one into a slot nobody reads any more: the loop stays branch free
+    // and every phase can use the same counted wait
+    auto stage_a = [&](int hf, int kt_) {
+        const int kt = kt_ < nk ? kt_ : nk - 1;
+        char *base = smem + (kt_ & 1) * BUF;
         int ky = 0, kx = 0, c0 = 0;
         if constexpr (AMODE == A_CONV) {
             const int tap = kt / cpt;
@@ -743,8 +746,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             glds16(src, base + ((g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8) * 128);
         }
     };
-    auto stage_b = [&](int hf, int kt) {
-        char *base = smem + (kt & 1) * BUF + BOFF;
+    auto stage_b = [&](int hf, int kt_) {
+        const int kt = kt_ < nk ? kt_ : nk - 1;
+        char *base = smem + (kt_ & 1) * BUF + BOFF;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int g = wave * 2 + u;
@@ -768,11 +772,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     if constexpr (EPI == EPI_RESID) resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
     f16x8 fa[2][4], fb0[4], fb1[4];
 
-    const int S = 4 * nk;                                // half tiles this block stages in total
     // prologue: A_0(0) B_0(0) B_1(0) A_1(0) A_0(1) B_0(1)
     stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
-    if (nk > 1) { stage_a(0, 1); stage_b(0, 1); }
-    vm_wait_halftiles(nk > 1 ? 4 : 2);                   // A_0(0), B_0(0) landed (this wave's share)
+    stage_a(0, 1); stage_b(0, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A_0(0), B_0(0) landed (this wave's share)
     PB_BAR();
     if (wr == 1) PB_BAR();                               // stagger the second wave group by one barrier
     if (p.dbg) ts1 = __builtin_readcyclecounter();
@@ -788,8 +791,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const f16x8 *)(sb + a_base + rt * 4096 + (c0 ^ (ks * 32)));
         }
-        if (VAR != 1 && VAR != 6 && t + 1 < nk) stage_b(1, t + 1);
-        if (VAR == 0 || VAR == 3 || VAR == 5) vm_wait_halftiles(S - (4 * t + 3));
+        if (VAR != 1 && VAR != 6) stage_b(1, t + 1);
+        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
         if (VAR != 5)
@@ -805,8 +808,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fb1[ks] = *(const f16x8 *)(sb + b_base + 4096 + (c0 ^ (ks * 32)));
         }
-        if (VAR != 1 && VAR != 6 && t + 1 < nk) stage_a(1, t + 1);
-        if (VAR == 0 || VAR == 3 || VAR == 5) vm_wait_halftiles(S - (4 * t + 4));
+        if (VAR != 1 && VAR != 6) stage_a(1, t + 1);
+        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
         if (VAR != 5)
@@ -824,8 +827,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 fa[rt][ks] = *(const f16x8 *)(sb + a_base + 8192 + rt * 4096 + (c0 ^ (ks * 32)));
-        if (VAR != 1 && VAR != 6 && t + 2 < nk) stage_a(0, t + 2);
-        if (VAR == 0 || VAR == 3 || VAR == 5) vm_wait_halftiles(S - (4 * t + 4));
+        if (VAR != 1 && VAR != 6) stage_a(0, t + 2);
+        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
         if (VAR != 5)
@@ -837,8 +840,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
         // ================= p3 =================
-        if (VAR != 1 && VAR != 6 && t + 2 < nk) stage_b(0, t + 2);
-        if (VAR == 0 || VAR == 3 || VAR == 5) vm_wait_halftiles(S - (4 * t + 6));
+        if (VAR != 1 && VAR != 6) stage_b(0, t + 2);
+        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
         if (VAR != 5)
@@ -1080,6 +1083,200 @@ __global__ __launch_bounds__(512) void gemm8b_kernel(const GemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 "quad" kernel: 4 waves, one per SIMD, each owning a 128 x 128 output block (256 accumulator registers), K in
+// slabs of 32.  Against the ping-pong kernel: a wave reads (128 + 128) x 32 halves per 32 MFMAs instead of (128 + 64) x 64
+// per 32 - a third less LDS traffic - and synchronises once per slab (32 MFMAs) instead of eight times per K tile.
+// LDS: ring of 4 slabs x {A 256 rows x 64 B, B 256 rows x 64 B}; the 16-byte chunk of a row is XOR-swizzled by
+// (row >> 2) & 3 on the DMA source side, which makes the ds_read_b128 lane groups conflict free for 64-byte rows.
+// Per slab t:   MFMA(t, ks0) || ds_read frags(t, ks1)
+//               lgkmcnt(0); vmcnt(16) -> slab t+1 landed; barrier; DMA slab t+4 into the buffer slab t just left
+//               MFMA(t, ks1) || ds_read frags(t+1, ks0)
+// ------------------------------------------------------------------------------------------------
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemmq_kernel(const GemmArgs p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int SLAB = 32768, BOFF = 16384;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    int tile_m, tile_n;
+    {
+        const int GN = tilesN < 4 ? tilesN : 4;
+        const int per_band = 8 * tilesN;
+        const int band = swz / per_band, rem = swz - band * per_band;
+        const int tilesM = nwg / tilesN;
+        const int bh = (tilesM - band * 8) < 8 ? (tilesM - band * 8) : 8;
+        const int grp = rem / (bh * GN), r2 = rem - grp * bh * GN;
+        const int gw = (tilesN - grp * GN) < GN ? (tilesN - grp * GN) : GN;
+        tile_m = band * 8 + r2 / gw;
+        tile_n = grp * GN + r2 % gw;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging: DMA j (0..3) of this wave covers the 16 rows starting at (wave * 4 + j) * 16, lane -> row + (lane >> 2),
+    //      LDS chunk position lane & 3 holds logical chunk (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)
+    const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
+    const int lrow = lane >> 2;
+    const int lchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;        // halves
+    const f16 *a_ptr[4], *b_ptr[4];
+    int a_iy0[4], a_ix0[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 16 + lrow;
+        const int m = m0 + row;
+        if constexpr (AMODE == A_DENSE) {
+            const int mc = m < p.M ? m : p.M - 1;
+            a_ptr[j] = p.A + (int64_t)mc * p.lda + lchunk;
+            a_ok[j] = true; a_iy0[j] = a_ix0[j] = 0;
+        } else {
+            const int ohw = p.cOH * p.cOW;
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+            a_ok[j] = m < p.M;
+            a_ptr[j] = p.A + (int64_t)b * p.cH * p.cW * cld + lchunk;
+            a_iy0[j] = oy * p.cStride - p.cPad;
+            a_ix0[j] = ox * p.cStride - padx;
+        }
+        b_ptr[j] = p.W + (int64_t)(n0 + col_map(row, epi_interleaved<EPI, 2>())) * p.K + lchunk;
+    }
+    const int ns = p.K >> 5;                               // slabs
+    const int cpt2 = AMODE == A_CONV ? p.cC >> 5 : 1;      // slabs per conv tap
+
+    auto stage = [&](int st) {
+        const int sc = st < ns ? st : ns - 1;              // past the end: re-read the last slab (dead slot)
+        char *base = smem + (st & 3) * SLAB + wave * 4096;
+        int ky = 0, kx = 0, c0 = 0;
+        if constexpr (AMODE == A_CONV) {
+            const int tap = sc / cpt2;
+            c0 = (sc - tap * cpt2) << 5;
+            ky = tap / p.cKW;
+            kx = tap - ky * p.cKW;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16 *src;
+            if constexpr (AMODE == A_DENSE) {
+                src = a_ptr[j] + sc * 32;
+            } else {
+                const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+                const bool ok = a_ok[j] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+                src = ok ? a_ptr[j] + ((iy * p.cW + ix) * cld + c0) : p.zero;
+            }
+            glds16(src, base + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(b_ptr[j] + sc * 32, base + BOFF + j * 1024);
+    };
+
+    // ---- fragments: tile i row li, logical chunk ks * 2 + lh at position (ks * 2 + lh) ^ ((li >> 2) & 3)
+    const int li = lane & 31, lh = lane >> 5;
+    const int fs = (li >> 2) & 3;
+    const int a_base = (wr * 128 + li) * 64;
+    const int b_base = BOFF + (wc * 128 + li) * 64;
+    int coff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) coff[ks] = ((ks * 2 + lh) ^ fs) * 16;
+
+    f32x16 accL[4][2], accR[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accL[i][j][r] = 0.f; accR[i][j][r] = 0.f; }
+    if constexpr (EPI == EPI_RESID) {
+        resid_io<4, 2, false>(p, accL, m0 + wr * 128, n0 + wc * 128, lane);
+        resid_io<4, 2, false>(p, accR, m0 + wr * 128, n0 + wc * 128 + 64, lane);
+    }
+    f16x8 fa[2][4], fb[2][4];
+    auto read_frags = [&](int buf, int st, int ks) {
+        const char *sb = smem + (st & 3) * SLAB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[buf][i] = *(const f16x8 *)(sb + a_base + i * 2048 + coff[ks]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[buf][j] = *(const f16x8 *)(sb + b_base + j * 2048 + coff[ks]);
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (j < 2) accL[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[buf][i], fb[buf][j], accL[i][j], 0, 0, 0);
+                else accR[i][j - 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[buf][i], fb[buf][j], accR[i][j - 2], 0, 0, 0);
+            }
+    };
+
+    stage(0); stage(1); stage(2); stage(3);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // slab 0 landed (this wave's share)
+    PB_BAR();
+    read_frags(0, 0, 0);
+    for (int t = 0; t < ns; ++t) {
+        read_frags(1, t, 1);
+        mma(0);
+        // issue order for the scheduler: the MFMAs depend only on reads of the previous half; the eight fragment reads of the
+        // next half go out behind the first eight MFMAs, so the last one has eight MFMAs (256 cycles) to land
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // slab t+1 landed; t+2, t+3 may still be in flight
+        PB_BAR();
+        stage(t + 4);
+        read_frags(0, t + 1, 0);                           // t + 1 == ns reads a stale slot; the values are never used
+        mma(1);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {       // fragment reads of the next slab first (they gate the next MFMA group) ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {       // ... then one DMA per MFMA (fire and forget)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (EPI == EPI_RESID) {
+        resid_io<4, 2, true>(p, accL, m0 + wr * 128, n0 + wc * 128, lane);
+        resid_io<4, 2, true>(p, accR, m0 + wr * 128, n0 + wc * 128 + 64, lane);
+    } else {
+        run_epilogue<EPI, 4, 2>(p, accL, smem, wave, lane, m0 + wr * 128, n0 + wc * 128, n0);
+        run_epilogue<EPI, 4, 2>(p, accR, smem, wave, lane, m0 + wr * 128, n0 + wc * 128 + 64, n0);
+    }
+}
+
+template <int AMODE, int EPI>
+int launch_gq(hipStream_t stream, const GemmArgs &a) {
+    constexpr int SMEM = 131072;
+    auto kern = gemmq_kernel<AMODE, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(256), SMEM, stream, a);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int AMODE, int EPI, int VAR = 0>
 int launch_g8(hipStream_t stream, const GemmArgs &a) {
     constexpr int SMEM = 131072;
@@ -1137,6 +1334,7 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
         if (tile == TILE_256) return a.Wf ? launch_g8b<AMODE, EPI>(s, a) : launch_g8<AMODE, EPI>(s, a);
         if (tile == TILE_256_SIMPLE) return launch_t<256, 256, 2, 4, AMODE, EPI>(s, a);
         if (tile == TILE_256x128) return launch_t<256, 128, 4, 2, AMODE, EPI>(s, a);
+        if (tile == TILE_QUAD) return launch_gq<AMODE, EPI>(s, a);
         return launch_t<128, 128, 2, 2, AMODE, EPI>(s, a);
     }
 }
