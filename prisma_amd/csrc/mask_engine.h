@@ -38,8 +38,8 @@ class MaskEngine : public EngineBase {
     int neck(int n);
     int head(int n);
     int head_level(int n, int lvl);
-    int post_frame(int b, int frame_index, float confidence, const std::vector<uint8_t> &keep_class, uint8_t *mask_out);
-    int ensure_post(size_t cands);
+    int post_chunk(int n, int first, float confidence, const std::vector<uint8_t> &keep_class, uint8_t *mask_out);
+    int ensure_post(size_t cands, int frames);
 
     int conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, const PackedW &w, float *out, int ldo);
     int conv_gn_relu(const f16 *in, int cC, int cLd, int n, int H, int W, int k, const ConvGN &c, f16 *tmp, f16 *out, int ldo);
@@ -79,6 +79,7 @@ class MaskEngine : public EngineBase {
 
     // post-processing scratch (grown on demand, outside the arena)
     size_t post_cap_ = 0;
+    int post_frames_ = 0;
     f16 *pk_ = nullptr;
     unsigned long long *bits_ = nullptr;
     float *plog_ = nullptr, *pstat_ = nullptr, *inter_ = nullptr, *sig_ = nullptr, *nmsf_ = nullptr;

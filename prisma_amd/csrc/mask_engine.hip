@@ -173,6 +173,7 @@ int MaskEngine::prepare(int n, int H, int W) {
         for (auto b : post)
             if (*b) { PB_HIP(hipFree(*b)); *b = nullptr; }
         post_cap_ = 0;
+        post_frames_ = 0;
     }
     net_size(cfg_, H, W, &nh_, &nw_, &Hp_, &Wp_);
     PB_CHECK(Hp_ >= 64 && Wp_ >= 64, PB_ERR_ARG, "mask_mmdet: network input %dx%d is too small", Hp_, Wp_);
@@ -397,150 +398,205 @@ int MaskEngine::head_level(int n, int lvl) {
     return 0;
 }
 
-int MaskEngine::ensure_post(size_t cands) {
+int MaskEngine::ensure_post(size_t cands, int frames) {
     const size_t HW4 = (size_t)lh_[0] * lw_[0];
     const size_t need = round_up((int64_t)std::max<size_t>(cands, 256), 256);
-    if (need <= post_cap_) return 0;
-    PB_CHECK(need <= (1u << 16), PB_ERR_MEMORY, "mask_mmdet: %zu candidate cells over score_thr in one frame", cands);
-    PB_HIP(hipStreamSynchronize(stream));
-    void **bufs[] = {(void **)&pk_, (void **)&plog_, (void **)&pstat_, (void **)&pidx_};
-    for (auto b : bufs)
-        if (*b) { PB_HIP(hipFree(*b)); *b = nullptr; }
-    PB_HIP(hipMalloc((void **)&pk_, need * 256 * 2));
-    PB_HIP(hipMalloc((void **)&plog_, need * HW4 * 4));
-    PB_HIP(hipMalloc((void **)&pstat_, need * 2 * 4));
-    PB_HIP(hipMalloc((void **)&pidx_, need * 4));
-    post_cap_ = need;
+    PB_CHECK(need <= (1u << 17), PB_ERR_MEMORY, "mask_mmdet: %zu candidate cells over score_thr in one chunk", cands);
+    if (need > post_cap_) {
+        PB_HIP(hipStreamSynchronize(stream));
+        void **bufs[] = {(void **)&pk_, (void **)&plog_, (void **)&pstat_, (void **)&pidx_};
+        for (auto b : bufs)
+            if (*b) { PB_HIP(hipFree(*b)); *b = nullptr; }
+        PB_HIP(hipMalloc((void **)&pk_, (need + 256) * 256 * 2));
+        PB_HIP(hipMalloc((void **)&plog_, need * HW4 * 4));
+        PB_HIP(hipMalloc((void **)&pstat_, need * 2 * 4));
+        PB_HIP(hipMalloc((void **)&pidx_, need * 4));
+        post_cap_ = need;
+    }
+    if (frames > post_frames_) {        // per-frame Matrix-NMS / final-mask scratch
+        PB_HIP(hipStreamSynchronize(stream));
+        void **bufs[] = {(void **)&bits_, (void **)&inter_, (void **)&nmsf_, (void **)&nmsi_, (void **)&sig_, (void **)&use_};
+        for (auto b : bufs)
+            if (*b) { PB_HIP(hipFree(*b)); *b = nullptr; }
+        PB_HIP(hipMalloc((void **)&bits_, (size_t)frames * 512 * (HW4 / 64) * 8));
+        PB_HIP(hipMalloc((void **)&inter_, (size_t)frames * 512 * 512 * 4));
+        PB_HIP(hipMalloc((void **)&nmsf_, (size_t)frames * 5 * 512 * 4));
+        PB_HIP(hipMalloc((void **)&nmsi_, (size_t)frames * 3 * 512 * 4));
+        PB_HIP(hipMalloc((void **)&sig_, (size_t)frames * cfg_.max_per_img * HW4 * 4));
+        PB_HIP(hipMalloc((void **)&use_, (size_t)frames * 512));
+        post_frames_ = frames;
+    }
     return 0;
 }
 
-// _get_results_single (solov2_head.py:647-766) + format_results + the band's accumulation for frame b of the chunk
-int MaskEngine::post_frame(int b, int frame_index, float confidence, const std::vector<uint8_t> &keep_class, uint8_t *mask_out) {
-    const int C = cfg_.num_classes, Cp = conv_cls_.N, n = last_n_;
+// _get_results_single (solov2_head.py:647-766) + format_results + the band's accumulation, for all frames of a chunk in three
+// passes so that the host decides once per pass (three stream syncs per chunk, not per frame):
+//   A  cells over score_thr -> gather their kernels -> dynamic convolution -> mask area / maskness sums
+//   B  area filter, maskness, sort, nms_pre -> bit masks -> pairwise intersections -> Matrix-NMS decay
+//   C  filter_thr, sort, max_per_img -> sigmoid rows -> upsample x4, crop, resize, threshold, accumulate
+int MaskEngine::post_chunk(int n, int first, float confidence, const std::vector<uint8_t> &keep_class, uint8_t *mask_out) {
+    const int C = cfg_.num_classes, Cp = conv_cls_.N;
     const int fh = lh_[0], fw = lw_[0], HW4 = fh * fw;
     const int64_t opix = (int64_t)pH_ * pW_;
-    Instances &res = results_[frame_index];
-    res = Instances();
-    uint8_t *out = mask_out + (int64_t)frame_index * opix * 3;
-    auto empty = [&]() -> int {
-        PB_HIP(hipMemsetAsync(out, 0, (size_t)opix * 3, stream));
+    struct Cand { int cell, label; float score; };
+    struct Kept { int row, label; float score, area; };
+    struct Fin { int row, label; float score; };
+    struct Frame {
+        std::vector<Cand> cand;
+        std::vector<float> stride_of, st, ns;
+        std::vector<Kept> kept;
+        size_t off = 0;             // first row of this frame in pk_ / plog_ / pstat_
+        bool done = false;
+    };
+    std::vector<Frame> fr(n);
+    int r;
+    auto finish_empty = [&](int b) -> int {
+        fr[b].done = true;
+        PB_HIP(hipMemsetAsync(mask_out + (int64_t)(first + b) * opix * 3, 0, (size_t)opix * 3, stream));
         return 0;
     };
-    // candidates in nonzero() order: cell-major, class-minor
-    struct Cand { int cell, label; float score; };
-    std::vector<Cand> cand;
-    const float *sc = h_scores_.data() + (int64_t)b * pts_ * Cp;
-    for (int p = 0; p < pts_; ++p)
-        for (int c = 0; c < C; ++c)
-            if (sc[(int64_t)p * Cp + c] > cfg_.score_thr) cand.push_back({p, c, sc[(int64_t)p * Cp + c]});
-    res.candidates = (int)cand.size();
-    if (cand.empty()) return empty();
-    int r;
-    if ((r = ensure_post(cand.size()))) return r;
-    const int K = (int)cand.size();
-    std::vector<int> rows(K);
-    std::vector<float> stride_of(K);
-    for (int i = 0; i < K; ++i) {
-        int lvl = 0;
-        while (cand[i].cell >= goff_[lvl + 1]) ++lvl;
-        rows[i] = n * goff_[lvl] + b * (goff_[lvl + 1] - goff_[lvl]) + (cand[i].cell - goff_[lvl]);     // level-major kernel rows
-        stride_of[i] = (float)cfg_.strides[lvl];
+    // ---------------- pass A ----------------
+    size_t total = 0;
+    for (int b = 0; b < n; ++b) {
+        Frame &f = fr[b];
+        results_[first + b] = Instances();
+        const float *sc = h_scores_.data() + (int64_t)b * pts_ * Cp;
+        for (int p = 0; p < pts_; ++p)          // nonzero() order: cell-major, class-minor
+            for (int c = 0; c < C; ++c)
+                if (sc[(int64_t)p * Cp + c] > cfg_.score_thr) f.cand.push_back({p, c, sc[(int64_t)p * Cp + c]});
+        results_[first + b].candidates = (int)f.cand.size();
+        f.off = total;
+        total += round_up((int64_t)f.cand.size(), 8);
     }
-    PB_HIP(hipMemcpyAsync(pidx_, rows.data(), (size_t)K * 4, hipMemcpyHostToDevice, stream));
-    tic(F_PP, 0, (double)K * 256 * 6);
-    r = launch_gather_rows_f16(stream, kp_, pidx_, pk_, K, (int)round_up(K, 256), 256);
-    toc();
-    if (r) return r;
-    {   // dynamic convolution: logits[k][pixel] = <kernel_k, mask_feats[pixel]>
-        GemmArgs a;
-        a.A = pk_; a.lda = 256; a.M = K; a.W = mf_ + (int64_t)b * HW4 * 256; a.K = 256; a.N = HW4;
-        a.out32 = plog_; a.ldo = HW4; a.scale = 1.f; a.zero = zero_;
+    if ((r = ensure_post(total, n))) return r;
+    std::vector<int> rows(total, 0);
+    for (int b = 0; b < n; ++b) {
+        Frame &f = fr[b];
+        f.stride_of.resize(f.cand.size());
+        for (size_t i = 0; i < f.cand.size(); ++i) {
+            int lvl = 0;
+            while (f.cand[i].cell >= goff_[lvl + 1]) ++lvl;
+            rows[f.off + i] = n * goff_[lvl] + b * (goff_[lvl + 1] - goff_[lvl]) + (f.cand[i].cell - goff_[lvl]);   // level-major kernel rows
+            f.stride_of[i] = (float)cfg_.strides[lvl];
+        }
+    }
+    if (total) {
+        PB_HIP(hipMemcpyAsync(pidx_, rows.data(), total * 4, hipMemcpyHostToDevice, stream));
+        tic(F_PP, 0, (double)total * 256 * 6);
+        r = launch_gather_rows_f16(stream, kp_, pidx_, pk_, (int)total, (int)total, 256);
+        toc();
+        if (r) return r;
+    }
+    for (int b = 0; b < n; ++b) {
+        Frame &f = fr[b];
+        const int K = (int)f.cand.size();
+        if (!K) { if ((r = finish_empty(b))) return r; continue; }
+        GemmArgs a;         // dynamic convolution: logits[k][pixel] = <kernel_k, mask_feats[pixel]>
+        a.A = pk_ + f.off * 256; a.lda = 256; a.M = K; a.W = mf_ + (int64_t)b * HW4 * 256; a.K = 256; a.N = HW4;
+        a.out32 = plog_ + f.off * HW4; a.ldo = HW4; a.scale = 1.f; a.zero = zero_;
         tic(F_GEMM, 2.0 * K * (double)HW4 * 256, 0);
         r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
         toc();
         if (r) return r;
+        tic(F_PP, 0, (double)K * HW4 * 4);
+        r = launch_mask_stats(stream, plog_ + f.off * HW4, K, HW4, HW4, cfg_.mask_thr, pstat_ + f.off * 2);
+        toc();
+        if (r) return r;
+        f.st.resize((size_t)K * 2);
+        PB_HIP(hipMemcpyAsync(f.st.data(), pstat_ + f.off * 2, (size_t)K * 8, hipMemcpyDeviceToHost, stream));
     }
-    tic(F_PP, 0, (double)K * HW4 * 4);
-    r = launch_mask_stats(stream, plog_, K, HW4, HW4, cfg_.mask_thr, pstat_);
-    toc();
-    if (r) return r;
-    std::vector<float> st((size_t)K * 2);
-    PB_HIP(hipMemcpyAsync(st.data(), pstat_, (size_t)K * 8, hipMemcpyDeviceToHost, stream));
     PB_HIP(hipStreamSynchronize(stream));
-    // keep = sum_masks > strides; cls_scores *= maskness
-    struct Kept { int row, label; float score, area; };
-    std::vector<Kept> kept;
-    for (int i = 0; i < K; ++i)
-        if (st[(size_t)i * 2] > stride_of[i]) kept.push_back({i, cand[i].label, cand[i].score * (st[(size_t)i * 2 + 1] / st[(size_t)i * 2]), st[(size_t)i * 2]});
-    if (kept.empty()) return empty();
-    std::stable_sort(kept.begin(), kept.end(), [](const Kept &x, const Kept &y) { return x.score > y.score; });
-    if ((int)kept.size() > cfg_.nms_pre) kept.resize(cfg_.nms_pre);
-    const int n2 = (int)kept.size();
-    if (!bits_) {
-        PB_HIP(hipMalloc((void **)&bits_, (size_t)512 * (HW4 / 64) * 8));
-        PB_HIP(hipMalloc((void **)&inter_, (size_t)512 * 512 * 4));
-        PB_HIP(hipMalloc((void **)&nmsf_, 5 * 512 * 4));
-        PB_HIP(hipMalloc((void **)&nmsi_, 2 * 512 * 4));
-        PB_HIP(hipMalloc((void **)&sig_, (size_t)cfg_.max_per_img * HW4 * 4));
-        PB_HIP(hipMalloc((void **)&use_, 512));
-    }
-    std::vector<int> li(1024);
-    std::vector<float> lf(1024);
-    for (int i = 0; i < n2; ++i) { li[i] = kept[i].row; li[512 + i] = kept[i].label; lf[i] = kept[i].area; lf[512 + i] = kept[i].score; }
-    PB_HIP(hipMemcpyAsync(nmsi_, li.data(), 1024 * 4, hipMemcpyHostToDevice, stream));
-    PB_HIP(hipMemcpyAsync(nmsf_, lf.data(), 1024 * 4, hipMemcpyHostToDevice, stream));
-    // binary masks as bit rows; pairwise intersections by popcount (matrix_nms.py:66-67), then the decay
-    tic(F_PP, 0, (double)n2 * HW4 * 4 + (double)n2 * n2 * (HW4 / 8));
-    r = launch_bitpack_rows(stream, plog_, HW4, nmsi_, n2, HW4, cfg_.mask_thr, bits_);
-    if (!r) r = launch_mask_intersections(stream, bits_, n2, HW4 / 64, inter_, 512);
-    if (!r) r = launch_matrix_nms(stream, inter_, 512, nmsf_, nmsi_ + 512, nmsf_ + 512, n2, cfg_.sigma, nmsf_ + 1536, nmsf_ + 1024);
-    toc();
-    if (r) return r;
-    std::vector<float> ns(n2);
-    PB_HIP(hipMemcpyAsync(ns.data(), nmsf_ + 1024, (size_t)n2 * 4, hipMemcpyDeviceToHost, stream));
-    PB_HIP(hipStreamSynchronize(stream));
-    struct Fin { int row, label; float score; };
-    std::vector<Fin> fin;
-    for (int i = 0; i < n2; ++i)
-        if (!(cfg_.filter_thr > 0.f) || ns[i] >= cfg_.filter_thr) fin.push_back({kept[i].row, kept[i].label, ns[i]});
-    if (fin.empty()) return empty();
-    std::stable_sort(fin.begin(), fin.end(), [](const Fin &x, const Fin &y) { return x.score > y.score; });
-    if ((int)fin.size() > cfg_.max_per_img) fin.resize(cfg_.max_per_img);
-    const int n3 = (int)fin.size();
-    // the band (mask_mmdet.py:43-49,139-147): classes in the keep list, score > 0.5 (getTotalMasks' default) and > --confidence
-    std::vector<uint8_t> use(n3);
-    std::vector<int> frow(n3);
-    for (int i = 0; i < n3; ++i) {
-        frow[i] = fin[i].row;
-        use[i] = keep_class[fin[i].label] && fin[i].score > 0.5f && fin[i].score > confidence;
-        res.scores.push_back(fin[i].score);
-        res.labels.push_back(fin[i].label);
-    }
-    PB_HIP(hipMemcpyAsync(nmsi_, frow.data(), (size_t)n3 * 4, hipMemcpyHostToDevice, stream));
-    PB_HIP(hipMemcpyAsync(use_, use.data(), (size_t)n3, hipMemcpyHostToDevice, stream));
-    tic(F_PP, 0, (double)n3 * HW4 * 8);
-    r = launch_sigmoid_rows(stream, plog_, HW4, nmsi_, n3, HW4, sig_);
-    toc();
-    if (r) return r;
-    uint8_t *inst = nullptr;
-    if (debug) {
-        const size_t need = (size_t)n3 * opix;
-        if (need > inst_bytes_) {
-            if (inst_) PB_HIP(hipFree(inst_));
-            PB_HIP(hipMalloc((void **)&inst_, need));
-            inst_bytes_ = need;
+    // ---------------- pass B ----------------
+    std::vector<std::vector<int>> li(n);
+    std::vector<std::vector<float>> lf(n);
+    for (int b = 0; b < n; ++b) {
+        Frame &f = fr[b];
+        if (f.done) continue;
+        const int K = (int)f.cand.size();
+        for (int i = 0; i < K; ++i)             // keep = sum_masks > strides; cls_scores *= maskness
+            if (f.st[(size_t)i * 2] > f.stride_of[i])
+                f.kept.push_back({i, f.cand[i].label, f.cand[i].score * (f.st[(size_t)i * 2 + 1] / f.st[(size_t)i * 2]), f.st[(size_t)i * 2]});
+        if (f.kept.empty()) { if ((r = finish_empty(b))) return r; continue; }
+        std::stable_sort(f.kept.begin(), f.kept.end(), [](const Kept &x, const Kept &y) { return x.score > y.score; });
+        if ((int)f.kept.size() > cfg_.nms_pre) f.kept.resize(cfg_.nms_pre);
+        const int n2 = (int)f.kept.size();
+        li[b].assign(1024, 0);
+        lf[b].assign(1024, 0.f);
+        for (int i = 0; i < n2; ++i) {
+            li[b][i] = (int)f.off + f.kept[i].row; li[b][512 + i] = f.kept[i].label;
+            lf[b][i] = f.kept[i].area; lf[b][512 + i] = f.kept[i].score;
         }
-        inst = inst_;
+        int *ni = nmsi_ + (size_t)b * 3 * 512;
+        float *nf = nmsf_ + (size_t)b * 5 * 512;
+        unsigned long long *bits = bits_ + (size_t)b * 512 * (HW4 / 64);
+        float *inter = inter_ + (size_t)b * 512 * 512;
+        PB_HIP(hipMemcpyAsync(ni, li[b].data(), 1024 * 4, hipMemcpyHostToDevice, stream));
+        PB_HIP(hipMemcpyAsync(nf, lf[b].data(), 1024 * 4, hipMemcpyHostToDevice, stream));
+        // binary masks as bit rows; pairwise intersections by popcount (matrix_nms.py:66-67), then the decay
+        tic(F_PP, 0, (double)n2 * HW4 * 4 + (double)n2 * n2 * (HW4 / 8));
+        r = launch_bitpack_rows(stream, plog_, HW4, ni, n2, HW4, cfg_.mask_thr, bits);
+        if (!r) r = launch_mask_intersections(stream, bits, n2, HW4 / 64, inter, 512);
+        if (!r) r = launch_matrix_nms(stream, inter, 512, nf, ni + 512, nf + 512, n2, cfg_.sigma, nf + 1536, nf + 1024);
+        toc();
+        if (r) return r;
+        f.ns.resize(n2);
+        PB_HIP(hipMemcpyAsync(f.ns.data(), nf + 1024, (size_t)n2 * 4, hipMemcpyDeviceToHost, stream));
     }
-    tic(F_PP, 0, (double)opix * (3 + 64.0 * n3));
-    r = launch_band_accumulate(stream, sig_, n3, fh, fw, nh_, nw_, pH_, pW_, cfg_.mask_thr, use_, out, inst);
-    toc();
-    if (r) return r;
-    if (debug) {
-        res.masks.resize((size_t)n3 * opix);
-        PB_HIP(hipMemcpyAsync(res.masks.data(), inst_, (size_t)n3 * opix, hipMemcpyDeviceToHost, stream));
+    PB_HIP(hipStreamSynchronize(stream));
+    // ---------------- pass C ----------------
+    std::vector<std::vector<int>> frow(n);
+    std::vector<std::vector<uint8_t>> use(n);
+    for (int b = 0; b < n; ++b) {
+        Frame &f = fr[b];
+        if (f.done) continue;
+        Instances &res = results_[first + b];
+        std::vector<Fin> fin;
+        for (size_t i = 0; i < f.kept.size(); ++i)
+            if (!(cfg_.filter_thr > 0.f) || f.ns[i] >= cfg_.filter_thr) fin.push_back({(int)f.off + f.kept[i].row, f.kept[i].label, f.ns[i]});
+        if (fin.empty()) { if ((r = finish_empty(b))) return r; continue; }
+        std::stable_sort(fin.begin(), fin.end(), [](const Fin &x, const Fin &y) { return x.score > y.score; });
+        if ((int)fin.size() > cfg_.max_per_img) fin.resize(cfg_.max_per_img);
+        const int n3 = (int)fin.size();
+        // the band (mask_mmdet.py:43-49,139-147): classes in the keep list, score > 0.5 (getTotalMasks' default) and > --confidence
+        frow[b].resize(n3);
+        use[b].resize(n3);
+        for (int i = 0; i < n3; ++i) {
+            frow[b][i] = fin[i].row;
+            use[b][i] = keep_class[fin[i].label] && fin[i].score > 0.5f && fin[i].score > confidence;
+            res.scores.push_back(fin[i].score);
+            res.labels.push_back(fin[i].label);
+        }
+        int *ni = nmsi_ + (size_t)b * 3 * 512 + 1024;
+        uint8_t *us = use_ + (size_t)b * 512;
+        float *sig = sig_ + (size_t)b * cfg_.max_per_img * HW4;
+        PB_HIP(hipMemcpyAsync(ni, frow[b].data(), (size_t)n3 * 4, hipMemcpyHostToDevice, stream));
+        PB_HIP(hipMemcpyAsync(us, use[b].data(), (size_t)n3, hipMemcpyHostToDevice, stream));
+        tic(F_PP, 0, (double)n3 * HW4 * 8);
+        r = launch_sigmoid_rows(stream, plog_, HW4, ni, n3, HW4, sig);
+        toc();
+        if (r) return r;
+        uint8_t *inst = nullptr;
+        if (debug) {        // parity dumps only: one frame at a time through a shared buffer
+            const size_t need = (size_t)n3 * opix;
+            if (need > inst_bytes_) {
+                PB_HIP(hipStreamSynchronize(stream));
+                if (inst_) PB_HIP(hipFree(inst_));
+                PB_HIP(hipMalloc((void **)&inst_, need));
+                inst_bytes_ = need;
+            }
+            inst = inst_;
+        }
+        tic(F_PP, 0, (double)opix * (3 + 64.0 * n3));
+        r = launch_band_accumulate(stream, sig, n3, fh, fw, nh_, nw_, pH_, pW_, cfg_.mask_thr, us, mask_out + (int64_t)(first + b) * opix * 3, inst);
+        toc();
+        if (r) return r;
+        if (debug) {
+            res.masks.resize((size_t)n3 * opix);
+            PB_HIP(hipMemcpyAsync(res.masks.data(), inst_, (size_t)n3 * opix, hipMemcpyDeviceToHost, stream));
+            PB_HIP(hipStreamSynchronize(stream));
+        }
     }
-    PB_HIP(hipStreamSynchronize(stream));       // host vectors (rows / use) go out of scope here
+    PB_HIP(hipStreamSynchronize(stream));       // the host index vectors of pass C go out of scope here
     return 0;
 }
 
@@ -571,9 +627,7 @@ int MaskEngine::run_chunk(const uint8_t *frames, int n, int first, float confide
     h_scores_.resize((size_t)n * pts_ * Cp);
     PB_HIP(hipMemcpyAsync(h_scores_.data(), cs_, h_scores_.size() * 4, hipMemcpyDeviceToHost, stream));
     PB_HIP(hipStreamSynchronize(stream));
-    for (int b = 0; b < n; ++b)
-        if ((r = post_frame(b, first + b, confidence, keep_class, mask_out))) return r;
-    return 0;
+    return post_chunk(n, first, confidence, keep_class, mask_out);
 }
 
 int MaskEngine::infer(const uint8_t *frames, int n, int H, int W, float confidence, const int32_t *keep, int n_keep,

@@ -13,10 +13,11 @@ frames = torch.from_numpy(synth.frames(B, 1080, 1920, seed=70)).cuda()
 out = torch.empty_like(frames)
 keep = [synth.COCO_CLASSES.index(c) for c in synth.BAND_CLASSES]
 net.infer_batch_dev(frames.data_ptr(), B, 1080, 1920, 0.5, keep, out.data_ptr()); net.sync()
-net.set_profiling(True)
+prof = os.environ.get('MASK_PROF', '1') == '1'
+net.set_profiling(prof)
 t0 = time.perf_counter()
 for _ in range(steps):
     net.infer_batch_dev(frames.data_ptr(), B, 1080, 1920, 0.5, keep, out.data_ptr()); net.sync()
 dt = (time.perf_counter() - t0) / steps
-st = net.kernel_stats()
+st = net.kernel_stats() if prof else []
 print("frames/s %.1f  ms/step %.2f  kernel ms %s" % (B / dt, dt * 1e3, {s["name"]: round(s["ms"], 2) for s in st}))
