@@ -46,6 +46,16 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_base) {
                                      (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
 }
 
+// Same LDS-DMA through the buffer path: `rsrc` addresses the whole tensor, `voff` is this lane's byte offset, `soff` a
+// wave-uniform byte offset (e.g. the K-tile advance, so the per-lane offsets stay loop invariant); out-of-range offsets
+// read zeros.
+__device__ __forceinline__ void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, void *lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

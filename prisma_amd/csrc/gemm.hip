@@ -640,7 +640,7 @@ __device__ __forceinline__ void vm_wait_halftiles(int n) {
 
 // VAR != 0 are timing-only ablations (wrong results): 1 no DMA in the loop, 2 no vmcnt waits, 3 no ds_reads,
 // 5 DMA + barriers only (no ds_reads, no MFMAs), 6 MFMAs + barriers only.
-template <int AMODE, int EPI, int VAR = 0>
+template <int AMODE, int EPI, int VAR = 0, bool BUFP = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     constexpr int BM = 256, BN = 256;
     constexpr int BUF = 65536, BOFF = 32768;
@@ -719,6 +719,36 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         }
     const int nk = p.K >> 6;
     const int cpt = AMODE == A_CONV ? p.cC >> 6 : 1;     // K tiles per conv tap
+    // BUFP: stage through the buffer path (`buffer_load_dwordx4 ... lds`) - measurably cheaper to issue than the flat
+    // `global_load_lds` (8192^3: 1145 -> 1245 TF, qkv / fc1 shapes +14 ... +17 %).  The resource covers the whole operand
+    // (dense, weights) or the one or two images this tile's rows fall into (conv: a whole DPT map batch exceeds 4 GB);
+    // the launcher only picks this variant when those spans fit 32-bit byte offsets.  Out-of-range offsets read zeros,
+    // which is how padded taps and rows >= M are fed.
+    __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, 0u), rsW = make_rsrc(p.W, 0u);
+    unsigned a_voff[2][2], b_voff[2][2];
+    if constexpr (BUFP) {
+        rsW = make_rsrc(p.W, (unsigned)((int64_t)((p.N + 255) / 256 * 256) * p.K * 2));
+        if constexpr (AMODE == A_DENSE) {
+            rsA = make_rsrc(p.A, (unsigned)((int64_t)p.M * p.lda * 2));
+        } else {
+            const int ohw = p.cOH * p.cOW, nimg = p.M / ohw, b0 = m0 / ohw;
+            const int64_t img = (int64_t)p.cH * p.cW * cld;
+            rsA = make_rsrc(p.A + b0 * img, (unsigned)((nimg - b0 < 2 ? nimg - b0 : 2) * img * 2));
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if constexpr (AMODE == A_DENSE) {
+                    a_voff[hf][u] = (unsigned)((a_ptr[hf][u] - p.A) * 2);
+                } else {
+                    const int ohw = p.cOH * p.cOW, b0 = m0 / ohw;
+                    const int m = m0 + a_row0[hf][u] + lrow;
+                    a_voff[hf][u] = (unsigned)((int64_t)(m / ohw - b0) * p.cH * p.cW * cld * 2) + cgu[u] * 16;
+                }
+                b_voff[hf][u] = (unsigned)((b_ptr[hf][u] - p.W) * 2);
+            }
+    }
 
     // staging past the last K tile re-reads the last one into a slot nobody reads any more: the loop stays branch free
     // and every phase can use the same counted wait
@@ -734,16 +764,17 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const f16 *src;
+            const int g = wave * 2 + u;
+            char *dst = base + ((g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8) * 128;
             if constexpr (AMODE == A_DENSE) {
-                src = a_ptr[hf][u] + kt * 64;
+                if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[hf][u], kt * 128, dst);
+                else glds16(a_ptr[hf][u] + kt * 64, dst);
             } else {
                 const int iy = a_iy0[hf][u] + ky, ix = a_ix0[hf][u] + kx;
                 const bool ok = a_ok[hf][u] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
-                src = ok ? a_ptr[hf][u] + ((iy * p.cW + ix) * cld + c0) : p.zero;
+                if constexpr (BUFP) glds16_buf(rsA, ok ? (int)(a_voff[hf][u] + (unsigned)(((iy * p.cW + ix) * cld + c0) * 2)) : (int)0xFFFFFF00u, 0, dst);
+                else glds16(ok ? a_ptr[hf][u] + ((iy * p.cW + ix) * cld + c0) : p.zero, dst);
             }
-            const int g = wave * 2 + u;
-            glds16(src, base + ((g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8) * 128);
         }
     };
     auto stage_b = [&](int hf, int kt_) {
@@ -752,7 +783,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int g = wave * 2 + u;
-            glds16(b_ptr[hf][u] + kt * 64, base + ((g >> 2) * 64 + hf * 32 + (g & 3) * 8) * 128);
+            if constexpr (BUFP) glds16_buf(rsW, b_voff[hf][u], kt * 128, base + ((g >> 2) * 64 + hf * 32 + (g & 3) * 8) * 128);
+            else glds16(b_ptr[hf][u] + kt * 64, base + ((g >> 2) * 64 + hf * 32 + (g & 3) * 8) * 128);
         }
     };
 
@@ -1277,10 +1309,10 @@ int launch_gq(hipStream_t stream, const GemmArgs &a) {
     return 0;
 }
 
-template <int AMODE, int EPI, int VAR = 0>
-int launch_g8(hipStream_t stream, const GemmArgs &a) {
+template <int AMODE, int EPI, int VAR, bool BUFP>
+int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
     constexpr int SMEM = 131072;
-    auto kern = gemm8_kernel<AMODE, EPI, VAR>;
+    auto kern = gemm8_kernel<AMODE, EPI, VAR, BUFP>;
     static bool attr_set = false;
     if (!attr_set) {
         PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1290,6 +1322,27 @@ int launch_g8(hipStream_t stream, const GemmArgs &a) {
     hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), SMEM, stream, a);
     PB_HIP(hipGetLastError());
     return 0;
+}
+
+// the buffer-path variant needs every DMA offset to fit an unsigned 32-bit byte count
+inline bool g8_buffer_ok(int amode, const GemmArgs &a) {
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("PB_GEMM_BUFFER"); env = e ? atoi(e) : 1; }
+    if (!env) return false;
+    const int64_t lim = (1LL << 32) - (1 << 20);
+    if ((int64_t)((a.N + 255) / 256 * 256) * a.K * 2 >= lim) return false;
+    if (amode == A_DENSE) return (int64_t)a.M * a.lda * 2 < lim;
+    const int cld = a.cLd ? a.cLd : a.cC;
+    const int64_t ohw = (int64_t)a.cOH * a.cOW;
+    return ohw >= 256 && a.M % ohw == 0 && 2 * (int64_t)a.cH * a.cW * cld * 2 < lim;
+}
+
+template <int AMODE, int EPI, int VAR = 0>
+int launch_g8(hipStream_t stream, const GemmArgs &a) {
+    if constexpr (VAR == 0) {
+        if (g8_buffer_ok(AMODE, a)) return launch_g8_impl<AMODE, EPI, 0, true>(stream, a);
+    }
+    return launch_g8_impl<AMODE, EPI, VAR, false>(stream, a);
 }
 
 template <int AMODE, int EPI>
