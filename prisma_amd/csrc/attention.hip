@@ -57,17 +57,26 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnArgs p) {
     for (int s = 0; s < 4; ++s) qf[s] = *(const f16x8 *)(Q + (int64_t)qrc * 64 + 16 * s + 8 * lh);
 
     // ---- staging: each thread moves 2 chunks of K and 2 of Vt per tile ----
+    //      through the buffer path (cheaper to issue than the flat global_load_lds): per-lane byte offsets are loop
+    //      invariant, the tile advance is a scalar offset, reads past the (b, head) block return zeros
     const int srow = tid >> 3;                               // 0..31 (+32 for the second chunk)
     const int cg = (tid & 7) ^ ((tid >> 4) & 7);
+    const __amdgpu_buffer_rsrc_t rsK = make_rsrc(K, (unsigned)(p.ntp * 64 * 2)), rsV = make_rsrc(Vt, (unsigned)(64 * p.ntp * 2));
+    int kvo[2], vvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = srow + 32 * i;
+        kvo[i] = r * 128 + cg * 16;
+        vvo[i] = (r * p.ntp + cg * 8) * 2;
+    }
     auto stage = [&](int buf, int t) {
         char *sK = smem + buf * 16384 + wave * 1024;
         char *sV = sK + 8192;
         const int key0 = t * 64;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = srow + 32 * i;
-            glds16(K + (int64_t)(key0 + r) * 64 + cg * 8, sK + i * 4096);
-            glds16(Vt + (int64_t)r * p.ntp + key0 + cg * 8, sV + i * 4096);
+            glds16_buf(rsK, kvo[i], key0 * 128, sK + i * 4096);
+            glds16_buf(rsV, vvo[i], key0 * 2, sV + i * 4096);
         }
     };
 
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnArgs p) {
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        stage((t + 1) & 1, t + 1 < nt ? t + 1 : t);            // past the end: re-read the last tile into the idle buffer
         const char *sK = smem + (t & 1) * 16384;
         const char *sV = sK + 8192;
 
