@@ -12,6 +12,7 @@ struct GemmArgs {
     const f16 *A = nullptr;
     int64_t lda = 0;
     const f16 *W = nullptr;
+    int bufmode = 0;                      // set by launch_gemm: 0 flat LDS-DMA, 1 buffer path over the whole operand, 2 (conv) over a two-image window
     const f16 *Wf = nullptr;              // optional: W in MFMA fragment order (pack_fragments); selects the register-B 256x256 kernel
     int K = 0, M = 0, N = 0;              // N = columns actually written (multiple of 8)
     // implicit-GEMM convolution: input [B, cH, cW, cC] (cC % 64 == 0), K = KH*KW*cC, rows = (b, oy, ox)

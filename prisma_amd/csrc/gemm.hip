@@ -470,7 +470,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
     }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool BUFP = false>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -527,24 +527,50 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
 
     int c_ky = 0, c_kx = 0, c_c0 = 0;                       // conv tap state of the NEXT stage call
     const int nk = p.K >> 6;
+    // BUFP: LDS-DMA through the buffer path (see gemm8_kernel); p.bufmode 1 = whole operand, 2 = two-image window (conv)
+    __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, 0u), rsW = make_rsrc(p.W, 0u);
+    unsigned a_voff[NA], b_voff[NB];
+    if constexpr (BUFP) {
+        rsW = make_rsrc(p.W, (unsigned)((int64_t)((p.N + 255) / 256 * 256) * p.K * 2));
+        int b0 = 0;
+        if constexpr (AMODE == A_DENSE) {
+            rsA = make_rsrc(p.A, (unsigned)((int64_t)p.M * p.lda * 2));
+        } else {
+            const int ohw = p.cOH * p.cOW, nimg = p.M / ohw;
+            const int64_t img = (int64_t)p.cH * p.cW * cld;
+            int cnt = nimg;
+            if (p.bufmode == 2) { b0 = m0 / ohw; cnt = nimg - b0 < 2 ? nimg - b0 : 2; }
+            rsA = make_rsrc(p.A + b0 * img, (unsigned)(cnt * img * 2));
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if constexpr (AMODE == A_DENSE) a_voff[i] = (unsigned)((a_ptr[i] - p.A) * 2);
+            else a_voff[i] = (unsigned)((int64_t)((m0 + srow + i * (NT / 8)) / (p.cOH * p.cOW) - b0) * p.cH * p.cW * cld * 2) + cg * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) b_voff[i] = (unsigned)((b_ptr[i] - p.W) * 2);
+    }
 
     auto stage = [&](int buf, int kt) {
         char *sA = smem + buf * STAGE + wave * 1024;
         char *sB = smem + buf * STAGE + A_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const f16 *src;
             if constexpr (AMODE == A_DENSE) {
-                src = a_ptr[i] + kt * 64;
+                if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[i], kt * 128, sA + i * (NT * 16));
+                else glds16(a_ptr[i] + kt * 64, sA + i * (NT * 16));
             } else {
                 const int iy = a_iy0[i] + c_ky, ix = a_ix0[i] + c_kx;
                 const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
-                src = ok ? a_ptr[i] + ((iy * p.cW + ix) * cld + c_c0) : p.zero;
+                if constexpr (BUFP) glds16_buf(rsA, ok ? (int)(a_voff[i] + (unsigned)(((iy * p.cW + ix) * cld + c_c0) * 2)) : (int)0xFFFFFF00u, 0, sA + i * (NT * 16));
+                else glds16(ok ? a_ptr[i] + ((iy * p.cW + ix) * cld + c_c0) : p.zero, sA + i * (NT * 16));
             }
-            glds16(src, sA + i * (NT * 16));
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) glds16(b_ptr[i] + kt * 64, sB + i * (NT * 16));
+        for (int i = 0; i < NB; ++i) {
+            if constexpr (BUFP) glds16_buf(rsW, (int)b_voff[i], kt * 128, sB + i * (NT * 16));
+            else glds16(b_ptr[i] + kt * 64, sB + i * (NT * 16));
+        }
         if constexpr (AMODE == A_CONV) {
             c_c0 += 64;
             if (c_c0 >= p.cC) {
@@ -731,9 +757,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         if constexpr (AMODE == A_DENSE) {
             rsA = make_rsrc(p.A, (unsigned)((int64_t)p.M * p.lda * 2));
         } else {
-            const int ohw = p.cOH * p.cOW, nimg = p.M / ohw, b0 = m0 / ohw;
+            const int ohw = p.cOH * p.cOW, nimg = p.M / ohw, b0 = p.bufmode == 2 ? m0 / ohw : 0;
             const int64_t img = (int64_t)p.cH * p.cW * cld;
-            rsA = make_rsrc(p.A + b0 * img, (unsigned)((nimg - b0 < 2 ? nimg - b0 : 2) * img * 2));
+            rsA = make_rsrc(p.A + b0 * img, (unsigned)((p.bufmode == 2 ? (nimg - b0 < 2 ? nimg - b0 : 2) : nimg) * img * 2));
         }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -742,7 +768,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 if constexpr (AMODE == A_DENSE) {
                     a_voff[hf][u] = (unsigned)((a_ptr[hf][u] - p.A) * 2);
                 } else {
-                    const int ohw = p.cOH * p.cOW, b0 = m0 / ohw;
+                    const int ohw = p.cOH * p.cOW, b0 = p.bufmode == 2 ? m0 / ohw : 0;
                     const int m = m0 + a_row0[hf][u] + lrow;
                     a_voff[hf][u] = (unsigned)((int64_t)(m / ohw - b0) * p.cH * p.cW * cld * 2) + cgu[u] * 16;
                 }
@@ -1324,23 +1350,28 @@ int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
     return 0;
 }
 
-// the buffer-path variant needs every DMA offset to fit an unsigned 32-bit byte count
-inline bool g8_buffer_ok(int amode, const GemmArgs &a) {
+// The buffer-path variants need every DMA offset to fit an unsigned 32-bit byte count: 1 = the whole A operand does,
+// 2 = (conv) any two consecutive images do and a BM-row tile never spans more than two, 0 = neither (flat path).
+inline int buffer_mode(int amode, const GemmArgs &a, int BM) {
     static int env = -1;
     if (env < 0) { const char *e = getenv("PB_GEMM_BUFFER"); env = e ? atoi(e) : 1; }
-    if (!env) return false;
+    if (!env) return 0;
     const int64_t lim = (1LL << 32) - (1 << 20);
-    if ((int64_t)((a.N + 255) / 256 * 256) * a.K * 2 >= lim) return false;
-    if (amode == A_DENSE) return (int64_t)a.M * a.lda * 2 < lim;
+    if ((int64_t)((a.N + 255) / 256 * 256) * a.K * 2 >= lim) return 0;
+    if (amode == A_DENSE) return (int64_t)a.M * a.lda * 2 < lim ? 1 : 0;
     const int cld = a.cLd ? a.cLd : a.cC;
-    const int64_t ohw = (int64_t)a.cOH * a.cOW;
-    return ohw >= 256 && a.M % ohw == 0 && 2 * (int64_t)a.cH * a.cW * cld * 2 < lim;
+    const int64_t ohw = (int64_t)a.cOH * a.cOW, img = (int64_t)a.cH * a.cW * cld * 2;
+    if (ohw <= 0 || a.M % ohw != 0) return 0;
+    if ((a.M / ohw) * img < lim) return 1;
+    return ohw >= BM && 2 * img < lim ? 2 : 0;
 }
 
 template <int AMODE, int EPI, int VAR = 0>
 int launch_g8(hipStream_t stream, const GemmArgs &a) {
     if constexpr (VAR == 0) {
-        if (g8_buffer_ok(AMODE, a)) return launch_g8_impl<AMODE, EPI, 0, true>(stream, a);
+        GemmArgs b = a;
+        b.bufmode = buffer_mode(AMODE, a, 256);
+        if (b.bufmode) return launch_g8_impl<AMODE, EPI, 0, true>(stream, b);
     }
     return launch_g8_impl<AMODE, EPI, VAR, false>(stream, a);
 }
@@ -1360,14 +1391,19 @@ int launch_g8b(hipStream_t stream, const GemmArgs &a) {
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool BUFP = false>
 int launch_t(hipStream_t stream, const GemmArgs &a) {
     constexpr int NT = WM * WN * 64;
     constexpr int TN = BN / WN / 32;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * (TN * 32 + 4) * 4;
     constexpr int SMEM = 2 * STAGE > WM * WN * EPIB ? 2 * STAGE : WM * WN * EPIB;
-    auto kern = gemm_kernel<BM, BN, WM, WN, AMODE, EPI>;
+    if constexpr (!BUFP && BM == 128 && BN == 128) {       // the work-horse small tile also has a buffer-path build
+        GemmArgs b = a;
+        b.bufmode = buffer_mode(AMODE, a, BM);
+        if (b.bufmode) return launch_t<BM, BN, WM, WN, AMODE, EPI, true>(stream, b);
+    }
+    auto kern = gemm_kernel<BM, BN, WM, WN, AMODE, EPI, BUFP>;
     static bool attr_set = false;
     if (!attr_set) {
         PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
