@@ -778,16 +778,19 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 
     // staging past the last K tile re-reads the last one into a slot nobody reads any more: the loop stays branch free
     // and every phase can use the same counted wait
+    // conv: each A half has its own tap cursor (ky, kx, c0) that steps one K tile per call - no divisions in the loop - and
+    // the per-lane pixel offset of tap (0, 0) is precomputed, so a DMA costs one add, two range tests and a select
+    int cur_ky[2] = {0, 0}, cur_kx[2] = {0, 0}, cur_c0[2] = {0, 0}, cur_kt[2] = {0, 0};
+    int a_pix0[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) a_pix0[hf][u] = AMODE == A_CONV ? (a_iy0[hf][u] * p.cW + a_ix0[hf][u]) * cld : 0;
     auto stage_a = [&](int hf, int kt_) {
         const int kt = kt_ < nk ? kt_ : nk - 1;
         char *base = smem + (kt_ & 1) * BUF;
-        int ky = 0, kx = 0, c0 = 0;
-        if constexpr (AMODE == A_CONV) {
-            const int tap = kt / cpt;
-            c0 = (kt - tap * cpt) << 6;
-            ky = tap / p.cKW;
-            kx = tap - ky * p.cKW;
-        }
+        const int ky = cur_ky[hf], kx = cur_kx[hf], c0 = cur_c0[hf];
+        const int tapoff = (ky * p.cW + kx) * cld + c0;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int g = wave * 2 + u;
@@ -796,11 +799,27 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[hf][u], kt * 128, dst);
                 else glds16(a_ptr[hf][u] + kt * 64, dst);
             } else {
-                const int iy = a_iy0[hf][u] + ky, ix = a_ix0[hf][u] + kx;
-                const bool ok = a_ok[hf][u] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
-                if constexpr (BUFP) glds16_buf(rsA, ok ? (int)(a_voff[hf][u] + (unsigned)(((iy * p.cW + ix) * cld + c0) * 2)) : (int)0xFFFFFF00u, 0, dst);
-                else glds16(ok ? a_ptr[hf][u] + ((iy * p.cW + ix) * cld + c0) : p.zero, dst);
+                const bool ok = a_ok[hf][u] && (unsigned)(a_iy0[hf][u] + ky) < (unsigned)p.cH && (unsigned)(a_ix0[hf][u] + kx) < (unsigned)p.cW;
+                const int eo = a_pix0[hf][u] + tapoff;                      // element offset inside the image
+                if constexpr (BUFP) {
+                    const unsigned oob = ok ? 0u : 0xFFFFFF00u;            // any out-of-range offset reads zeros
+                    glds16_buf(rsA, (int)((a_voff[hf][u] + (unsigned)(eo * 2)) | oob), 0, dst);
+                } else {
+                    glds16(ok ? a_ptr[hf][u] + eo : p.zero, dst);
+                }
             }
+        }
+        if constexpr (AMODE == A_CONV) {
+            // branch-free step; past the end the cursor stays on the last K tile
+            const int adv = cur_kt[hf] < nk - 1 ? 1 : 0;
+            cur_kt[hf] += adv;
+            const int c1 = cur_c0[hf] + 64 * adv;
+            const int w1 = c1 >= p.cC ? 1 : 0;
+            cur_c0[hf] = w1 ? 0 : c1;
+            const int x1 = cur_kx[hf] + w1;
+            const int w2 = x1 == p.cKW ? 1 : 0;
+            cur_kx[hf] = w2 ? 0 : x1;
+            cur_ky[hf] += w2;
         }
     };
     auto stage_b = [&](int hf, int kt_) {

@@ -14,9 +14,9 @@ for (M, N, K) in [(512, 512, 256), (700, 768, 320), (1000, 256, 64), (300, 1024,
         err = np.abs(got - ref).max() / np.abs(ref).max()
         print(f"M={M} N={N} K={K} tile={tile} relmax {err:.2e}", flush=True)
 B = 32; M = B * 2448
-for name, m, n, k, epi in [("qkv", M, 3072, 1024, 0), ("fc1n", M, 4096, 1024, 0), ("sq8k", 8192, 8192, 8192, 0)]:
+for name, m, n, k, epi in [("qkv", M, 3072, 1024, 0), ("fc1", M, 4096, 1024, 1), ("fc2", M, 1024, 4096, 2), ("proj", M, 1024, 1024, 2), ("sq8k", 8192, 8192, 8192, 0)]:
     row = []
-    for t in (2,):
+    for t in (2, 6):
         ms = ops.gemm_bench(m, n, k, tile=t, epi=epi, iters=10)
         row.append(f"tile{t}: {ms:7.3f} ms {2.0 * m * n * k / ms / 1e9:7.1f} TF")
     print(f"{name:6s} M={m} N={n} K={k} epi={epi} | " + " | ".join(row), flush=True)
