@@ -562,8 +562,12 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             } else {
                 const int iy = a_iy0[i] + c_ky, ix = a_ix0[i] + c_kx;
                 const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
-                if constexpr (BUFP) glds16_buf(rsA, ok ? (int)(a_voff[i] + (unsigned)(((iy * p.cW + ix) * cld + c_c0) * 2)) : (int)0xFFFFFF00u, 0, sA + i * (NT * 16));
-                else glds16(ok ? a_ptr[i] + ((iy * p.cW + ix) * cld + c_c0) : p.zero, sA + i * (NT * 16));
+                if constexpr (BUFP) {      // branch-free: OR-ing all ones into the offset makes it out of range -> the load returns zeros
+                    const unsigned oob = ok ? 0u : 0xFFFFFF00u;
+                    glds16_buf(rsA, (int)((a_voff[i] + (unsigned)(((iy * p.cW + ix) * cld + c_c0) * 2)) | oob), 0, sA + i * (NT * 16));
+                } else {
+                    glds16(ok ? a_ptr[i] + ((iy * p.cW + ix) * cld + c_c0) : p.zero, sA + i * (NT * 16));
+                }
             }
         }
 #pragma unroll
