@@ -320,7 +320,7 @@ def main():
         symbols = {"gemm_f16": "gemm8_kernel<0,0,0> (fc1 + DPT 1x1/convT GEMMs, fp16 out)",
                    "gemm_f16_resid": "gemm8_kernel<0,1,0> (proj + fc2, accumulating onto the fp32 residual)",
                    "gemm_f16_qkv": "gemm8_kernel<0,2,0> (qkv projection)", "conv_igemm_f16": "gemm8_kernel<1,0,0> (implicit-GEMM convs)",
-                   "attention": "attn_kernel<2>"}
+                   "attention": "attnq_kernel<1,2,0,false,8>"}
         dom_name, g = max(((k, v) for k, v in fam.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic(symbols.get(dom_name, dom_name).split(" ")[0], B)

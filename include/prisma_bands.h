@@ -215,6 +215,8 @@ int pb_op_gemm(pb_ctx *ctx, const float *A, const float *W, const float *bias, f
  * epi: 0 fp16 store, 1 bias+GELU fp16 store, 2 LayerScale + fp32 residual read-modify-write. */
 int pb_op_gemm_bench(pb_ctx *ctx, int M, int N, int K, int tile, int epi, int iters, double *ms_out);
 /* LayerNorm over the last dim, eps 1e-6 (vision_transformer.py:95). */
+/* times `iters` launches of the fused attention kernel on random Q, K, V (variant 0 = default); ms per launch */
+int pb_op_attention_bench(pb_ctx *ctx, int B, int heads, int N, int variant, int iters, double *ms_out);
 int pb_op_layernorm(pb_ctx *ctx, const float *x, const float *g, const float *b, float *y, int rows, int D);
 /* softmax(q k^T * 64^-0.5) v per (batch, head); q,k,v,o: [B, heads, N, 64] float32
  * (dinov2/layers/attention.py:49-62). */

@@ -531,6 +531,31 @@ int pb_op_gemm_bench(pb_ctx *c, int M, int N, int K, int tile, int epi, int iter
     return 0;
 }
 
+int pb_op_attention_bench(pb_ctx *c, int B, int heads, int N, int variant, int iters, double *ms_out) {
+    PB_CHECK(c && B > 0 && heads > 0 && N > 0 && iters > 0 && ms_out, PB_ERR_ARG, "attention_bench: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const int ntp = (int)round_up(N, 16), D = heads * 64;
+    const size_t n = (size_t)B * heads * ntp * 64;
+    DevMem dq, dk, dv, dout;
+    PB_TRY(dq.alloc(n * 2 + 32768)); PB_TRY(dk.alloc(n * 2 + 32768)); PB_TRY(dv.alloc(n * 2 + 32768));
+    PB_TRY(dout.alloc((size_t)B * ntp * D * 2));
+    PB_TRY(launch_fill_random_f16(c->stream, dq.as<f16>(), (int64_t)n, 11u, 3.f * PB_QSCALE));
+    PB_TRY(launch_fill_random_f16(c->stream, dk.as<f16>(), (int64_t)n, 12u, 3.f));
+    PB_TRY(launch_fill_random_f16(c->stream, dv.as<f16>(), (int64_t)n, 13u, 1.f));
+    hipEvent_t e0, e1;
+    PB_HIP(hipEventCreate(&e0)); PB_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) PB_TRY(launch_attention(c->stream, dq.as<f16>(), dk.as<f16>(), dv.as<f16>(), dout.as<f16>(), B, heads, ntp, N, D, variant));
+    PB_HIP(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; ++i) PB_TRY(launch_attention(c->stream, dq.as<f16>(), dk.as<f16>(), dv.as<f16>(), dout.as<f16>(), B, heads, ntp, N, D, variant));
+    PB_HIP(hipEventRecord(e1, c->stream));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    PB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_out = ms / iters;
+    return 0;
+}
+
 int pb_op_layernorm(pb_ctx *c, const float *x, const float *g, const float *b, float *y, int rows, int D) {
     PB_CHECK(c && x && g && b && y && rows > 0, PB_ERR_ARG, "op_layernorm: bad arguments");
     PB_HIP(hipSetDevice(c->device));
@@ -559,7 +584,7 @@ int pb_op_attention(pb_ctx *c, const float *q, const float *k, const float *v, f
         for (int t = 0; t < N; ++t)
             for (int d = 0; d < 64; ++d) {
                 const size_t s = (i * N + t) * 64 + d;
-                hq[(i * ntp + t) * 64 + d] = (f16)(q[s] * 0.125f);
+                hq[(i * ntp + t) * 64 + d] = (f16)(q[s] * PB_QSCALE);
                 hk[(i * ntp + t) * 64 + d] = (f16)k[s];
                 hv[(i * 64 + d) * ntp + t] = (f16)v[s];
             }

@@ -10,7 +10,10 @@ typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Q is stored pre-multiplied by head_dim^-0.5 * log2(e) (head_dim = 64): attention then needs a subtract + v_exp_f32 per score
+#define PB_QSCALE (0.125f * 1.4426950408889634f)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define PB_WAVE 64

@@ -12,7 +12,7 @@
 
 namespace {
 // families follow the kernel symbols rocprofv3 reports: gemm8_kernel<0,0,0> (fp16-out GEMMs: fc1, DPT 1x1 / convT),
-// <0,1,0> (residual-accumulating proj / fc2), <0,2,0> (qkv), <1,0,0> (implicit-GEMM convs), attn_kernel, ...
+// <0,1,0> (residual-accumulating proj / fc2), <0,2,0> (qkv), <1,0,0> (implicit-GEMM convs), attnq_kernel, ...
 const char *kFam[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost", "gemm_f16_resid",
                       "gemm_f16_qkv"};
 enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_GEMM_RESID = 6, F_GEMM_QKV = 7, F_COUNT = 8 };
@@ -512,7 +512,7 @@ int DepthEngine::vit(int n) {
         {
             GemmArgs a;
             a.A = Y_; a.lda = D; a.M = M;
-            a.q = Q_; a.k = K_; a.vt = Vt_; a.ntp = ntp_; a.heads = cfg_.heads; a.D = D; a.qscale = 0.125f;
+            a.q = Q_; a.k = K_; a.vt = Vt_; a.ntp = ntp_; a.heads = cfg_.heads; a.D = D; a.qscale = PB_QSCALE;
             if ((r = gemm(A_DENSE, EPI_QKV, a, b.qkv))) return r;
         }
         tic(F_ATTN, 4.0 * n * cfg_.heads * (double)ntok_ * ntok_ * 64.0, (double)n * ntok_ * D * 2.0 * 4.0);

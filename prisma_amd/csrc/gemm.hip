@@ -61,6 +61,25 @@ __device__ __forceinline__ float fast_gelu(float x) {
     return fmaxf(x, 0.f) - a * __builtin_amdgcn_exp2f(p);
 }
 
+// two values per instruction where the ISA has a packed form (v_pk_fma_f32): the fc1 epilogue is VALU bound
+__device__ __forceinline__ void fast_gelu2(float &x0, float &x1) {
+    const f32x2 x = {x0, x1};
+    // v_med3_f32 clamps without the canonicalising v_max that fminf / fmaxf put in front of every operand
+    const f32x2 a = {__builtin_amdgcn_fmed3f(fabsf(x0), 0.f, 6.5f), __builtin_amdgcn_fmed3f(fabsf(x1), 0.f, 6.5f)};
+    const f32x2 c5 = {-0.00047330817324109375f, -0.00047330817324109375f}, c4 = {0.007084541954100132f, 0.007084541954100132f},
+                c3 = {-0.051827322691679f, -0.051827322691679f}, c2 = {-0.45999252796173096f, -0.45999252796173096f},
+                c1 = {-1.1507878303527832f, -1.1507878303527832f}, c0 = {-1.000037670135498f, -1.000037670135498f};
+    f32x2 p = __builtin_elementwise_fma(a, c5, c4);
+    p = __builtin_elementwise_fma(a, p, c3);
+    p = __builtin_elementwise_fma(a, p, c2);
+    p = __builtin_elementwise_fma(a, p, c1);
+    p = __builtin_elementwise_fma(a, p, c0);
+    const f32x2 e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+    const f32x2 r = {__builtin_amdgcn_fmed3f(x0, 0.f, 3.0e38f), __builtin_amdgcn_fmed3f(x1, 0.f, 3.0e38f)};
+    const f32x2 o = __builtin_elementwise_fma(-a, e, r);
+    x0 = o[0]; x1 = o[1];
+}
+
 template <int EPI>
 __device__ __forceinline__ void epi_cols(const GemmArgs &p, int n, bool nok, float (&cb)[8], float (&cg)[8]) {
 #pragma unroll
@@ -333,7 +352,7 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
             }
             if (p.act == ACT_GELU) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { v0[q] = fast_gelu(v0[q]); v1[q] = fast_gelu(v1[q]); }
+                for (int q = 0; q < 8; ++q) fast_gelu2(v0[q], v1[q]);
             } else if (p.act == ACT_RELU) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }

@@ -3,7 +3,7 @@
 #include "common.h"
 
 int launch_attention(hipStream_t s, const f16 *q, const f16 *k, const f16 *vt, f16 *o, int B, int heads, int ntp,
-                     int ntok, int ldo);
+                     int ntok, int ldo, int variant = 0);
 
 // LayerNorm(eps) of fp32 rows -> fp16 rows.  Input row r = (b, t) of [B, ntp, D]; only t < ntok are
 // normalised.  drop_cls = 0: output row = input row (same [B, ntp] indexing, ld = D).

@@ -96,6 +96,12 @@ class Ops(_Ctx):
         check(self.lib.pb_op_gemm_bench(self.ctx, M, N, K, tile, epi, iters, C.byref(ms)))
         return ms.value
 
+    def attention_bench(self, B: int, heads: int, N: int, variant: int = 0, iters: int = 10) -> float:
+        """mean milliseconds per launch of the fused attention kernel on device-resident random Q, K, V."""
+        ms = C.c_double()
+        check(self.lib.pb_op_attention_bench(self.ctx, B, heads, N, variant, iters, C.byref(ms)))
+        return ms.value
+
     def layernorm(self, x, g, b) -> np.ndarray:
         x, g, b = _f32(x), _f32(g), _f32(b)
         out = np.empty_like(x)
