@@ -26,7 +26,7 @@ BAND = "mask"
 MODEL = "models/solov2_r101_fpn_3x_coco_20220511_095119-c559a076.pth"
 CLASSES = list(synth.BAND_CLASSES)
 CONFIDENCE_THRESHOLD = 0.5
-BATCH = int(os.environ.get("PRISMA_BATCH", "8"))
+BATCH = int(os.environ.get("PRISMA_BATCH", "32"))
 
 model = None
 data = None

@@ -102,7 +102,7 @@ def mask_leg(args, local_rank, world, rank, dist):
     H, W, B = 1080, 1920, args.mask_frames
     cfg = synth.MASK_CFGS["r101"]
     wts = synth.solov2_weights(cfg)
-    net = engine.MaskMMDet(wts, cfg, device=local_rank, max_batch=min(B, 8))
+    net = engine.MaskMMDet(wts, cfg, device=local_rank, max_batch=min(B, 32))      # chunks of 32: 580 fps against 484 at 8
     frames = synth.frames(B, H, W, seed=70 + rank)
     d_frames = torch.from_numpy(frames).cuda()
     d_out = torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda")
@@ -161,7 +161,7 @@ def pipeline_leg(args, local_rank, world, rank, dist):
     dn = engine.DepthAnything(synth.depth_anything_weights("vitl", seed=1234), "vitl", device=local_rank, max_batch=B)
     fn = engine.FlowRaft(synth.raft_weights(seed=4321), device=local_rank)
     mcfg = synth.MASK_CFGS["r101"]
-    mn = engine.MaskMMDet(synth.solov2_weights(mcfg), mcfg, device=local_rank, max_batch=min(B, 8))
+    mn = engine.MaskMMDet(synth.solov2_weights(mcfg), mcfg, device=local_rank, max_batch=min(B, 32))
     frames = torch.from_numpy(synth.frame_pair_sequence(B, H, W, seed=90 + rank)).cuda()
     d_rgb = torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda")
     d_mm = torch.empty((2, B), dtype=torch.float32, device="cuda")
@@ -178,21 +178,39 @@ def pipeline_leg(args, local_rank, world, rank, dist):
         mn.infer_batch_dev(frames.data_ptr(), B, H, W, 0.5, keep, m_out.data_ptr())
         fn.sync(); mn.sync()
 
-    step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    def step2():            # the two bands BASELINE.json's metric names: depth_anything ViT-L + flow_raft on every 1080p frame
+        dn.infer_dev(frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), d_mm[0].data_ptr(), d_mm[1].data_ptr(), True)
+        dn.sync()
+        fn.infer_sequence_dev(frames.data_ptr(), B, H, W, 0.75, 12, False, 0, f_rgb.data_ptr(), f_mx.data_ptr())
+        fn.sync()
+
+    def timed(fn_step, steps):
+        fn_step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     steps = max(1, args.steps // 2)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = timed(step, steps)
+    dt2 = timed(step2, steps)
     for n_ in (dn, fn, mn):
         n_.close()
     return {"metric": "frames/sec (depth_anything + flow_raft + mask_mmdet on every 1080p frame)", "value": round(world * B * steps / dt, 3),
             "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "frames_per_step_per_gpu": B,
-            "note": "depth first, then flow and mask concurrently on their own streams; flow at --scale 0.75 (816 x 1440), forward pairs only"}
+            "note": "depth first, then flow and mask concurrently on their own streams; flow at --scale 0.75 (816 x 1440), forward pairs only",
+            "depth_plus_flow": {"metric": "frames/sec (depth_anything ViT-L + flow_raft, 1080p)", "value": round(world * B * steps / dt2, 3),
+                                "unit": "frames/s", "ms_per_step": round(dt2 / steps * 1e3, 3),
+                                "note": "both bands on every frame of the clip, one after the other on the same GPU"}}
 
 
 def pmc_traffic(symbol, batch):
@@ -224,7 +242,7 @@ def main():
     ap.add_argument("--latency", action="store_true", help="also time one 1280x720 frame at batch 1 (BASELINE configs[1])")
     ap.add_argument("--host-chunks", type=int, default=4, help="batches pushed through the host-pointer API for the PCIe-inclusive rate (0 = skip)")
     ap.add_argument("--pipeline-frames", type=int, default=32, help="frames per step of the three-band pipeline leg (0 = skip)")
-    ap.add_argument("--mask-frames", type=int, default=8, help="frames per step of the mask_mmdet leg (0 = skip that leg)")
+    ap.add_argument("--mask-frames", type=int, default=32, help="frames per step of the mask_mmdet leg (0 = skip that leg)")
     ap.add_argument("--flow-pairs", type=int, default=8, help="frame pairs per GPU per step of the flow_raft leg (0 = skip)")
     args = ap.parse_args()
 

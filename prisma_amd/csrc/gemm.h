@@ -5,7 +5,7 @@
 enum { A_DENSE = 0, A_CONV = 1 };
 enum { EPI_STD = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_PIXSHUF = 3, EPI_PATCH = 4, EPI_HEAD = 5, EPI_F32 = 6 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
-enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256_SIMPLE = 4, TILE_256x128 = 5, TILE_QUAD = 6 };
+enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256_SIMPLE = 4, TILE_256x128 = 5, TILE_QUAD = 6, TILE_256x128_S3 = 7, TILE_128_S3 = 8 };
 
 struct GemmArgs {
     // operands: A row-major fp16 [M, lda] (dense) or NHWC image (conv); W fp16 [Npad, K], K % 64 == 0

@@ -489,7 +489,17 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
     }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool BUFP = false>
+__device__ __forceinline__ void vm_wait_halftiles(int n) {
+    if (n >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// NS LDS stages (2 or 3).  With 2 the DMA of tile kt+1 has one tile of MFMAs (~0.5k cycles) to land; with 3 the loads run
+// two tiles ahead and the wait before the barrier leaves the newest stage in flight (counted vmcnt, never drained).
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool BUFP = false, int NS = 2>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -631,13 +641,24 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int t = 0; t < TN; ++t) bf[buf][t] = *(const f16x8 *)(sb + b_off[t] + c);
     };
+    static_assert(NS == 2 || (NS == 3 && (NA + NB == 8 || NA + NB == 6 || NA + NB == 4)), "stage count / DMAs per stage");
     stage(0, 0);
+    if constexpr (NS == 3) { if (nk > 1) stage(1, 1); }
+    int cbuf = 0;                                           // buffer of tile kt
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NS == 3 && kt + 1 < nk) vm_wait_halftiles((NA + NB) / 2);   // all but the newest stage (NA + NB DMAs) landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const char *sb = smem + (kt & 1) * STAGE;
+        const char *sb = smem + cbuf * STAGE;
         load_frags(0, sb, 0);
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if constexpr (NS == 3) {
+            int nb = cbuf + 2; nb = nb >= 3 ? nb - 3 : nb;
+            if (kt + 2 < nk) stage(nb, kt + 2);
+            cbuf = cbuf == 2 ? 0 : cbuf + 1;
+        } else {
+            if (kt + 1 < nk) stage(cbuf ^ 1, kt + 1);
+            cbuf ^= 1;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) load_frags((ks + 1) & 1, sb, ks + 1);
@@ -672,13 +693,6 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
 // issuing waves' counted s_waitcnt vmcnt + barrier (RAW); vmcnt never drains to 0 in steady state
 // (8 DMAs = 4 half tiles stay in flight).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void vm_wait_halftiles(int n) {
-    if (n >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (n == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
 
 #define PB_BAR()                                  \
     do {                                          \
@@ -869,10 +883,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if constexpr (EPI == EPI_RESID) resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
     f16x8 fa[2][4], fb0[4], fb1[4];
+    if constexpr (EPI == EPI_RESID) resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
 
-    // prologue: A_0(0) B_0(0) B_1(0) A_1(0) A_0(1) B_0(1)
+    // prologue: A_0(0) B_0(0) B_1(0) A_1(0) A_0(1) B_0(1)   (issuing these BEFORE the residual loads measured 5 % slower on proj)
     stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
     stage_a(0, 1); stage_b(0, 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A_0(0), B_0(0) landed (this wave's share)
@@ -1433,19 +1447,19 @@ int launch_g8b(hipStream_t stream, const GemmArgs &a) {
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool BUFP = false>
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool BUFP = false, int NS = 2>
 int launch_t(hipStream_t stream, const GemmArgs &a) {
     constexpr int NT = WM * WN * 64;
     constexpr int TN = BN / WN / 32;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * (TN * 32 + 4) * 4;
-    constexpr int SMEM = 2 * STAGE > WM * WN * EPIB ? 2 * STAGE : WM * WN * EPIB;
-    if constexpr (!BUFP && BM == 128 && BN == 128) {       // the work-horse small tile also has a buffer-path build
+    constexpr int SMEM = NS * STAGE > WM * WN * EPIB ? NS * STAGE : WM * WN * EPIB;
+    if constexpr (!BUFP && ((BM == 128 && BN == 128) || NS == 3)) {       // the small tiles also have a buffer-path build
         GemmArgs b = a;
         b.bufmode = buffer_mode(AMODE, a, BM);
-        if (b.bufmode) return launch_t<BM, BN, WM, WN, AMODE, EPI, true>(stream, b);
+        if (b.bufmode) return launch_t<BM, BN, WM, WN, AMODE, EPI, true, NS>(stream, b);
     }
-    auto kern = gemm_kernel<BM, BN, WM, WN, AMODE, EPI, BUFP>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, AMODE, EPI, BUFP, NS>;
     static bool attr_set = false;
     if (!attr_set) {
         PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1465,6 +1479,10 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
         if (tile == TILE_256) return a.Wf ? launch_g8b<AMODE, EPI>(s, a) : launch_g8<AMODE, EPI>(s, a);
         if (tile == TILE_256_SIMPLE) return launch_t<256, 256, 2, 4, AMODE, EPI>(s, a);
         if (tile == TILE_256x128) return launch_t<256, 128, 4, 2, AMODE, EPI>(s, a);
+        if constexpr (EPI == EPI_STD || EPI == EPI_F32) {
+            if (tile == TILE_256x128_S3) return launch_t<256, 128, 4, 2, AMODE, EPI, false, 3>(s, a);
+            if (tile == TILE_128_S3) return launch_t<128, 128, 2, 2, AMODE, EPI, false, 3>(s, a);
+        }
         if (tile == TILE_QUAD) return launch_gq<AMODE, EPI>(s, a);
         return launch_t<128, 128, 2, 2, AMODE, EPI>(s, a);
     }
@@ -1514,6 +1532,9 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         // 256x256 needs wide N and enough tiles to fill 256 CUs; the q/k/v split needs D % BN == 0
         const bool wide = a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256;
         tile = wide && (epi != EPI_QKV || a.D % 256 == 0) ? TILE_256 : TILE_128;
+        static int small_tile = -1;
+        if (small_tile < 0) { const char *e = getenv("PB_TILE_SMALL"); small_tile = e ? atoi(e) : TILE_128; }
+        if (tile == TILE_128 && (epi == EPI_STD || epi == EPI_F32) && small_tile != TILE_128) tile = small_tile;
     }
     if (epi == EPI_QKV) PB_CHECK(a.D % (tile == TILE_128 ? 128 : 256) == 0 && a.ntp % 8 == 0, -1, "qkv epilogue: D=%d ntp=%d", a.D, a.ntp);
     if (amode == A_DENSE && epi == EPI_STD && tile > 16) {      // timing-only ablations of the ping-pong kernel
