@@ -40,8 +40,10 @@ class EngineBase {
     // helpers launch on cur_ (the ctx stream unless a derived engine forks work onto side streams)
     void tic(int fam, double flops, double bytes);
     void toc();
+    // fusion hooks of one conv() call: a second (ReLU'd) copy of the output, and the SepConvGRU epilogues (gemm.h ACT_GRU_*)
+    struct ConvFuse { f16 *out2 = nullptr; float *gru_h = nullptr; const f16 *gru_z = nullptr; f16 *gru_rh = nullptr; };
     int conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w, f16 *out, int ldo,
-             int act, int pre_relu = 0, const f16 *add1 = nullptr);
+             int act, int pre_relu = 0, const f16 *add1 = nullptr, const ConvFuse *fuse = nullptr);
     int dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1 = nullptr);
 
     std::map<std::string, const pb_tensor *> tmap_;

@@ -148,13 +148,14 @@ int EngineBase::commit_arena(const char *what) {
 }
 
 int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w, f16 *out,
-                     int ldo, int act, int pre_relu, const f16 *add1) {
+                     int ldo, int act, int pre_relu, const f16 *add1, const ConvFuse *fuse) {
     GemmArgs a;
     a.A = in; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_;
     a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = kw; a.cStride = stride; a.cPad = kh / 2; a.cPadX = kw / 2;
     a.cOH = (H + 2 * (kh / 2) - kh) / stride + 1; a.cOW = (W + 2 * (kw / 2) - kw) / stride + 1;
     a.M = n * a.cOH * a.cOW;
     a.out = out; a.ldo = ldo; a.act = act; a.pre_relu = pre_relu; a.add1 = add1;
+    if (fuse) { a.out2 = fuse->out2; a.gru_h = fuse->gru_h; a.gru_z = fuse->gru_z; a.gru_rh = fuse->gru_rh; }
     PB_CHECK(w.K == kh * kw * cC, PB_ERR_STATE, "conv: packed K %d != %d*%d*%d", w.K, kh, kw, cC);
     tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
     int r = launch_gemm(cur_, A_CONV, EPI_STD, conv_tile, a);

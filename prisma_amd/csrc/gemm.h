@@ -4,7 +4,9 @@
 
 enum { A_DENSE = 0, A_CONV = 1 };
 enum { EPI_STD = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_PIXSHUF = 3, EPI_PATCH = 4, EPI_HEAD = 5, EPI_F32 = 6 };
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4,
+       ACT_GRU_ZR = 5,     // N = 256 = [z | r]: z = sigmoid -> out; r = sigmoid, r * gru_h -> gru_rh (ld 384), nothing to out
+       ACT_GRU_Q = 6 };    // N = 128: q = tanh; h = (1 - z) h + z q with z from gru_z (ld 256), h in gru_h (fp32, ld 128); h -> out
 enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256_SIMPLE = 4, TILE_256x128 = 5, TILE_QUAD = 6, TILE_256x128_S3 = 7, TILE_128_S3 = 8 };
 
 struct GemmArgs {
@@ -28,6 +30,9 @@ struct GemmArgs {
     const f16 *add1 = nullptr, *add2 = nullptr;   // v += add[m*ldo + n]
     int64_t ldo = 0;
     int act = ACT_NONE;
+    float *gru_h = nullptr;        // SepConvGRU fusion (RAFT update.py:55-76), see ACT_GRU_*
+    const f16 *gru_z = nullptr;
+    f16 *gru_rh = nullptr;
     int pre_relu = 0;                     // EPI_STD: v = relu(acc + bias) before the skip adds
     float *out32 = nullptr;               // EPI_F32: out32[m*ldo + n] = (acc + bias) * scale
     float scale = 1.f;

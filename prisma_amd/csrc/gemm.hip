@@ -299,6 +299,7 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
     for (int th = 0; th < TM * 2; ++th) {                   // 8 accumulator registers (= 16 rows) per pass
         const int tm = th >> 1, r0 = (th & 1) * 8;
         int64_t off[8];
+        int mr[8];
         bool ok[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -306,6 +307,7 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
             const int m = wave_m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             ok[q] = !CHECK || (nok && m < p.M);
             const int mc = (!CHECK || m < p.M) ? m : p.M - 1;
+            mr[q] = mc;
             if constexpr (EPI == EPI_QKV) {
                 const int b = mc / p.ntp, t = mc - b * p.ntp;
                 off[q] = ((int64_t)b * p.heads * p.ntp + t) * 64;
@@ -362,6 +364,38 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
             } else if (p.act == ACT_TANH) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] = tanhf(v0[q]); v1[q] = tanhf(v1[q]); }
+            } else if (p.act == ACT_GRU_ZR) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
+                if (wave_n0 >= 128) {            // r columns (a wave's 64 columns are all z or all r): r * h -> gru_rh
+                    f32x2 h[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) h[q] = *(const f32x2 *)(p.gru_h + (int64_t)mr[q] * 128 + (nc - 128));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        f16x2 o;
+                        o[0] = (f16)(v0[q] * h[q][0]); o[1] = (f16)(v1[q] * h[q][1]);
+                        if (!CHECK || ok[q]) *(f16x2 *)(p.gru_rh + (int64_t)mr[q] * 384 + (nc - 128)) = o;
+                    }
+                    continue;
+                }
+            } else if (p.act == ACT_GRU_Q) {
+                f32x2 h[8];
+                f16x2 z[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    h[q] = *(const f32x2 *)(p.gru_h + (int64_t)mr[q] * 128 + nc);
+                    z[q] = *(const f16x2 *)(p.gru_z + (int64_t)mr[q] * 256 + nc);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float z0 = (float)z[q][0], z1 = (float)z[q][1];
+                    f32x2 hn;
+                    hn[0] = (1.f - z0) * h[q][0] + z0 * tanhf(v0[q]);
+                    hn[1] = (1.f - z1) * h[q][1] + z1 * tanhf(v1[q]);
+                    if (!CHECK || ok[q]) *(f32x2 *)(p.gru_h + (int64_t)mr[q] * 128 + nc) = hn;
+                    v0[q] = hn[0]; v1[q] = hn[1];
+                }
             }
         }
         f16 *dst = EPI == EPI_QKV ? qk_base : p.out;

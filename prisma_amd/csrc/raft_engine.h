@@ -40,9 +40,9 @@ class RaftEngine : public EngineBase {
     float *pyr_[4] = {};
     f16 *fpool_[4] = {};                              // avg-pooled target features of levels 1..3
     int pld_[4] = {};
-    float *h32_ = nullptr, *flow_ = nullptr, *delta_ = nullptr, *mask_ = nullptr, *up_ = nullptr;
+    float *h32_ = nullptr, *flow_ = nullptr, *mask_ = nullptr, *up_ = nullptr;
     f16 *hx_ = nullptr, *hx2_ = nullptr, *corr_ = nullptr, *c1_ = nullptr, *corflo_ = nullptr, *fa_ = nullptr, *f1_ = nullptr,
-        *zrb_ = nullptr, *qb_ = nullptr, *fh_ = nullptr, *m0_ = nullptr;
+        *zrb_ = nullptr, *fh_ = nullptr, *m0_ = nullptr;
     unsigned *maxd_ = nullptr;
     int last_nd_ = 0;
     std::map<std::string, Stage> stages_;

@@ -172,12 +172,12 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         }
         const int64_t rows = round_up(ND * P_, 256);
         h32_ = (float *)carve((size_t)rows * 128 * 4); flow_ = (float *)carve((size_t)rows * 2 * 4);
-        delta_ = (float *)carve((size_t)rows * 8 * 4); mask_ = (float *)carve((size_t)rows * 576 * 4);
+        mask_ = (float *)carve((size_t)rows * 576 * 4);
         hx_ = (f16 *)carve((size_t)rows * 384 * 2); hx2_ = (f16 *)carve((size_t)rows * 384 * 2);
         corr_ = (f16 *)carve((size_t)rows * 384 * 2); c1_ = (f16 *)carve((size_t)rows * 256 * 2);
         corflo_ = (f16 *)carve((size_t)rows * 256 * 2); fa_ = (f16 *)carve((size_t)rows * 128 * 2);
         f1_ = (f16 *)carve((size_t)rows * 128 * 2); zrb_ = (f16 *)carve((size_t)rows * 256 * 2);
-        qb_ = (f16 *)carve((size_t)rows * 128 * 2); fh_ = (f16 *)carve((size_t)rows * 256 * 2);
+        fh_ = (f16 *)carve((size_t)rows * 256 * 2);
         m0_ = (f16 *)carve((size_t)rows * 256 * 2);
         up_ = (float *)carve((size_t)ND * sh_ * sw_ * 2 * 4);
         maxd_ = (unsigned *)carve((size_t)ND * 4);
@@ -314,7 +314,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
             }
             tic(F_ELT, 0, 0);
             r = launch_init_state(stream, ctx_ + (int64_t)(i + d) * P_ * 256, h32_ + (int64_t)n * P_ * 128,
-                                  hx_ + (int64_t)n * P_ * 384, flow_ + (int64_t)n * P_ * 2, P_);
+                                  hx_ + (int64_t)n * P_ * 384, hx2_ + (int64_t)n * P_ * 384, flow_ + (int64_t)n * P_ * 2, P_);
             toc();
             if (r) return r;
         }
@@ -334,39 +334,26 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         if (r) return r;
         if ((r = dense(fa_, 128, rows, convf1_, f1_, 128, ACT_RELU))) return r;
         if ((r = conv(f1_, 128, 128, ND, h8_, w8_, 3, 3, 1, convf2_, corflo_ + 192, 256, ACT_RELU))) return r;
-        if ((r = conv(corflo_, 256, 256, ND, h8_, w8_, 3, 3, 1, convm_, hx_ + 256, 384, ACT_RELU))) return r;
+        // HX = [h | inp | motion] feeds the z / r convs, HX2 = [r * h | inp | motion] the q conv: the motion features are
+        // written to both by the producing conv (its ReLU'd second output), r * h and the state update by the GRU epilogues
+        ConvFuse dup; dup.out2 = hx2_ + 256;
+        if ((r = conv(corflo_, 256, 256, ND, h8_, w8_, 3, 3, 1, convm_, hx_ + 256, 384, ACT_RELU, 0, nullptr, &dup))) return r;
         tic(F_ELT, 0, 0);
-        r = launch_put_flow(stream, flow_, hx_, rows);
+        r = launch_put_flow(stream, flow_, hx_, hx2_, rows);
         toc();
         if (r) return r;
         // SepConvGRU: (1 x 5) then (5 x 1)
         for (int half = 0; half < 2; ++half) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1;
-            if ((r = conv(hx_, 384, 384, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_SIGMOID))) return r;
-            tic(F_ELT, 0, 0);
-            r = launch_gru_rh(stream, zrb_, h32_, hx_, hx2_, rows);
-            toc();
-            if (r) return r;
-            if ((r = conv(hx2_, 384, 384, ND, h8_, w8_, kh, kw, 1, q_[half], qb_, 128, ACT_TANH))) return r;
-            tic(F_ELT, 0, 0);
-            r = launch_gru_update(stream, zrb_, qb_, h32_, hx_, rows);
-            toc();
-            if (r) return r;
+            ConvFuse fz; fz.gru_h = h32_; fz.gru_rh = hx2_;
+            if ((r = conv(hx_, 384, 384, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_GRU_ZR, 0, nullptr, &fz))) return r;
+            ConvFuse fq; fq.gru_h = h32_; fq.gru_z = zrb_;
+            if ((r = conv(hx2_, 384, 384, ND, h8_, w8_, kh, kw, 1, q_[half], hx_, 384, ACT_GRU_Q, 0, nullptr, &fq))) return r;
         }
         // FlowHead -> delta_flow (fp32), coords1 += delta
         if ((r = conv(hx_, 128, 384, ND, h8_, w8_, 3, 3, 1, fh1_, fh_, 256, ACT_RELU))) return r;
-        {
-            GemmArgs a;
-            a.A = fh_; a.W = fh2_.w; a.K = fh2_.K; a.N = 8; a.bias = fh2_.bias; a.zero = zero_;
-            a.cH = h8_; a.cW = w8_; a.cC = 256; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cOH = h8_; a.cOW = w8_;
-            a.M = (int)rows; a.out32 = delta_; a.ldo = 8; a.scale = 1.f;
-            tic(F_CONV, 2.0 * rows * 2.0 * fh2_.Kreal, 0);
-            r = launch_gemm(stream, A_CONV, EPI_F32, TILE_128, a);
-            toc();
-            if (r) return r;
-        }
-        tic(F_ELT, 0, 0);
-        r = launch_flow_update(stream, flow_, delta_, rows);
+        tic(F_CONV, 2.0 * rows * 2.0 * fh2_.Kreal, 0);
+        r = launch_flow_head2(stream, fh_, fh2_.w, fh2_.bias, flow_, ND, h8_, w8_);
         toc();
         if (r) return r;
     }

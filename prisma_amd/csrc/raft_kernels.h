@@ -10,14 +10,13 @@ int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 
 int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *stats);
 int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, const float *sb, f16 *out, int B, int HW,
                     int C, int ldc);
-int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, float *flow, int64_t rows);
+int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows);
 int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, int h, int w, int src_ld);
 int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C);
 int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], const int ld[4], const float *flow,
                        int P, int w8, f16 *out, int64_t rows);
-int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, int64_t rows);
-int launch_gru_rh(hipStream_t s, const f16 *zr, const float *h32, const f16 *hx, f16 *hx2, int64_t rows);
-int launch_gru_update(hipStream_t s, const f16 *zr, const f16 *q, float *h32, f16 *hx, int64_t rows);
+int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W);
+int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows);
 int launch_flow_update(hipStream_t s, float *flow, const float *delta, int64_t rows);
 int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, int h8, int w8, int pad_l, int pad_t, int sh,
                     int sw, float *out, unsigned *maxd);

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a
 // cnet output [rows][256] fp16 -> net = tanh(c[:128]) (fp32 master + fp16 copy in HX[:, 0:128]),
 // inp = relu(c[128:]) in HX[:, 128:256]; flow = 0.
 __global__ __launch_bounds__(256) void init_state_kernel(const f16 *__restrict__ c, float *__restrict__ h32,
-                                                          f16 *__restrict__ hx, float *__restrict__ flow, int64_t rows) {
+                                                          f16 *__restrict__ hx, f16 *__restrict__ hx2, float *__restrict__ flow, int64_t rows) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * 32) return;
     const int c8 = (int)(i % 32);
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void init_state_kernel(const f16 *__restrict__
         for (int j = 0; j < 8; ++j) o[j] = (f16)fmaxf((float)v[j], 0.f);
     }
     *(f16x8 *)(hx + r * 384 + c8 * 8) = o;
+    if (c8 >= 16) *(f16x8 *)(hx2 + r * 384 + c8 * 8) = o;      // the context half of the q conv's input [r * h | inp | motion]
     if (c8 == 0) { flow[r * 2] = 0.f; flow[r * 2 + 1] = 0.f; }
 }
 
@@ -251,50 +252,61 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const floa
 }
 
 // flow (fp32 [rows][2]) -> HX[:, 382:384] (the last two input channels of the GRU, update.py:97)
-__global__ void put_flow_kernel(const float *__restrict__ flow, f16 *__restrict__ hx, int64_t rows) {
+__global__ void put_flow_kernel(const float *__restrict__ flow, f16 *__restrict__ hx, f16 *__restrict__ hx2, int64_t rows) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     f16x2 o;
     o[0] = (f16)flow[r * 2]; o[1] = (f16)flow[r * 2 + 1];
     *(f16x2 *)(hx + r * 384 + 382) = o;
+    *(f16x2 *)(hx2 + r * 384 + 382) = o;
 }
 
-// HX2[:, 0:128] = r * h ; HX2[:, 128:384] = HX[:, 128:384]        (zr = [z | r], fp16 [rows][256])
-__global__ __launch_bounds__(256) void gru_rh_kernel(const f16 *__restrict__ zr, const float *__restrict__ h32,
-                                                      const f16 *__restrict__ hx, f16 *__restrict__ hx2, int64_t rows) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * 48) return;
-    const int c8 = (int)(i % 48);
-    const int64_t r = i / 48;
-    if (c8 < 16) {
-        const f16x8 rr = *(const f16x8 *)(zr + r * 256 + 128 + c8 * 8);
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)rr[j] * h32[r * 128 + c8 * 8 + j]);
-        *(f16x8 *)(hx2 + r * 384 + c8 * 8) = o;
-    } else {
-        *(f16x8 *)(hx2 + r * 384 + c8 * 8) = *(const f16x8 *)(hx + r * 384 + c8 * 8);
-    }
-}
+// r * h and h = (1 - z) h + z q are epilogues of the z / r and q convolutions (gemm.h ACT_GRU_ZR / ACT_GRU_Q)
 
-// h = (1 - z) * h + z * q ; fp32 master + fp16 copy into HX[:, 0:128]
-__global__ __launch_bounds__(256) void gru_update_kernel(const f16 *__restrict__ zr, const f16 *__restrict__ q,
-                                                          float *__restrict__ h32, f16 *__restrict__ hx, int64_t rows) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * 16) return;
-    const int c8 = (int)(i % 16);
-    const int64_t r = i / 16;
-    const f16x8 z = *(const f16x8 *)(zr + r * 256 + c8 * 8);
-    const f16x8 qq = *(const f16x8 *)(q + r * 128 + c8 * 8);
-    f16x8 o;
+// FlowHead conv2 (update.py:11-12: 3x3, 256 -> 2) + coords1 += delta_flow, as a direct convolution: with two output
+// channels an implicit GEMM spends 98 % of its MFMAs on padding columns (73 us per iteration at 720p / 8 pairs).  Half a
+// wave per pixel, 8 input channels per lane; the 2 x 9 x 8 weights of a lane stay in registers across the pixel loop,
+// the 3x3 neighbourhood comes through L1 / L2, products accumulate in fp32 (v_dot2_f32_f16), one 5-step butterfly per pixel.
+__global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__ x, const f16 *__restrict__ w, const float *__restrict__ bias,
+                                                          float *__restrict__ flow, int64_t rows, int H, int W) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
+    f16x8 wv[2][9];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float zz = (float)z[j];
-        const float h = (1.f - zz) * h32[r * 128 + c8 * 8 + j] + zz * (float)qq[j];
-        h32[r * 128 + c8 * 8 + j] = h;
-        o[j] = (f16)h;
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[o][t] = *(const f16x8 *)(w + (o * 9 + t) * 256 + cl * 8);
+    const float b0 = bias[0], b1 = bias[1];
+    const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t pp = wid; pp * 2 < rows; pp += nw) {
+        const int64_t p = pp * 2 + half;
+        const bool live = p < rows;
+        const int64_t pc = live ? p : rows - 1;
+        const int hw = H * W;
+        const int64_t img = pc / hw;
+        const int rem = (int)(pc - img * hw), y = rem / W, xx = rem - y * W;
+        const f16 *base = x + img * hw * 256 + cl * 8;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = y + ky - 1, ix = xx + kx - 1;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    const f16x8 v = *(const f16x8 *)(base + ((int64_t)iy * W + ix) * 256);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f16x2 vv = {v[2 * j], v[2 * j + 1]};
+                        const f16x2 w0 = {wv[0][ky * 3 + kx][2 * j], wv[0][ky * 3 + kx][2 * j + 1]};
+                        const f16x2 w1 = {wv[1][ky * 3 + kx][2 * j], wv[1][ky * 3 + kx][2 * j + 1]};
+                        a0 = __builtin_amdgcn_fdot2(vv, w0, a0, false);
+                        a1 = __builtin_amdgcn_fdot2(vv, w1, a1, false);
+                    }
+                }
+            }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
+        if (cl == 0 && live) { flow[p * 2] += a0 + b0; flow[p * 2 + 1] += a1 + b1; }
     }
-    *(f16x8 *)(hx + r * 384 + c8 * 8) = o;
 }
 
 // coords1 += delta_flow  (flow = coords1 - coords0 is what is stored)
@@ -427,8 +439,8 @@ int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, 
                        ldc, 1.f / (float)HW);
     LAUNCH_CHECK();
 }
-int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, float *flow, int64_t rows) {
-    hipLaunchKernelGGL(init_state_kernel, dim3(nblk(rows * 32)), dim3(256), 0, s, c, h32, hx, flow, rows);
+int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows) {
+    hipLaunchKernelGGL(init_state_kernel, dim3(nblk(rows * 32)), dim3(256), 0, s, c, h32, hx, hx2, flow, rows);
     LAUNCH_CHECK();
 }
 int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, int h, int w, int src_ld) {
@@ -447,16 +459,15 @@ int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], 
     hipLaunchKernelGGL(corr_lookup_kernel, dim3(nblk(rows * 36)), dim3(256), 0, s, py, flow, P, w8, out, rows);
     LAUNCH_CHECK();
 }
-int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, int64_t rows) {
-    hipLaunchKernelGGL(put_flow_kernel, dim3(nblk(rows)), dim3(256), 0, s, flow, hx, rows);
+int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows) {
+    hipLaunchKernelGGL(put_flow_kernel, dim3(nblk(rows)), dim3(256), 0, s, flow, hx, hx2, rows);
     LAUNCH_CHECK();
 }
-int launch_gru_rh(hipStream_t s, const f16 *zr, const float *h32, const f16 *hx, f16 *hx2, int64_t rows) {
-    hipLaunchKernelGGL(gru_rh_kernel, dim3(nblk(rows * 48)), dim3(256), 0, s, zr, h32, hx, hx2, rows);
-    LAUNCH_CHECK();
-}
-int launch_gru_update(hipStream_t s, const f16 *zr, const f16 *q, float *h32, f16 *hx, int64_t rows) {
-    hipLaunchKernelGGL(gru_update_kernel, dim3(nblk(rows * 16)), dim3(256), 0, s, zr, q, h32, hx, rows);
+int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W) {
+    const int64_t rows = (int64_t)n * H * W;
+    unsigned g = nblk(rows * 32);
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(flow_head2_kernel, dim3(g), dim3(256), 0, s, x, w, bias, flow, rows, H, W);
     LAUNCH_CHECK();
 }
 int launch_flow_update(hipStream_t s, float *flow, const float *delta, int64_t rows) {
