@@ -35,7 +35,8 @@ class RaftEngine : public EngineBase {
     int *xi_ = nullptr, *xc_ = nullptr, *yi_ = nullptr, *yc_ = nullptr;
     f16 *img_ = nullptr, *colA_ = nullptr;
     f16 *r1_[7] = {}, *r2_[7] = {}, *r3_[7] = {};     // scratch maps at 1/2, 1/4, 1/8 resolution: t1 t2 t3 outA outB stem stem_n
-    float *st_[3] = {};                               // instance-norm statistics
+    float *st_[3] = {};                               // instance-norm statistics {mean, rstd} per (frame, channel)
+    float *stp_ = nullptr;                            // ... and their per-chunk partial sums
     f16 *fmap_ = nullptr, *ctx_ = nullptr;
     float *pyr_[4] = {};
     f16 *fpool_[4] = {};                              // avg-pooled target features of levels 1..3

@@ -163,6 +163,7 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         for (auto &b : r2_) b = (f16 *)carve((size_t)round_up((int64_t)F * h4 * w4, 256) * 128 * 2);
         for (auto &b : r3_) b = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 128 * 2);
         for (auto &b : st_) b = (float *)carve((size_t)F * 256 * 2 * 4);
+        stp_ = (float *)carve((size_t)in_stats_chunks(h2 * w2) * F * 256 * 2 * 4);     // per-chunk partial sums of the largest map
         fmap_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2 + slack);
         ctx_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2);
         for (int l = 0; l < 4; ++l) {
@@ -237,7 +238,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         };
         auto stats = [&](const f16 *t, float *st, int HW, int C) -> int {
             tic(F_ELT, 0, 0);
-            int rr = launch_in_stats(stream, t, F, HW, C, C, st);
+            int rr = launch_in_stats(stream, t, F, HW, C, C, stp_, st);
             toc();
             return rr;
         };

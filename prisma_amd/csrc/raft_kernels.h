@@ -7,7 +7,8 @@ int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, 
                      uint8_t *scaled_out);
 int launch_im2col7_img(hipStream_t s, const f16 *x, int B, int H, int W, int OH, int OW, f16 *out, int Kp);
 int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp);
-int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *stats);
+int in_stats_chunks(int HW);
+int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *part, float *stats);
 int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, const float *sb, f16 *out, int B, int HW,
                     int C, int ldc);
 int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows);

@@ -83,10 +83,13 @@ __global__ __launch_bounds__(256) void im2col7_kernel(const T *__restrict__ x, i
 
 // ------------------------------------------------------------------------------------------------
 // InstanceNorm2d (no affine, eps 1e-5, biased variance over H x W per sample and channel).
-// stats[b][c] = {sum, sum of squares}; blocks cover pixel chunks, threads cover (pixel lane, 8 channels).
+// instance norm (extractor.py norm_fn='instance': nn.InstanceNorm2d defaults - biased variance, eps 1e-5, no affine).
+// Pass 1: every block sums one pixel chunk of one image and writes its {sum, sum of squares} per channel to part[chunk][b][c]
+// - no atomics, so the result does not depend on block scheduling.  Pass 2: one thread per (b, c) adds the chunks in order and
+// stores {mean, 1 / sqrt(var + eps)}.  Threads cover (pixel lane, 8 channels).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void in_stats_kernel(const f16 *__restrict__ x, int HW, int C8, int ldc,
-                                                        float *__restrict__ stats, int chunk) {
+                                                        float *__restrict__ part, int chunk) {
     __shared__ float red[256 * 16];
     const int b = blockIdx.y;
     const int c8 = threadIdx.x % C8, pl = threadIdx.x / C8, npl = blockDim.x / C8;
@@ -108,19 +111,31 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const f16 *__restrict__ x
         for (int o = 1; o < npl; ++o)
 #pragma unroll
             for (int j = 0; j < 16; ++j) red[c8 * 16 + j] += red[(o * C8 + c8) * 16 + j];
+        float *dst = part + (((int64_t)blockIdx.x * gridDim.y + b) * C8 * 8 + c8 * 8) * 2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            atomicAdd(&stats[((int64_t)b * C8 * 8 + c8 * 8 + j) * 2 + 0], red[c8 * 16 + j]);
-            atomicAdd(&stats[((int64_t)b * C8 * 8 + c8 * 8 + j) * 2 + 1], red[c8 * 16 + 8 + j]);
-        }
+        for (int j = 0; j < 8; ++j) { dst[j * 2] = red[c8 * 16 + j]; dst[j * 2 + 1] = red[c8 * 16 + 8 + j]; }
     }
 }
 
-// out = relu( relu(IN(a)) + (b ? (sb ? IN(b) : b) : 0) )   [second relu only when b is given]
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float *__restrict__ part, int nchunk, int BC, float inv_hw,
+                                                           float *__restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        const float2 v = *(const float2 *)(part + ((int64_t)k * BC + i) * 2);
+        s += v.x; q += v.y;
+    }
+    const float mean = s * inv_hw;
+    const float var = fmaxf(q * inv_hw - mean * mean, 0.f);
+    stats[i * 2] = mean;
+    stats[i * 2 + 1] = rsqrtf(var + 1e-5f);
+}
+
+// out = relu( relu(IN(a)) + (b ? (sb ? IN(b) : b) : 0) )   [second relu only when b is given];  sa / sb = {mean, rstd}
 __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a, const float *__restrict__ sa,
                                                         const f16 *__restrict__ bsrc, const float *__restrict__ sb,
-                                                        f16 *__restrict__ out, int B, int HW, int C8, int ldc,
-                                                        float inv_hw) {
+                                                        f16 *__restrict__ out, int B, int HW, int C8, int ldc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * HW * C8) return;
     const int c8 = (int)(i % C8);
@@ -130,22 +145,23 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a
     const f16x8 va = *(const f16x8 *)(a + o);
     f16x8 vb;
     if (bsrc) vb = *(const f16x8 *)(bsrc + o);
+    const f32x4 *st = (const f32x4 *)(sa + ((int64_t)b * C8 * 8 + c8 * 8) * 2);
+    f32x4 ms[4], ms2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ms[j] = st[j];
+    if (bsrc && sb) {
+        const f32x4 *s2 = (const f32x4 *)(sb + ((int64_t)b * C8 * 8 + c8 * 8) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ms2[j] = s2[j];
+    }
     f16x8 r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int c = c8 * 8 + j;
-        const float *st = sa + ((int64_t)b * C8 * 8 + c) * 2;
-        const float mean = st[0] * inv_hw;
-        const float var = fmaxf(st[1] * inv_hw - mean * mean, 0.f);
-        float v = fmaxf(((float)va[j] - mean) * rsqrtf(var + 1e-5f), 0.f);
+        const float mean = ms[j >> 1][(j & 1) * 2], rstd = ms[j >> 1][(j & 1) * 2 + 1];
+        float v = fmaxf(((float)va[j] - mean) * rstd, 0.f);
         if (bsrc) {
             float w = (float)vb[j];
-            if (sb) {
-                const float *s2 = sb + ((int64_t)b * C8 * 8 + c) * 2;
-                const float m2 = s2[0] * inv_hw;
-                const float v2 = fmaxf(s2[1] * inv_hw - m2 * m2, 0.f);
-                w = (w - m2) * rsqrtf(v2 + 1e-5f);
-            }
+            if (sb) w = (w - ms2[j >> 1][(j & 1) * 2]) * ms2[j >> 1][(j & 1) * 2 + 1];
             v = fmaxf(v + w, 0.f);
         }
         r[j] = (f16)v;
@@ -426,17 +442,17 @@ int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 
                        out, Kp);
     LAUNCH_CHECK();
 }
-int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *stats) {
+int in_stats_chunks(int HW) { return (HW + 2047) / 2048; }
+int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *part, float *stats) {
     PB_CHECK(C % 8 == 0 && C <= 256 && 256 % (C / 8) == 0, -1, "instance norm: C=%d unsupported", C);
-    PB_HIP(hipMemsetAsync(stats, 0, (size_t)B * C * 2 * 4, s));
-    const int chunk = 4096;
-    hipLaunchKernelGGL(in_stats_kernel, dim3((HW + chunk - 1) / chunk, B), dim3(256), 0, s, x, HW, C / 8, ldc, stats, chunk);
+    const int chunk = 2048, nchunk = in_stats_chunks(HW);
+    hipLaunchKernelGGL(in_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, HW, C / 8, ldc, part, chunk);
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, nchunk, B * C, 1.f / (float)HW, stats);
     LAUNCH_CHECK();
 }
 int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, const float *sb, f16 *out, int B, int HW,
                     int C, int ldc) {
-    hipLaunchKernelGGL(in_apply_kernel, dim3(nblk((int64_t)B * HW * (C / 8))), dim3(256), 0, s, a, sa, b, sb, out, B, HW, C / 8,
-                       ldc, 1.f / (float)HW);
+    hipLaunchKernelGGL(in_apply_kernel, dim3(nblk((int64_t)B * HW * (C / 8))), dim3(256), 0, s, a, sa, b, sb, out, B, HW, C / 8, ldc);
     LAUNCH_CHECK();
 }
 int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows) {
