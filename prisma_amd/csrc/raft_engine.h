@@ -38,7 +38,9 @@ class RaftEngine : public EngineBase {
     float *st_[3] = {};                               // instance-norm statistics {mean, rstd} per (frame, channel)
     float *stp_ = nullptr;                            // ... and their per-chunk partial sums
     f16 *fmap_ = nullptr, *ctx_ = nullptr;
-    float *pyr_[4] = {};
+    f16 *pyr_[4] = {};                                // correlation volume levels: fp16 [pairs * P, pld_] in 8 x 8 target tiles
+    f16 *ftile_[4] = {};                              // target features / 16 in tile order (B operand of the volume GEMM)
+    int lwp_[4] = {};
     f16 *fpool_[4] = {};                              // avg-pooled target features of levels 1..3
     int pld_[4] = {};
     float *h32_ = nullptr, *flow_ = nullptr, *mask_ = nullptr, *up_ = nullptr;

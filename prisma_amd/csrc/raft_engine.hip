@@ -167,9 +167,12 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         fmap_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2 + slack);
         ctx_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2);
         for (int l = 0; l < 4; ++l) {
-            pld_[l] = (int)round_up(lh_[l] * lw_[l], 8);      // row stride of level l (the GEMM epilogue writes 8-column groups)
-            pyr_[l] = (float *)carve((size_t)ND * P_ * pld_[l] * 4 + slack);
+            // level l of the volume: fp16, one row per source pixel, targets in 8 x 8 tiles (raft_kernels.hip corr_tile_kernel)
+            lwp_[l] = (int)round_up(lw_[l], 8);
+            pld_[l] = (int)round_up(lh_[l], 8) * lwp_[l];
+            pyr_[l] = (f16 *)carve((size_t)ND * P_ * pld_[l] * 2 + slack);
             fpool_[l] = l == 0 ? nullptr : (f16 *)carve((size_t)round_up((int64_t)F * lh_[l] * lw_[l], 256) * 256 * 2 + slack);
+            ftile_[l] = (f16 *)carve((size_t)(F * (int64_t)pld_[l] + 256) * 256 * 2 + slack);
         }
         const int64_t rows = round_up(ND * P_, 256);
         h32_ = (float *)carve((size_t)rows * 128 * 4); flow_ = (float *)carve((size_t)rows * 2 * 4);
@@ -292,9 +295,10 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     // ---- all-pairs correlation pyramid, recurrent state ----
     // corr.py:22-27 pools the volume over the target dims; pooling is linear, so level l is the correlation of fmap1 with the
     // l-times avg-pooled target features: three small pooling passes over [F, P, 256] instead of three over the 4 P^2-byte volume
-    for (int l = 1; l < 4; ++l) {
+    for (int l = 0; l < 4; ++l) {
         tic(F_ELT, 0, 0);
-        r = launch_avgpool2_nhwc(stream, l == 1 ? fmap_ : fpool_[l - 1], fpool_[l], F, lh_[l - 1], lw_[l - 1], 256);
+        if (l > 0) r = launch_avgpool2_nhwc(stream, l == 1 ? fmap_ : fpool_[l - 1], fpool_[l], F, lh_[l - 1], lw_[l - 1], 256);
+        if (!r) r = launch_corr_tile(stream, l == 0 ? fmap_ : fpool_[l], ftile_[l], F, lh_[l], lw_[l], lwp_[l], pld_[l]);
         toc();
         if (r) return r;
     }
@@ -302,14 +306,13 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         for (int d = 0; d < dirs; ++d) {
             const int n = i * dirs + d;
             for (int l = 0; l < 4; ++l) {
-                const int Pl = lh_[l] * lw_[l];
                 GemmArgs a;
                 a.A = fmap_ + (int64_t)(i + d) * P_ * 256; a.lda = 256; a.M = P_;
-                a.W = (l == 0 ? fmap_ + (int64_t)(i + 1 - d) * P_ * 256 : fpool_[l] + (int64_t)(i + 1 - d) * Pl * 256);
+                a.W = ftile_[l] + (int64_t)(i + 1 - d) * pld_[l] * 256;
                 a.K = 256; a.N = pld_[l];
-                a.out32 = pyr_[l] + (int64_t)n * P_ * pld_[l]; a.ldo = pld_[l]; a.scale = 1.f / 16.f; a.zero = zero_;
-                tic(F_GEMM, 2.0 * P_ * (double)Pl * 256, 0);
-                r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
+                a.out = pyr_[l] + (int64_t)n * P_ * pld_[l]; a.ldo = pld_[l]; a.zero = zero_;
+                tic(F_GEMM, 2.0 * P_ * (double)lh_[l] * lw_[l] * 256, 0);
+                r = launch_gemm(stream, A_DENSE, EPI_STD, TILE_AUTO, a);
                 toc();
                 if (r) return r;
             }
@@ -323,7 +326,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     // ---- GRU iterations (raft.py:124-144, update.py:122-136) ----
     for (int it = 0; it < iters; ++it) {
         tic(F_ELT, 0, 0);
-        r = launch_corr_lookup(stream, pyr_, lh_, lw_, pld_, flow_, P_, w8_, corr_, rows);
+        r = launch_corr_lookup(stream, pyr_, lh_, lw_, lwp_, pld_, flow_, P_, w8_, corr_, rows);
         toc();
         if (r) return r;
         // BasicMotionEncoder

@@ -12,10 +12,10 @@ int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, 
 int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, const float *sb, f16 *out, int B, int HW,
                     int C, int ldc);
 int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows);
-int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, int h, int w, int src_ld);
 int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C);
-int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], const int ld[4], const float *flow,
-                       int P, int w8, f16 *out, int64_t rows);
+int launch_corr_tile(hipStream_t s, const f16 *x, f16 *y, int F, int h, int w, int wp, int npad);
+int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], const int w[4], const int wp[4], const int ld[4],
+                       const float *flow, int P, int w8, f16 *out, int64_t rows);
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W);
 int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows);
 int launch_flow_update(hipStream_t s, float *flow, const float *delta, int64_t rows);

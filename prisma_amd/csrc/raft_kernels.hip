@@ -195,18 +195,6 @@ __global__ __launch_bounds__(256) void init_state_kernel(const f16 *__restrict__
     if (c8 == 0) { flow[r * 2] = 0.f; flow[r * 2 + 1] = 0.f; }
 }
 
-// ------------------------------------------------------------------------------------------------
-// correlation pyramid: level l+1 = avg_pool2d(level l, 2, 2) over the target dims (floor on odd sizes)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t NP,
-                                                         int h, int w, int oh, int ow, int src_ld) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NP * oh * ow) return;
-    const int x = (int)(i % ow), y = (int)((i / ow) % oh);
-    const int64_t p = i / ((int64_t)ow * oh);
-    const float *s = src + p * src_ld + (int64_t)(2 * y) * w + 2 * x;
-    dst[i] = 0.25f * ((s[0] + s[1]) + (s[w] + s[w + 1]));
-}
 
 // ------------------------------------------------------------------------------------------------
 // 9x9 x 4-level lookup (corr.py:29-50): channel k = l*81 + i*9 + j samples x = cx/2^l + (i-4),
@@ -231,39 +219,105 @@ __global__ __launch_bounds__(256) void avgpool2_nhwc_kernel(const f16 *__restric
     *(f16x8 *)(y + i * 8) = o;
 }
 
-struct PyrPtrs { const float *lv[4]; int h[4], w[4], ld[4]; };
+// Target features of one pyramid level -> the B operand of the correlation GEMM: scaled by 1/16 (with fmap1 unscaled that
+// is corr.py:58's 1/sqrt(256), exact in fp16) and re-ordered into 8 x 8 pixel tiles, row(y, x) = tile * 64 + (y & 7) * 8 +
+// (x & 7), tile = (y >> 3) * (wp >> 3) + (x >> 3).  The GEMM then writes every source pixel's correlation row in that order,
+// so the 10 x 10 window a lookup reads spans ~5 tiles of 128 bytes instead of 10 rows in 13 lines.  Pad rows stay zero.
+__global__ __launch_bounds__(256) void corr_tile_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int F, int h, int w, int wp,
+                                                         int npad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)F * h * w * 32) return;
+    const int c = (int)(i & 31);
+    const int64_t pix = i >> 5;
+    const int px = (int)(pix % w), py = (int)((pix / w) % h), f = (int)(pix / ((int64_t)w * h));
+    const f16x8 v = *(const f16x8 *)(x + pix * 256 + c * 8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)((float)v[j] * 0.0625f);
+    const int row = ((py >> 3) * (wp >> 3) + (px >> 3)) * 64 + (py & 7) * 8 + (px & 7);
+    *(f16x8 *)(y + ((int64_t)f * npad + row) * 256 + c * 8) = o;
+}
 
+struct PyrPtrs { const f16 *lv[4]; int h[4], w[4], wp[4], ld[4]; };
+
+// CorrBlock.__call__ (corr.py:29-50): 9 x 9 bilinear window on each of the 4 levels around coords / 2^l, zero outside.
+// A block covers 7 pixels, i.e. 28 (pixel, level) windows:
+//   1. the 9 + 9 sample coordinates of every window, once (the reference's normalise / un-normalise round trip costs a
+//      division each);
+//   2. the window itself, 11 rows x 3 tile-row segments of 8 targets, as aligned 16-byte loads from the tiled volume into
+//      the LDS - out-of-range rows / tiles are stored as zeros, which is the reference's padding_mode='zeros';
+//   3. one thread per (pixel, level, window column) blends its 9 rows from the LDS copy (no bounds tests left);
+//   4. the 7 x 324 results leave as whole 8-byte vectors of consecutive channels.
+// (The scalar-gather version of step 3 - 36 two-byte global loads per thread - took 215 us per call at 720p x 8 pairs
+// whatever the volume layout; it was bound by the number of gather instructions.)
 __global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const float *__restrict__ flow, int P, int w8,
                                                            f16 *__restrict__ out, int64_t rows) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * 36) return;
-    const int li = (int)(i % 36);
-    const int64_t r = i / 36;
-    const int l = li / 9, wi = li - l * 9;
-    const int p = (int)(r % P);
-    const float cx = (float)(p % w8) + flow[r * 2], cy = (float)(p / w8) + flow[r * 2 + 1];
-    const float inv = 1.f / (float)(1 << l);
-    const int h = py.h[l], w = py.w[l];
-    const float *vol = py.lv[l] + r * (int64_t)py.ld[l];
-    // reproduce grid_sample's round trip: normalise then un-normalise (align_corners=True)
-    const float x = ((2.f * (cx * inv + (float)(wi - 4)) / (float)(w - 1) - 1.f) + 1.f) * 0.5f * (float)(w - 1);
-    const float x0f = floorf(x);
-    const int x0 = (int)x0f;
-    const float ax = x - x0f;
-    const bool okx0 = (unsigned)x0 < (unsigned)w, okx1 = (unsigned)(x0 + 1) < (unsigned)w;
-    f16 *dst = out + r * 384 + l * 81 + wi * 9;
+    __shared__ __attribute__((aligned(16))) f16 win[28 * 11 * 24];
+    __shared__ __attribute__((aligned(8))) f16 tile[7 * 324];
+    __shared__ int ci[28 * 18];
+    __shared__ float ca[28 * 18];
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 7;
+    for (int idx = t; idx < 28 * 18; idx += 256) {
+        const int k = idx % 18, pl = idx / 18, l = pl & 3, pr = pl >> 2;
+        const int64_t r = r0 + pr < rows ? r0 + pr : rows - 1;
+        const int p = (int)(r % P);
+        const float inv = 1.f / (float)(1 << l);
+        float v;
+        if (k < 9) {
+            const float cx = (float)(p % w8) + flow[r * 2];
+            const int w = py.w[l];
+            // reproduce grid_sample's round trip: normalise then un-normalise (align_corners=True)
+            v = ((2.f * (cx * inv + (float)(k - 4)) / (float)(w - 1) - 1.f) + 1.f) * 0.5f * (float)(w - 1);
+        } else {
+            const float cy = (float)(p / w8) + flow[r * 2 + 1];
+            const int h = py.h[l];
+            v = ((2.f * (cy * inv + (float)(k - 13)) / (float)(h - 1) - 1.f) + 1.f) * 0.5f * (float)(h - 1);
+        }
+        const float f = floorf(v);
+        // far out-of-range samples are all zero anyway: clamp so that the integer arithmetic below cannot overflow
+        ci[idx] = (int)fminf(fmaxf(f, -65536.f), 65536.f);
+        ca[idx] = v - f;
+    }
+    __syncthreads();
+    for (int idx = t; idx < 28 * 33; idx += 256) {
+        const int seg = idx % 3, row = (idx / 3) % 11, pl = idx / 33, l = pl & 3, pr = pl >> 2;
+        const int64_t r = r0 + pr < rows ? r0 + pr : rows - 1;
+        const int hp8 = py.ld[l] / py.wp[l], wt = py.wp[l] >> 3;
+        const int y = ci[pl * 18 + 9] + row, tx = (ci[pl * 18] >> 3) + seg;
+        f16x8 v;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const float y = ((2.f * (cy * inv + (float)(j - 4)) / (float)(h - 1) - 1.f) + 1.f) * 0.5f * (float)(h - 1);
-        const float y0f = floorf(y);
-        const int y0 = (int)y0f;
-        const float ay = y - y0f;
-        const bool oky0 = (unsigned)y0 < (unsigned)h, oky1 = (unsigned)(y0 + 1) < (unsigned)h;
-        const float v00 = (oky0 && okx0) ? vol[y0 * w + x0] : 0.f;
-        const float v01 = (oky0 && okx1) ? vol[y0 * w + x0 + 1] : 0.f;
-        const float v10 = (oky1 && okx0) ? vol[(y0 + 1) * w + x0] : 0.f;
-        const float v11 = (oky1 && okx1) ? vol[(y0 + 1) * w + x0 + 1] : 0.f;
-        dst[j] = (f16)(v00 * (1.f - ax) * (1.f - ay) + v01 * ax * (1.f - ay) + v10 * (1.f - ax) * ay + v11 * ax * ay);
+        for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
+        if ((unsigned)y < (unsigned)hp8 && (unsigned)tx < (unsigned)wt)
+            v = *(const f16x8 *)(py.lv[l] + r * (int64_t)py.ld[l] + ((y >> 3) * wt + tx) * 64 + (y & 7) * 8);
+        *(f16x8 *)(win + (pl * 11 + row) * 24 + seg * 8) = v;
+    }
+    __syncthreads();
+    if (t < 252) {
+        const int li = t % 36, pr = t / 36;
+        const int l = li / 9, wi = li - l * 9;
+        const int pl = pr * 4 + l, cb = pl * 18;
+        const int xb = ci[cb] & ~7, yb = ci[cb + 9];
+        int xo = ci[cb + wi] - xb;
+        const float ax = ca[cb + wi];
+        xo = xo < 0 ? 0 : (xo > 22 ? 22 : xo);                  // always in range (spread of the 9 floors <= 9); defensive
+        const f16 *wp = win + pl * 11 * 24 + xo;
+        f16 *dst = tile + pr * 324 + l * 81 + wi * 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            int yo = ci[cb + 9 + j] - yb;
+            const float ay = ca[cb + 9 + j];
+            yo = yo < 0 ? 0 : (yo > 9 ? 9 : yo);
+            const float v00 = (float)wp[yo * 24], v01 = (float)wp[yo * 24 + 1];
+            const float v10 = (float)wp[yo * 24 + 24], v11 = (float)wp[yo * 24 + 25];
+            dst[j] = (f16)(v00 * (1.f - ax) * (1.f - ay) + v01 * ax * (1.f - ay) + v10 * (1.f - ax) * ay + v11 * ax * ay);
+        }
+    }
+    __syncthreads();
+    for (int v = t; v < 7 * 81; v += 256) {
+        const int pr = v / 81, c4 = v - pr * 81;
+        const int64_t r = r0 + pr;
+        if (r < rows) *(f16x4 *)(out + r * 384 + c4 * 4) = *(const f16x4 *)(tile + pr * 324 + c4 * 4);
     }
 }
 
@@ -284,7 +338,9 @@ __global__ void put_flow_kernel(const float *__restrict__ flow, f16 *__restrict_
 // wave per pixel, 8 input channels per lane; the 2 x 9 x 8 weights of a lane stay in registers across the pixel loop,
 // the 3x3 neighbourhood comes through L1 / L2, products accumulate in fp32 (v_dot2_f32_f16), one 5-step butterfly per pixel.
 __global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__ x, const f16 *__restrict__ w, const float *__restrict__ bias,
-                                                          float *__restrict__ flow, int64_t rows, int H, int W) {
+                                                          float *__restrict__ flow, int nseg, int H, int W, int segw) {
+    // half a wave walks a horizontal run of `segw` pixels with a 3 x 3 window of channel vectors in registers: every step
+    // loads one new column (3 vectors) instead of 9
     const int lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
     f16x8 wv[2][9];
 #pragma unroll
@@ -292,36 +348,50 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__
 #pragma unroll
         for (int t = 0; t < 9; ++t) wv[o][t] = *(const f16x8 *)(w + (o * 9 + t) * 256 + cl * 8);
     const float b0 = bias[0], b1 = bias[1];
-    const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t pp = wid; pp * 2 < rows; pp += nw) {
-        const int64_t p = pp * 2 + half;
-        const bool live = p < rows;
-        const int64_t pc = live ? p : rows - 1;
-        const int hw = H * W;
-        const int64_t img = pc / hw;
-        const int rem = (int)(pc - img * hw), y = rem / W, xx = rem - y * W;
-        const f16 *base = x + img * hw * 256 + cl * 8;
+    const int wid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int seg = wid * 2 + half;                    // segment = (image, row, run of segw pixels)
+    if (seg >= nseg) return;
+    const int spr = (W + segw - 1) / segw;             // segments per row
+    const int sx = seg % spr, y = (seg / spr) % H, img = seg / (spr * H);
+    const int xa = sx * segw, xb = xa + segw < W ? xa + segw : W;
+    const f16 *base = x + ((int64_t)img * H * W) * 256 + cl * 8;
+    f16x8 zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (f16)0.f;
+    auto col = [&](int ix, f16x8 (&c)[3]) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+            c[ky] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? *(const f16x8 *)(base + ((int64_t)iy * W + ix) * 256) : zero;
+        }
+    };
+    f16x8 c0[3], c1[3], c2[3];
+    col(xa - 1, c0); col(xa, c1);
+    for (int ix = xa; ix < xb; ++ix) {
+        col(ix + 1, c2);
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int iy = y + ky - 1, ix = xx + kx - 1;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                    const f16x8 v = *(const f16x8 *)(base + ((int64_t)iy * W + ix) * 256);
+                const f16x8 v = kx == 0 ? c0[ky] : (kx == 1 ? c1[ky] : c2[ky]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f16x2 vv = {v[2 * j], v[2 * j + 1]};
-                        const f16x2 w0 = {wv[0][ky * 3 + kx][2 * j], wv[0][ky * 3 + kx][2 * j + 1]};
-                        const f16x2 w1 = {wv[1][ky * 3 + kx][2 * j], wv[1][ky * 3 + kx][2 * j + 1]};
-                        a0 = __builtin_amdgcn_fdot2(vv, w0, a0, false);
-                        a1 = __builtin_amdgcn_fdot2(vv, w1, a1, false);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const f16x2 vv = {v[2 * j], v[2 * j + 1]};
+                    const f16x2 w0 = {wv[0][ky * 3 + kx][2 * j], wv[0][ky * 3 + kx][2 * j + 1]};
+                    const f16x2 w1 = {wv[1][ky * 3 + kx][2 * j], wv[1][ky * 3 + kx][2 * j + 1]};
+                    a0 = __builtin_amdgcn_fdot2(vv, w0, a0, false);
+                    a1 = __builtin_amdgcn_fdot2(vv, w1, a1, false);
                 }
             }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
-        if (cl == 0 && live) { flow[p * 2] += a0 + b0; flow[p * 2 + 1] += a1 + b1; }
+        if (cl == 0) {
+            const int64_t p = ((int64_t)img * H + y) * W + ix;
+            flow[p * 2] += a0 + b0; flow[p * 2 + 1] += a1 + b1;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) { c0[ky] = c1[ky]; c1[ky] = c2[ky]; }
     }
 }
 
@@ -459,20 +529,20 @@ int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2
     hipLaunchKernelGGL(init_state_kernel, dim3(nblk(rows * 32)), dim3(256), 0, s, c, h32, hx, hx2, flow, rows);
     LAUNCH_CHECK();
 }
-int launch_corr_pool(hipStream_t s, const float *src, float *dst, int64_t NP, int h, int w, int src_ld) {
-    hipLaunchKernelGGL(corr_pool_kernel, dim3(nblk(NP * (h / 2) * (w / 2))), dim3(256), 0, s, src, dst, NP, h, w, h / 2, w / 2, src_ld);
-    LAUNCH_CHECK();
-}
 int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C) {
     const int OH = H / 2, OW = W / 2;
     hipLaunchKernelGGL(avgpool2_nhwc_kernel, dim3(nblk((int64_t)n * OH * OW * (C / 8))), dim3(256), 0, s, x, y, n, H, W, OH, OW, C / 8);
     LAUNCH_CHECK();
 }
-int launch_corr_lookup(hipStream_t s, const float *const lv[4], const int h[4], const int w[4], const int ld[4], const float *flow,
-                       int P, int w8, f16 *out, int64_t rows) {
+int launch_corr_tile(hipStream_t s, const f16 *x, f16 *y, int F, int h, int w, int wp, int npad) {
+    hipLaunchKernelGGL(corr_tile_kernel, dim3(nblk((int64_t)F * h * w * 32)), dim3(256), 0, s, x, y, F, h, w, wp, npad);
+    LAUNCH_CHECK();
+}
+int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], const int w[4], const int wp[4], const int ld[4],
+                       const float *flow, int P, int w8, f16 *out, int64_t rows) {
     PyrPtrs py;
-    for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; py.ld[i] = ld[i]; }
-    hipLaunchKernelGGL(corr_lookup_kernel, dim3(nblk(rows * 36)), dim3(256), 0, s, py, flow, P, w8, out, rows);
+    for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; py.wp[i] = wp[i]; py.ld[i] = ld[i]; }
+    hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)((rows + 6) / 7)), dim3(256), 0, s, py, flow, P, w8, out, rows);
     LAUNCH_CHECK();
 }
 int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows) {
@@ -480,10 +550,8 @@ int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t
     LAUNCH_CHECK();
 }
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W) {
-    const int64_t rows = (int64_t)n * H * W;
-    unsigned g = nblk(rows * 32);
-    if (g > 256 * 16) g = 256 * 16;
-    hipLaunchKernelGGL(flow_head2_kernel, dim3(g), dim3(256), 0, s, x, w, bias, flow, rows, H, W);
+    const int segw = 16, nseg = n * H * ((W + segw - 1) / segw);
+    hipLaunchKernelGGL(flow_head2_kernel, dim3((nseg + 7) / 8), dim3(256), 0, s, x, w, bias, flow, nseg, H, W, segw);
     LAUNCH_CHECK();
 }
 int launch_flow_update(hipStream_t s, float *flow, const float *delta, int64_t rows) {
