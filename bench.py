@@ -24,6 +24,53 @@ GFLOP_PER_FRAME = 2583.1          # ViT-L @ 518x924, mul
 PEAK_F16_TFLOPS = 2500.0          # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 
 
+class Ranks:
+    """torch.distributed glue of the bench: one process per GPU over RCCL ("nccl"); PRISMA_BENCH_BACKEND=gloo runs the same
+    control flow with CPU-side collectives so that world_size > 1 can be exercised on a box with fewer GPUs than ranks."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        ngpu = max(torch.cuda.device_count(), 1)
+        self.device = int(os.environ.get("LOCAL_RANK", "0")) % ngpu
+        self.backend = os.environ.get("PRISMA_BENCH_BACKEND", "nccl")
+        self.dist = None
+        torch.cuda.set_device(self.device)
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
+            else:
+                dist.init_process_group(self.backend)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_gather(self, out, src):
+        """out [world, ...] <- src [...] of every rank (device tensors; staged through the host for a CPU backend)"""
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(out.view(-1), src.view(-1))
+        else:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(o.view(-1), src.detach().cpu().view(-1))
+            out.copy_(o)
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
 def cpu_baseline(weights, cfg, H, W):
     """Oracle (CPU restatement of the reference, torch fp32 on the host cores) on a bounded sample."""
     from oracle import depth_oracle as O
@@ -40,7 +87,8 @@ def cpu_baseline(weights, cfg, H, W):
                       f"{dt:.1f} s wall"}
 
 
-def flow_leg(args, local_rank, world, rank, dist):
+def flow_leg(args, R):
+    local_rank, world, rank = R.device, R.world, R.rank
     """Secondary line: flow_raft on 1280x720 frames, 12 GRU iterations, 8 forward pairs per GPU per step
     (BASELINE.json configs[2]); no --scale so the reference's 1559.6 GFLOP/pair-direction figure applies."""
     from prisma_amd import engine, synth
@@ -58,15 +106,13 @@ def flow_leg(args, local_rank, world, rank, dist):
         net.sync()
 
     step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    R.barrier()
     steps = max(1, args.steps // 2)
     t0 = time.perf_counter()
     for _ in range(steps):                      # timed without per-kernel events: ~300 small launches per step
         step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    R.barrier()
+    dt = R.max_over_ranks(time.perf_counter() - t0)
     net.set_profiling(timing=True)              # the per-kernel breakdown comes from extra, untimed steps
     fam = {}
     for _ in range(steps):
@@ -94,7 +140,8 @@ def flow_leg(args, local_rank, world, rank, dist):
     return out
 
 
-def mask_leg(args, local_rank, world, rank, dist):
+def mask_leg(args, R):
+    local_rank, world, rank = R.device, R.world, R.rank
     """Third line: the mask band (SOLOv2 R-101 FPN) on 1920x1080 frames, args.mask_frames per GPU per step, resident in
     HBM (BASELINE.json configs[4] runs it beside depth and flow).  FLOP count: the convolution / GEMM launches'
     own multiply-adds (the dynamic convolution depends on how many grid cells fire)."""
@@ -114,15 +161,13 @@ def mask_leg(args, local_rank, world, rank, dist):
         net.sync()
 
     step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    R.barrier()
     steps = max(1, args.steps // 2)
     t0 = time.perf_counter()
     for _ in range(steps):                      # timed without per-kernel events: ~300 small launches per step
         step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    R.barrier()
+    dt = R.max_over_ranks(time.perf_counter() - t0)
     net.set_profiling(timing=True)              # the per-kernel breakdown comes from extra, untimed steps
     fam = {}
     for _ in range(steps):
@@ -152,7 +197,8 @@ def mask_leg(args, local_rank, world, rank, dist):
     return out
 
 
-def pipeline_leg(args, local_rank, world, rank, dist):
+def pipeline_leg(args, R):
+    local_rank, world, rank = R.device, R.world, R.rank
     """BASELINE.json configs[4]: every frame of a 1080p clip goes through depth_anything, flow_raft (forward pairs, the band's
     default --scale 0.75, 12 iterations) and mask_mmdet, fused pre / post-processing, frames resident in HBM.  One step =
     args.pipeline_frames frames through the three bands back to back on this rank's GPU."""
@@ -186,19 +232,12 @@ def pipeline_leg(args, local_rank, world, rank, dist):
 
     def timed(fn_step, steps):
         fn_step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        R.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn_step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        R.barrier()
+        return R.max_over_ranks(time.perf_counter() - t0)
 
     steps = max(1, args.steps // 2)
     dt = timed(step, steps)
@@ -246,16 +285,10 @@ def main():
     ap.add_argument("--flow-pairs", type=int, default=8, help="frame pairs per GPU per step of the flow_raft leg (0 = skip)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the bands engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    R = Ranks()
+    rank, local_rank, world = R.rank, R.device, R.world
 
     from prisma_amd import engine, synth
     cfg = synth.DEPTH_CFGS[args.encoder]
@@ -278,12 +311,9 @@ def main():
         net.infer_dev(d_frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), d_mm[0].data_ptr(), d_mm[1].data_ptr(), True)
         net.sync()
         if world > 1:
-            dist.all_gather_into_tensor(gathered.view(-1), d_mm.view(-1))
+            R.all_gather(gathered, d_mm)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = R.barrier
 
     for _ in range(args.warmup):
         step()
@@ -298,10 +328,7 @@ def main():
     dt = time.perf_counter() - t0
     fam = {s["name"]: {k: s[k] for k in ("ms", "flops", "bytes", "launches")} for s in net.kernel_stats()}
     net.set_profiling(timing=False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = R.max_over_ranks(dt)
 
     # latency of BASELINE.json configs[1]: one 1280x720 frame, batch 1 (rank 0 only, outside the timed region above)
     lat_b1 = None
@@ -327,9 +354,9 @@ def main():
         assert h_rgb.shape == hf.shape and np.isfinite(h_mn).all()
         del hf, h_rgb
     net.close()
-    flow = flow_leg(args, local_rank, world, rank, dist) if args.flow_pairs > 0 else None
-    mask = mask_leg(args, local_rank, world, rank, dist) if args.mask_frames > 0 else None
-    pipe = pipeline_leg(args, local_rank, world, rank, dist) if args.pipeline_frames > 1 else None
+    flow = flow_leg(args, R) if args.flow_pairs > 0 else None
+    mask = mask_leg(args, R) if args.mask_frames > 0 else None
+    pipe = pipeline_leg(args, R) if args.pipeline_frames > 1 else None
 
     if rank == 0:
         fps = world * B * args.steps / dt
@@ -377,9 +404,7 @@ def main():
         if pipe:
             out["pipeline"] = pipe
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":
