@@ -71,20 +71,24 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def cpu_baseline(weights, cfg, H, W):
-    """Oracle (CPU restatement of the reference, torch fp32 on the host cores) on a bounded sample."""
+def cpu_baseline(weights, cfg, rweights, frames, flow_scale, flow_iters):
+    """Oracle (CPU restatement of the reference, torch fp32 on the host cores) on a bounded sample: one frame through the depth
+    band and one frame pair through the flow band (as the reference's infer does it: forward and backward in one batch of 2)."""
     from oracle import depth_oracle as O
-    from prisma_amd import synth
+    from oracle import raft_oracle as RO
     cores = min(os.cpu_count() or 1, 32)      # torch CPU GEMMs stop scaling (and regress) past ~32 threads
     torch.set_num_threads(cores)
-    frame = synth.frames(1, H, W, seed=99)[0]
+    H, W = frames.shape[1:3]
     t0 = time.time()
-    d = O.infer(weights, frame, cfg.depth, cfg.heads)
+    d = O.infer(weights, frames[0], cfg.depth, cfg.heads)
     O.encode_depth_video(d, flip=True)
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 frame {W}x{H}, oracle/depth_oracle.py (torch fp32 CPU restatement of the reference), "
-                      f"{dt:.1f} s wall"}
+    t1 = time.time()
+    RO.infer_pair(rweights, frames[0], frames[1], scale=flow_scale, iters=flow_iters)
+    t2 = time.time()
+    return {"value": round(1.0 / (t2 - t0), 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 frame {W}x{H} through oracle/depth_oracle.py ({t1 - t0:.1f} s) + 1 frame pair through oracle/raft_oracle.py "
+                      f"(--scale {flow_scale}, {flow_iters} iterations, both directions like the reference's infer: {t2 - t1:.1f} s); "
+                      f"torch fp32 CPU restatements of the reference"}
 
 
 def flow_leg(args, R):
@@ -223,11 +227,6 @@ def pipeline_leg(args, R):
         mn.infer_batch_dev(frames.data_ptr(), B, H, W, 0.5, keep, m_out.data_ptr())
         dn.sync(); fn.sync(); mn.sync()
 
-    def step2():            # the two bands BASELINE.json's metric names: depth_anything ViT-L + flow_raft on every 1080p frame
-        dn.infer_dev(frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), d_mm[0].data_ptr(), d_mm[1].data_ptr(), True)
-        fn.infer_sequence_dev(frames.data_ptr(), B, H, W, 0.75, 12, False, 0, f_rgb.data_ptr(), f_mx.data_ptr())
-        dn.sync(); fn.sync()
-
     def timed(fn_step, steps):
         fn_step()
         R.barrier()
@@ -239,15 +238,11 @@ def pipeline_leg(args, R):
 
     steps = max(1, args.steps // 2)
     dt = timed(step, steps)
-    dt2 = timed(step2, steps)
     for n_ in (dn, fn, mn):
         n_.close()
     return {"metric": "frames/sec (depth_anything + flow_raft + mask_mmdet on every 1080p frame)", "value": round(world * B * steps / dt, 3),
             "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "frames_per_step_per_gpu": B,
-            "note": "the three bands enqueued together on their own streams (tools/pipeline_order_bench.py: 121 frames/s against 116 one after the other); flow at --scale 0.75 (816 x 1440), forward pairs only",
-            "depth_plus_flow": {"metric": "frames/sec (depth_anything ViT-L + flow_raft, 1080p)", "value": round(world * B * steps / dt2, 3),
-                                "unit": "frames/s", "ms_per_step": round(dt2 / steps * 1e3, 3),
-                                "note": "both bands on every frame of the clip, enqueued together on their own streams (152 frames/s against 145 one after the other)"}}
+            "note": "the three bands enqueued together on their own streams (tools/pipeline_order_bench.py: 121 frames/s against 116 one after the other); flow at --scale 0.75 (816 x 1440), forward pairs only"}
 
 
 def pmc_traffic(symbol, batch):
@@ -269,19 +264,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="frames of the clip per GPU per step")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--encoder", default="vitl")
+    ap.add_argument("--flow-scale", type=float, default=0.75, help="flow_raft --scale (the band's default)")
+    ap.add_argument("--flow-iters", type=int, default=12, help="GRU iterations (BASELINE.json configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256, 4 simple 256")
     ap.add_argument("--conv-tile", type=int, default=0)
+    ap.add_argument("--all-legs", action="store_true", help="also run the per-band legs below with their usual sizes (depth only, flow 720p, mask, pipeline, PCIe)")
     ap.add_argument("--latency", action="store_true", help="also time one 1280x720 frame at batch 1 (BASELINE configs[1])")
-    ap.add_argument("--host-chunks", type=int, default=4, help="batches pushed through the host-pointer API for the PCIe-inclusive rate (0 = skip)")
-    ap.add_argument("--pipeline-frames", type=int, default=32, help="frames per step of the three-band pipeline leg (0 = skip)")
-    ap.add_argument("--mask-frames", type=int, default=32, help="frames per step of the mask_mmdet leg (0 = skip that leg)")
-    ap.add_argument("--flow-pairs", type=int, default=8, help="frame pairs per GPU per step of the flow_raft leg (0 = skip)")
+    ap.add_argument("--host-chunks", type=int, default=0, help="batches pushed through the host-pointer API for the PCIe-inclusive rate")
+    ap.add_argument("--pipeline-frames", type=int, default=0, help="frames per step of the three-band pipeline leg")
+    ap.add_argument("--mask-frames", type=int, default=0, help="frames per step of the mask_mmdet leg")
+    ap.add_argument("--flow-pairs", type=int, default=0, help="frame pairs per GPU per step of the 720p flow_raft leg (BASELINE configs[2])")
+    ap.add_argument("--depth-leg", action="store_true", help="depth_anything alone at the same batch (the shape north_star's roofline target names)")
     args = ap.parse_args()
+    if args.all_legs:
+        args.latency = args.depth_leg = True
+        args.host_chunks, args.pipeline_frames, args.mask_frames, args.flow_pairs = 4, 32, 32, 8
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the bands engine has no CPU path")
@@ -291,42 +293,66 @@ def main():
     from prisma_amd import engine, synth
     cfg = synth.DEPTH_CFGS[args.encoder]
     weights = synth.depth_anything_weights(cfg, seed=1234)
+    rweights = synth.raft_weights(seed=4321)
     B, H, W = args.batch, args.height, args.width
-    net = engine.DepthAnything(weights, cfg, device=local_rank, max_batch=B)
-    net.set_option("gemm_tile", args.gemm_tile)
-    net.set_option("conv_tile", args.conv_tile)
+    dn = engine.DepthAnything(weights, cfg, device=local_rank, max_batch=B)
+    dn.set_option("gemm_tile", args.gemm_tile)
+    dn.set_option("conv_tile", args.conv_tile)
+    fn = engine.FlowRaft(rweights, device=local_rank)
 
-    # synthetic frames, distinct per rank, resident in HBM before the timed region
-    base = synth.frames(min(B, 4), H, W, seed=1000 + rank)
-    frames = np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B]
+    # one synthetic clip per rank (a seeded noise texture shifted by a known step per frame, so the flow is not degenerate),
+    # resident in HBM before the timed region; one step = both bands over the whole clip
+    frames = synth.frame_pair_sequence(B, H, W, seed=1000 + rank)
     d_frames = torch.from_numpy(frames).cuda()
     d_rgb = torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda")
-    d_mm = torch.empty((2, B), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((world, 2, B), dtype=torch.float32, device="cuda") if world > 1 else None
+    sh, sw = engine.flow_out_size(H, W, args.flow_scale)
+    f_rgb = torch.empty((B - 1, sh, sw, 3), dtype=torch.uint8, device="cuda")
+    scal = torch.zeros((3, B), dtype=torch.float32, device="cuda")      # per-frame depth min, depth max, flow max displacement
+    gathered = torch.empty((world, 3, B), dtype=torch.float32, device="cuda") if world > 1 else None
     torch.cuda.synchronize()
 
     def step():
-        net.infer_dev(d_frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), d_mm[0].data_ptr(), d_mm[1].data_ptr(), True)
-        net.sync()
+        # the two bands are independent: both are enqueued on their own streams and share the GPU
+        dn.infer_dev(d_frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
+        fn.infer_sequence_dev(d_frames.data_ptr(), B, H, W, args.flow_scale, args.flow_iters, False, 0, f_rgb.data_ptr(), scal[2].data_ptr())
+        dn.sync(); fn.sync()
         if world > 1:
-            R.all_gather(gathered, d_mm)
-
-    barrier = R.barrier
+            R.all_gather(gathered, scal)                                  # the only exchange: 12 bytes per frame
 
     for _ in range(args.warmup):
         step()
-    # every launch of the timed region is bracketed by HIP events on the ctx stream; the records accumulate over the K
+    # every launch of the timed region is bracketed by HIP events on its band's stream; the records accumulate over the K
     # steps and are read once after the closing barrier, so no event query sits inside the timed region
-    net.set_profiling(timing=True, accumulate=True)
-    barrier()
+    dn.set_profiling(timing=True, accumulate=True)
+    fn.set_profiling(timing=True, accumulate=True)
+    R.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
+    R.barrier()
     dt = time.perf_counter() - t0
-    fam = {s["name"]: {k: s[k] for k in ("ms", "flops", "bytes", "launches")} for s in net.kernel_stats()}
-    net.set_profiling(timing=False)
+    fam = {}
+    for band, net_ in (("depth", dn), ("flow", fn)):
+        for s in net_.kernel_stats():
+            fam[band + "/" + s["name"]] = {k: s[k] for k in ("ms", "flops", "bytes", "launches")}
+        net_.set_profiling(timing=False)
     dt = R.max_over_ranks(dt)
+    # the same launches with each band alone on the GPU (untimed extra steps): what the kernels do when nothing competes
+    alone = {}
+    if rank == 0:
+        dn.set_profiling(timing=True, accumulate=True)
+        fn.set_profiling(timing=True, accumulate=True)
+        for _ in range(2):
+            dn.infer_dev(d_frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
+            dn.sync()
+            fn.infer_sequence_dev(d_frames.data_ptr(), B, H, W, args.flow_scale, args.flow_iters, False, 0, f_rgb.data_ptr(), scal[2].data_ptr())
+            fn.sync()
+        for band, net_ in (("depth", dn), ("flow", fn)):
+            for s in net_.kernel_stats():
+                alone[band + "/" + s["name"]] = {k: s[k] for k in ("ms", "flops", "bytes", "launches")}
+            net_.set_profiling(timing=False)
+    sc = scal.cpu().numpy()
+    assert np.isfinite(sc).all() and (sc[1] > sc[0]).all() and (sc[2, :B - 1] > 0).all(), "degenerate depth range / flow"
 
     # latency of BASELINE.json configs[1]: one 1280x720 frame, batch 1 (rank 0 only, outside the timed region above)
     lat_b1 = None
@@ -336,67 +362,101 @@ def main():
         for i in range(8):
             if i == 3:
                 torch.cuda.synchronize(); t1 = time.perf_counter()
-            net.infer_dev(f1.data_ptr(), 1, 720, 1280, 0, r1.data_ptr(), d_mm[0].data_ptr(), d_mm[1].data_ptr(), True)
-            net.sync()
+            dn.infer_dev(f1.data_ptr(), 1, 720, 1280, 0, r1.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
+            dn.sync()
         lat_b1 = (time.perf_counter() - t1) / 5 * 1e3
     # PCIe-inclusive rate (never `value`): the host-pointer entry point over 4 chunks from pageable numpy memory -
     # pinned staging + H2D / compute / D2H on three streams (abi.hip pb_depth_infer_batch)
     host_fps = None
     if rank == 0 and args.host_chunks > 0:
         hf = np.concatenate([frames] * args.host_chunks)
-        net.set_profiling(timing=False)
-        net.infer_batch(hf[:B], want_depth=False, want_rgb=True, flip=True)
+        dn.infer_batch(hf[:B], want_depth=False, want_rgb=True, flip=True)
         t1 = time.perf_counter()
-        _, h_rgb, h_mn, h_mx = net.infer_batch(hf, want_depth=False, want_rgb=True, flip=True)
+        _, h_rgb, h_mn, h_mx = dn.infer_batch(hf, want_depth=False, want_rgb=True, flip=True)
         host_fps = len(hf) / (time.perf_counter() - t1)
         assert h_rgb.shape == hf.shape and np.isfinite(h_mn).all()
         del hf, h_rgb
-    net.close()
+    depth_only = None
+    if args.depth_leg:                       # depth_anything alone, same batch: the shape north_star's roofline target is quoted on
+        def dstep():
+            dn.infer_dev(d_frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
+            dn.sync()
+        dstep()
+        dn.set_profiling(timing=True, accumulate=True)
+        R.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            dstep()
+        R.barrier()
+        ddt = R.max_over_ranks(time.perf_counter() - t1)
+        dfam = {s["name"]: s for s in dn.kernel_stats()}
+        dn.set_profiling(timing=False)
+        att = dfam.get("attention")
+        depth_only = {"metric": "frames/sec (depth_anything ViT-L, 1080p, batch 32 per GPU)", "value": round(world * B * args.steps / ddt, 3),
+                      "unit": "frames/s", "ms_per_step": round(ddt / args.steps * 1e3, 3),
+                      "model_tflops": round(B * args.steps / ddt * GFLOP_PER_FRAME / 1e3, 2),
+                      "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(dfam.items())},
+                      "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in dfam.items() if v["flops"] > 0 and v["ms"] > 0},
+                      "attention_frac_of_peak": round(att["flops"] / (att["ms"] * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4) if att and att["ms"] > 0 else None}
+    dn.close(); fn.close()
     flow = flow_leg(args, R) if args.flow_pairs > 0 else None
     mask = mask_leg(args, R) if args.mask_frames > 0 else None
     pipe = pipeline_leg(args, R) if args.pipeline_frames > 1 else None
 
     if rank == 0:
         fps = world * B * args.steps / dt
-        mm = d_mm.cpu().numpy()
-        assert np.isfinite(mm).all() and (mm[1] > mm[0]).all(), "degenerate depth range"
-        symbols = {"gemm_f16": "gemm8_kernel<0,0,0> (fc1 + DPT 1x1/convT GEMMs, fp16 out)",
-                   "gemm_f16_resid": "gemm8_kernel<0,1,0> (proj + fc2, accumulating onto the fp32 residual)",
-                   "gemm_f16_qkv": "gemm8_kernel<0,2,0> (qkv projection)", "conv_igemm_f16": "gemm8_kernel<1,0,0> (implicit-GEMM convs)",
-                   "attention": "attnq_kernel<1,2,0,false,8>"}
+        symbols = {"depth/gemm_f16": "gemm8_kernel<0,0,0,true> (depth: fc1 + DPT 1x1/convT GEMMs, fp16 out)",
+                   "depth/gemm_f16_resid": "gemm8_kernel<0,1,0,true> (depth: proj + fc2, accumulating onto the fp32 residual)",
+                   "depth/gemm_f16_qkv": "gemm8_kernel<0,2,0,true> (depth: qkv projection)",
+                   "depth/conv_igemm_f16": "gemm8_kernel<1,0,0,true> (depth: implicit-GEMM convs of the DPT head)",
+                   "depth/attention": "attnq_kernel<1,2,0,false,8> (depth: fused attention)",
+                   "flow/conv_igemm_f16_tile128": "gemm_kernel<128,128,2,2,1,0,true,2> (flow: implicit-GEMM convs with N < 256 or < 256 tiles)",
+                   "flow/conv_igemm_f16": "gemm8_kernel<1,0,0,true> (flow: implicit-GEMM convs on the 256 x 256 ping-pong kernel)",
+                   "flow/gemm_f16": "gemm8_kernel<0,0,0,true> (flow: correlation volume + 1x1 GEMMs)"}
         dom_name, g = max(((k, v) for k, v in fam.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic(symbols.get(dom_name, dom_name).split(" ")[0], B)
-        mm_ms = sum(v["ms"] for k, v in fam.items() if k.startswith("gemm"))
-        mm_fl = sum(v["flops"] for k, v in fam.items() if k.startswith("gemm"))
+        ga = alone.get(dom_name)
+        ach_a = ga["flops"] / (ga["ms"] * 1e-3) / 1e12 if ga and ga["ms"] > 0 else 0.0
+        tot_fl = sum(v["flops"] for v in fam.values())
         out = {
-            "metric": "frames/sec (depth_anything ViT-L, 1080p)",
+            "metric": "frames/sec (depth_anything ViT-L + flow_raft, 1080p)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"depth_anything {args.encoder} (DINOv2 ViT-L/14 + DPT head), {W}x{H} synthetic "
-                                   f"uint8 frames resident in HBM, batch {B} per GPU, fused pre/post-process "
-                                   f"(resize+normalise in, heat-encoded uint8 + min/max out), seeded synthetic weights",
-                       "batch_per_gpu": B, "frame": [H, W], "net_input": list(engine.net_size(H, W)),
-                       "parallelism": f"frames sharded over {world} GPU(s); min/max all-gather only"},
-            "roofline": {"bound": "mfma", "kernel": symbols.get(dom_name, dom_name),
+            "config": {"workload": f"every frame of a {B}-frame {W}x{H} synthetic uint8 clip (resident in HBM, one clip per GPU) through "
+                                   f"depth_anything {args.encoder} (DINOv2 ViT-L/14 + DPT head, one batch of {B}, heat-encoded uint8 + min/max out) and "
+                                   f"flow_raft (its {B - 1} consecutive forward pairs, --scale {args.flow_scale} -> {sw}x{sh}, {args.flow_iters} GRU iterations, "
+                                   f"HSV-encoded uint8 + max displacement out); fused pre/post-process, seeded synthetic weights; "
+                                   f"BASELINE.json configs[3] (depth, 32 frames per GPU) plus the flow band the metric names",
+                       "frames_per_gpu_per_step": B, "frame": [H, W], "depth_net_input": list(engine.net_size(H, W)), "flow_net_input": [sh, sw],
+                       "parallelism": f"one clip per GPU on {world} GPU(s); per-frame scalars all-gathered (12 bytes per frame), nothing else crosses GPUs"},
+            "roofline": {"bound": "mfma", "kernel": symbols.get(dom_name, dom_name), "family": dom_name,
                          "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                          "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5),
-                         "flop_per_launch": g["flops"] / max(g["launches"], 1)},
-            "gemm_family_tflops": round(mm_fl / (mm_ms * 1e-3) / 1e12, 2) if mm_ms > 0 else None,
-            "model_tflops": round(fps * GFLOP_PER_FRAME / 1e3 / world, 2),
+                         "flop_per_launch": g["flops"] / max(g["launches"], 1),
+                         "note": "HIP events on each band's stream inside the timed region; the two bands share the GPU there, so a launch's duration "
+                                 "includes what the other band's kernels cost it - the *_alone fields are the same launches with one band on the GPU at a time",
+                         "avg_launch_ms_alone": round(ga["ms"] / max(ga["launches"], 1), 5) if ga else None,
+                         "achieved_alone": round(ach_a, 2) if ga else None, "frac_alone": round(ach_a / PEAK_F16_TFLOPS, 4) if ga else None},
+            "model_tflops": round(tot_fl / dt / 1e12, 2),
             "pcie_inclusive_fps": round(host_fps, 2) if host_fps else None,
             "latency_720p_batch1_ms": round(lat_b1, 3) if lat_b1 is not None else None,
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(fam.items())},
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items()
                               if v["flops"] > 0 and v["ms"] > 0},
+            "kernel_ms_per_step_alone": {k: round(v["ms"] / 2, 3) for k, v in sorted(alone.items())},
+            "kernel_tflops_alone": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in alone.items()
+                                    if v["flops"] > 0 and v["ms"] > 0},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(weights, cfg, H, W)
+            out["cpu_baseline"] = cpu_baseline(weights, cfg, rweights, frames, args.flow_scale, args.flow_iters)
+        if depth_only:
+            out["depth_anything"] = depth_only
         if flow:
-            out["flow_raft"] = flow
+            out["flow_raft_720p"] = flow
         if mask:
             out["mask_mmdet"] = mask
         if pipe:

@@ -21,7 +21,8 @@ class EngineBase {
     const f16 *zero_page() const { return zero_; }
 
   protected:
-    enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_COUNT = 6 };
+    // kernel families of the per-launch timer; convolutions are split by the GEMM kernel that runs them (launch_gemm's choice)
+    enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_CONV128 = 6, F_COUNT = 7 };
 
     // create the ctx stream, index the float32 tensors by name, allocate the zero page
     int begin_load(const pb_tensor *w, int n);

@@ -5,7 +5,7 @@
 #include <algorithm>
 
 namespace {
-const char *kFam[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost"};
+const char *kFam[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost", "conv_igemm_f16_tile128"};
 inline int cp64(int c) { return (int)round_up(c, 64); }
 }  // namespace
 
@@ -157,7 +157,9 @@ int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh
     a.out = out; a.ldo = ldo; a.act = act; a.pre_relu = pre_relu; a.add1 = add1;
     if (fuse) { a.out2 = fuse->out2; a.gru_h = fuse->gru_h; a.gru_z = fuse->gru_z; a.gru_rh = fuse->gru_rh; }
     PB_CHECK(w.K == kh * kw * cC, PB_ERR_STATE, "conv: packed K %d != %d*%d*%d", w.K, kh, kw, cC);
-    tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
+    // same predicate as launch_gemm's TILE_AUTO: the 256 x 256 ping-pong kernel needs N % 256 == 0 and >= 256 tiles
+    const bool wide = conv_tile == TILE_256 || (conv_tile == TILE_AUTO && a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256);
+    tic(wide ? F_CONV : F_CONV128, 2.0 * a.M * (double)a.N * w.Kreal, 0);
     int r = launch_gemm(cur_, A_CONV, EPI_STD, conv_tile, a);
     toc();
     return r;

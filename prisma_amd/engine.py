@@ -74,6 +74,18 @@ class _Ctx:
         check(self.lib.pb_set_option(self.ctx, key.encode(), int(value)))
 
 
+    def set_profiling(self, timing: bool = True, debug_stages: bool = False, accumulate: bool = False):
+        """per-launch HIP-event timing (read with kernel_stats), debug stage snapshots, and `accumulate`: keep the records of
+        earlier infer calls so that a timed loop can be queried once after it ends"""
+        check(self.lib.pb_set_profiling(self.ctx, (1 if timing else 0) | (2 if debug_stages else 0) | (4 if accumulate else 0)))
+
+    def kernel_stats(self) -> List[dict]:
+        arr = (_lib.pb_kernel_stat * 16)()
+        n = check(self.lib.pb_get_kernel_stats(self.ctx, arr, 16))
+        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes,
+                     launches=arr[i].launches) for i in range(n)]
+
+
 class Ops(_Ctx):
     """Single-kernel entry points (pb_op_*) used by the parity tests."""
 
@@ -212,15 +224,6 @@ class DepthAnything(_Ctx):
         check(self.lib.pb_depth_infer_batch_dev(self.ctx, v(frames_ptr), n, H, W, v(depth_ptr), v(rgb_ptr),
                                                 v(min_ptr), v(max_ptr), int(flip)))
 
-    def set_profiling(self, timing: bool = True, debug_stages: bool = False, accumulate: bool = False):
-        check(self.lib.pb_set_profiling(self.ctx, (1 if timing else 0) | (2 if debug_stages else 0) | (4 if accumulate else 0)))
-
-    def kernel_stats(self) -> List[dict]:
-        arr = (_lib.pb_kernel_stat * 16)()
-        n = check(self.lib.pb_get_kernel_stats(self.ctx, arr, 16))
-        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes,
-                     launches=arr[i].launches) for i in range(n)]
-
     def stage(self, name: str, cap: int = 1 << 26) -> np.ndarray:
         out = np.empty(cap, np.float32)
         shape = (C.c_int64 * 4)()
@@ -303,15 +306,6 @@ class FlowRaft(_Ctx):
         check(self.lib.pb_flow_infer_sequence_dev(self.ctx, v(frames_ptr), F, H, W, C.c_float(scale), iters, int(backward),
                                                   v(flow_ptr), v(rgb_ptr), v(max_ptr)))
 
-    def set_profiling(self, timing: bool = True, debug_stages: bool = False):
-        check(self.lib.pb_set_profiling(self.ctx, (1 if timing else 0) | (2 if debug_stages else 0)))
-
-    def kernel_stats(self) -> List[dict]:
-        arr = (_lib.pb_kernel_stat * 16)()
-        n = check(self.lib.pb_get_kernel_stats(self.ctx, arr, 16))
-        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes,
-                     launches=arr[i].launches) for i in range(n)]
-
     def stage(self, name: str, cap: int = 1 << 26) -> np.ndarray:
         out = np.empty(cap, np.float32)
         shape = (C.c_int64 * 4)()
@@ -388,15 +382,6 @@ class MaskMMDet(_Ctx):
             masks = np.empty((cap, H, W), np.uint8)
         k = check(self.lib.pb_mask_get_instances(self.ctx, frame, cap, _ptr(sc), _ptr(lb), _ptr(masks), C.byref(cand)))
         return sc[:k].copy(), lb[:k].copy(), (masks[:k].view(np.bool_) if with_masks else None), cand.value
-
-    def set_profiling(self, timing: bool = True, debug_stages: bool = False):
-        check(self.lib.pb_set_profiling(self.ctx, (1 if timing else 0) | (2 if debug_stages else 0)))
-
-    def kernel_stats(self) -> List[dict]:
-        arr = (_lib.pb_kernel_stat * 16)()
-        n = check(self.lib.pb_get_kernel_stats(self.ctx, arr, 16))
-        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes,
-                     launches=arr[i].launches) for i in range(n)]
 
     def stage(self, name: str, cap: int = 1 << 27) -> np.ndarray:
         out = np.empty(cap, np.float32)
