@@ -1488,7 +1488,7 @@ int launch_t(hipStream_t stream, const GemmArgs &a) {
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * (TN * 32 + 4) * 4;
     constexpr int SMEM = NS * STAGE > WM * WN * EPIB ? NS * STAGE : WM * WN * EPIB;
-    if constexpr (!BUFP && ((BM == 128 && BN == 128) || NS == 3)) {       // the small tiles also have a buffer-path build
+    if constexpr (!BUFP && ((BM == 128 && BN == 128) || NS == 3 || BN == 64)) {       // the small tiles also have a buffer-path build
         GemmArgs b = a;
         b.bufmode = buffer_mode(AMODE, a, BM);
         if (b.bufmode) return launch_t<BM, BN, WM, WN, AMODE, EPI, true, NS>(stream, b);
@@ -1513,6 +1513,9 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
         if (tile == TILE_256) return a.Wf ? launch_g8b<AMODE, EPI>(s, a) : launch_g8<AMODE, EPI>(s, a);
         if (tile == TILE_256_SIMPLE) return launch_t<256, 256, 2, 4, AMODE, EPI>(s, a);
         if (tile == TILE_256x128) return launch_t<256, 128, 4, 2, AMODE, EPI>(s, a);
+        if constexpr (EPI == EPI_STD) {
+            if (tile == TILE_256x64) return launch_t<256, 64, 4, 1, AMODE, EPI>(s, a);
+        }
         if constexpr (EPI == EPI_STD || EPI == EPI_F32) {
             if (tile == TILE_256x128_S3) return launch_t<256, 128, 4, 2, AMODE, EPI, false, 3>(s, a);
             if (tile == TILE_128_S3) return launch_t<128, 128, 2, 2, AMODE, EPI, false, 3>(s, a);
@@ -1566,6 +1569,10 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         // 256x256 needs wide N and enough tiles to fill 256 CUs; the q/k/v split needs D % BN == 0
         const bool wide = a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256;
         tile = wide && (epi != EPI_QKV || a.D % 256 == 0) ? TILE_256 : TILE_128;
+        // N <= 64 (RAFT / ResNet stems and first stages): a 128-wide tile spends half its MFMAs and B loads on padding columns
+        static int n64_tile = -1;
+        if (n64_tile < 0) { const char *e = getenv("PB_TILE_N64"); n64_tile = e ? atoi(e) : TILE_256x64; }
+        if (tile == TILE_128 && epi == EPI_STD && a.N <= 64 && n64_tile != TILE_128) tile = n64_tile;
         static int small_tile = -1;
         if (small_tile < 0) { const char *e = getenv("PB_TILE_SMALL"); small_tile = e ? atoi(e) : TILE_128; }
         if (tile == TILE_128 && (epi == EPI_STD || epi == EPI_F32) && small_tile != TILE_128) tile = small_tile;
