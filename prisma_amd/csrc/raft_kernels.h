@@ -18,7 +18,6 @@ int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], co
                        const float *flow, int P, int w8, f16 *out, int64_t rows);
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W);
 int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows);
-int launch_flow_update(hipStream_t s, float *flow, const float *delta, int64_t rows);
 int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, int h8, int w8, int pad_l, int pad_t, int sh,
                     int sw, float *out, unsigned *maxd);
 int launch_flow_encode(hipStream_t s, const float *flow, int N, int sh, int sw, const unsigned *maxd, uint8_t *rgb,

@@ -334,9 +334,9 @@ __global__ void put_flow_kernel(const float *__restrict__ flow, f16 *__restrict_
 // r * h and h = (1 - z) h + z q are epilogues of the z / r and q convolutions (gemm.h ACT_GRU_ZR / ACT_GRU_Q)
 
 // FlowHead conv2 (update.py:11-12: 3x3, 256 -> 2) + coords1 += delta_flow, as a direct convolution: with two output
-// channels an implicit GEMM spends 98 % of its MFMAs on padding columns (73 us per iteration at 720p / 8 pairs).  Half a
-// wave per pixel, 8 input channels per lane; the 2 x 9 x 8 weights of a lane stay in registers across the pixel loop,
-// the 3x3 neighbourhood comes through L1 / L2, products accumulate in fp32 (v_dot2_f32_f16), one 5-step butterfly per pixel.
+// channels an implicit GEMM spends 98 % of its MFMAs on padding columns (73 us per iteration at 720p / 8 pairs; this: 36 us).
+// Half a wave per run of 16 pixels, 8 input channels per lane; the 2 x 9 x 8 weights of a lane and a sliding 3 x 3 window of
+// channel vectors stay in registers, products accumulate in fp32 (v_dot2_f32_f16), one 5-step butterfly per pixel.
 __global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__ x, const f16 *__restrict__ w, const float *__restrict__ bias,
                                                           float *__restrict__ flow, int nseg, int H, int W, int segw) {
     // half a wave walks a horizontal run of `segw` pixels with a 3 x 3 window of channel vectors in registers: every step
@@ -393,14 +393,6 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) { c0[ky] = c1[ky]; c1[ky] = c2[ky]; }
     }
-}
-
-// coords1 += delta_flow  (flow = coords1 - coords0 is what is stored)
-__global__ void flow_update_kernel(float *__restrict__ flow, const float *__restrict__ delta, int64_t rows) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    flow[r * 2] += delta[r * 8];
-    flow[r * 2 + 1] += delta[r * 8 + 1];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -552,10 +544,6 @@ int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W) {
     const int segw = 16, nseg = n * H * ((W + segw - 1) / segw);
     hipLaunchKernelGGL(flow_head2_kernel, dim3((nseg + 7) / 8), dim3(256), 0, s, x, w, bias, flow, nseg, H, W, segw);
-    LAUNCH_CHECK();
-}
-int launch_flow_update(hipStream_t s, float *flow, const float *delta, int64_t rows) {
-    hipLaunchKernelGGL(flow_update_kernel, dim3(nblk(rows)), dim3(256), 0, s, flow, delta, rows);
     LAUNCH_CHECK();
 }
 int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, int h8, int w8, int pad_l, int pad_t, int sh,
