@@ -398,6 +398,12 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 }
             }
         }
+        if constexpr (EPI == EPI_PIXSHUF) {
+            if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            }
+        }
         f16 *dst = EPI == EPI_QKV ? qk_base : p.out;
         if (EPI != EPI_STD || p.out) {
 #pragma unroll
@@ -1591,6 +1597,7 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
     PB_CASE(A_DENSE, EPI_RESID);
     PB_CASE(A_DENSE, EPI_QKV);
     PB_CASE(A_DENSE, EPI_PIXSHUF);
+    PB_CASE(A_CONV, EPI_PIXSHUF);
     PB_CASE(A_DENSE, EPI_PATCH);
     PB_CASE(A_CONV, EPI_STD);
     PB_CASE(A_CONV, EPI_HEAD);

@@ -33,7 +33,7 @@ class RaftEngine : public EngineBase {
     int sh_ = 0, sw_ = 0, Hp_ = 0, Wp_ = 0, padl_ = 0, padt_ = 0, h8_ = 0, w8_ = 0, P_ = 0, P8_ = 0;
     int lh_[4] = {0, 0, 0, 0}, lw_[4] = {0, 0, 0, 0};
     int *xi_ = nullptr, *xc_ = nullptr, *yi_ = nullptr, *yc_ = nullptr;
-    f16 *img_ = nullptr, *colA_ = nullptr;
+    f16 *img_ = nullptr;                              // padded frames, 4 x 4 space-to-depth: [F, Hp / 4, Wp / 4, 64] fp16
     f16 *r1_[7] = {}, *r2_[7] = {}, *r3_[7] = {};     // scratch maps at 1/2, 1/4, 1/8 resolution: t1 t2 t3 outA outB stem stem_n
     float *st_[3] = {};                               // instance-norm statistics {mean, rstd} per (frame, channel)
     float *stp_ = nullptr;                            // ... and their per-chunk partial sums

@@ -58,19 +58,33 @@ int RaftEngine::load(const pb_tensor *w, int n) {
         Enc &E = e == 0 ? fnet_ : cnet_;
         const bool bnf = e == 1;
         std::vector<float> sc, sf;
-        {   // stem 7x7/s2: im2col order k = tap*3 + c, K 147 -> 192
+        {   // stem 7x7 / stride 2 (extractor.py:124,171): on the 4 x 4 space-to-depth image (64 channels = (dy, dx, c), raft_prep) it is a
+            // 3x3 / stride 1 convolution whose 4 x 64 output channels are the 2 x 2 output pixels of a block - an implicit GEMM on the
+            // ping-pong kernel with the pixel-shuffle epilogue instead of an im2col round trip (2.8 GB per 32 frames at 1080p x 0.75).
+            // W2[(sy, sx, o)][(ty, tx)][(dy, dx, c)] = w[o][c][ky][kx],  ky = 4 (ty - 1) + dy - 2 sy + 3 (same in x), zero outside 0..6
             auto iw = tmap_.find(en + ".conv1.weight"), ib = tmap_.find(en + ".conv1.bias");
             PB_CHECK(iw != tmap_.end() && ib != tmap_.end(), PB_ERR_ARG, "missing %s.conv1", en.c_str());
             if (bnf && (r = fold_bn(en + ".norm1", 64, sc, sf))) return r;
             const float *wt = (const float *)iw->second->data, *bs = (const float *)ib->second->data;
-            std::vector<float> g((size_t)64 * 147), bb(64);
-            for (int o = 0; o < 64; ++o) {
-                const float s = bnf ? sc[o] : 1.f;
-                for (int c = 0; c < 3; ++c)
-                    for (int tp = 0; tp < 49; ++tp) g[(size_t)o * 147 + tp * 3 + c] = wt[((size_t)o * 3 + c) * 49 + tp] * s;
-                bb[o] = bs[o] * s + (bnf ? sf[o] : 0.f);
-            }
-            if ((r = pack(g.data(), 64, 147, 192, E.stem, bb.data()))) return r;
+            std::vector<float> g((size_t)256 * 576, 0.f), bb(256);
+            for (int sy = 0; sy < 2; ++sy)
+                for (int sx = 0; sx < 2; ++sx)
+                    for (int o = 0; o < 64; ++o) {
+                        const float s = bnf ? sc[o] : 1.f;
+                        const int n = (sy * 2 + sx) * 64 + o;
+                        bb[n] = bs[o] * s + (bnf ? sf[o] : 0.f);
+                        for (int ty = 0; ty < 3; ++ty)
+                            for (int tx = 0; tx < 3; ++tx)
+                                for (int dy = 0; dy < 4; ++dy)
+                                    for (int dx = 0; dx < 4; ++dx) {
+                                        const int ky = 4 * (ty - 1) + dy - 2 * sy + 3, kx = 4 * (tx - 1) + dx - 2 * sx + 3;
+                                        if (ky < 0 || ky > 6 || kx < 0 || kx > 6) continue;
+                                        for (int c = 0; c < 3; ++c)
+                                            g[(size_t)n * 576 + (ty * 3 + tx) * 64 + (dy * 4 + dx) * 4 + c] = wt[((size_t)o * 3 + c) * 49 + ky * 7 + kx] * s;
+                                    }
+                    }
+            if ((r = pack(g.data(), 256, 576, 576, E.stem, bb.data()))) return r;
+            E.stem.Kreal = 147;
         }
         for (int li = 0; li < 3; ++li)
             for (int bi = 0; bi < 2; ++bi) {
@@ -158,7 +172,6 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         xi_ = (int *)carve((size_t)sw_ * 16); xc_ = (int *)carve((size_t)sw_ * 16);
         yi_ = (int *)carve((size_t)sh_ * 16); yc_ = (int *)carve((size_t)sh_ * 16);
         img_ = (f16 *)carve((size_t)F * Hp_ * Wp_ * 8);
-        colA_ = (f16 *)carve((size_t)round_up((int64_t)F * h2 * w2, 256) * 192 * 2);
         for (auto &b : r1_) b = (f16 *)carve((size_t)round_up((int64_t)F * h2 * w2, 256) * 64 * 2);
         for (auto &b : r2_) b = (f16 *)carve((size_t)round_up((int64_t)F * h4 * w4, 256) * 128 * 2);
         for (auto &b : r3_) b = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 128 * 2);
@@ -221,11 +234,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
 
     // ---- frame prep + stem im2col (shared by fnet and cnet) ----
     tic(F_PP, 0, (double)F * H * W * 3);
-    r = launch_raft_prep(stream, frames, F, H, W, sh_, sw_, Hp_, Wp_, padl_, padt_, scale != 1.f, xi_, xc_, yi_, yc_, img_, nullptr);
-    toc();
-    if (r) return r;
-    tic(F_ELT, 0, 0);
-    r = launch_im2col7_img(stream, img_, F, Hp_, Wp_, h2, w2, colA_, 192);
+    r = launch_raft_prep(stream, frames, F, H, W, sh_, sw_, Hp_, Wp_, padl_, padt_, scale != 1.f, xi_, xc_, yi_, yc_, img_, nullptr, 1);
     toc();
     if (r) return r;
 
@@ -246,7 +255,18 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
             return rr;
         };
         // stem (BasicEncoder.forward, extractor.py:171-192)
-        if ((r = dense(colA_, 192, (int64_t)F * h2 * w2, E.stem, r1_[5], 64, inorm ? ACT_NONE : ACT_RELU))) return r;
+        {
+            GemmArgs a;
+            a.A = img_; a.W = E.stem.w; a.K = E.stem.K; a.N = 256; a.bias = E.stem.bias; a.zero = zero_;
+            a.cH = Hp_ / 4; a.cW = Wp_ / 4; a.cC = 64; a.cLd = 64; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1;
+            a.cOH = a.cH; a.cOW = a.cW; a.M = F * a.cH * a.cW;
+            a.out = r1_[5]; a.ldo = 64; a.act = inorm ? ACT_NONE : ACT_RELU;
+            a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
+            tic(F_CONV, 2.0 * F * h2 * w2 * 64.0 * 147, 0);
+            r = launch_gemm(stream, A_CONV, EPI_PIXSHUF, TILE_AUTO, a);
+            toc();
+            if (r) return r;
+        }
         const f16 *x = r1_[5];
         if (inorm) {
             if ((r = stats(r1_[5], st_[0], h2 * w2, 64))) return r;

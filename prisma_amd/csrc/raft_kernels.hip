@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
                                                         int sw, int Hp, int Wp, int pad_l, int pad_t, int resize,
                                                         const int *__restrict__ xi, const int *__restrict__ xc,
                                                         const int *__restrict__ yi, const int *__restrict__ yc,
-                                                        f16 *__restrict__ out, uint8_t *__restrict__ scaled_out) {
+                                                        f16 *__restrict__ out, uint8_t *__restrict__ scaled_out, int s2d) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)F * Hp * Wp) return;
     const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), f = (int)(i / ((int64_t)Wp * Hp));
@@ -54,7 +54,10 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = (f16)(2.f * ((float)v[c] / 255.f) - 1.f);
     o[3] = (f16)0.f;
-    *(f16x4 *)(out + i * 4) = o;
+    // s2d: 4 x 4 pixel blocks become the 64 channels ((dy * 4 + dx) * 4 + c) of a [F, Hp / 4, Wp / 4] map - the layout in which the
+    // 7x7 / stride-2 stem is a 3x3 convolution with 4 x 64 output channels (raft_engine.hip)
+    const int64_t oi = s2d ? ((((int64_t)f * (Hp >> 2) + (y >> 2)) * (Wp >> 2) + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)) : i;
+    *(f16x4 *)(out + oi * 4) = o;
     if (scaled_out && y >= pad_t && y < pad_t + sh && x >= pad_l && x < pad_l + sw) {
         uint8_t *d = scaled_out + (((int64_t)f * sh + (y - pad_t)) * sw + (x - pad_l)) * 3;
         d[0] = (uint8_t)v[0]; d[1] = (uint8_t)v[1]; d[2] = (uint8_t)v[2];
@@ -489,9 +492,9 @@ __global__ void fill_u32_kernel(unsigned *p, unsigned v, int n) {
 
 int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, int sh, int sw, int Hp, int Wp, int pad_l,
                      int pad_t, int resize, const int *xi, const int *xc, const int *yi, const int *yc, f16 *out,
-                     uint8_t *scaled_out) {
+                     uint8_t *scaled_out, int s2d) {
     hipLaunchKernelGGL(raft_prep_kernel, dim3(nblk((int64_t)F * Hp * Wp)), dim3(256), 0, s, frames, F, H, W, sh, sw, Hp, Wp,
-                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out);
+                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d);
     LAUNCH_CHECK();
 }
 int launch_im2col7_img(hipStream_t s, const f16 *x, int B, int H, int W, int OH, int OW, f16 *out, int Kp) {
