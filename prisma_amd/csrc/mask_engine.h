@@ -62,7 +62,7 @@ class MaskEngine : public EngineBase {
     int lh_[6] = {}, lw_[6] = {};            // feature sizes at strides 4, 8, 16, 32, 64 (index 0..4); [5] = stride 2
     int pts_ = 0, goff_[6] = {};
     int *xt_ = nullptr, *yt_ = nullptr;
-    f16 *img_ = nullptr, *colA_ = nullptr, *stem_out_ = nullptr, *pool_ = nullptr;
+    f16 *img_ = nullptr, *stem_out_ = nullptr, *pool_ = nullptr;      // img_: 4 x 4 space-to-depth of the padded input
     float *chw_ = nullptr;
     f16 *sx_[4][2] = {}, *st1_[4] = {}, *st2_[4] = {}, *sds_[4] = {};
     const f16 *c_[4] = {};

@@ -106,16 +106,31 @@ int MaskEngine::load(const pb_tensor *w, int n) {
     PB_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     int r;
     std::vector<float> sc, sf;
-    {   // stem 7x7/s2 (resnet.py:560-580, no bias) + bn1: im2col order k = tap*3 + c, K 147 -> 192
+    {   // stem 7x7 / stride 2 (resnet.py:560-580, no bias) + bn1: on the 4 x 4 space-to-depth image (mask_prep) it is a 3x3 / stride 1
+        // convolution whose 4 x 64 output channels are the 2 x 2 output pixels of a block (pixel-shuffle epilogue), cf. raft_engine.hip:
+        // W2[(sy, sx, o)][(ty, tx)][(dy, dx, c)] = w[o][c][ky][kx],  ky = 4 (ty - 1) + dy - 2 sy + 3 (same in x), zero outside 0..6
         auto iw = tmap_.find("backbone.conv1.weight");
         PB_CHECK(iw != tmap_.end(), PB_ERR_ARG, "missing backbone.conv1.weight");
         if ((r = fold_bn("backbone.bn1", 64, sc, sf))) return r;
         const float *wt = (const float *)iw->second->data;
-        std::vector<float> g((size_t)64 * 147);
-        for (int o = 0; o < 64; ++o)
-            for (int c = 0; c < 3; ++c)
-                for (int tp = 0; tp < 49; ++tp) g[(size_t)o * 147 + tp * 3 + c] = wt[((size_t)o * 3 + c) * 49 + tp] * sc[o];
-        if ((r = pack(g.data(), 64, 147, 192, stem_, sf.data()))) return r;
+        std::vector<float> g((size_t)256 * 576, 0.f), bb(256);
+        for (int sy = 0; sy < 2; ++sy)
+            for (int sx = 0; sx < 2; ++sx)
+                for (int o = 0; o < 64; ++o) {
+                    const int nn = (sy * 2 + sx) * 64 + o;
+                    bb[nn] = sf[o];
+                    for (int ty = 0; ty < 3; ++ty)
+                        for (int tx = 0; tx < 3; ++tx)
+                            for (int dy = 0; dy < 4; ++dy)
+                                for (int dx = 0; dx < 4; ++dx) {
+                                    const int ky = 4 * (ty - 1) + dy - 2 * sy + 3, kx = 4 * (tx - 1) + dx - 2 * sx + 3;
+                                    if (ky < 0 || ky > 6 || kx < 0 || kx > 6) continue;
+                                    for (int c = 0; c < 3; ++c)
+                                        g[(size_t)nn * 576 + (ty * 3 + tx) * 64 + (dy * 4 + dx) * 4 + c] = wt[((size_t)o * 3 + c) * 49 + ky * 7 + kx] * sc[o];
+                                }
+                }
+        if ((r = pack(g.data(), 256, 576, 576, stem_, bb.data()))) return r;
+        stem_.Kreal = 147;
     }
     int inpl = 64;
     for (int li = 0; li < 4; ++li) {
@@ -193,7 +208,6 @@ int MaskEngine::prepare(int n, int H, int W) {
         xt_ = (int *)carve((size_t)nw_ * 16); yt_ = (int *)carve((size_t)nh_ * 16);
         img_ = (f16 *)carve((size_t)B * Hp_ * Wp_ * 8 + slack);
         chw_ = debug ? (float *)carve((size_t)B * 3 * Hp_ * Wp_ * 4) : nullptr;
-        colA_ = (f16 *)carve(rows(5) * 192 * 2);
         stem_out_ = (f16 *)carve(rows(5) * 64 * 2);
         pool_ = (f16 *)carve(rows(0) * 64 * 2 + slack);
         for (int s = 0; s < 4; ++s) {
@@ -265,11 +279,18 @@ int MaskEngine::conv_gn_relu(const f16 *in, int cC, int cLd, int n, int H, int W
 int MaskEngine::backbone(int n) {
     int r;
     const int H2 = lh_[5], W2 = lw_[5];
-    tic(F_ELT, 0, 0);
-    r = launch_im2col7_img(stream, img_, n, Hp_, Wp_, H2, W2, colA_, 192);
-    toc();
-    if (r) return r;
-    if ((r = dense(colA_, 192, (int64_t)n * H2 * W2, stem_, stem_out_, 64, ACT_RELU))) return r;
+    {
+        GemmArgs a;
+        a.A = img_; a.W = stem_.w; a.K = stem_.K; a.N = 256; a.bias = stem_.bias; a.zero = zero_;
+        a.cH = Hp_ / 4; a.cW = Wp_ / 4; a.cC = 64; a.cLd = 64; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1;
+        a.cOH = a.cH; a.cOW = a.cW; a.M = n * a.cH * a.cW;
+        a.out = stem_out_; a.ldo = 64; a.act = ACT_RELU;
+        a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
+        tic(F_CONV, 2.0 * n * H2 * W2 * 64.0 * 147, 0);
+        r = launch_gemm(cur_, A_CONV, EPI_PIXSHUF, TILE_AUTO, a);
+        toc();
+        if (r) return r;
+    }
     tic(F_ELT, 0, 0);
     r = launch_maxpool3x3s2(stream, stem_out_, pool_, n, H2, W2, 64);
     toc();

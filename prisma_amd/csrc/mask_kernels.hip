@@ -34,7 +34,8 @@ __device__ __forceinline__ void lerp_src(int dst, float scale, int in, int &i0, 
 // ------------------------------------------------------------------------------------------------
 // frame prep: uint8 RGB [n][H][W][3] -> OpenCV 8-bit INTER_LINEAR resize to (nh, nw) (11-bit fixed-point
 // coefficients, tables from the host) -> (v - mean) * (1 / std) in fp32 -> zero pad to (Hp, Wp) ->
-// fp16 [n][Hp][Wp][4] (channel 3 = 0).  One thread per padded pixel.
+// fp16, 4 x 4 pixel blocks as 64 channels ((dy * 4 + dx) * 4 + c, channel 3 = 0) of a [n][Hp / 4][Wp / 4] map: the layout in which the
+// 7x7 / stride-2 stem is a 3x3 convolution with 4 x 64 output channels (mask_engine.hip).  One thread per padded pixel.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_prep_kernel(const uint8_t *__restrict__ frames, int n, int H, int W, int nh, int nw,
                                                         int Hp, int Wp, const int4 *__restrict__ xt,
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(const uint8_t *__restric
             o[c] = (f16)v[c];
         }
     }
-    *(f16x4 *)(out + i * 4) = o;
+    *(f16x4 *)(out + ((((int64_t)f * (Hp >> 2) + (y >> 2)) * (Wp >> 2) + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)) * 4) = o;
     if (chw)
 #pragma unroll
         for (int c = 0; c < 3; ++c) chw[(((int64_t)f * 3 + c) * Hp + y) * Wp + x] = v[c];

@@ -5,7 +5,6 @@
 int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, int sh, int sw, int Hp, int Wp, int pad_l,
                      int pad_t, int resize, const int *xi, const int *xc, const int *yi, const int *yc, f16 *out,
                      uint8_t *scaled_out, int s2d = 0);
-int launch_im2col7_img(hipStream_t s, const f16 *x, int B, int H, int W, int OH, int OW, f16 *out, int Kp);
 int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp);
 int in_stats_chunks(int HW);
 int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *part, float *stats);

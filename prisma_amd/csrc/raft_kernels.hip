@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// im2col for the two 7x7 convolutions whose input has 3 (image, stride 2) or 2 (flow, stride 1) channels:
+// im2col for the 7x7 convolution of the 2-channel flow (BasicMotionEncoder.convf1; the image stems are space-to-depth convs):
 // rows = output pixels, k = (ky*7 + kx)*C + c, zero padded to Kp.  One thread per (row, tap).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int CS>
@@ -495,11 +495,6 @@ int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, 
                      uint8_t *scaled_out, int s2d) {
     hipLaunchKernelGGL(raft_prep_kernel, dim3(nblk((int64_t)F * Hp * Wp)), dim3(256), 0, s, frames, F, H, W, sh, sw, Hp, Wp,
                        pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d);
-    LAUNCH_CHECK();
-}
-int launch_im2col7_img(hipStream_t s, const f16 *x, int B, int H, int W, int OH, int OW, f16 *out, int Kp) {
-    hipLaunchKernelGGL((im2col7_kernel<f16, 4>), dim3(nblk((int64_t)B * OH * OW * 49)), dim3(256), 0, s, x, B, H, W, 3, 2, OH,
-                       OW, out, Kp);
     LAUNCH_CHECK();
 }
 int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp) {
