@@ -249,13 +249,13 @@ def pmc_traffic(symbol, batch):
     """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC summary (tools/pmc_summary.py; separate
     FETCH_SIZE / WRITE_SIZE passes over this same bench command at batch 32).  PMC passes cannot run inside the timed
     bench, so the figure is read from profiles/ and only reported when the batch matches the one it was taken at."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01j_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01k_pmc_traffic.json")
     if batch != 32 or not os.path.exists(path):
         return None, None
     want = symbol.replace(" ", "")
     for name, v in json.load(open(path))["kernels"].items():
         if want in name.replace(" ", ""):
-            return round(v["fetch_bytes"] + v["write_bytes"]), "profiles/r01j_pmc_traffic.json"
+            return round(v["fetch_bytes"] + v["write_bytes"]), "profiles/r01k_pmc_traffic.json"
     return None, None
 
 
