@@ -63,7 +63,6 @@ __device__ __forceinline__ float fast_gelu(float x) {
 
 // two values per instruction where the ISA has a packed form (v_pk_fma_f32): the fc1 epilogue is VALU bound
 __device__ __forceinline__ void fast_gelu2(float &x0, float &x1) {
-    const f32x2 x = {x0, x1};
     // v_med3_f32 clamps without the canonicalising v_max that fminf / fmaxf put in front of every operand
     const f32x2 a = {__builtin_amdgcn_fmed3f(fabsf(x0), 0.f, 6.5f), __builtin_amdgcn_fmed3f(fabsf(x1), 0.f, 6.5f)};
     const f32x2 c5 = {-0.00047330817324109375f, -0.00047330817324109375f}, c4 = {0.007084541954100132f, 0.007084541954100132f},
@@ -545,8 +544,6 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;       // 16-byte chunks per thread per stage
-    constexpr int ES = TN * 32 + 4;                         // epilogue patch row stride (floats)
-    constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * ES * 4;
     static_assert(NA >= 1 && NB >= 1, "tile too small for the block");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -821,7 +818,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             b_ptr[hf][u] = p.W + (int64_t)(n0 + col_map(b_row0[hf][u] + lrow, epi_interleaved<EPI, 2>())) * p.K + cgu[u] * 8;
         }
     const int nk = p.K >> 6;
-    const int cpt = AMODE == A_CONV ? p.cC >> 6 : 1;     // K tiles per conv tap
     // BUFP: stage through the buffer path (`buffer_load_dwordx4 ... lds`) - measurably cheaper to issue than the flat
     // `global_load_lds` (8192^3: 1145 -> 1245 TF, qkv / fc1 shapes +14 ... +17 %).  The resource covers the whole operand
     // (dense, weights) or the one or two images this tile's rows fall into (conv: a whole DPT map batch exceeds 4 GB);
@@ -1120,7 +1116,6 @@ template <int AMODE, bool BUFP>
 __global__ __launch_bounds__(512) void gemm8n_kernel(const GemmArgs p) {
     constexpr int BM = 256, BN = 128;
     constexpr int BUF = 49152, BOFF = 32768;
-    constexpr int EPI = EPI_STD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -1195,7 +1190,6 @@ __global__ __launch_bounds__(512) void gemm8n_kernel(const GemmArgs p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) b_ptr[u] = p.W + (int64_t)(n0 + b_row0[u] + lrow) * p.K + cgu[u] * 8;
     const int nk = p.K >> 6;
-    const int cpt = AMODE == A_CONV ? p.cC >> 6 : 1;     // K tiles per conv tap
     // BUFP: stage through the buffer path (`buffer_load_dwordx4 ... lds`) - measurably cheaper to issue than the flat
     // `global_load_lds` (8192^3: 1145 -> 1245 TF, qkv / fc1 shapes +14 ... +17 %).  The resource covers the whole operand
     // (dense, weights) or the one or two images this tile's rows fall into (conv: a whole DPT map batch exceeds 4 GB);
@@ -1360,9 +1354,8 @@ __global__ __launch_bounds__(512) void gemm8n_kernel(const GemmArgs p) {
 // K tile re-read the last one (harmless: their LDS slots / registers are dead) so the count never changes.
 template <int AMODE, int EPI>
 __global__ __launch_bounds__(512) void gemm8b_kernel(const GemmArgs p) {
-    constexpr int VAR = 0;
     constexpr int BM = 256, BN = 256;
-    constexpr int BUF = 65536, BOFF = 32768;
+    constexpr int BUF = 65536;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
