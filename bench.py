@@ -31,11 +31,13 @@ class Ranks:
     def __init__(self):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        ngpu = max(torch.cuda.device_count(), 1)
+        self.gpu = torch.cuda.is_available()              # False only in the CPU unit test of this class
+        ngpu = max(torch.cuda.device_count(), 1) if self.gpu else 1
         self.device = int(os.environ.get("LOCAL_RANK", "0")) % ngpu
         self.backend = os.environ.get("PRISMA_BENCH_BACKEND", "nccl")
         self.dist = None
-        torch.cuda.set_device(self.device)
+        if self.gpu:
+            torch.cuda.set_device(self.device)
         if self.world > 1:
             import torch.distributed as dist
             self.dist = dist
@@ -47,7 +49,8 @@ class Ranks:
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
-        torch.cuda.synchronize()
+        if self.gpu:
+            torch.cuda.synchronize()
 
     def max_over_ranks(self, x):
         if self.world == 1:
