@@ -19,6 +19,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_depth  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
+from common.pipe import AsyncSink, prefetch  # noqa: E402
 from prisma_amd import engine, shard, synth  # noqa: E402
 
 BAND = "depth_anything"
@@ -124,11 +125,11 @@ def process_video(a):
         init_model(device=rk.device)
     first, last = rk.frames(n)
     lo, hi, held = [], [], []
-    for s in range(first, last, BATCH):
-        frames = np.stack([src[i] for i in range(s, min(last, s + BATCH))])
-        want_depth = bool(a.npy or a.subpath)
-        depth, rgb, mn, mx = model.infer_batch(frames, want_depth=want_depth, want_rgb=True, flip=_flip())
-        for j in range(len(frames)):
+    want_depth = bool(a.npy or a.subpath)
+
+    def emit(s, depth, rgb):
+        # runs on the sink thread, chunk after chunk in order: video frames, .npy / .png dumps (reference :215-225)
+        for j in range(len(rgb)):
             if rk.world == 1:
                 out.write(rgb[j])
             else:
@@ -138,8 +139,16 @@ def process_video(a):
             if a.subpath:
                 write_depth(os.path.join(a.subpath, "{:05d}.png".format(s + j)), depth[j], heat_to_rgb,
                             normalize=True, flip=_flip(), heatmap=True, encode_range=True)
+
+    # the decode of chunk i+1 and the encode / writes of chunk i-1 overlap the engine's work on chunk i
+    sink = AsyncSink(depth=2)
+    load = lambda s: np.stack([src[i] for i in range(s, min(last, s + BATCH))])      # noqa: E731
+    for s, frames in prefetch(load, range(first, last, BATCH)):
+        depth, rgb, mn, mx = model.infer_batch(frames, want_depth=want_depth, want_rgb=True, flip=_flip())
+        sink.submit(emit, s, depth, rgb)
         lo += [float(v) for v in mn]
         hi += [float(v) for v in mx]
+    sink.close()
     if rk.world > 1:
         every = rk.gather(np.stack(held) if held else np.zeros((0, h, w, 3), np.uint8), n)
         mm = rk.gather(np.asarray([lo, hi], np.float32).T.reshape(-1, 2), n)

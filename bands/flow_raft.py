@@ -19,6 +19,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 from common.io import FrameReader, VideoWriter, check_overwrite, write_flo, write_flow_png  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
+from common.pipe import prefetch  # noqa: E402
 from prisma_amd import engine, shard, synth  # noqa: E402
 
 BAND = "flow_raft"
@@ -89,9 +90,9 @@ def process_video(args):
     sh, sw = engine.flow_out_size(h, w, args.scale)
     first, last = rk.frames(n - 1)                       # pair indices owned by this rank
     cols = {"rgb_f": [], "rgb_b": [], "mask_f": [], "mask_b": [], "mx": []}
-    for s in range(first, last, CHUNK):
+    load = lambda s: np.stack([src[i] for i in range(s, min(last, s + CHUNK) + 1)])  # noqa: E731  (1-frame halo)
+    for s, frames in prefetch(load, range(first, last, CHUNK)):     # the next chunk decodes while this one is on the GPU
         e = min(last, s + CHUNK)
-        frames = np.stack([src[i] for i in range(s, e + 1)])                          # 1-frame halo
         mask = None
         if want_mask:
             flow, rgb, mx, mask = model.infer_sequence_masks(frames, scale=args.scale, iters=args.iterations,

@@ -20,6 +20,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_rgb  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
+from common.pipe import prefetch  # noqa: E402
 from prisma_amd import engine, shard, synth  # noqa: E402
 
 BAND = "mask"
@@ -95,8 +96,8 @@ def process_video(args):
         create_folder(args.subpath)
     first, last = rk.frames(n)
     held = []
-    for s in range(first, last, BATCH):
-        frames = np.stack([src[i] for i in range(s, min(last, s + BATCH))])
+    load = lambda s: np.stack([src[i] for i in range(s, min(last, s + BATCH))])      # noqa: E731
+    for s, frames in prefetch(load, range(first, last, BATCH)):      # the next chunk decodes while this one is on the GPU
         masks = model.infer_batch(frames, args.confidence, keep_ids())
         for j in range(len(frames)):
             if args.subpath:        # COLMAP wants black objects on white (reference :149-150)
