@@ -248,18 +248,31 @@ def pipeline_leg(args, R):
             "note": "the three bands enqueued together on their own streams (tools/pipeline_order_bench.py: 121 frames/s against 116 one after the other); flow at --scale 0.75 (816 x 1440), forward pairs only"}
 
 
-def pmc_traffic(symbol, batch):
-    """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC summary (tools/pmc_summary.py; separate
-    FETCH_SIZE / WRITE_SIZE passes over this same bench command at batch 32).  PMC passes cannot run inside the timed
-    bench, so the figure is read from profiles/ and only reported when the batch matches the one it was taken at."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01k_pmc_traffic.json")
-    if batch != 32 or not os.path.exists(path):
-        return None, None
+def pmc_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC summary of THIS command (tools/pmc_summary.py; separate
+    FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md).  PMC passes cannot run inside the
+    timed bench, so the figure is read from profiles/ (newest round first)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     want = symbol.replace(" ", "")
-    for name, v in json.load(open(path))["kernels"].items():
-        if want in name.replace(" ", ""):
-            return round(v["fetch_bytes"] + v["write_bytes"]), "profiles/r01k_pmc_traffic.json"
+    for name in ("r02_pmc_traffic.json", "r01k_pmc_traffic.json"):
+        path = os.path.join(here, name)
+        if not os.path.exists(path):
+            continue
+        for kname, v in json.load(open(path))["kernels"].items():
+            if want in kname.replace(" ", ""):
+                return round(v["fetch_bytes"] + v["write_bytes"]), "profiles/" + name
     return None, None
+
+
+SYMBOLS = {"depth/gemm_f16": "gemm8_kernel<0,0,0,true> (depth: fc1 + DPT 1x1/convT GEMMs, fp16 out)",
+           "depth/gemm_f16_resid": "gemm8_kernel<0,1,0,true> (depth: proj + fc2, accumulating onto the fp32 residual)",
+           "depth/gemm_f16_qkv": "gemm8_kernel<0,2,0,true> (depth: qkv projection)",
+           "depth/conv_igemm_f16": "gemm8_kernel<1,0,0,true> (depth: implicit-GEMM convs of the DPT head)",
+           "depth/attention": "attnq_kernel<1,2,0,false,8> (depth: fused attention)",
+           "flow/conv_igemm_f16_tile128": "gemm_kernel<128,128,2,2,1,0,true,2> (flow: implicit-GEMM convs with N < 256 or < 256 tiles)",
+           "flow/conv_igemm_f16": "gemm8_kernel<1,0,0,true> (flow: implicit-GEMM convs on the 256 x 256 ping-pong kernel)",
+           "flow/gemm_f16": "gemm8_kernel<0,0,0,true> (flow: correlation volume + 1x1 GEMMs)"}
+PREC_NAME = {0: "f16", 1: "split-f16"}
 
 
 def main():
@@ -273,19 +286,22 @@ def main():
     ap.add_argument("--encoder", default="vitl")
     ap.add_argument("--flow-scale", type=float, default=0.75, help="flow_raft --scale (the band's default)")
     ap.add_argument("--flow-iters", type=int, default=12, help="GRU iterations (BASELINE.json configs[2])")
+    ap.add_argument("--precision", type=int, default=0, choices=(0, 1),
+                    help="pb_precision of the timed `value`: 0 = one fp16 MFMA pass per GEMM (dtype f16), 1 = split-fp16 (meets the 1e-3 "
+                         "max-norm bound the parity tests assert); the other mode is timed too and reported under `other_precision`")
+    ap.add_argument("--one-precision", action="store_true", help="skip the second precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256, 4 simple 256")
     ap.add_argument("--conv-tile", type=int, default=0)
-    ap.add_argument("--all-legs", action="store_true", help="also run the per-band legs below with their usual sizes (depth only, flow 720p, mask, pipeline, PCIe)")
+    ap.add_argument("--all-legs", action="store_true", help="also run the per-band legs below with their usual sizes (flow 720p, mask, pipeline, PCIe)")
     ap.add_argument("--latency", action="store_true", help="also time one 1280x720 frame at batch 1 (BASELINE configs[1])")
     ap.add_argument("--host-chunks", type=int, default=0, help="batches pushed through the host-pointer API for the PCIe-inclusive rate")
     ap.add_argument("--pipeline-frames", type=int, default=0, help="frames per step of the three-band pipeline leg")
     ap.add_argument("--mask-frames", type=int, default=0, help="frames per step of the mask_mmdet leg")
     ap.add_argument("--flow-pairs", type=int, default=0, help="frame pairs per GPU per step of the 720p flow_raft leg (BASELINE configs[2])")
-    ap.add_argument("--depth-leg", action="store_true", help="depth_anything alone at the same batch (the shape north_star's roofline target names)")
     args = ap.parse_args()
     if args.all_legs:
-        args.latency = args.depth_leg = True
+        args.latency = True
         args.host_chunks, args.pipeline_frames, args.mask_frames, args.flow_pairs = 4, 32, 32, 8
 
     if not torch.cuda.is_available():
@@ -298,10 +314,6 @@ def main():
     weights = synth.depth_anything_weights(cfg, seed=1234)
     rweights = synth.raft_weights(seed=4321)
     B, H, W = args.batch, args.height, args.width
-    dn = engine.DepthAnything(weights, cfg, device=local_rank, max_batch=B)
-    dn.set_option("gemm_tile", args.gemm_tile)
-    dn.set_option("conv_tile", args.conv_tile)
-    fn = engine.FlowRaft(rweights, device=local_rank)
 
     # one synthetic clip per rank (a seeded noise texture shifted by a known step per frame, so the flow is not degenerate),
     # resident in HBM before the timed region; one step = both bands over the whole clip
@@ -314,150 +326,154 @@ def main():
     gathered = torch.empty((world, 3, B), dtype=torch.float32, device="cuda") if world > 1 else None
     torch.cuda.synchronize()
 
-    def step():
-        # the two bands are independent: both are enqueued on their own streams and share the GPU
-        dn.infer_dev(d_frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
-        fn.infer_sequence_dev(d_frames.data_ptr(), B, H, W, args.flow_scale, args.flow_iters, False, 0, f_rgb.data_ptr(), scal[2].data_ptr())
-        dn.sync(); fn.sync()
-        if world > 1:
-            R.all_gather(gathered, scal)                                  # the only exchange: 12 bytes per frame
+    def run_mode(prec, steps, warmup, extras):
+        """K timed steps in one precision mode.  A step runs the depth band, then the flow band (each on its ctx stream, one
+        after the other: a launch's HIP-event duration is then the kernel's own, the same thing rocprofv3 reports), then the
+        12-byte-per-frame scalar all-gather.  Returns wall time, per-family launch records and per-band wall times."""
+        dn = engine.DepthAnything(weights, cfg, device=local_rank, max_batch=B, precision=prec)
+        dn.set_option("gemm_tile", args.gemm_tile)
+        dn.set_option("conv_tile", args.conv_tile)
+        fn = engine.FlowRaft(rweights, device=local_rank, precision=prec)
 
-    for _ in range(args.warmup):
-        step()
-    # every launch of the timed region is bracketed by HIP events on its band's stream; the records accumulate over the K
-    # steps and are read once after the closing barrier, so no event query sits inside the timed region
-    dn.set_profiling(timing=True, accumulate=True)
-    fn.set_profiling(timing=True, accumulate=True)
-    R.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    R.barrier()
-    dt = time.perf_counter() - t0
-    fam = {}
-    for band, net_ in (("depth", dn), ("flow", fn)):
-        for s in net_.kernel_stats():
-            fam[band + "/" + s["name"]] = {k: s[k] for k in ("ms", "flops", "bytes", "launches")}
-        net_.set_profiling(timing=False)
-    dt = R.max_over_ranks(dt)
-    # the same launches with each band alone on the GPU (untimed extra steps): what the kernels do when nothing competes
-    alone = {}
-    if rank == 0:
-        dn.set_profiling(timing=True, accumulate=True)
-        fn.set_profiling(timing=True, accumulate=True)
-        for _ in range(2):
+        def depth():
             dn.infer_dev(d_frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
             dn.sync()
+
+        def flow():
             fn.infer_sequence_dev(d_frames.data_ptr(), B, H, W, args.flow_scale, args.flow_iters, False, 0, f_rgb.data_ptr(), scal[2].data_ptr())
             fn.sync()
+
+        band_s = [0.0, 0.0]
+
+        def step():
+            a = time.perf_counter()
+            depth()
+            b = time.perf_counter()
+            flow()
+            c = time.perf_counter()
+            band_s[0] += b - a; band_s[1] += c - b
+            if world > 1:
+                R.all_gather(gathered, scal)                              # the only exchange: 12 bytes per frame
+
+        for _ in range(warmup):
+            step()
+        # every launch of the timed region is bracketed by HIP events on its band's stream; the records accumulate over the K
+        # steps and are read once after the closing barrier, so no event query sits inside the timed region
+        dn.set_profiling(timing=True, accumulate=True)
+        fn.set_profiling(timing=True, accumulate=True)
+        band_s[0] = band_s[1] = 0.0
+        R.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        R.barrier()
+        dt = time.perf_counter() - t0
+        fam = {}
         for band, net_ in (("depth", dn), ("flow", fn)):
             for s in net_.kernel_stats():
-                alone[band + "/" + s["name"]] = {k: s[k] for k in ("ms", "flops", "bytes", "launches")}
+                fam[band + "/" + s["name"]] = {k: s[k] for k in ("ms", "flops", "bytes", "launches")}
             net_.set_profiling(timing=False)
-    sc = scal.cpu().numpy()
-    assert np.isfinite(sc).all() and (sc[1] > sc[0]).all() and (sc[2, :B - 1] > 0).all(), "degenerate depth range / flow"
+        dt = R.max_over_ranks(dt)
+        sc = scal.cpu().numpy()
+        assert np.isfinite(sc).all() and (sc[1] > sc[0]).all() and (sc[2, :B - 1] > 0).all(), "degenerate depth range / flow"
+        res = {"dt": dt, "fam": fam, "depth_s": band_s[0], "flow_s": band_s[1]}
+        if extras and rank == 0:
+            # latency of BASELINE.json configs[1]: one 1280x720 frame, batch 1 (outside the timed region above)
+            if args.latency:
+                f1 = torch.from_numpy(synth.frames(1, 720, 1280, seed=7)).cuda()
+                r1 = torch.empty((1, 720, 1280, 3), dtype=torch.uint8, device="cuda")
+                for i in range(8):
+                    if i == 3:
+                        torch.cuda.synchronize(); t1 = time.perf_counter()
+                    dn.infer_dev(f1.data_ptr(), 1, 720, 1280, 0, r1.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
+                    dn.sync()
+                res["lat_b1"] = (time.perf_counter() - t1) / 5 * 1e3
+            # PCIe-inclusive rate (never `value`): the host-pointer entry point over 4 chunks from pageable numpy memory -
+            # pinned staging + H2D / compute / D2H on three streams (abi.hip pb_depth_infer_batch)
+            if args.host_chunks > 0:
+                hf = np.concatenate([frames] * args.host_chunks)
+                dn.infer_batch(hf[:B], want_depth=False, want_rgb=True, flip=True)
+                t1 = time.perf_counter()
+                _, h_rgb, h_mn, h_mx = dn.infer_batch(hf, want_depth=False, want_rgb=True, flip=True)
+                res["host_fps"] = len(hf) / (time.perf_counter() - t1)
+                assert h_rgb.shape == hf.shape and np.isfinite(h_mn).all()
+                del hf, h_rgb
+        dn.close(); fn.close()
+        return res
 
-    # latency of BASELINE.json configs[1]: one 1280x720 frame, batch 1 (rank 0 only, outside the timed region above)
-    lat_b1 = None
-    if rank == 0 and args.latency:
-        f1 = torch.from_numpy(synth.frames(1, 720, 1280, seed=7)).cuda()
-        r1 = torch.empty((1, 720, 1280, 3), dtype=torch.uint8, device="cuda")
-        for i in range(8):
-            if i == 3:
-                torch.cuda.synchronize(); t1 = time.perf_counter()
-            dn.infer_dev(f1.data_ptr(), 1, 720, 1280, 0, r1.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
-            dn.sync()
-        lat_b1 = (time.perf_counter() - t1) / 5 * 1e3
-    # PCIe-inclusive rate (never `value`): the host-pointer entry point over 4 chunks from pageable numpy memory -
-    # pinned staging + H2D / compute / D2H on three streams (abi.hip pb_depth_infer_batch)
-    host_fps = None
-    if rank == 0 and args.host_chunks > 0:
-        hf = np.concatenate([frames] * args.host_chunks)
-        dn.infer_batch(hf[:B], want_depth=False, want_rgb=True, flip=True)
-        t1 = time.perf_counter()
-        _, h_rgb, h_mn, h_mx = dn.infer_batch(hf, want_depth=False, want_rgb=True, flip=True)
-        host_fps = len(hf) / (time.perf_counter() - t1)
-        assert h_rgb.shape == hf.shape and np.isfinite(h_mn).all()
-        del hf, h_rgb
-    depth_only = None
-    if args.depth_leg:                       # depth_anything alone, same batch: the shape north_star's roofline target is quoted on
-        def dstep():
-            dn.infer_dev(d_frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
-            dn.sync()
-        dstep()
-        dn.set_profiling(timing=True, accumulate=True)
-        R.barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            dstep()
-        R.barrier()
-        ddt = R.max_over_ranks(time.perf_counter() - t1)
-        dfam = {s["name"]: s for s in dn.kernel_stats()}
-        dn.set_profiling(timing=False)
-        att = dfam.get("attention")
-        depth_only = {"metric": "frames/sec (depth_anything ViT-L, 1080p, batch 32 per GPU)", "value": round(world * B * args.steps / ddt, 3),
-                      "unit": "frames/s", "ms_per_step": round(ddt / args.steps * 1e3, 3),
-                      "model_tflops": round(B * args.steps / ddt * GFLOP_PER_FRAME / 1e3, 2),
-                      "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(dfam.items())},
-                      "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in dfam.items() if v["flops"] > 0 and v["ms"] > 0},
-                      "attention_frac_of_peak": round(att["flops"] / (att["ms"] * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4) if att and att["ms"] > 0 else None}
-    dn.close(); fn.close()
+    main_res = run_mode(args.precision, args.steps, args.warmup, True)
+    other_res = None if args.one_precision else run_mode(1 - args.precision, max(1, min(args.steps, 3)), 1, False)
     flow = flow_leg(args, R) if args.flow_pairs > 0 else None
     mask = mask_leg(args, R) if args.mask_frames > 0 else None
     pipe = pipeline_leg(args, R) if args.pipeline_frames > 1 else None
 
     if rank == 0:
+        dt, fam = main_res["dt"], main_res["fam"]
         fps = world * B * args.steps / dt
-        symbols = {"depth/gemm_f16": "gemm8_kernel<0,0,0,true> (depth: fc1 + DPT 1x1/convT GEMMs, fp16 out)",
-                   "depth/gemm_f16_resid": "gemm8_kernel<0,1,0,true> (depth: proj + fc2, accumulating onto the fp32 residual)",
-                   "depth/gemm_f16_qkv": "gemm8_kernel<0,2,0,true> (depth: qkv projection)",
-                   "depth/conv_igemm_f16": "gemm8_kernel<1,0,0,true> (depth: implicit-GEMM convs of the DPT head)",
-                   "depth/attention": "attnq_kernel<1,2,0,false,8> (depth: fused attention)",
-                   "flow/conv_igemm_f16_tile128": "gemm_kernel<128,128,2,2,1,0,true,2> (flow: implicit-GEMM convs with N < 256 or < 256 tiles)",
-                   "flow/conv_igemm_f16": "gemm8_kernel<1,0,0,true> (flow: implicit-GEMM convs on the 256 x 256 ping-pong kernel)",
-                   "flow/gemm_f16": "gemm8_kernel<0,0,0,true> (flow: correlation volume + 1x1 GEMMs)"}
+        # roofline kernel: the family with the most launch time in the timed region (bands run one after the other, so this is
+        # the kernel's own time - the criterion rocprofv3's per-symbol totals reproduce)
         dom_name, g = max(((k, v) for k, v in fam.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(symbols.get(dom_name, dom_name).split(" ")[0], B)
-        ga = alone.get(dom_name)
-        ach_a = ga["flops"] / (ga["ms"] * 1e-3) / 1e12 if ga and ga["ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(SYMBOLS.get(dom_name, dom_name).split(" ")[0])
         tot_fl = sum(v["flops"] for v in fam.values())
+        band_fl = {b: sum(v["flops"] for k, v in fam.items() if k.startswith(b + "/")) for b in ("depth", "flow")}
+
+        def mode_summary(res, steps):
+            return {"value": round(world * B * steps / res["dt"], 3), "unit": "frames/s", "ms_per_step": round(res["dt"] / steps * 1e3, 3),
+                    "depth_ms_per_step": round(res["depth_s"] / steps * 1e3, 3), "flow_ms_per_step": round(res["flow_s"] / steps * 1e3, 3)}
+
         out = {
             "metric": "frames/sec (depth_anything ViT-L + flow_raft, 1080p)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "vs_baseline": None, "dtype": PREC_NAME[args.precision], "data": "synthetic",
             "config": {"workload": f"every frame of a {B}-frame {W}x{H} synthetic uint8 clip (resident in HBM, one clip per GPU) through "
-                                   f"depth_anything {args.encoder} (DINOv2 ViT-L/14 + DPT head, one batch of {B}, heat-encoded uint8 + min/max out) and "
+                                   f"depth_anything {args.encoder} (DINOv2 ViT-L/14 + DPT head, one batch of {B}, heat-encoded uint8 + min/max out) and then "
                                    f"flow_raft (its {B - 1} consecutive forward pairs, --scale {args.flow_scale} -> {sw}x{sh}, {args.flow_iters} GRU iterations, "
                                    f"HSV-encoded uint8 + max displacement out); fused pre/post-process, seeded synthetic weights; "
                                    f"BASELINE.json configs[3] (depth, 32 frames per GPU) plus the flow band the metric names",
                        "frames_per_gpu_per_step": B, "frame": [H, W], "depth_net_input": list(engine.net_size(H, W)), "flow_net_input": [sh, sw],
+                       "precision": PREC_NAME[args.precision],
                        "parallelism": f"one clip per GPU on {world} GPU(s); per-frame scalars all-gathered (12 bytes per frame), nothing else crosses GPUs"},
-            "roofline": {"bound": "mfma", "kernel": symbols.get(dom_name, dom_name), "family": dom_name,
+            "precision_modes": {
+                "f16": "one fp16 MFMA pass per GEMM / conv, fp32 accumulate; vs the fp32 reference: L2 < 1e-3, max-norm up to 1.6e-3 (tests: conftest.TOL[0])",
+                "split-f16": "hi + lo fp16 operands where the error budget needs them (2-3 passes over K); max-norm and L2 < 1e-3 on every reference vector (the tests' default)"},
+            "roofline": {"bound": "mfma", "kernel": SYMBOLS.get(dom_name, dom_name), "family": dom_name,
                          "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                         "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5),
+                         "algorithmic_bytes": round(g["bytes"] / max(g["launches"], 1)),
+                         "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5), "launches_per_step": g["launches"] / args.steps,
                          "flop_per_launch": g["flops"] / max(g["launches"], 1),
-                         "note": "HIP events on each band's stream inside the timed region; the two bands share the GPU there, so a launch's duration "
-                                 "includes what the other band's kernels cost it - the *_alone fields are the same launches with one band on the GPU at a time",
-                         "avg_launch_ms_alone": round(ga["ms"] / max(ga["launches"], 1), 5) if ga else None,
-                         "achieved_alone": round(ach_a, 2) if ga else None, "frac_alone": round(ach_a / PEAK_F16_TFLOPS, 4) if ga else None},
+                         "selection": "family with the largest summed launch time in the timed region (bands run one after the other; HIP events on the band's stream)",
+                         "step_frac": round(tot_fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
+                         "depth_frac_alone": round(band_fl["depth"] / main_res["depth_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
+                         "flow_frac_alone": round(band_fl["flow"] / main_res["flow_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
+                         "note": "flops are algorithmic multiply-adds (2 M N K of the layer, padding and split-fp16 passes not counted); *_frac_alone = a "
+                                 "band's flops / its wall time inside the step / peak; step_frac = all launches' flops / step wall time / peak"},
             "model_tflops": round(tot_fl / dt / 1e12, 2),
-            "pcie_inclusive_fps": round(host_fps, 2) if host_fps else None,
-            "latency_720p_batch1_ms": round(lat_b1, 3) if lat_b1 is not None else None,
+            "depth_anything": {"metric": f"frames/sec (depth_anything ViT-L, 1080p, batch {B} per GPU, inside the step)",
+                               "value": round(world * B * args.steps / main_res["depth_s"], 3), "unit": "frames/s",
+                               "ms_per_step": round(main_res["depth_s"] / args.steps * 1e3, 3),
+                               "model_tflops": round(B * args.steps / main_res["depth_s"] * GFLOP_PER_FRAME / 1e3, 2)},
+            "flow_raft": {"metric": f"frame-pairs/sec (flow_raft, 1080p x {args.flow_scale}, {args.flow_iters} iterations, forward, inside the step)",
+                          "value": round(world * (B - 1) * args.steps / main_res["flow_s"], 3), "unit": "pairs/s",
+                          "ms_per_step": round(main_res["flow_s"] / args.steps * 1e3, 3)},
+            "pcie_inclusive_fps": round(main_res["host_fps"], 2) if "host_fps" in main_res else None,
+            "latency_720p_batch1_ms": round(main_res["lat_b1"], 3) if "lat_b1" in main_res else None,
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(fam.items())},
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items()
                               if v["flops"] > 0 and v["ms"] > 0},
-            "kernel_ms_per_step_alone": {k: round(v["ms"] / 2, 3) for k, v in sorted(alone.items())},
-            "kernel_tflops_alone": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in alone.items()
-                                    if v["flops"] > 0 and v["ms"] > 0},
+            "kernel_launches_per_step": {k: v["launches"] / args.steps for k, v in sorted(fam.items())},
         }
+        out["this_precision"] = dict(mode_summary(main_res, args.steps), precision=PREC_NAME[args.precision])
+        if other_res:
+            osteps = max(1, min(args.steps, 3))
+            ofam = other_res["fam"]
+            out["other_precision"] = dict(mode_summary(other_res, osteps), precision=PREC_NAME[1 - args.precision], steps=osteps,
+                                          kernel_ms_per_step={k: round(v["ms"] / osteps, 3) for k, v in sorted(ofam.items())})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, cfg, rweights, frames, args.flow_scale, args.flow_iters)
-        if depth_only:
-            out["depth_anything"] = depth_only
         if flow:
             out["flow_raft_720p"] = flow
         if mask:

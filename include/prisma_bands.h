@@ -62,7 +62,22 @@ typedef struct {
                                * carry conv2.*, seed_bin_regressor.*, seed_projector.*, projectors.*, attractors.*,
                                * conditional_log_binomial.mlp.* (ZoeDepth state dict, `core.core.` prefix stripped);
                                * the network input is 392 x 518, depth_out is metric depth, use flip = 0 */
+    int32_t precision;        /* pb_precision: 0 = one fp16 MFMA pass per GEMM, 1 = split-fp16 (see pb_precision)        */
 } pb_depth_cfg;
+
+/* Arithmetic of the GEMMs / convolutions (everything else - LayerNorm, softmax, residual streams, GRU state, norms'
+ * statistics - is fp32 in both modes).
+ *   PB_PREC_F16   : operands rounded to fp16 once, fp32 accumulation.  Against the fp32 reference: relative L2 < 1e-3,
+ *                   max-norm error up to 1.6e-3 of the output range on the 24-block ViT-L.
+ *   PB_PREC_SPLIT : the operands the error budget is dominated by are kept as hi + lo fp16 pairs and the products
+ *                   a_hi w_hi + a_lo w_hi + a_hi w_lo accumulate in the same fp32 MFMA accumulators (2-3 passes over K):
+ *                   max-norm and L2 error < 1e-3 on every reference vector - the mode the parity tests assert 1e-3 in. */
+typedef enum { PB_PREC_F16 = 0, PB_PREC_SPLIT = 1 } pb_precision;
+
+/* flow_raft options (cfg of pb_create; NULL = all zero). */
+typedef struct {
+    int32_t precision;        /* pb_precision */
+} pb_flow_cfg;
 
 /* SOLOv2 geometry and test_cfg for band = "mask_mmdet" (the values live in the mmdet config the reference downloads,
  * models/solov2_r101_fpn_3x_coco.py -> _base_ solov2_r50_fpn_1x_coco.py; bands/mask_mmdet.py:26-27). */
@@ -84,6 +99,7 @@ typedef struct {
     float filter_thr;            /* 0.05                                                                          */
     float sigma;                 /* 2.0 (gaussian Matrix NMS)                                                     */
     int32_t max_batch;           /* frames per backbone launch the arena is sized for (>= 1)                      */
+    int32_t precision;           /* pb_precision                                                                  */
 } pb_mask_cfg;
 
 const char *pb_last_error(void);
@@ -202,8 +218,7 @@ typedef struct {
  * this call) instead of restarting at every infer call. */
 int pb_set_profiling(pb_ctx *ctx, int enabled);
 /* Tuning / A-B switches: "gemm_tile", "conv_tile" = 0 auto, 1 128x128, 2 256x256 ping-pong,
- * 4 256x256 single-barrier; "gemm_breg" = 1: weights of the 256x256 GEMMs go straight to registers in MFMA
- * fragment order instead of through the LDS (experiment, measured slower; default 0). */
+ * 4 256x256 single-barrier. */
 int pb_set_option(pb_ctx *ctx, const char *key, int value);
 int pb_get_kernel_stats(pb_ctx *ctx, pb_kernel_stat *out, int cap);
 

@@ -222,6 +222,55 @@ def raft_case(hgt=125, wid=157, seed=21, iters=12):
                         flow_it0=st["flow_it0"])
 
 
+def raft_full_case(seed=41, iters=12):
+    """BASELINE configs[2] / [4] at full size: the REAL reference RAFT + InputPadder on (a) 8 consecutive-frame pairs of a 9-frame
+    1280x720 sequence, forward direction, 12 iterations (configs[2]: batch of 8 pairs, no --scale), committed as 1/8-strided
+    samples + float64 sums per pair; (b) one 1920x1080 pair at the band's default --scale 0.75 (810x1440 -> pad 816x1440,
+    configs[4]); cv2 is absent here, so the reference network is fed the oracle's 8-bit cubic resize (unpinned, GPU == oracle bit
+    for bit) - the golden pins the network at that size.  The reference runs one pair per call (batch 1), like its band script."""
+    import argparse
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    from raft.raft import RAFT
+    from common.flow import InputPadder
+    from oracle import raft_oracle as R
+    w = synth.raft_weights(seed=4321)
+    m = RAFT(argparse.Namespace()).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
+
+    def ref_pair(a_u8, c_u8):
+        a = torch.from_numpy(np.ascontiguousarray(a_u8)).permute(2, 0, 1).float()[None]
+        c = torch.from_numpy(np.ascontiguousarray(c_u8)).permute(2, 0, 1).float()[None]
+        padder = InputPadder(a.shape)
+        p1, p2 = padder.pad(a, c)
+        with torch.no_grad():
+            _, up = m(p1, p2, iters=iters, test_mode=True)
+        return padder.unpad(up[0]).permute(1, 2, 0).numpy()
+
+    import time
+    fr = synth.frame_pair_sequence(9, 720, 1280, seed=seed)
+    s8, sums = [], []
+    for i in range(8):
+        t0 = time.time()
+        f = ref_pair(fr[i], fr[i + 1])
+        s8.append(f[::8, ::8].copy())
+        sums.append([f[..., 0].astype(np.float64).sum(), f[..., 1].astype(np.float64).sum(), np.abs(f.astype(np.float64)).sum()])
+        if i == 0:
+            f_o, _ = R.infer_pair(w, fr[0], fr[1], scale=1.0, iters=iters)
+            e = relerr(f_o, f)
+            assert e < 2e-4, e
+            print(f"[raft 720p] oracle vs reference rel err {e:.2e}")
+        print(f"[raft 720p] pair {i}: {time.time() - t0:.1f} s, |flow| max {np.abs(f).max():.2f}, mean {f.reshape(-1, 2).mean(0)}", flush=True)
+    big = synth.frame_pair_sequence(2, 1080, 1920, seed=seed + 1)
+    a, c = R.cv_resize_cubic_u8(big[0], 0.75), R.cv_resize_cubic_u8(big[1], 0.75)
+    assert a.shape == (810, 1440, 3)
+    f1080 = ref_pair(a, c)
+    print(f"[raft 1080p x0.75] |flow| max {np.abs(f1080).max():.2f}, mean {f1080.reshape(-1, 2).mean(0)}")
+    np.savez_compressed(os.path.join(GOLD, "raft_full.npz"), frame_seed=np.array(seed), iters=np.array(iters),
+                        fwd720_s8=np.stack(s8), sums720=np.array(sums), fwd1080_s8=f1080[::8, ::8].copy(),
+                        sums1080=np.array([f1080[..., 0].astype(np.float64).sum(), f1080[..., 1].astype(np.float64).sum(),
+                                           np.abs(f1080.astype(np.float64)).sum()]))
+
+
 def mask_case(seed=5):
     """Self-vector of oracle/solov2_oracle.py (the mask band's reference cannot be imported: mmcv is absent)."""
     from oracle import solov2_oracle as SO
@@ -236,6 +285,37 @@ def mask_case(seed=5):
     np.savez_compressed(os.path.join(GOLD, "solov2_tiny_180x300.npz"), frame_seed=np.array(seed), cls_logit4=cps[4].numpy(),
                         mask_feats_sub=mf.numpy()[0, ::16, ::4, ::4].copy(), scores=sc.numpy(), labels=lb.numpy(), mask_image=img)
 
+
+
+def matrix_nms_case(seed=3):
+    """mask_matrix_nms of the REAL reference file (bands/mmdet/core/post_processing/matrix_nms.py:5-121 imports only torch, so
+    it loads without mmcv): inputs + outputs committed, and the oracle's restatement asserted equal - the one piece of the
+    mask band that can be pinned in this container."""
+    import importlib.util
+    from oracle import solov2_oracle as SO
+    spec = importlib.util.spec_from_file_location("ref_matrix_nms", os.path.join(REF, "bands/mmdet/core/post_processing/matrix_nms.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    out = {}
+    for case, (n, h, w, ncls, nms_pre, max_num) in enumerate([(40, 24, 32, 3, 500, 100), (90, 40, 56, 5, 60, 25), (12, 16, 16, 1, 500, 100)]):
+        rng = np.random.default_rng(seed + case)
+        yy, xx = np.mgrid[0:h, 0:w]
+        masks = np.stack([((yy - rng.uniform(4, h - 4)) ** 2 + (xx - rng.uniform(4, w - 4)) ** 2) < rng.uniform(9, 60) for _ in range(n)])
+        labels = rng.integers(0, ncls, n)
+        scores = rng.uniform(0.06, 0.9, n).astype(np.float32)
+        areas = masks.reshape(n, -1).sum(1).astype(np.float32)
+        import dataclasses
+        cfg = dataclasses.replace(synth.MASK_CFGS["tiny"], nms_pre=nms_pre, max_per_img=max_num)
+        tm, tl, ts, ta = torch.from_numpy(masks), torch.from_numpy(labels), torch.from_numpy(scores), torch.from_numpy(areas)
+        r_sc, r_lb, r_mk, r_keep = ref.mask_matrix_nms(tm, tl, ts, filter_thr=cfg.filter_thr, nms_pre=cfg.nms_pre, max_num=cfg.max_per_img,
+                                                       kernel="gaussian", sigma=cfg.sigma, mask_area=ta)
+        o_sc, o_lb, o_keep = SO.matrix_nms(tm, tl, ts, ta, cfg)
+        assert torch.equal(r_sc, o_sc) and torch.equal(r_lb, o_lb) and torch.equal(r_keep, o_keep) and torch.equal(r_mk, tm[o_keep])
+        out.update({f"masks{case}": np.packbits(masks, axis=-1), f"shape{case}": np.array([n, h, w]), f"labels{case}": labels,
+                    f"scores{case}": scores, f"areas{case}": areas, f"cfg{case}": np.array([nms_pre, max_num, cfg.filter_thr, cfg.sigma]),
+                    f"out_scores{case}": r_sc.numpy(), f"out_labels{case}": r_lb.numpy(), f"out_keep{case}": r_keep.numpy()})
+        print(f"[matrix nms] case {case}: {n} candidates -> {len(r_sc)} kept: oracle == reference (exact)")
+    np.savez_compressed(os.path.join(GOLD, "matrix_nms.npz"), **out)
 
 
 def zoe_layers_case(seed=31):
@@ -292,9 +372,11 @@ def zoe_layers_case(seed=31):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full", "raft", "mask", "zoe"]
+    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full", "raft", "mask", "nms", "zoe"]
     if "mask" in which:
         mask_case()
+    if "nms" in which:
+        matrix_nms_case()
     if "zoe" in which:
         zoe_layers_case()
     if "encode" in which:
@@ -305,6 +387,8 @@ if __name__ == "__main__":
         small_case("vitl_d4", 90, 120, 12)
     if "full" in which:
         full_case()
+    if "raft_full" in which:
+        raft_full_case()
     if "raft" in which:
         raft_case()
         raft_case(131, 181, 33, 8)      # pads to 136x184: 17 x 23 = 391 feature pixels, not a multiple of 8

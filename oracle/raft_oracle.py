@@ -221,10 +221,14 @@ def infer_pair(w, prev_u8: np.ndarray, curr_u8: np.ndarray, scale: float = 0.75,
     return np.ascontiguousarray(up[0].transpose(1, 2, 0)), np.ascontiguousarray(up[1].transpose(1, 2, 0))
 
 
-def process_flow(flow: np.ndarray):
+def process_flow(flow: np.ndarray, exact_atan2: bool = False):
     """bands/common/encode.py:98-126 (+ hue_to_rgb :13-28, saturation :73-78): polar HSV-style encode.
     dtypes follow numpy's promotion in the reference: distances / angle / hue*6 in the flow's float32,
-    the colour ramp and the saturation blend in float64; uint8 conversion truncates."""
+    the colour ramp and the saturation blend in float64; uint8 conversion truncates.
+    exact_atan2: np.arctan2 on float32 is host dependent (SVML, <= 4 ULP, on AVX512 builds; libm elsewhere - 38 % of random
+    inputs differ in the last bit between the two), so the reference's bytes are only defined up to that.  False follows
+    numpy on this host (bit-identical to the reference run on the same host: tests/golden/encode.npz); True is the
+    correctly rounded float32 arctan2 (double evaluation, rounded once) - the definition the HIP kernel implements."""
     flow = np.asarray(flow, np.float32)
     dist = np.sqrt(np.square(flow[..., 0]) + np.square(flow[..., 1]))
     mx = dist.max()
@@ -232,7 +236,8 @@ def process_flow(flow: np.ndarray):
         dx = flow[..., 0] / float(mx)
         dy = flow[..., 1] / float(mx)
         rad = np.sqrt(np.square(dx) + np.square(dy))
-        a = (np.arctan2(dy, dx) / np.pi + 1.0) * 0.5                       # float32
+        at = np.arctan2(dy.astype(np.float64), dx.astype(np.float64)).astype(np.float32) if exact_atan2 else np.arctan2(dy, dx)
+        a = (at / np.pi + 1.0) * 0.5                                       # float32
         rgb = np.zeros(a.shape + (3,), np.float64)
         rgb[..., 0] = a * 6.0
         rgb[..., 1] = a * 6.0 + 4.0

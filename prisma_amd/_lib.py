@@ -19,7 +19,22 @@ class pb_tensor(C.Structure):
 
 class pb_depth_cfg(C.Structure):
     _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32), ("features", C.c_int32),
-                ("out_channels", C.c_int32 * 4), ("pos_grid", C.c_int32), ("max_batch", C.c_int32), ("metric", C.c_int32)]
+                ("out_channels", C.c_int32 * 4), ("pos_grid", C.c_int32), ("max_batch", C.c_int32), ("metric", C.c_int32),
+                ("precision", C.c_int32)]
+
+
+class pb_flow_cfg(C.Structure):
+    _fields_ = [("precision", C.c_int32)]
+
+
+PREC_F16, PREC_SPLIT = 0, 1
+
+
+def default_precision() -> int:
+    """pb_precision the engine classes use when none is given: PRISMA_PRECISION=0 selects the single-pass fp16 mode
+    (faster; max-norm error up to 1.6e-3 against the fp32 reference), anything else / unset the split-fp16 mode that
+    meets the 1e-3 bound the parity tests assert."""
+    return PREC_F16 if os.environ.get("PRISMA_PRECISION", "1") == "0" else PREC_SPLIT
 
 
 class pb_mask_cfg(C.Structure):
@@ -27,7 +42,7 @@ class pb_mask_cfg(C.Structure):
                 ("feat_channels", C.c_int32), ("stacked_convs", C.c_int32), ("num_grids", C.c_int32 * 5),
                 ("strides", C.c_int32 * 5), ("mask_feat_channels", C.c_int32), ("mask_out_channels", C.c_int32),
                 ("nms_pre", C.c_int32), ("max_per_img", C.c_int32), ("score_thr", C.c_float), ("mask_thr", C.c_float),
-                ("filter_thr", C.c_float), ("sigma", C.c_float), ("max_batch", C.c_int32)]
+                ("filter_thr", C.c_float), ("sigma", C.c_float), ("max_batch", C.c_int32), ("precision", C.c_int32)]
 
 
 class pb_kernel_stat(C.Structure):

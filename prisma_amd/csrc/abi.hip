@@ -139,11 +139,17 @@ int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *we
         c->stream = c->depth->stream;
         c->zero = (f16 *)c->depth->zero_page();
     } else if (!strcmp(band, "flow_raft")) {
-        if (!weights || n_weights <= 0) {
+        if (!weights || n_weights <= 0 || (cfg && cfg_bytes != sizeof(pb_flow_cfg))) {
             delete c;
-            PB_CHECK(false, PB_ERR_ARG, "flow_raft: needs weights");
+            PB_CHECK(false, PB_ERR_ARG, "flow_raft: needs weights (and cfg = NULL or a pb_flow_cfg of %zu bytes, got %zu)", sizeof(pb_flow_cfg), cfg_bytes);
+        }
+        const int prec = cfg ? ((const pb_flow_cfg *)cfg)->precision : PB_PREC_F16;
+        if (prec != PB_PREC_F16 && prec != PB_PREC_SPLIT) {
+            delete c;
+            PB_CHECK(false, PB_ERR_ARG, "flow_raft: precision %d unknown", prec);
         }
         c->raft = new RaftEngine(device_id);
+        c->raft->split_w_ = prec == PB_PREC_SPLIT;
         int r = c->raft->load(weights, n_weights);
         if (r) {
             delete c->raft;
@@ -425,7 +431,6 @@ int pb_set_option(pb_ctx *c, const char *key, int value) {
     int *v = c->depth ? &c->depth->conv_tile : (c->raft ? &c->raft->conv_tile : (c->mask ? &c->mask->conv_tile : &c->conv_tile));
     if (!strcmp(key, "gemm_tile")) *g = value;
     else if (!strcmp(key, "conv_tile")) *v = value;
-    else if (!strcmp(key, "gemm_breg") && c->depth) c->depth->breg = value;
     else PB_CHECK(false, PB_ERR_ARG, "unknown option '%s'", key);
     return 0;
 }

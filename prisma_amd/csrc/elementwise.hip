@@ -12,14 +12,15 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                         const float *__restrict__ bt, f16 *__restrict__ y, int B,
-                                                        int ntp, int ntok, int D, float eps, int drop_cls) {
+                                                        int ntp, int ntok, int D, float eps, int drop_cls, int ldy,
+                                                        int lo_off) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= (int64_t)B * ntok) return;
     const int b = (int)(r / ntok), t = (int)(r - (int64_t)b * ntok);
     if (drop_cls && t == 0) return;
     const float *xr = x + ((int64_t)b * ntp + t) * D;
-    f16 *yr = drop_cls ? y + ((int64_t)b * (ntok - 1) + (t - 1)) * D : y + ((int64_t)b * ntp + t) * D;
+    f16 *yr = drop_cls ? y + ((int64_t)b * (ntok - 1) + (t - 1)) * ldy : y + ((int64_t)b * ntp + t) * ldy;
     f32x4 v[4];
     float s = 0.f;
 #pragma unroll
@@ -49,10 +50,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
         const int c = lane * 4 + 256 * j;
         if (c < D) {
             const f32x4 gg = *(const f32x4 *)(g + c), bb = *(const f32x4 *)(bt + c);
-            f16x4 o;
+            f16x4 o, l;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (f16)((v[j][e] - mean) * rstd * gg[e] + bb[e]);
+            for (int e = 0; e < 4; ++e) {
+                const float t = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+                o[e] = (f16)t;
+                l[e] = (f16)(t - (float)o[e]);
+            }
             *(f16x4 *)(yr + c) = o;
+            if (lo_off) *(f16x4 *)(yr + c + lo_off) = l;       // split-fp16 consumers read [hi | lo] (gemm.h)
         }
     }
 }
@@ -125,7 +131,7 @@ __host__ __device__ inline float bilerp_scale(int in, int out, int align) {
 
 __global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int B,
                                                             int H, int W, int OH, int OW, int C8, int ldc, int align,
-                                                            float sy, float sx) {
+                                                            float sy, float sx, int lo_off) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * OH * OW * C8) return;
     const int c = (int)(i % C8);
@@ -142,6 +148,24 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const f16 *__restric
     const f16x8 v11 = *(const f16x8 *)(base + ((int64_t)y1 * W + x1) * ldc);
     const float hy = 1.f - ly, hx = 1.f - lx;
     f16x8 o;
+    if (lo_off) {        // split-fp16 maps [hi | lo]: interpolate hi + lo, store the result's hi and lo
+        const f16x8 l00 = *(const f16x8 *)(base + ((int64_t)y0 * W + x0) * ldc + lo_off);
+        const f16x8 l01 = *(const f16x8 *)(base + ((int64_t)y0 * W + x1) * ldc + lo_off);
+        const f16x8 l10 = *(const f16x8 *)(base + ((int64_t)y1 * W + x0) * ldc + lo_off);
+        const f16x8 l11 = *(const f16x8 *)(base + ((int64_t)y1 * W + x1) * ldc + lo_off);
+        f16x8 l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = (float)v00[j] + (float)l00[j], b2 = (float)v01[j] + (float)l01[j];
+            const float c2 = (float)v10[j] + (float)l10[j], d = (float)v11[j] + (float)l11[j];
+            const float t = hy * (hx * a + lx * b2) + ly * (hx * c2 + lx * d);
+            o[j] = (f16)t;
+            l[j] = (f16)(t - (float)o[j]);
+        }
+        *(f16x8 *)(y + pix * ldc + c * 8) = o;
+        *(f16x8 *)(y + pix * ldc + c * 8 + lo_off) = l;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         o[j] = (f16)(hy * (hx * (float)v00[j] + lx * (float)v01[j]) + ly * (hx * (float)v10[j] + lx * (float)v11[j]));
@@ -300,10 +324,10 @@ inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t
 }  // namespace
 
 int launch_layernorm(hipStream_t s, const float *x, const float *g, const float *b, f16 *y, int B, int ntp, int ntok,
-                     int D, float eps, int drop_cls) {
+                     int D, float eps, int drop_cls, int ldy, int lo_off) {
     PB_CHECK(D % 4 == 0 && D <= 1024, -1, "layernorm: D=%d unsupported", D);
     hipLaunchKernelGGL(layernorm_kernel, dim3(nblk((int64_t)B * ntok, 4)), dim3(256), 0, s, x, g, b, y, B, ntp, ntok,
-                       D, eps, drop_cls);
+                       D, eps, drop_cls, ldy ? ldy : D, lo_off);
     PB_HIP(hipGetLastError());
     return 0;
 }
@@ -323,11 +347,11 @@ int launch_preprocess(hipStream_t s, const uint8_t *frames, int B, int H, int W,
 }
 
 int launch_bilinear_nhwc(hipStream_t s, const f16 *x, f16 *y, int B, int H, int W, int OH, int OW, int C, int ldc,
-                         int align) {
+                         int align, int lo_off) {
     PB_CHECK(C % 8 == 0 && ldc % 8 == 0, -1, "bilinear: C=%d ldc=%d must be multiples of 8", C, ldc);
     const float sy = bilerp_scale(H, OH, align), sx = bilerp_scale(W, OW, align);
     hipLaunchKernelGGL(bilinear_nhwc_kernel, dim3(nblk((int64_t)B * OH * OW * (C / 8))), dim3(256), 0, s, x, y, B, H,
-                       W, OH, OW, C / 8, ldc, align, sy, sx);
+                       W, OH, OW, C / 8, ldc, align, sy, sx, lo_off);
     PB_HIP(hipGetLastError());
     return 0;
 }

@@ -14,7 +14,9 @@ struct PackedW {
     f16 *w = nullptr;        // [Npad, K] fp16, K % 64 == 0
     float *bias = nullptr;   // [N] fp32 or null
     int N = 0, K = 0, Kreal = 0;
-    mutable f16 *wf[2] = {nullptr, nullptr};   // fragment-order copies (plain / interleaved columns), built on first use
+    // split-fp16 packing (gemm.h kwrap): per tap the K axis holds the segments [w_hi | w_hi (if sa) | w_lo (if sw)] of Cseg
+    // channels each; the activation operand must then be [hi | lo (if sa)] with Cseg channels per part
+    int sa = 0, sw = 0, Cseg = 0;
 };
 
 struct Stage {
@@ -50,8 +52,6 @@ class DepthEngine {
     int device = 0;
     bool debug = false;
     int gemm_tile = TILE_AUTO, conv_tile = TILE_AUTO;
-    int breg = 0;            // 1: 256x256 GEMMs read the weights in fragment order straight into registers (gemm8b_kernel);
-                             // measured 3-8 % slower than the LDS path (both wave rows fetch B from L2), so off by default
     KernelTimer timer;
 
     // scratch for op-level tests
@@ -74,13 +74,18 @@ class DepthEngine {
               const f16 *add2, int act, int stride, int outC);
     void *carve(size_t bytes);
     int upload_f32(const float *src, size_t n, float **dst);
-    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias);
+    // taps > 1: src is [N][taps][K / taps] and every tap is padded to Kpad / taps; sa / sw: split-fp16 segments (PackedW)
+    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias, int taps = 1, int sa = 0, int sw = 0);
     const pb_tensor *find(const std::string &name) const;
     void tic(int fam, double flops, double bytes);
     void toc();
     void snapshot(const std::string &name);
 
     pb_depth_cfg cfg_;
+    // PB_PREC_SPLIT (tools/precision_budget.py): ViT linears and the metric head keep their weights as hi + lo (2 passes);
+    // the DPT head keeps weights AND feature maps as hi + lo (3 passes; maps are [hi | lo] per pixel, hs_ = 2)
+    int vit_sw_ = 0, head_sa_ = 0, head_sw_ = 0, hs_ = 1;
+    int batch_cap(int H, int W) const;          // frames per chunk the 32-bit tensor offsets allow for this frame size
     std::map<std::string, const pb_tensor *> tmap_;
     std::vector<void *> owned_;                 // permanent device allocations (weights)
     // weights

@@ -6,6 +6,7 @@
 #include "engine.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -90,23 +91,34 @@ int DepthEngine::upload_f32(const float *src, size_t n, float **dst) {
     return 0;
 }
 
-// src: host fp32 [N, K] row-major (already in GEMM order).  Pads rows to a multiple of 256 and K to Kpad.
-int DepthEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias) {
+// src: host fp32 [N, K] row-major (already in GEMM order; K = taps x channels).  Pads rows to a multiple of 256 and every
+// tap to Kpad / taps channels.  Split-fp16 (sa / sw): each tap becomes the segments [w_hi | w_hi | w_lo] (PackedW, gemm.h).
+int DepthEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias, int taps, int sa, int sw) {
     const int64_t Np = round_up(N, 256);
-    std::vector<f16> h((size_t)Np * Kpad, (f16)0.f);
-    for (int n = 0; n < N; ++n) {
-        const float *s = src + (int64_t)n * K;
-        f16 *d = h.data() + (int64_t)n * Kpad;
-        for (int k = 0; k < K; ++k) d[k] = (f16)s[k];
-    }
+    const int segs = 1 + sa + sw, Cin = K / taps, Cp = Kpad / taps;
+    PB_CHECK(K % taps == 0 && Kpad % taps == 0 && Cp >= Cin && (segs == 1 || Cp % 64 == 0), PB_ERR_ARG, "pack: K %d / Kpad %d / taps %d", K, Kpad, taps);
+    const int64_t Kt = (int64_t)taps * segs * Cp;
+    std::vector<f16> h((size_t)Np * Kt, (f16)0.f);
+    for (int n = 0; n < N; ++n)
+        for (int t = 0; t < taps; ++t) {
+            const float *s = src + (int64_t)n * K + (int64_t)t * Cin;
+            f16 *d = h.data() + (int64_t)n * Kt + (int64_t)t * segs * Cp;
+            for (int k = 0; k < Cin; ++k) {
+                const f16 hi = (f16)s[k];
+                d[k] = hi;
+                if (sa) d[Cp + k] = hi;
+                if (sw) d[(1 + sa) * Cp + k] = (f16)(s[k] - (float)hi);
+            }
+        }
     void *p = nullptr;
     PB_HIP(hipMalloc(&p, h.size() * 2));
     owned_.push_back(p);
     PB_HIP(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     out.w = (f16 *)p;
     out.N = N;
-    out.K = Kpad;
+    out.K = (int)Kt;
     out.Kreal = K;
+    out.sa = sa; out.sw = sw; out.Cseg = Cp;
     out.bias = nullptr;
     if (bias) return upload_f32(bias, N, &out.bias);
     return 0;
@@ -120,6 +132,15 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         tmap_[w[i].name] = &w[i];
     }
     const int D = cfg_.embed_dim, Hd = 4 * D, F = cfg_.features;
+    PB_CHECK(cfg_.precision == PB_PREC_F16 || cfg_.precision == PB_PREC_SPLIT, PB_ERR_ARG, "precision %d unknown", cfg_.precision);
+    if (cfg_.precision == PB_PREC_SPLIT) {
+        vit_sw_ = 1; head_sa_ = 1; head_sw_ = 1;
+        // experiment switches (tools/precision_budget.py rows): PB_SPLIT=<vit_w><head_a><head_w>, e.g. 110
+        if (const char *e = getenv("PB_SPLIT")) {
+            if (strlen(e) == 3) { vit_sw_ = e[0] == '1'; head_sa_ = e[1] == '1'; head_sw_ = e[2] == '1'; }
+        }
+        hs_ = head_sa_ ? 2 : 1;
+    }
     PB_CHECK(D % 128 == 0 && D <= 1024 && D / cfg_.heads == 64, PB_ERR_ARG, "embed_dim %d / heads %d unsupported", D,
              cfg_.heads);
     PB_CHECK(F % 64 == 0 && cfg_.depth >= 4, PB_ERR_ARG, "features %d / depth %d unsupported", F, cfg_.depth);
@@ -145,7 +166,7 @@ int DepthEngine::load(const pb_tensor *w, int n) {
     {   // patch embedding: conv weight [D,3,14,14] is already [N, K=588] in (c, py, px) order
         NEED(wt, P + "patch_embed.proj.weight", (int64_t)D * 588);
         NEED(bs, P + "patch_embed.proj.bias", D);
-        int r = pack(wt, D, 588, 640, patch_, bs);
+        int r = pack(wt, D, 588, 640, patch_, bs, 1, 0, vit_sw_);
         if (r) return r;
         UP(cls_, P + "cls_token", D);
         const int g = cfg_.pos_grid;
@@ -161,7 +182,7 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         UP(B.ls1, b + "ls1.gamma", D);     UP(B.ls2, b + "ls2.gamma", D);
         int r;
         { NEED(wt, b + "attn.qkv.weight", (int64_t)3 * D * D); NEED(bs, b + "attn.qkv.bias", 3 * D);
-          if ((r = pack(wt, 3 * D, D, D, B.qkv, bs))) return r; }
+          if ((r = pack(wt, 3 * D, D, D, B.qkv, bs, 1, 0, vit_sw_))) return r; }
         // LayerScale (layer_scale.py:27-28) is folded into the weights: x + g*(W y + b) = x + (g.W) y + g.b, so the GEMM
         // can accumulate straight onto the residual stream
         auto pack_scaled = [&](const float *wt, const float *bs, const float *g, int N, int K, PackedW &out) -> int {
@@ -170,12 +191,12 @@ int DepthEngine::load(const pb_tensor *w, int n) {
                 for (int k = 0; k < K; ++k) ws[(size_t)n * K + k] = wt[(size_t)n * K + k] * g[n];
                 bb[n] = bs[n] * g[n];
             }
-            return pack(ws.data(), N, K, K, out, bb.data());
+            return pack(ws.data(), N, K, K, out, bb.data(), 1, 0, vit_sw_);
         };
         { NEED(wt, b + "attn.proj.weight", (int64_t)D * D); NEED(bs, b + "attn.proj.bias", D); NEED(g1, b + "ls1.gamma", D);
           if ((r = pack_scaled(wt, bs, g1, D, D, B.proj))) return r; }
         { NEED(wt, b + "mlp.fc1.weight", (int64_t)Hd * D); NEED(bs, b + "mlp.fc1.bias", Hd);
-          if ((r = pack(wt, Hd, D, D, B.fc1, bs))) return r; }
+          if ((r = pack(wt, Hd, D, D, B.fc1, bs, 1, 0, vit_sw_))) return r; }
         { NEED(wt, b + "mlp.fc2.weight", (int64_t)D * Hd); NEED(bs, b + "mlp.fc2.bias", D); NEED(g2, b + "ls2.gamma", D);
           if ((r = pack_scaled(wt, bs, g2, D, Hd, B.fc2))) return r; }
     }
@@ -196,7 +217,7 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         for (int o = 0; o < co; ++o)
             for (int c = 0; c < ci; ++c)
                 for (int t = 0; t < ks * ks; ++t) g[(size_t)o * K + t * cip + c] = wt[((size_t)o * ci + c) * ks * ks + t];
-        int r = pack(g.data(), co, K, K, out, bs);
+        int r = pack(g.data(), co, K, K, out, bs, ks * ks, head_sa_, head_sw_);
         out.Kreal = ks * ks * ci;
         return r;
     };
@@ -210,7 +231,7 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         for (int ci = 0; ci < c; ++ci)
             for (int o = 0; o < c; ++o)
                 for (int t = 0; t < s * s; ++t) g[((size_t)t * c + o) * cip + ci] = wt[((size_t)ci * c + o) * s * s + t];
-        int r = pack(g.data(), s * s * c, cip, cip, out, nullptr);
+        int r = pack(g.data(), s * s * c, cip, cip, out, nullptr, 1, head_sa_, head_sw_);
         out.Kreal = c;
         if (r) return r;
         return upload_f32(bs, c, &out.bias);
@@ -356,6 +377,15 @@ int pb_depth_net_size(int H, int W, int *net_h, int *net_w) {
     return 0;
 }
 
+int DepthEngine::batch_cap(int H, int W) const {
+    int nh = 0, nw = 0;
+    if (pb_depth_net_size(H, W, &nh, &nw)) return 1;
+    if (cfg_.metric) { nh = 392; nw = 518; }
+    const int64_t Fp = cp64(cfg_.features), F2p = cp64(cfg_.features / 2);
+    const int64_t per = std::max((int64_t)nh * nw * F2p, (int64_t)16 * (nh / 14) * (nw / 14) * 4 * Fp) * hs_;   // elements of the largest map of one frame
+    return (int)std::max<int64_t>(1, ((1LL << 31) - 1) / per);
+}
+
 int DepthEngine::prepare(int B, int H, int W) {
     if (B <= pB_ && H == pH_ && W == pW_) return 0;
     B = std::max(B, (pH_ == H && pW_ == W) ? pB_ : 0);
@@ -367,8 +397,8 @@ int DepthEngine::prepare(int B, int H, int W) {
     lh_[0] = 4 * gh_; lw_[0] = 4 * gw_; lh_[1] = 2 * gh_; lw_[1] = 2 * gw_; lh_[2] = gh_; lw_[2] = gw_;
     lh_[3] = (gh_ - 1) / 2 + 1; lw_[3] = (gw_ - 1) / 2 + 1;
     const int D = cfg_.embed_dim, F = cfg_.features, Fp = cp64(F), F2p = cp64(F / 2);
-    // GEMM row indices and per-tensor element offsets are 32-bit in the kernels
-    PB_CHECK((int64_t)B * nh_ * nw_ * F2p < (1LL << 31) && (int64_t)B * 4 * lh_[0] * lw_[0] * Fp < (1LL << 31), PB_ERR_ARG,
+    // GEMM row indices and per-tensor element offsets are 32-bit in the kernels (infer() chunks by batch_cap)
+    PB_CHECK((int64_t)B * nh_ * nw_ * F2p * hs_ < (1LL << 31) && (int64_t)B * 4 * lh_[0] * lw_[0] * Fp * hs_ < (1LL << 31), PB_ERR_ARG,
              "batch %d too large for %dx%d frames (32-bit tensor offsets); lower max_batch", B, H, W);
     const int64_t rows = round_up((int64_t)B * ntp_, 256);
     const size_t slack = 32768;
@@ -385,21 +415,22 @@ int DepthEngine::prepare(int B, int H, int W) {
         Q_ = (f16 *)carve(qkb); K_ = (f16 *)carve(qkb); Vt_ = (f16 *)carve(qkb);
         AO_ = (f16 *)carve((size_t)rows * D * 2);
         Hd_ = (f16 *)carve((size_t)rows * 4 * D * 2);
-        for (int i = 0; i < 4; ++i) feat_[i] = (f16 *)carve((size_t)round_up((int64_t)B * P_, 256) * D * 2);
+        // split-fp16 head (hs_ = 2): every head map holds [hi | lo] per pixel / token
+        for (int i = 0; i < 4; ++i) feat_[i] = (f16 *)carve((size_t)round_up((int64_t)B * P_, 256) * D * 2 * hs_);
         for (int i = 0; i < 4; ++i) {
-            const size_t pix = (size_t)round_up((int64_t)B * lh_[i] * lw_[i], 256);
+            const size_t pix = (size_t)round_up((int64_t)B * lh_[i] * lw_[i], 256) * hs_;
             const int ocp = cp64(cfg_.out_channels[i]);
-            pj_[i] = (f16 *)carve((size_t)round_up((int64_t)B * P_, 256) * ocp * 2);
+            pj_[i] = (f16 *)carve((size_t)round_up((int64_t)B * P_, 256) * ocp * 2 * hs_);
             lay_[i] = i == 2 ? pj_[2] : (f16 *)carve(pix * ocp * 2);
             rnraw_[i] = (f16 *)carve(pix * Fp * 2); rnrelu_[i] = (f16 *)carve(pix * Fp * 2);
             tmp_[i] = (f16 *)carve(pix * Fp * 2);
             sraw_[i] = (f16 *)carve(pix * Fp * 2); srelu_[i] = (f16 *)carve(pix * Fp * 2);
             yb_[i] = (f16 *)carve(pix * Fp * 2); ocb_[i] = (f16 *)carve(pix * Fp * 2);
             const int th = i == 0 ? 2 * lh_[0] : lh_[i - 1], tw = i == 0 ? 2 * lw_[0] : lw_[i - 1];
-            path_[i] = (f16 *)carve((size_t)round_up((int64_t)B * th * tw, 256) * Fp * 2);
+            path_[i] = (f16 *)carve((size_t)round_up((int64_t)B * th * tw, 256) * Fp * 2 * hs_);
         }
-        o1_ = (f16 *)carve((size_t)round_up((int64_t)B * 4 * lh_[0] * lw_[0], 256) * F2p * 2);
-        up_ = (f16 *)carve((size_t)round_up((int64_t)B * nh_ * nw_, 256) * F2p * 2);
+        o1_ = (f16 *)carve((size_t)round_up((int64_t)B * 4 * lh_[0] * lw_[0], 256) * F2p * 2 * hs_);
+        up_ = (f16 *)carve((size_t)round_up((int64_t)B * nh_ * nw_, 256) * F2p * 2 * hs_);
         netd_ = (float *)carve((size_t)B * nh_ * nw_ * 4);
         full_ = (float *)carve((size_t)B * H * W * 4);
         mm_ = (unsigned *)carve((size_t)B * 8);
@@ -444,6 +475,16 @@ int DepthEngine::prepare(int B, int H, int W) {
 int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int tile) {
     a.W = w.w;
     a.K = w.K;
+    if (w.sa || w.sw) {          // split-fp16 segments along K (gemm.h): the callers pass cC / lda of ONE part
+        if (amode == A_CONV) {
+            PB_CHECK(a.cC == w.Cseg, PB_ERR_STATE, "split conv: %d channels per part, weights packed for %d", a.cC, w.Cseg);
+            if (!a.cLd) a.cLd = (1 + w.sa) * a.cC;
+            a.cC = (1 + w.sa + w.sw) * w.Cseg;
+            a.kwrap = w.sw ? (1 + w.sa) * w.Cseg : 0;
+        } else {
+            a.kwrap = w.sw ? (1 + w.sa) * w.Cseg / 64 : 0;
+        }
+    }
     if (!a.N) a.N = w.N;
     if (!a.bias) a.bias = w.bias;
     a.zero = zero_;
@@ -451,18 +492,6 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
     const double bytes = 2.0 * ((double)a.M * w.Kreal + (double)a.N * w.Kreal + (double)a.M * a.N);
     tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes);
     if (tile == TILE_AUTO) tile = amode == A_CONV ? conv_tile : gemm_tile;
-    if (breg && w.N % 256 == 0 && (tile == TILE_AUTO || tile == TILE_256) && epi != EPI_HEAD) {
-        const int il = (epi == EPI_STD || epi == EPI_QKV || epi == EPI_PIXSHUF) ? 1 : 0;
-        if (!w.wf[il]) {
-            void *q = nullptr;
-            PB_HIP(hipMalloc(&q, (size_t)round_up(w.N, 256) * w.K * 2));
-            owned_.push_back(q);
-            int rp = launch_frag_pack(stream, w.w, (f16 *)q, (int)round_up(w.N, 256), w.K, il);
-            if (rp) return rp;
-            w.wf[il] = (f16 *)q;
-        }
-        a.Wf = w.wf[il];
-    }
     int r = launch_gemm(stream, amode, epi, tile, a);
     toc();
     return r;
@@ -475,7 +504,8 @@ int DepthEngine::conv3(const f16 *in, int inC, int n, int H, int W, const Packed
     a.cH = H; a.cW = W; a.cC = inC; a.cKW = 3; a.cStride = stride; a.cPad = 1;
     a.cOH = (H + 2 - 3) / stride + 1; a.cOW = (W + 2 - 3) / stride + 1;
     a.M = n * a.cOH * a.cOW;
-    a.out = out; a.out2 = out2; a.add1 = add1; a.add2 = add2; a.act = act; a.ldo = outC;
+    a.out = out; a.out2 = out2; a.add1 = add1; a.add2 = add2; a.act = act; a.ldo = hs_ * outC;
+    a.lo_off = head_sa_ ? outC : 0;
     return gemm(A_CONV, EPI_STD, a, w, TILE_AUTO);
 }
 
@@ -542,10 +572,10 @@ int DepthEngine::vit(int n) {
         const int tap = i - (cfg_.depth - 4);
         if (tap >= 0) {
             tic(F_LN, 0, ln_bytes);
-            r = launch_layernorm(stream, X_, normg_, normb_, feat_[tap], n, ntp_, ntok_, D, 1e-6f, 1);
+            r = launch_layernorm(stream, X_, normg_, normb_, feat_[tap], n, ntp_, ntok_, D, 1e-6f, 1, hs_ * D, head_sa_ ? D : 0);
             toc();
             if (r) return r;
-            stages_["feat" + std::to_string(tap)] = Stage{feat_[tap], 3, 0, P_, 1, D, D, (int64_t)P_ * D};
+            stages_["feat" + std::to_string(tap)] = Stage{feat_[tap], 3, 0, P_, 1, D, hs_ * D, (int64_t)P_ * D};
         }
     }
     return 0;
@@ -555,26 +585,28 @@ int DepthEngine::head(int n) {
     const int D = cfg_.embed_dim, F = cfg_.features, Fp = cp64(F), F2 = F / 2, F2p = cp64(F2);
     const int *oc = cfg_.out_channels;
     int r;
-    auto nhwc = [&](const std::string &name, const f16 *p, int c, int h, int w, int ld) {
-        stages_[name] = Stage{p, 1, 0, c, h, w, ld, 0};
+    const int hs = hs_;                                  // 2: maps are [hi | lo] per pixel (split fp16), lo at + padded channels
+    auto lo = [&](int cp) { return head_sa_ ? cp : 0; };
+    auto nhwc = [&](const std::string &name, const f16 *p, int c, int h, int w, int ld, bool split = true) {
+        stages_[name] = Stage{p, 1, 0, c, h, w, (split ? hs : 1) * ld, 0};
     };
     auto bil = [&](const f16 *x, f16 *y, int h, int w, int oh, int ow, int c, int ld) -> int {
-        tic(F_ELT, 0, (double)n * ((double)h * w + (double)oh * ow) * c * 2.0);
-        int rr = launch_bilinear_nhwc(stream, x, y, n, h, w, oh, ow, c, ld, 1);
+        tic(F_ELT, 0, (double)n * ((double)h * w + (double)oh * ow) * c * 2.0 * hs);
+        int rr = launch_bilinear_nhwc(stream, x, y, n, h, w, oh, ow, c, hs * ld, 1, lo(ld));
         toc();
         return rr;
     };
     // reassemble: 1x1 projection of each tap, then x4 / x2 transposed convs, identity, 3x3 stride 2
     for (int i = 0; i < 4; ++i) {
         GemmArgs a;
-        a.A = feat_[i]; a.lda = D; a.M = n * P_; a.out = pj_[i]; a.ldo = cp64(oc[i]);
+        a.A = feat_[i]; a.lda = hs * D; a.M = n * P_; a.out = pj_[i]; a.ldo = hs * cp64(oc[i]); a.lo_off = lo(cp64(oc[i]));
         if ((r = gemm(A_DENSE, EPI_STD, a, proj_[i]))) return r;
     }
     for (int i = 0; i < 2; ++i) {
         const int s = i == 0 ? 4 : 2;
         GemmArgs a;
-        a.A = pj_[i]; a.lda = cp64(oc[i]); a.M = n * P_;
-        a.out = lay_[i]; a.ldo = cp64(oc[i]); a.ps_s = s; a.ps_h = gh_; a.ps_w = gw_; a.ps_co = oc[i];
+        a.A = pj_[i]; a.lda = hs * cp64(oc[i]); a.M = n * P_;
+        a.out = lay_[i]; a.ldo = hs * cp64(oc[i]); a.lo_off = lo(cp64(oc[i])); a.ps_s = s; a.ps_h = gh_; a.ps_w = gw_; a.ps_co = oc[i];
         if ((r = gemm(A_DENSE, EPI_PIXSHUF, a, i == 0 ? rs0_ : rs1_))) return r;
     }
     if ((r = conv3(pj_[3], cp64(oc[3]), n, gh_, gw_, rs3_, lay_[3], nullptr, nullptr, nullptr, ACT_NONE, 2, cp64(oc[3]))))
@@ -599,7 +631,7 @@ int DepthEngine::head(int n) {
         if ((r = conv3(tmp_[lv], Fp, n, h, w, rcu_[lv][1][1], yb_[lv], nullptr, sr, nullptr, ACT_NONE, 1, Fp))) return r;
         {   // out_conv (1x1) commutes with the bilinear resize (both linear, taps sum to 1): run it at low res
             GemmArgs a;
-            a.A = yb_[lv]; a.lda = Fp; a.M = n * h * w; a.out = ocb_[lv]; a.ldo = Fp;
+            a.A = yb_[lv]; a.lda = hs * Fp; a.M = n * h * w; a.out = ocb_[lv]; a.ldo = hs * Fp; a.lo_off = lo(Fp);
             if ((r = gemm(A_DENSE, EPI_STD, a, outc_[lv]))) return r;
         }
         const int th = lv == 0 ? 2 * h : lh_[lv - 1], tw = lv == 0 ? 2 * w : lw_[lv - 1];
@@ -620,7 +652,7 @@ int DepthEngine::head(int n) {
         r = launch_dot32_relu(stream, act32_, 32, w2_, b2_, netd_, a.M);
         toc();
         if (r) return r;
-        nhwc("output_conv2_0", act32_, 32, nh_, nw_, 32);
+        nhwc("output_conv2_0", act32_, 32, nh_, nw_, 32, false);
     } else {   // output_conv2: 3x3 -> ReLU -> 1x1 -> ReLU fused in one implicit-GEMM launch
         GemmArgs a;
         a.A = up_;
@@ -674,12 +706,13 @@ int DepthEngine::infer(const uint8_t *frames, int n, int H, int W, float *depth_
                        float *mx, int flip) {
     PB_CHECK(frames && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "infer: bad arguments");
     PB_HIP(hipSetDevice(device));
-    const int cap = std::max(1, cfg_.max_batch);
+    const int cap = std::min(std::max(1, cfg_.max_batch), batch_cap(H, W));
     int r = prepare(std::min(n, cap), H, W);
     if (r) return r;
     timer.reset();
-    for (int i = 0; i < n; i += cap) {
-        const int c = std::min(cap, n - i);
+    const int step = (n + (n + cap - 1) / cap - 1) / ((n + cap - 1) / cap);      // balanced chunks of at most cap frames
+    for (int i = 0; i < n; i += step) {
+        const int c = std::min(step, n - i);
         const int64_t px = (int64_t)H * W;
         r = run_chunk(frames + i * px * 3, c, depth_out ? depth_out + i * px : nullptr,
                       rgb_out ? rgb_out + i * px * 3 : nullptr, mn ? mn + i : nullptr, mx ? mx + i : nullptr, flip);

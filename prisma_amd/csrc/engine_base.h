@@ -18,6 +18,7 @@ class EngineBase {
     bool debug = false;
     KernelTimer timer;
     int conv_tile = TILE_AUTO;
+    int split_w_ = 0;            // PB_PREC_SPLIT: weights packed as hi + lo fp16, two passes over K (set before load)
     const f16 *zero_page() const { return zero_; }
 
   protected:
@@ -28,11 +29,16 @@ class EngineBase {
     int begin_load(const pb_tensor *w, int n);
     const pb_tensor *find(const std::string &name) const;
     // src: host fp32 [N, K] in GEMM order -> device fp16 [round_up(N, 256), Kpad] (+ fp32 bias, zero padded)
-    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias);
+    // taps: src is [N][taps][K / taps] (only matters with split_w_: the hi / lo segments alternate per tap)
+    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias, int taps = 1);
     // eval-mode BatchNorm2d (eps 1e-5) as a per-channel (scale, shift)
     int fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift);
     // conv weight [co, ci, kh, kw] (+ bias) -> rows [co][(ky * kw + kx) * round_up(ci, 64) + c], optional per-output affine
     int pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out);
+
+    // direct launch_gemm callers: K, and with split-fp16 weights the K wrap / channel bookkeeping of gemm.h (a.cC, a.cLd of
+    // ONE part must be set before the call for convolutions)
+    void set_weights(GemmArgs &a, const PackedW &w, bool is_conv) const;
 
     void *carve(size_t bytes);
     // grow the arena to the planned size (after the planning pass) and zero it

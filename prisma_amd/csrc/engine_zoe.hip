@@ -64,7 +64,7 @@ int DepthEngine::load_metric() {
         const pb_tensor *tw = find(name + ".weight"), *tb = find(name + ".bias");
         PB_CHECK(tw && tb && tw->shape[0] == co && tw->shape[1] == ci, PB_ERR_ARG, "missing or mis-shaped weight '%s' [%d, %d]",
                  name.c_str(), co, ci);
-        int r = pack((const float *)tw->data, co, ci, kpad, out, (const float *)tb->data);
+        int r = pack((const float *)tw->data, co, ci, kpad, out, (const float *)tb->data, 1, 0, vit_sw_);
         return r;
     };
     auto mlp = [&](const std::string &name, int cin, int kin, int mid, int kmid, int cout, Mlp2 &m) -> int {
@@ -151,7 +151,7 @@ int DepthEngine::metric_head(int n) {
         stages_[name] = Stage{p, 0, 0, (int64_t)hh * ww, 1, 64, 64, (int64_t)hh * ww * 64};
         return 0;
     };
-    const int Fp = 256;
+    const int Fp = 256 * hs_;            // row stride of the DPT head's maps ([hi | lo] per pixel in split-fp16 mode; hi is read)
     // ---- bottleneck, seed bins, seed embedding (zoedepth_v1.py:170-182) ----
     int h = lh_[3], w = lw_[3];
     int64_t rows = (int64_t)n * h * w;

@@ -7,7 +7,7 @@ enum { EPI_STD = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_PIXSHUF = 3, EPI_PATCH = 4, 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4,
        ACT_GRU_ZR = 5,     // N = 256 = [z | r]: z = sigmoid -> out; r = sigmoid, r * gru_h -> gru_rh (ld 384), nothing to out
        ACT_GRU_Q = 6 };    // N = 128: q = tanh; h = (1 - z) h + z q with z from gru_z (ld 256), h in gru_h (fp32, ld 128); h -> out
-enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256_SIMPLE = 4, TILE_256x128 = 5, TILE_QUAD = 6, TILE_256x128_S3 = 7, TILE_128_S3 = 8, TILE_256x64 = 9, TILE_256x128_PP = 10 };
+enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256_SIMPLE = 4, TILE_256x128 = 5, TILE_256x128_S3 = 7, TILE_128_S3 = 8, TILE_256x64 = 9 };
 
 struct GemmArgs {
     // operands: A row-major fp16 [M, lda] (dense) or NHWC image (conv); W fp16 [Npad, K], K % 64 == 0
@@ -15,13 +15,20 @@ struct GemmArgs {
     int64_t lda = 0;
     const f16 *W = nullptr;
     int bufmode = 0;                      // set by launch_gemm: 0 flat LDS-DMA, 1 buffer path over the whole operand, 2 (conv) over a two-image window
-    const f16 *Wf = nullptr;              // optional: W in MFMA fragment order (pack_fragments); selects the register-B 256x256 kernel
     int K = 0, M = 0, N = 0;              // N = columns actually written (multiple of 8)
     // implicit-GEMM convolution: input [B, cH, cW, cC] (cC % 64 == 0), K = KH*KW*cC, rows = (b, oy, ox)
     // kernel KH x cKW (tap = ky * cKW + kx), padding (cPadY, cPadX); cLd = pixel stride in elements (0 = cC), so a
     // channel slice [0, cC) of a wider NHWC buffer can be convolved in place
     int cH = 0, cW = 0, cC = 0, cOH = 0, cOW = 0, cKW = 1, cStride = 1, cPad = 0, cPadX = -1, cLd = 0;
     const f16 *zero = nullptr;            // >= 16 bytes of zeros: source of padded taps / rows >= M
+    // split-fp16 operands (precision mode): the K axis is a concatenation of segments [a_hi w_hi | a_lo w_hi | a_hi w_lo]
+    // (any subset after the first).  W holds the segments back to back; A holds [hi | lo] (or just hi) and its K index wraps:
+    // dense: K tile kt reads A tile (kt >= kwrap ? kt - kwrap : kt); conv: channel cursor c reads channel (c >= kwrap ? c - kwrap : c)
+    // of a pixel (cC = channels per tap of the concatenated K axis, cLd = pixel stride of the [hi | lo] image).  0 = off.
+    int kwrap = 0;
+    // fp16 outputs (out, out2) also store the rounding residual (f16)(v - (float)(f16)v) at element offset +lo_off, and the
+    // skip tensors add1 / add2 are read as hi + lo.  0 = off.
+    int lo_off = 0;
     // epilogue
     const float *bias = nullptr;          // [N]
     const float *gamma = nullptr;         // LayerScale [N] (EPI_RESID)
@@ -58,6 +65,3 @@ struct GemmArgs {
 
 // Launches the kernel on `stream`.  tile: TILE_AUTO picks from the shape.
 int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a);
-// Packed weights [Npad % 256 == 0][K] -> MFMA fragment order for GemmArgs::Wf; `interleaved` must match the epilogue
-// the weight is used with (EPI_STD, EPI_QKV, EPI_PIXSHUF store interleaved column pairs).
-int launch_frag_pack(hipStream_t s, const f16 *W, f16 *Wf, int Npad, int K, int interleaved);

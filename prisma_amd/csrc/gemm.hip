@@ -136,10 +136,20 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
         if (p.add1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += (float)x.a1[j];
+            if (p.lo_off) {
+                const f16x8 l = *(const f16x8 *)(p.add1 + o + p.lo_off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
+            }
         }
         if (p.add2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += (float)x.a2[j];
+            if (p.lo_off) {
+                const f16x8 l = *(const f16x8 *)(p.add2 + o + p.lo_off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
+            }
         }
         if (p.out) {
             f16x8 r;
@@ -160,12 +170,27 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
                 for (int j = 0; j < 8; ++j) r[j] = (f16)v[j];
             }
             *(f16x8 *)(p.out + o) = r;
+            if (p.lo_off) {                  // (only the linear / ReLU activations are used with split outputs)
+                f16x8 l;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = p.act == ACT_RELU ? fmaxf(v[j], 0.f) : v[j];
+                    l[j] = (f16)(t - (float)(f16)t);
+                }
+                *(f16x8 *)(p.out + o + p.lo_off) = l;
+            }
         }
         if (p.out2) {
             f16x8 r;
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] = (f16)fmaxf(v[j], 0.f);
             *(f16x8 *)(p.out2 + o) = r;
+            if (p.lo_off) {
+                f16x8 l;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float t = fmaxf(v[j], 0.f); l[j] = (f16)(t - (float)(f16)t); }
+                *(f16x8 *)(p.out2 + o + p.lo_off) = l;
+            }
         }
     } else if constexpr (EPI == EPI_F32) {
         float *r = p.out32 + (int64_t)m * p.ldo + n;
@@ -210,6 +235,12 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = (f16)(v[j] + cb[j]);
         *(f16x8 *)(p.out + row * p.ldo + co) = r;
+        if (p.lo_off) {
+            f16x8 l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t = v[j] + cb[j]; l[j] = (f16)(t - (float)(f16)t); }
+            *(f16x8 *)(p.out + row * p.ldo + co + p.lo_off) = l;
+        }
     } else if constexpr (EPI == EPI_PATCH) {
         const int b = m / p.ppi, pi = m - b * p.ppi;
         float *r = p.resid + ((int64_t)b * p.ntp + 1 + pi) * p.ldr + n;
@@ -269,7 +300,7 @@ __device__ __forceinline__ int col_map(int r, bool il) {        // tile-local B 
     return il ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;
 }
 
-template <int EPI, int TM, bool CHECK>
+template <int EPI, int TM, bool CHECK, bool LO>
 __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     const int n = wave_n0 + 2 * li;
@@ -335,6 +366,12 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add1 + off[q]);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                if constexpr (LO) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add1 + off[q] + p.lo_off);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                }
             }
             if (p.add2) {
                 f16x2 a[8];
@@ -342,6 +379,12 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add2 + off[q]);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                if constexpr (LO) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add2 + off[q] + p.lo_off);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                }
             }
             if (p.out2) {
 #pragma unroll
@@ -349,6 +392,15 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                     f16x2 o2;
                     o2[0] = (f16)fmaxf(v0[q], 0.f); o2[1] = (f16)fmaxf(v1[q], 0.f);
                     if (!CHECK || ok[q]) *(f16x2 *)(p.out2 + off[q]) = o2;
+                }
+                if constexpr (LO) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float r0 = fmaxf(v0[q], 0.f), r1 = fmaxf(v1[q], 0.f);
+                        f16x2 o2;
+                        o2[0] = (f16)(r0 - (float)(f16)r0); o2[1] = (f16)(r1 - (float)(f16)r1);
+                        if (!CHECK || ok[q]) *(f16x2 *)(p.out2 + off[q] + p.lo_off) = o2;
+                    }
                 }
             }
             if (p.act == ACT_GELU) {
@@ -411,6 +463,16 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 o[0] = (f16)(v0[q] * qs); o[1] = (f16)(v1[q] * qs);
                 if (!CHECK || ok[q]) *(f16x2 *)(dst + off[q]) = o;
             }
+            if constexpr (EPI != EPI_QKV) {
+                if constexpr (LO) {              // split-fp16 consumers read [hi | lo]
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        f16x2 o;
+                        o[0] = (f16)(v0[q] - (float)(f16)v0[q]); o[1] = (f16)(v1[q] - (float)(f16)v1[q]);
+                        if (!CHECK || ok[q]) *(f16x2 *)(dst + off[q] + p.lo_off) = o;
+                    }
+                }
+            }
         }
     }
 }
@@ -418,8 +480,16 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
 template <int EPI, int TM>
 __device__ __forceinline__ void direct_epilogue_f16(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
     // interior tiles (the common case) store without per-lane predicates: each predicate costs an exec-mask branch
-    if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false>(p, acc, wave_m0, wave_n0, lane);
-    else direct_epilogue_f16_impl<EPI, TM, true>(p, acc, wave_m0, wave_n0, lane);
+    // split-fp16 outputs (p.lo_off) take their own copy of the code: the plain path keeps its register allocation
+    if constexpr (EPI == EPI_STD || EPI == EPI_PIXSHUF) {
+        if (p.lo_off) {
+            if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false, true>(p, acc, wave_m0, wave_n0, lane);
+            else direct_epilogue_f16_impl<EPI, TM, true, true>(p, acc, wave_m0, wave_n0, lane);
+            return;
+        }
+    }
+    if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false, false>(p, acc, wave_m0, wave_n0, lane);
+    else direct_epilogue_f16_impl<EPI, TM, true, false>(p, acc, wave_m0, wave_n0, lane);
 }
 
 // Accumulators -> per-wave LDS patch -> 8-column chunks -> fused store.  `smem` must be free of live
@@ -620,19 +690,21 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     auto stage = [&](int buf, int kt) {
         char *sA = smem + buf * STAGE + wave * 1024;
         char *sB = smem + buf * STAGE + A_BYTES + wave * 1024;
+        const int ka = (p.kwrap && kt >= p.kwrap) ? kt - p.kwrap : kt;            // split-fp16 segments re-read A (gemm.h)
+        const int cs = (p.kwrap && c_c0 >= p.kwrap) ? c_c0 - p.kwrap : c_c0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if constexpr (AMODE == A_DENSE) {
-                if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[i], kt * 128, sA + i * (NT * 16));
-                else glds16(a_ptr[i] + kt * 64, sA + i * (NT * 16));
+                if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[i], ka * 128, sA + i * (NT * 16));
+                else glds16(a_ptr[i] + ka * 64, sA + i * (NT * 16));
             } else {
                 const int iy = a_iy0[i] + c_ky, ix = a_ix0[i] + c_kx;
                 const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
                 if constexpr (BUFP) {      // branch-free: OR-ing all ones into the offset makes it out of range -> the load returns zeros
                     const unsigned oob = ok ? 0u : 0xFFFFFF00u;
-                    glds16_buf(rsA, (int)((a_voff[i] + (unsigned)(((iy * p.cW + ix) * cld + c_c0) * 2)) | oob), 0, sA + i * (NT * 16));
+                    glds16_buf(rsA, (int)((a_voff[i] + (unsigned)(((iy * p.cW + ix) * cld + cs) * 2)) | oob), 0, sA + i * (NT * 16));
                 } else {
-                    glds16(ok ? a_ptr[i] + ((iy * p.cW + ix) * cld + c_c0) : p.zero, sA + i * (NT * 16));
+                    glds16(ok ? a_ptr[i] + ((iy * p.cW + ix) * cld + cs) : p.zero, sA + i * (NT * 16));
                 }
             }
         }
@@ -860,10 +932,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) a_pix0[hf][u] = AMODE == A_CONV ? (a_iy0[hf][u] * p.cW + a_ix0[hf][u]) * cld : 0;
     auto stage_a = [&](int hf, int kt_) {
-        const int kt = kt_ < nk ? kt_ : nk - 1;
+        const int ktc = kt_ < nk ? kt_ : nk - 1;
+        const int kt = (p.kwrap && ktc >= p.kwrap) ? ktc - p.kwrap : ktc;         // split-fp16 segments re-read A (gemm.h)
         char *base = smem + (kt_ & 1) * BUF;
         const int ky = cur_ky[hf], kx = cur_kx[hf], c0 = cur_c0[hf];
-        const int tapoff = (ky * p.cW + kx) * cld + c0;
+        const int tapoff = (ky * p.cW + kx) * cld + ((p.kwrap && c0 >= p.kwrap) ? c0 - p.kwrap : c0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int g = wave * 2 + u;
@@ -1018,740 +1091,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     }
 }
 
-// fp16 epilogue of the 128 x 32 wave tile (gemm8n_kernel): in the MFMA layout a lane owns ONE column of the strip, which would
-// mean 2-byte stores.  For every pair of consecutive rows the two lanes of a column pair swap one value (lane 2j keeps row r and
-// gets its neighbour's column of row r, lane 2j + 1 keeps row r + 1), so each lane ends up with two neighbouring columns of one
-// row and everything after that - bias, skip tensor, ReLU'd copy, activation, the GRU state update - works on (v0, v1) pairs
-// exactly like direct_epilogue_f16_impl, with 4-byte stores.  EPI_STD with act in {none, relu, ACT_GRU_Q} only.
-template <bool CHECK>
-__device__ __forceinline__ void direct_epilogue_n1(const GemmArgs &p, f32x16 (&acc)[4][1], int wave_m0, int wave_n0, int lane) {
-    const int li = lane & 31, lh = lane >> 5, odd = li & 1;
-    const int n = wave_n0 + (li & ~1);                       // first column of this lane's pair
-    const bool nok = n < p.N;
-    const int nc = nok ? n : 0;
-    float b0 = 0.f, b1 = 0.f;
-    if (p.bias) { b0 = p.bias[nc]; b1 = p.bias[nc + 1]; }
-#pragma unroll
-    for (int th = 0; th < 8; ++th) {                        // 8 accumulator registers (= 8 rows per half wave) per pass
-        const int tm = th >> 1, r0 = (th & 1) * 8;
-        float v0[4], v1[4];
-        int mr[4];
-        bool ok[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + 2 * j;                        // rows r, r + 1 of the pass are consecutive image rows
-            const float x = acc[tm][0][r], y = acc[tm][0][r + 1];
-            const float got = __shfl_xor(odd ? x : y, 1);
-            v0[j] = (odd ? got : x) + b0;
-            v1[j] = (odd ? y : got) + b1;
-            const int rr = r + odd;
-            const int m = wave_m0 + tm * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-            ok[j] = !CHECK || (nok && m < p.M);
-            mr[j] = (!CHECK || m < p.M) ? m : p.M - 1;
-        }
-        if (p.pre_relu) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); }
-        }
-        if (p.add1) {
-            f16x2 a[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = *(const f16x2 *)(p.add1 + (int64_t)mr[j] * p.ldo + nc);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v0[j] += (float)a[j][0]; v1[j] += (float)a[j][1]; }
-        }
-        if (p.out2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f16x2 o2;
-                o2[0] = (f16)fmaxf(v0[j], 0.f); o2[1] = (f16)fmaxf(v1[j], 0.f);
-                if (!CHECK || ok[j]) *(f16x2 *)(p.out2 + (int64_t)mr[j] * p.ldo + nc) = o2;
-            }
-        }
-        if (p.act == ACT_RELU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); }
-        } else if (p.act == ACT_GRU_Q) {
-            f32x2 h[4];
-            f16x2 z[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                h[j] = *(const f32x2 *)(p.gru_h + (int64_t)mr[j] * 128 + nc);
-                z[j] = *(const f16x2 *)(p.gru_z + (int64_t)mr[j] * 256 + nc);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float z0 = (float)z[j][0], z1 = (float)z[j][1];
-                f32x2 hn;
-                hn[0] = (1.f - z0) * h[j][0] + z0 * tanhf(v0[j]);
-                hn[1] = (1.f - z1) * h[j][1] + z1 * tanhf(v1[j]);
-                if (!CHECK || ok[j]) *(f32x2 *)(p.gru_h + (int64_t)mr[j] * 128 + nc) = hn;
-                v0[j] = hn[0]; v1[j] = hn[1];
-            }
-        }
-        if (p.out) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f16x2 o;
-                o[0] = (f16)v0[j]; o[1] = (f16)v1[j];
-                if (!CHECK || ok[j]) *(f16x2 *)(p.out + (int64_t)mr[j] * p.ldo + nc) = o;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 256 x 128 x 64 ping-pong kernel for layers the 256-wide one does not fit (N = 128, 192: the flow band's N = 128
-// convolutions).  Same two staggered wave groups (rows 0-127 / 128-255), but four 32-column strips per group, so a wave owns
-// 128 x 32 (acc[4][1]) and a K tile has TWO phases of 8 MFMAs:
-//     p0: read B[4] + A(i0)[8] | mfma (i0)        p1: read A(i1)[8] | mfma (i1)
-// LDS: 2 K-tile buffers x {A 32 KB, B 16 KB} = 96 KB.  Staging pieces of 16 KB (2 DMAs per thread): A_0 / A_1 = rows
-// {64 i .. +64} of both wave groups, B = the 128 weight rows; schedule  p0: A_1(t+1)   p1: A_0(t+2), B(t+2)  - every piece is
-// re-staged one phase after its last ds_read and read two phases (A_1) or three (A_0, B) after it was issued; in both phases
-// the counted wait is vmcnt(6) (the newest three pieces may still be in flight).  6 LDS-DMA instructions per wave and 16 MFMAs
-// (128 x 128 tile: 8 per 16; the 256 x 256 kernel: 8 per 32).  Epilogue: adjacent lanes swap one value per row pair so that
-// every lane stores two neighbouring fp16 columns (direct_epilogue_n1).
-// ------------------------------------------------------------------------------------------------
-template <int AMODE, bool BUFP>
-__global__ __launch_bounds__(512) void gemm8n_kernel(const GemmArgs p) {
-    constexpr int BM = 256, BN = 128;
-    constexpr int BUF = 49152, BOFF = 32768;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int wr = wave >> 2, wc = wave & 3;
-    stagger_start(p.stagger, 256);
-
-    const int tilesN = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    // Within an XCD's contiguous range, walk 8 (M) x GN (N) super-tiles so that the ~32 tiles in flight on
-    // the XCD share few A and W panels (fewer L2 misses -> less MALL/HBM traffic; loop time is unchanged).
-    int tile_m, tile_n;
-    {
-        const int GN = tilesN < 4 ? tilesN : 4;
-        const int per_band = 8 * tilesN;                 // tiles in a band of 8 M-panels
-        const int band = swz / per_band, rem = swz - band * per_band;
-        const int tilesM = nwg / tilesN;
-        const int bh = (tilesM - band * 8) < 8 ? (tilesM - band * 8) : 8;   // M-panels in this band
-        const int grp = rem / (bh * GN), r2 = rem - grp * bh * GN;
-        const int gw = (tilesN - grp * GN) < GN ? (tilesN - grp * GN) : GN; // N-panels in this group
-        tile_m = band * 8 + r2 / gw;
-        tile_n = grp * GN + r2 % gw;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- staging geometry: half tile h in {A_0, A_1, B_0, B_1}, two DMAs (u = 0, 1) per thread ----
-    // DMA (wave, u) covers the 8 LDS rows starting at row0; lane -> row0 + (lane >> 3), chunk lane & 7.
-    const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
-    const int lrow = lane >> 3;
-    int a_row0[2][2], b_row0[2];                     // tile-local first row of a DMA: A [half][u], B [u]
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int g = wave * 2 + u;
-            a_row0[hf][u] = (g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8;
-        }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) b_row0[u] = (wave * 2 + u) * 8;
-    // swizzled global chunk of this lane's LDS slot: row0 is a multiple of 8 with (row0 >> 3) & 1 == u
-    int cgu[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) cgu[u] = (lane & 7) ^ ((4 * u + (lane >> 4)) & 7);
-
-    const f16 *a_ptr[2][2];
-    int a_iy0[2][2], a_ix0[2][2];
-    bool a_ok[2][2];
-    const f16 *b_ptr[2];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int m = m0 + a_row0[hf][u] + lrow;
-            if constexpr (AMODE == A_DENSE) {
-                const int mc = m < p.M ? m : p.M - 1;
-                a_ptr[hf][u] = p.A + (int64_t)mc * p.lda + cgu[u] * 8;
-                a_ok[hf][u] = true;
-                a_iy0[hf][u] = a_ix0[hf][u] = 0;
-            } else {
-                const int ohw = p.cOH * p.cOW;
-                const int b = m / ohw, rem = m - b * ohw;
-                const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
-                a_ok[hf][u] = m < p.M;
-                a_ptr[hf][u] = p.A + (int64_t)b * p.cH * p.cW * cld + cgu[u] * 8;
-                a_iy0[hf][u] = oy * p.cStride - p.cPad;
-                a_ix0[hf][u] = ox * p.cStride - padx;
-            }
-        }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) b_ptr[u] = p.W + (int64_t)(n0 + b_row0[u] + lrow) * p.K + cgu[u] * 8;
-    const int nk = p.K >> 6;
-    // BUFP: stage through the buffer path (`buffer_load_dwordx4 ... lds`) - measurably cheaper to issue than the flat
-    // `global_load_lds` (8192^3: 1145 -> 1245 TF, qkv / fc1 shapes +14 ... +17 %).  The resource covers the whole operand
-    // (dense, weights) or the one or two images this tile's rows fall into (conv: a whole DPT map batch exceeds 4 GB);
-    // the launcher only picks this variant when those spans fit 32-bit byte offsets.  Out-of-range offsets read zeros,
-    // which is how padded taps and rows >= M are fed.
-    __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, 0u), rsW = make_rsrc(p.W, 0u);
-    unsigned a_voff[2][2], b_voff[2];
-    if constexpr (BUFP) {
-        rsW = make_rsrc(p.W, (unsigned)((int64_t)((p.N + 255) / 256 * 256) * p.K * 2));
-        if constexpr (AMODE == A_DENSE) {
-            rsA = make_rsrc(p.A, (unsigned)((int64_t)p.M * p.lda * 2));
-        } else {
-            const int ohw = p.cOH * p.cOW, nimg = p.M / ohw, b0 = p.bufmode == 2 ? m0 / ohw : 0;
-            const int64_t img = (int64_t)p.cH * p.cW * cld;
-            rsA = make_rsrc(p.A + b0 * img, (unsigned)((p.bufmode == 2 ? (nimg - b0 < 2 ? nimg - b0 : 2) : nimg) * img * 2));
-        }
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if constexpr (AMODE == A_DENSE) {
-                    a_voff[hf][u] = (unsigned)((a_ptr[hf][u] - p.A) * 2);
-                } else {
-                    const int ohw = p.cOH * p.cOW, b0 = p.bufmode == 2 ? m0 / ohw : 0;
-                    const int m = m0 + a_row0[hf][u] + lrow;
-                    a_voff[hf][u] = (unsigned)((int64_t)(m / ohw - b0) * p.cH * p.cW * cld * 2) + cgu[u] * 16;
-                }
-            }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) b_voff[u] = (unsigned)((b_ptr[u] - p.W) * 2);
-    }
-
-    // staging past the last K tile re-reads the last one into a slot nobody reads any more: the loop stays branch free
-    // and every phase can use the same counted wait
-    // conv: each A half has its own tap cursor (ky, kx, c0) that steps one K tile per call - no divisions in the loop - and
-    // the per-lane pixel offset of tap (0, 0) is precomputed, so a DMA costs one add, two range tests and a select
-    int cur_ky[2] = {0, 0}, cur_kx[2] = {0, 0}, cur_c0[2] = {0, 0}, cur_kt[2] = {0, 0};
-    int a_pix0[2][2];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) a_pix0[hf][u] = AMODE == A_CONV ? (a_iy0[hf][u] * p.cW + a_ix0[hf][u]) * cld : 0;
-    auto stage_a = [&](int hf, int kt_) {
-        const int kt = kt_ < nk ? kt_ : nk - 1;
-        char *base = smem + (kt_ & 1) * BUF;
-        const int ky = cur_ky[hf], kx = cur_kx[hf], c0 = cur_c0[hf];
-        const int tapoff = (ky * p.cW + kx) * cld + c0;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int g = wave * 2 + u;
-            char *dst = base + ((g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8) * 128;
-            if constexpr (AMODE == A_DENSE) {
-                if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[hf][u], kt * 128, dst);
-                else glds16(a_ptr[hf][u] + kt * 64, dst);
-            } else {
-                const bool ok = a_ok[hf][u] && (unsigned)(a_iy0[hf][u] + ky) < (unsigned)p.cH && (unsigned)(a_ix0[hf][u] + kx) < (unsigned)p.cW;
-                const int eo = a_pix0[hf][u] + tapoff;                      // element offset inside the image
-                if constexpr (BUFP) {
-                    const unsigned oob = ok ? 0u : 0xFFFFFF00u;            // any out-of-range offset reads zeros
-                    glds16_buf(rsA, (int)((a_voff[hf][u] + (unsigned)(eo * 2)) | oob), 0, dst);
-                } else {
-                    glds16(ok ? a_ptr[hf][u] + eo : p.zero, dst);
-                }
-            }
-        }
-        if constexpr (AMODE == A_CONV) {
-            // branch-free step; past the end the cursor stays on the last K tile
-            const int adv = cur_kt[hf] < nk - 1 ? 1 : 0;
-            cur_kt[hf] += adv;
-            const int c1 = cur_c0[hf] + 64 * adv;
-            const int w1 = c1 >= p.cC ? 1 : 0;
-            cur_c0[hf] = w1 ? 0 : c1;
-            const int x1 = cur_kx[hf] + w1;
-            const int w2 = x1 == p.cKW ? 1 : 0;
-            cur_kx[hf] = w2 ? 0 : x1;
-            cur_ky[hf] += w2;
-        }
-    };
-    auto stage_b = [&](int kt_) {
-        const int kt = kt_ < nk ? kt_ : nk - 1;
-        char *base = smem + (kt_ & 1) * BUF + BOFF;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            char *dst = base + (wave * 2 + u) * 8 * 128;
-            if constexpr (BUFP) glds16_buf(rsW, b_voff[u], kt * 128, dst);
-            else glds16(b_ptr[u] + kt * 64, dst);
-        }
-    };
-
-    // ---- fragment addressing: chunk(ks) = (lh ^ fsw) ^ 2 ks  ->  byte offset = c0 ^ (32 ks) ----
-    const int li = lane & 31, lh = lane >> 5;
-    const int c0 = (lh ^ ((li >> 1) & 7)) * 16;
-    const int a_base = (wr * 128 + li) * 128;            // + i*8192 + rt*4096
-    const int b_base = BOFF + (wc * 32 + li) * 128;
-
-    f32x16 acc[4][1];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-    f16x8 fa[2][4], fb0[4];
-
-    // prologue: A_0(0) B(0) A_1(0) A_0(1) B(1)
-    stage_a(0, 0); stage_b(0); stage_a(1, 0); stage_a(0, 1); stage_b(1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // A_0(0), B(0) landed (this wave's share)
-    PB_BAR();
-    if (wr == 1) PB_BAR();                               // stagger the second wave group by one barrier
-
-    for (int t = 0; t < nk; ++t) {
-        const char *sb = smem + (t & 1) * BUF;
-        // ================= p0 =================
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fb0[ks] = *(const f16x8 *)(sb + b_base + (c0 ^ (ks * 32)));
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const f16x8 *)(sb + a_base + rt * 4096 + (c0 ^ (ks * 32)));
-        stage_a(1, t + 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        PB_BAR();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[rt][0], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        PB_BAR();
-        // ================= p1 =================
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                fa[rt][ks] = *(const f16x8 *)(sb + a_base + 8192 + rt * 4096 + (c0 ^ (ks * 32)));
-        stage_a(0, t + 2); stage_b(t + 2);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        PB_BAR();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[2 + rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[2 + rt][0], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        PB_BAR();
-    }
-    if (wr == 0) PB_BAR();                               // re-align the two wave groups
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int wave_m0 = m0 + wr * 128, wave_n0 = n0 + wc * 32;
-    if (wave_m0 + 128 <= p.M && wave_n0 + 32 <= p.N) direct_epilogue_n1<false>(p, acc, wave_m0, wave_n0, lane);
-    else direct_epilogue_n1<true>(p, acc, wave_m0, wave_n0, lane);
-}
-
-// Same tile walk and A staging as gemm8_kernel, but the B operand (packed weights) never touches the LDS: p.Wf holds
-// the weights pre-swizzled into MFMA fragment order - [tile_n][k tile][wave column][j][ks][lane][8 halves] - so a wave's
-// eight B fragments of a K tile are one contiguous 8 KB block read with eight coalesced 16-byte global loads straight
-// into registers, one K tile ahead.  That halves the LDS traffic (no B DMA writes, no B fragment reads); the price is
-// that both wave rows fetch the same B block from L2.  VMEM ops per thread and K tile, in issue order:
-//     p0: B_j0(t+1) x4 | p1: A_1(t+1) x2 | p2: B_j1(t+1) x4, A_0(t+2) x2 | p3: -
-// with `s_waitcnt vmcnt(8)` in p1 (B_j1(t), A_1(t) landed) and p3 (A_0(t+1), B_j0(t+1) landed); loads past the last
-// K tile re-read the last one (harmless: their LDS slots / registers are dead) so the count never changes.
-template <int AMODE, int EPI>
-__global__ __launch_bounds__(512) void gemm8b_kernel(const GemmArgs p) {
-    constexpr int BM = 256, BN = 256;
-    constexpr int BUF = 65536;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int wr = wave >> 2, wc = wave & 3;
-    long long ts0 = 0, ts1 = 0, ts2 = 0, tr0 = 0;
-    stagger_start(p.stagger, 256);
-    if (p.dbg) { ts0 = __builtin_readcyclecounter(); tr0 = wall_clock64(); }
-
-    const int tilesN = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    // Within an XCD's contiguous range, walk 8 (M) x GN (N) super-tiles so that the ~32 tiles in flight on
-    // the XCD share few A and W panels (fewer L2 misses -> less MALL/HBM traffic; loop time is unchanged).
-    int tile_m, tile_n;
-    {
-        const int GN = tilesN < 4 ? tilesN : 4;
-        const int per_band = 8 * tilesN;                 // tiles in a band of 8 M-panels
-        const int band = swz / per_band, rem = swz - band * per_band;
-        const int tilesM = nwg / tilesN;
-        const int bh = (tilesM - band * 8) < 8 ? (tilesM - band * 8) : 8;   // M-panels in this band
-        const int grp = rem / (bh * GN), r2 = rem - grp * bh * GN;
-        const int gw = (tilesN - grp * GN) < GN ? (tilesN - grp * GN) : GN; // N-panels in this group
-        tile_m = band * 8 + r2 / gw;
-        tile_n = grp * GN + r2 % gw;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- staging geometry: half tile h in {A_0, A_1, B_0, B_1}, two DMAs (u = 0, 1) per thread ----
-    // DMA (wave, u) covers the 8 LDS rows starting at row0; lane -> row0 + (lane >> 3), chunk lane & 7.
-    const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
-    const int lrow = lane >> 3;
-    int a_row0[2][2];                                // [half][u], tile-local row of the DMA's first row
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int g = wave * 2 + u;
-            a_row0[hf][u] = (g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8;
-        }
-    // swizzled global chunk of this lane's LDS slot: row0 is a multiple of 8 with (row0 >> 3) & 1 == u
-    int cgu[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) cgu[u] = (lane & 7) ^ ((4 * u + (lane >> 4)) & 7);
-
-    const f16 *a_ptr[2][2];
-    int a_iy0[2][2], a_ix0[2][2];
-    bool a_ok[2][2];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int m = m0 + a_row0[hf][u] + lrow;
-            if constexpr (AMODE == A_DENSE) {
-                const int mc = m < p.M ? m : p.M - 1;
-                a_ptr[hf][u] = p.A + (int64_t)mc * p.lda + cgu[u] * 8;
-                a_ok[hf][u] = true;
-                a_iy0[hf][u] = a_ix0[hf][u] = 0;
-            } else {
-                const int ohw = p.cOH * p.cOW;
-                const int b = m / ohw, rem = m - b * ohw;
-                const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
-                a_ok[hf][u] = m < p.M;
-                a_ptr[hf][u] = p.A + (int64_t)b * p.cH * p.cW * cld + cgu[u] * 8;
-                a_iy0[hf][u] = oy * p.cStride - p.cPad;
-                a_ix0[hf][u] = ox * p.cStride - padx;
-            }
-        }
-    const int nk = p.K >> 6;
-    const int cpt = AMODE == A_CONV ? p.cC >> 6 : 1;     // K tiles per conv tap
-
-    auto stage_a_to = [&](int hf, int kt, int slot) {
-        char *base = smem + slot * BUF;
-        int ky = 0, kx = 0, c0 = 0;
-        if constexpr (AMODE == A_CONV) {
-            const int tap = kt / cpt;
-            c0 = (kt - tap * cpt) << 6;
-            ky = tap / p.cKW;
-            kx = tap - ky * p.cKW;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const f16 *src;
-            if constexpr (AMODE == A_DENSE) {
-                src = a_ptr[hf][u] + kt * 64;
-            } else {
-                const int iy = a_iy0[hf][u] + ky, ix = a_ix0[hf][u] + kx;
-                const bool ok = a_ok[hf][u] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
-                src = ok ? a_ptr[hf][u] + ((iy * p.cW + ix) * cld + c0) : p.zero;
-            }
-            const int g = wave * 2 + u;
-            glds16(src, base + ((g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8) * 128);
-        }
-    };
-    // this wave's fragment blocks: 8 KB per K tile, block (j, ks) at + (j * 4 + ks) * 1 KB, lane l at + l * 16 B
-    const f16 *bf = p.Wf + (((int64_t)tile_n * nk * 4 + wc) * 8) * 512 + lane * 8;
-    auto load_b = [&](f16x8 (&dst)[4], int j, int kt) {
-        const int kc = kt < nk ? kt : nk - 1;
-        const f16 *src = bf + (int64_t)kc * (4 * 8 * 512) + j * 4 * 512;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const f16x8 *)(src + ks * 512);
-    };
-    // ---- fragment addressing: chunk(ks) = (lh ^ fsw) ^ 2 ks  ->  byte offset = c0 ^ (32 ks) ----
-    const int li = lane & 31, lh = lane >> 5;
-    const int c0 = (lh ^ ((li >> 1) & 7)) * 16;
-    const int a_base = (wr * 128 + li) * 128;            // + i*8192 + rt*4096
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if constexpr (EPI == EPI_RESID) resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-    f16x8 fa[2][4], fb0[4], fb1[4], fbn0[4], fbn1[4];
-
-    // prologue: B_j0(0) A_0(0) B_j1(0) | A_1(0) A_0(1); the first three must have landed before the loop
-    load_b(fb0, 0, 0); stage_a_to(0, 0, 0); load_b(fb1, 1, 0); stage_a_to(1, 0, 0); stage_a_to(0, 1 < nk ? 1 : 0, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    PB_BAR();
-    if (wr == 1) PB_BAR();                               // stagger the second wave group by one barrier
-    if (p.dbg) ts1 = __builtin_readcyclecounter();
-
-    for (int t = 0; t < nk; ++t) {
-        const char *sb = smem + (t & 1) * BUF;
-        const int ta = t + 1 < nk ? t + 1 : nk - 1, tb = t + 2 < nk ? t + 2 : nk - 1;
-        // ================= p0 =================
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const f16x8 *)(sb + a_base + rt * 4096 + (c0 ^ (ks * 32)));
-        load_b(fbn0, 0, t + 1);
-        PB_BAR();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[rt][0], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        PB_BAR();
-        // ================= p1 =================
-        stage_a_to(1, ta, (t + 1) & 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // B_j1(t) in registers, A_1(t) in the LDS
-        PB_BAR();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[rt][1], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        PB_BAR();
-        // ================= p2 =================
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                fa[rt][ks] = *(const f16x8 *)(sb + a_base + 8192 + rt * 4096 + (c0 ^ (ks * 32)));
-        load_b(fbn1, 1, t + 1);
-        stage_a_to(0, tb, t & 1);
-        PB_BAR();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[2 + rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[2 + rt][1], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        PB_BAR();
-        // ================= p3 =================
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A_0(t+1) in the LDS, B_j0(t+1) in registers
-        PB_BAR();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[2 + rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[2 + rt][0], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { fb0[ks] = fbn0[ks]; fb1[ks] = fbn1[ks]; }
-        PB_BAR();
-    }
-    if (wr == 0) PB_BAR();                               // re-align the two wave groups
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (p.dbg) ts2 = __builtin_readcyclecounter();
-    if constexpr (EPI == EPI_RESID) resid_io<4, 2, true>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-    else run_epilogue<EPI, 4, 2>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, n0);
-    if (p.dbg && tid == 0) {
-        const long long t_issue = __builtin_readcyclecounter();      // all epilogue stores issued, none waited for
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long *d = p.dbg + (long long)blockIdx.x * 8;
-        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter(); d[4] = tr0; d[5] = wall_clock64();
-        d[6] = t_issue; d[7] = swz;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 256 x 256 "quad" kernel: 4 waves, one per SIMD, each owning a 128 x 128 output block (256 accumulator registers), K in
-// slabs of 32.  Against the ping-pong kernel: a wave reads (128 + 128) x 32 halves per 32 MFMAs instead of (128 + 64) x 64
-// per 32 - a third less LDS traffic - and synchronises once per slab (32 MFMAs) instead of eight times per K tile.
-// LDS: ring of 4 slabs x {A 256 rows x 64 B, B 256 rows x 64 B}; the 16-byte chunk of a row is XOR-swizzled by
-// (row >> 2) & 3 on the DMA source side, which makes the ds_read_b128 lane groups conflict free for 64-byte rows.
-// Per slab t:   MFMA(t, ks0) || ds_read frags(t, ks1)
-//               lgkmcnt(0); vmcnt(16) -> slab t+1 landed; barrier; DMA slab t+4 into the buffer slab t just left
-//               MFMA(t, ks1) || ds_read frags(t+1, ks0)
-// ------------------------------------------------------------------------------------------------
-template <int AMODE, int EPI>
-__global__ __launch_bounds__(256) void gemmq_kernel(const GemmArgs p) {
-    constexpr int BM = 256, BN = 256;
-    constexpr int SLAB = 32768, BOFF = 16384;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int wr = wave >> 1, wc = wave & 1;
-
-    const int tilesN = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    int tile_m, tile_n;
-    {
-        const int GN = tilesN < 4 ? tilesN : 4;
-        const int per_band = 8 * tilesN;
-        const int band = swz / per_band, rem = swz - band * per_band;
-        const int tilesM = nwg / tilesN;
-        const int bh = (tilesM - band * 8) < 8 ? (tilesM - band * 8) : 8;
-        const int grp = rem / (bh * GN), r2 = rem - grp * bh * GN;
-        const int gw = (tilesN - grp * GN) < GN ? (tilesN - grp * GN) : GN;
-        tile_m = band * 8 + r2 / gw;
-        tile_n = grp * GN + r2 % gw;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- staging: DMA j (0..3) of this wave covers the 16 rows starting at (wave * 4 + j) * 16, lane -> row + (lane >> 2),
-    //      LDS chunk position lane & 3 holds logical chunk (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)
-    const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
-    const int lrow = lane >> 2;
-    const int lchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;        // halves
-    const f16 *a_ptr[4], *b_ptr[4];
-    int a_iy0[4], a_ix0[4];
-    bool a_ok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * 4 + j) * 16 + lrow;
-        const int m = m0 + row;
-        if constexpr (AMODE == A_DENSE) {
-            const int mc = m < p.M ? m : p.M - 1;
-            a_ptr[j] = p.A + (int64_t)mc * p.lda + lchunk;
-            a_ok[j] = true; a_iy0[j] = a_ix0[j] = 0;
-        } else {
-            const int ohw = p.cOH * p.cOW;
-            const int b = m / ohw, rem = m - b * ohw;
-            const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
-            a_ok[j] = m < p.M;
-            a_ptr[j] = p.A + (int64_t)b * p.cH * p.cW * cld + lchunk;
-            a_iy0[j] = oy * p.cStride - p.cPad;
-            a_ix0[j] = ox * p.cStride - padx;
-        }
-        b_ptr[j] = p.W + (int64_t)(n0 + col_map(row, epi_interleaved<EPI, 2>())) * p.K + lchunk;
-    }
-    const int ns = p.K >> 5;                               // slabs
-    const int cpt2 = AMODE == A_CONV ? p.cC >> 5 : 1;      // slabs per conv tap
-
-    auto stage = [&](int st) {
-        const int sc = st < ns ? st : ns - 1;              // past the end: re-read the last slab (dead slot)
-        char *base = smem + (st & 3) * SLAB + wave * 4096;
-        int ky = 0, kx = 0, c0 = 0;
-        if constexpr (AMODE == A_CONV) {
-            const int tap = sc / cpt2;
-            c0 = (sc - tap * cpt2) << 5;
-            ky = tap / p.cKW;
-            kx = tap - ky * p.cKW;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f16 *src;
-            if constexpr (AMODE == A_DENSE) {
-                src = a_ptr[j] + sc * 32;
-            } else {
-                const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-                const bool ok = a_ok[j] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
-                src = ok ? a_ptr[j] + ((iy * p.cW + ix) * cld + c0) : p.zero;
-            }
-            glds16(src, base + j * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(b_ptr[j] + sc * 32, base + BOFF + j * 1024);
-    };
-
-    // ---- fragments: tile i row li, logical chunk ks * 2 + lh at position (ks * 2 + lh) ^ ((li >> 2) & 3)
-    const int li = lane & 31, lh = lane >> 5;
-    const int fs = (li >> 2) & 3;
-    const int a_base = (wr * 128 + li) * 64;
-    const int b_base = BOFF + (wc * 128 + li) * 64;
-    int coff[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) coff[ks] = ((ks * 2 + lh) ^ fs) * 16;
-
-    f32x16 accL[4][2], accR[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { accL[i][j][r] = 0.f; accR[i][j][r] = 0.f; }
-    if constexpr (EPI == EPI_RESID) {
-        resid_io<4, 2, false>(p, accL, m0 + wr * 128, n0 + wc * 128, lane);
-        resid_io<4, 2, false>(p, accR, m0 + wr * 128, n0 + wc * 128 + 64, lane);
-    }
-    f16x8 fa[2][4], fb[2][4];
-    auto read_frags = [&](int buf, int st, int ks) {
-        const char *sb = smem + (st & 3) * SLAB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[buf][i] = *(const f16x8 *)(sb + a_base + i * 2048 + coff[ks]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[buf][j] = *(const f16x8 *)(sb + b_base + j * 2048 + coff[ks]);
-    };
-    auto mma = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (j < 2) accL[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[buf][i], fb[buf][j], accL[i][j], 0, 0, 0);
-                else accR[i][j - 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[buf][i], fb[buf][j], accR[i][j - 2], 0, 0, 0);
-            }
-    };
-
-    stage(0); stage(1); stage(2); stage(3);
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // slab 0 landed (this wave's share)
-    PB_BAR();
-    read_frags(0, 0, 0);
-    for (int t = 0; t < ns; ++t) {
-        read_frags(1, t, 1);
-        mma(0);
-        // issue order for the scheduler: the MFMAs depend only on reads of the previous half; the eight fragment reads of the
-        // next half go out behind the first eight MFMAs, so the last one has eight MFMAs (256 cycles) to land
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // slab t+1 landed; t+2, t+3 may still be in flight
-        PB_BAR();
-        stage(t + 4);
-        read_frags(0, t + 1, 0);                           // t + 1 == ns reads a stale slot; the values are never used
-        mma(1);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {       // fragment reads of the next slab first (they gate the next MFMA group) ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {       // ... then one DMA per MFMA (fire and forget)
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if constexpr (EPI == EPI_RESID) {
-        resid_io<4, 2, true>(p, accL, m0 + wr * 128, n0 + wc * 128, lane);
-        resid_io<4, 2, true>(p, accR, m0 + wr * 128, n0 + wc * 128 + 64, lane);
-    } else {
-        run_epilogue<EPI, 4, 2>(p, accL, smem, wave, lane, m0 + wr * 128, n0 + wc * 128, n0);
-        run_epilogue<EPI, 4, 2>(p, accR, smem, wave, lane, m0 + wr * 128, n0 + wc * 128 + 64, n0);
-    }
-}
-
-template <int AMODE, int EPI>
-int launch_gq(hipStream_t stream, const GemmArgs &a) {
-    constexpr int SMEM = 131072;
-    auto kern = gemmq_kernel<AMODE, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
-    }
-    const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(256), SMEM, stream, a);
-    PB_HIP(hipGetLastError());
-    return 0;
-}
-
 template <int AMODE, int EPI, int VAR, bool BUFP>
 int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
     constexpr int SMEM = 131072;
@@ -1793,42 +1132,6 @@ int launch_g8(hipStream_t stream, const GemmArgs &a) {
     return launch_g8_impl<AMODE, EPI, VAR, false>(stream, a);
 }
 
-template <int AMODE, bool BUFP>
-int launch_g8n_impl(hipStream_t stream, const GemmArgs &a) {
-    constexpr int SMEM = 98304;
-    auto kern = gemm8n_kernel<AMODE, BUFP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
-    }
-    const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 127) / 128;
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), SMEM, stream, a);
-    PB_HIP(hipGetLastError());
-    return 0;
-}
-template <int AMODE>
-int launch_g8n(hipStream_t stream, const GemmArgs &a) {
-    GemmArgs b = a;
-    b.bufmode = buffer_mode(AMODE, a, 256);
-    return b.bufmode ? launch_g8n_impl<AMODE, true>(stream, b) : launch_g8n_impl<AMODE, false>(stream, b);
-}
-
-template <int AMODE, int EPI>
-int launch_g8b(hipStream_t stream, const GemmArgs &a) {
-    constexpr int SMEM = 131072;
-    auto kern = gemm8b_kernel<AMODE, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
-    }
-    const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), SMEM, stream, a);
-    PB_HIP(hipGetLastError());
-    return 0;
-}
-
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool BUFP = false, int NS = 2>
 int launch_t(hipStream_t stream, const GemmArgs &a) {
     constexpr int NT = WM * WN * 64;
@@ -1858,54 +1161,21 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
     if constexpr (EPI == EPI_HEAD) {
         return launch_t<256, 32, 4, 1, AMODE, EPI>(s, a);
     } else {
-        if (tile == TILE_256) return a.Wf ? launch_g8b<AMODE, EPI>(s, a) : launch_g8<AMODE, EPI>(s, a);
+        if (tile == TILE_256) return launch_g8<AMODE, EPI>(s, a);
         if (tile == TILE_256_SIMPLE) return launch_t<256, 256, 2, 4, AMODE, EPI>(s, a);
         if (tile == TILE_256x128) return launch_t<256, 128, 4, 2, AMODE, EPI>(s, a);
         if constexpr (EPI == EPI_STD) {
             if (tile == TILE_256x64) return launch_t<256, 64, 4, 1, AMODE, EPI>(s, a);
-            if (tile == TILE_256x128_PP) {
-                // the strip epilogue knows bias / pre_relu / add1 / out2 / relu / the GRU state update; anything else takes the 128 tile
-                const bool ok = (a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_GRU_Q) && !a.add2;
-                if (ok) return launch_g8n<AMODE>(s, a);
-                return launch_t<128, 128, 2, 2, AMODE, EPI>(s, a);
-            }
         }
         if constexpr (EPI == EPI_STD || EPI == EPI_F32) {
             if (tile == TILE_256x128_S3) return launch_t<256, 128, 4, 2, AMODE, EPI, false, 3>(s, a);
             if (tile == TILE_128_S3) return launch_t<128, 128, 2, 2, AMODE, EPI, false, 3>(s, a);
         }
-        if (tile == TILE_QUAD) return launch_gq<AMODE, EPI>(s, a);
         return launch_t<128, 128, 2, 2, AMODE, EPI>(s, a);
     }
 }
 
 }  // namespace
-
-namespace {
-// W [Npad][K] row-major -> fragment order [tile_n][k tile][wave column][j][ks][lane][8] (see gemm8b_kernel)
-__global__ __launch_bounds__(256) void frag_pack_kernel(const f16 *__restrict__ W, f16 *__restrict__ Wf, int nk, int K, int il,
-                                                        int64_t chunks) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= chunks) return;
-    const int lane = (int)(i & 63);
-    const int ks = (int)((i >> 6) & 3), j = (int)((i >> 8) & 1), wc = (int)((i >> 9) & 3);
-    const int64_t tk = i >> 11;                                   // tile_n * nk + kt
-    const int kt = (int)(tk % nk);
-    const int64_t tn = tk / nk;
-    const int li = lane & 31, lh = lane >> 5;
-    const int r = wc * 64 + j * 32 + li;
-    const int col = il ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;
-    *(f16x8 *)(Wf + i * 8) = *(const f16x8 *)(W + (tn * 256 + col) * K + kt * 64 + ks * 16 + lh * 8);
-}
-}  // namespace
-
-int launch_frag_pack(hipStream_t s, const f16 *W, f16 *Wf, int Npad, int K, int interleaved) {
-    PB_CHECK(Npad % 256 == 0 && K % 64 == 0, -1, "frag_pack: Npad=%d K=%d", Npad, K);
-    const int64_t chunks = (int64_t)Npad * K / 8;
-    hipLaunchKernelGGL(frag_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, W, Wf, K / 64, K, interleaved, chunks);
-    PB_HIP(hipGetLastError());
-    return 0;
-}
 
 int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a_in) {
     GemmArgs a = a_in;

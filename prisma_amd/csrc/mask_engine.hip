@@ -97,6 +97,8 @@ int MaskEngine::load(const pb_tensor *w, int n) {
                  cfg_.mask_out_channels == 256 && cfg_.stacked_convs >= 1 && cfg_.nms_pre > 0 && cfg_.nms_pre <= 512 &&
                  cfg_.max_per_img > 0 && cfg_.max_batch >= 1,
              PB_ERR_ARG, "mask_mmdet: unsupported configuration");
+    PB_CHECK(cfg_.precision == PB_PREC_F16 || cfg_.precision == PB_PREC_SPLIT, PB_ERR_ARG, "mask_mmdet: precision %d unknown", cfg_.precision);
+    split_w_ = cfg_.precision == PB_PREC_SPLIT;
     int r0 = begin_load(w, n);
     if (r0) return r0;
     for (int l = 0; l < 5; ++l) {
@@ -129,7 +131,7 @@ int MaskEngine::load(const pb_tensor *w, int n) {
                                         g[(size_t)nn * 576 + (ty * 3 + tx) * 64 + (dy * 4 + dx) * 4 + c] = wt[((size_t)o * 3 + c) * 49 + ky * 7 + kx] * sc[o];
                                 }
                 }
-        if ((r = pack(g.data(), 256, 576, 576, stem_, bb.data()))) return r;
+        if ((r = pack(g.data(), 256, 576, 576, stem_, bb.data(), 9))) return r;
         stem_.Kreal = 147;
     }
     int inpl = 64;
@@ -232,12 +234,12 @@ int MaskEngine::prepare(int n, int H, int W) {
             rs_[l] = (l == 0 || l == 4) ? (f16 *)carve(rows(fl) * 256 * 2 + slack) : nullptr;
             grid_[l] = (f16 *)carve(grows * 320 * 2 + slack);
             for (auto &b : hk_[l]) b = (f16 *)carve(grows * fc * 2 + slack);
-            gstl_[l] = (float *)carve((size_t)B * 512 * 2 * 4); gaffl_[l] = (float *)carve((size_t)B * 512 * 2 * 4);
+            gstl_[l] = (float *)carve((size_t)B * gn_chunks(cfg_.num_grids[l] * cfg_.num_grids[l]) * 512 * 2 * 4); gaffl_[l] = (float *)carve((size_t)B * 512 * 2 * 4);
         }
         kp_ = (float *)carve((size_t)B * pts_ * 256 * 4 + slack);
         cl_ = (float *)carve((size_t)B * pts_ * Cp * 4 + slack);
         cs_ = (float *)carve((size_t)B * pts_ * Cp * 4 + slack);
-        gst_ = (float *)carve((size_t)B * 512 * 2 * 4); gaff_ = (float *)carve((size_t)B * 512 * 2 * 4);
+        gst_ = (float *)carve((size_t)B * gn_chunks(lh_[0] * lw_[0]) * 512 * 2 * 4); gaff_ = (float *)carve((size_t)B * 512 * 2 * 4);
         if (pass == 0) {
             const int rc = commit_arena("mask");
             if (rc) return rc;
@@ -255,11 +257,12 @@ int MaskEngine::prepare(int n, int H, int W) {
 
 int MaskEngine::conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, const PackedW &w, float *out, int ldo) {
     GemmArgs a;
-    a.A = in; a.W = w.w; a.K = w.K; a.N = w.N; a.bias = w.bias; a.zero = zero_;
+    a.A = in; a.N = w.N;
     a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1; a.cOH = H; a.cOW = W;
     a.M = n * H * W;
     a.out32 = out; a.ldo = ldo; a.scale = 1.f;
-    PB_CHECK(w.K == 9 * cC, PB_ERR_STATE, "conv_f32: packed K %d != 9*%d", w.K, cC);
+    set_weights(a, w, true);
+    PB_CHECK(w.K == 9 * a.cC, PB_ERR_STATE, "conv_f32: packed K %d != 9*%d", w.K, a.cC);
     tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
     int r = launch_gemm(cur_, A_CONV, EPI_F32, TILE_128, a);
     toc();
@@ -281,8 +284,9 @@ int MaskEngine::backbone(int n) {
     const int H2 = lh_[5], W2 = lw_[5];
     {
         GemmArgs a;
-        a.A = img_; a.W = stem_.w; a.K = stem_.K; a.N = 256; a.bias = stem_.bias; a.zero = zero_;
+        a.A = img_; a.N = 256;
         a.cH = Hp_ / 4; a.cW = Wp_ / 4; a.cC = 64; a.cLd = 64; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1;
+        set_weights(a, stem_, true);
         a.cOH = a.cH; a.cOW = a.cW; a.M = n * a.cH * a.cW;
         a.out = stem_out_; a.ldo = 64; a.act = ACT_RELU;
         a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;

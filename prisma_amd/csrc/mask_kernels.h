@@ -12,6 +12,9 @@ int launch_subsample2(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, 
 int launch_coord_concat(hipStream_t s, const f16 *x, f16 *y, int n, int h, int w, int C, int ldi);
 int launch_bilinear(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int OH, int OW, int C, int ldi, int ldo,
                     int accumulate);
+// `stats` is the partial-sum scratch: n * gn_chunks(HW) * C * 2 floats
+enum { GN_CHUNK = 256 };
+int gn_chunks(int HW);
 int launch_gn_relu(hipStream_t s, const f16 *x, f16 *y, int n, int HW, int C, int ldc, int ldo, int groups, const float *gamma,
                    const float *beta, float *stats, float *aff);
 int launch_cls_points_nms(hipStream_t s, const float *logit, float *score, int n, int pts_total, int off, int g, int C);

@@ -188,10 +188,12 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const f16 *__restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------
-// GroupNorm(32 groups, eps 1e-5) + ReLU: per-(sample, channel) sums (atomics) -> per-(sample, channel) affine
-// -> one fused apply pass.  x: [n][HW][ldc] fp16.
+// GroupNorm(32 groups, eps 1e-5) + ReLU: per-(sample, chunk of 256 pixels, channel) partial sums -> one wave per
+// (sample, group) adds them in a fixed order -> per-(sample, channel) affine -> one fused apply pass.  No atomics, and the
+// chunking depends on the map size only, so a frame's statistics (hence its mask image) do not depend on which other frames
+// share the launch or on block scheduling.  x: [n][HW][ldc] fp16; part: [n][nchunk][C][2].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_kernel(const f16 *__restrict__ x, int HW, int C8, int ldc, float *__restrict__ stats,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16 *__restrict__ x, int HW, int C8, int ldc, float *__restrict__ part,
                                                        int chunk) {
     __shared__ float red[256 * 16];
     const int b = blockIdx.y;
@@ -214,31 +216,41 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16 *__restrict__ x
         for (int o = 1; o < npl; ++o)
 #pragma unroll
             for (int j = 0; j < 16; ++j) red[c8 * 16 + j] += red[(o * C8 + c8) * 16 + j];
+        float *dst = part + (((int64_t)b * gridDim.x + blockIdx.x) * C8 * 8 + c8 * 8) * 2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            atomicAdd(&stats[((int64_t)b * C8 * 8 + c8 * 8 + j) * 2 + 0], red[c8 * 16 + j]);
-            atomicAdd(&stats[((int64_t)b * C8 * 8 + c8 * 8 + j) * 2 + 1], red[c8 * 16 + 8 + j]);
+            dst[j * 2 + 0] = red[c8 * 16 + j];
+            dst[j * 2 + 1] = red[c8 * 16 + 8 + j];
         }
     }
 }
 
-// stats [n][C][2] -> affine [n][C][2] = (rstd_g * gamma_c, beta_c - mean_g * rstd_g * gamma_c)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
+// part [n][nchunk][C][2] -> affine [n][C][2] = (rstd_g * gamma_c, beta_c - mean_g * rstd_g * gamma_c); one wave per (sample, group):
+// lane l adds the (chunk, channel) items l, l + 64, ... in that order, then a fixed butterfly
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ part, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float *__restrict__ aff, int n, int C,
-                                                          int cpg, float inv_cnt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * C) return;
-    const int c = i % C, b = i / C, g0 = c / cpg * cpg;
+                                                          int cpg, int nchunk, float inv_cnt) {
+    const int lane = threadIdx.x & 63;
+    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);          // (sample, group)
+    const int groups = C / cpg;
+    if (wg >= n * groups) return;
+    const int b = wg / groups, g0 = (wg - b * groups) * cpg;
     float s = 0.f, q = 0.f;
-    for (int k = 0; k < cpg; ++k) {
-        s += stats[((int64_t)b * C + g0 + k) * 2];
-        q += stats[((int64_t)b * C + g0 + k) * 2 + 1];
+    for (int it = lane; it < nchunk * cpg; it += 64) {
+        const int ch = it / cpg, k = it - ch * cpg;
+        const float *p = part + (((int64_t)b * nchunk + ch) * C + g0 + k) * 2;
+        s += p[0]; q += p[1];
     }
+    s = wave_sum(s); q = wave_sum(q);
     const float mean = s * inv_cnt;
     const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
-    const float r = rsqrtf(var + 1e-5f) * gamma[c];
-    aff[(int64_t)i * 2] = r;
-    aff[(int64_t)i * 2 + 1] = beta[c] - mean * r;
+    const float rs = rsqrtf(var + 1e-5f);
+    for (int k = lane; k < cpg; k += 64) {
+        const int c = g0 + k;
+        const float r = rs * gamma[c];
+        aff[((int64_t)b * C + c) * 2] = r;
+        aff[((int64_t)b * C + c) * 2 + 1] = beta[c] - mean * r;
+    }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const f16 *__restrict__ x, const float *__restrict__ aff,
@@ -473,16 +485,15 @@ int launch_bilinear(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, in
                        ldo, (float)H / (float)OH, (float)W / (float)OW, accumulate);
     LAUNCH_CHECK();
 }
+int gn_chunks(int HW) { return (HW + GN_CHUNK - 1) / GN_CHUNK; }
 int launch_gn_relu(hipStream_t s, const f16 *x, f16 *y, int n, int HW, int C, int ldc, int ldo, int groups, const float *gamma,
                    const float *beta, float *stats, float *aff) {
     const int C8 = C / 8;
     PB_CHECK(C % 8 == 0 && C8 <= 256 && 256 % C8 == 0 && C % groups == 0, -1, "group norm: C=%d groups=%d unsupported", C, groups);
-    PB_HIP(hipMemsetAsync(stats, 0, (size_t)n * C * 2 * 4, s));
-    // ~2048 blocks over the batch: big maps get short chunks (more parallelism), small maps one block per sample
-    const int chunk = (int)std::min<int64_t>(2048, std::max<int64_t>(64, ((int64_t)HW * n + 2047) / 2048));
-    hipLaunchKernelGGL(gn_stats_kernel, dim3((HW + chunk - 1) / chunk, n), dim3(256), 0, s, x, HW, C8, ldc, stats, chunk);
+    const int chunk = GN_CHUNK, nchunk = gn_chunks(HW);           // fixed: the partition must not depend on the batch
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, n), dim3(256), 0, s, x, HW, C8, ldc, stats, chunk);
     const int cpg = C / groups;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nblk((int64_t)n * C)), dim3(256), 0, s, stats, gamma, beta, aff, n, C, cpg,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((n * groups + 3) / 4), dim3(256), 0, s, stats, gamma, beta, aff, n, C, cpg, nchunk,
                        1.f / ((float)HW * (float)cpg));
     hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(nblk((int64_t)n * HW * C8)), dim3(256), 0, s, x, aff, y, n, HW, C8, ldc, ldo);
     LAUNCH_CHECK();

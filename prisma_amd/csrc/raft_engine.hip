@@ -83,7 +83,7 @@ int RaftEngine::load(const pb_tensor *w, int n) {
                                             g[(size_t)n * 576 + (ty * 3 + tx) * 64 + (dy * 4 + dx) * 4 + c] = wt[((size_t)o * 3 + c) * 49 + ky * 7 + kx] * s;
                                     }
                     }
-            if ((r = pack(g.data(), 256, 576, 576, E.stem, bb.data()))) return r;
+            if ((r = pack(g.data(), 256, 576, 576, E.stem, bb.data(), 9))) return r;
             E.stem.Kreal = 147;
         }
         for (int li = 0; li < 3; ++li)
@@ -138,7 +138,7 @@ int RaftEngine::load(const pb_tensor *w, int n) {
                 bb[part * 128 + o] = bs[o];
             }
         }
-        if ((r = pack(g.data(), 256, K, K, zr_[half], bb.data()))) return r;
+        if ((r = pack(g.data(), 256, K, K, zr_[half], bb.data(), 5))) return r;
         if ((r = pack_conv(u + "gru.convq" + sfx, true, nullptr, nullptr, q_[half]))) return r;
     }
     if ((r = pack_conv(u + "flow_head.conv1", true, nullptr, nullptr, fh1_))) return r;
@@ -257,8 +257,9 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         // stem (BasicEncoder.forward, extractor.py:171-192)
         {
             GemmArgs a;
-            a.A = img_; a.W = E.stem.w; a.K = E.stem.K; a.N = 256; a.bias = E.stem.bias; a.zero = zero_;
+            a.A = img_; a.N = 256;
             a.cH = Hp_ / 4; a.cW = Wp_ / 4; a.cC = 64; a.cLd = 64; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1;
+            set_weights(a, E.stem, true);
             a.cOH = a.cH; a.cOW = a.cW; a.M = F * a.cH * a.cW;
             a.out = r1_[5]; a.ldo = 64; a.act = inorm ? ACT_NONE : ACT_RELU;
             a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
@@ -377,7 +378,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         // FlowHead -> delta_flow (fp32), coords1 += delta
         if ((r = conv(hx_, 128, 384, ND, h8_, w8_, 3, 3, 1, fh1_, fh_, 256, ACT_RELU))) return r;
         tic(F_CONV, 2.0 * rows * 2.0 * fh2_.Kreal, 0);
-        r = launch_flow_head2(stream, fh_, fh2_.w, fh2_.bias, flow_, ND, h8_, w8_);
+        r = launch_flow_head2(stream, fh_, fh2_.w, fh2_.bias, flow_, ND, h8_, w8_, fh2_.sw);
         toc();
         if (r) return r;
     }
@@ -387,7 +388,8 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     if ((r = conv(hx_, 128, 384, ND, h8_, w8_, 3, 3, 1, mk0_, m0_, 256, ACT_RELU))) return r;
     {
         GemmArgs a;
-        a.A = m0_; a.lda = 256; a.W = mk2_.w; a.K = mk2_.K; a.N = 576; a.bias = mk2_.bias; a.zero = zero_; a.M = (int)rows;
+        a.A = m0_; a.lda = 256; a.N = 576; a.M = (int)rows;
+        set_weights(a, mk2_, false);
         a.out32 = mask_; a.ldo = 576; a.scale = 0.25f;
         tic(F_GEMM, 2.0 * rows * 576.0 * 256, 0);
         r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);

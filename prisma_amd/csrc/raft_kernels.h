@@ -15,7 +15,7 @@ int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int 
 int launch_corr_tile(hipStream_t s, const f16 *x, f16 *y, int F, int h, int w, int wp, int npad);
 int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], const int w[4], const int wp[4], const int ld[4],
                        const float *flow, int P, int w8, f16 *out, int64_t rows);
-int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W);
+int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W, int split = 0);
 int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows);
 int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, int h8, int w8, int pad_l, int pad_t, int sh,
                     int sw, float *out, unsigned *maxd);

@@ -340,16 +340,22 @@ __global__ void put_flow_kernel(const float *__restrict__ flow, f16 *__restrict_
 // channels an implicit GEMM spends 98 % of its MFMAs on padding columns (73 us per iteration at 720p / 8 pairs; this: 36 us).
 // Half a wave per run of 16 pixels, 8 input channels per lane; the 2 x 9 x 8 weights of a lane and a sliding 3 x 3 window of
 // channel vectors stay in registers, products accumulate in fp32 (v_dot2_f32_f16), one 5-step butterfly per pixel.
+// SPLIT: the packed weights are [o][tap][w_hi (256) | w_lo (256)] (split-fp16 precision mode) and both parts are applied.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__ x, const f16 *__restrict__ w, const float *__restrict__ bias,
                                                           float *__restrict__ flow, int nseg, int H, int W, int segw) {
     // half a wave walks a horizontal run of `segw` pixels with a 3 x 3 window of channel vectors in registers: every step
     // loads one new column (3 vectors) instead of 9
     const int lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
-    f16x8 wv[2][9];
+    constexpr int WS = SPLIT ? 512 : 256;
+    f16x8 wv[2][9], wl[SPLIT ? 2 : 1][SPLIT ? 9 : 1];
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wv[o][t] = *(const f16x8 *)(w + (o * 9 + t) * 256 + cl * 8);
+        for (int t = 0; t < 9; ++t) {
+            wv[o][t] = *(const f16x8 *)(w + (o * 9 + t) * WS + cl * 8);
+            if constexpr (SPLIT) wl[o][t] = *(const f16x8 *)(w + (o * 9 + t) * WS + 256 + cl * 8);
+        }
     const float b0 = bias[0], b1 = bias[1];
     const int wid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int seg = wid * 2 + half;                    // segment = (image, row, run of segw pixels)
@@ -385,6 +391,12 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__
                     const f16x2 w1 = {wv[1][ky * 3 + kx][2 * j], wv[1][ky * 3 + kx][2 * j + 1]};
                     a0 = __builtin_amdgcn_fdot2(vv, w0, a0, false);
                     a1 = __builtin_amdgcn_fdot2(vv, w1, a1, false);
+                    if constexpr (SPLIT) {
+                        const f16x2 l0 = {wl[0][ky * 3 + kx][2 * j], wl[0][ky * 3 + kx][2 * j + 1]};
+                        const f16x2 l1 = {wl[1][ky * 3 + kx][2 * j], wl[1][ky * 3 + kx][2 * j + 1]};
+                        a0 = __builtin_amdgcn_fdot2(vv, l0, a0, false);
+                        a1 = __builtin_amdgcn_fdot2(vv, l1, a1, false);
+                    }
                 }
             }
 #pragma unroll
@@ -461,7 +473,11 @@ __global__ __launch_bounds__(256) void flow_encode_kernel(const float *__restric
         const float *f = flow + ((int64_t)n * per + i) * 2;
         const float dx = __fdiv_rn(f[0], mx), dy = __fdiv_rn(f[1], mx);
         const float rad = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
-        const float a = __fmul_rn(__fadd_rn(__fdiv_rn(atan2f(dy, dx), 3.14159265358979323846f), 1.0f), 0.5f);
+        // np.arctan2 on float32 is not one function: numpy dispatches to SVML (<= 4 ULP) on AVX512 hosts and to libm elsewhere, so
+        // the reference's last bit depends on its CPU.  The engine (and oracle.process_flow(exact_atan2=True)) take the
+        // correctly rounded float32 value: atan2 in double, rounded once.
+        const float at = (float)atan2((double)dy, (double)dx);
+        const float a = __fmul_rn(__fadd_rn(__fdiv_rn(at, 3.14159265358979323846f), 1.0f), 0.5f);
         const float h6 = __fmul_rn(a, 6.0f);
         const float offs[3] = {0.f, 4.f, 2.f};
         uint8_t o[3];
@@ -539,9 +555,10 @@ int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t
     hipLaunchKernelGGL(put_flow_kernel, dim3(nblk(rows)), dim3(256), 0, s, flow, hx, hx2, rows);
     LAUNCH_CHECK();
 }
-int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W) {
+int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W, int split) {
     const int segw = 16, nseg = n * H * ((W + segw - 1) / segw);
-    hipLaunchKernelGGL(flow_head2_kernel, dim3((nseg + 7) / 8), dim3(256), 0, s, x, w, bias, flow, nseg, H, W, segw);
+    if (split) hipLaunchKernelGGL(flow_head2_kernel<true>, dim3((nseg + 7) / 8), dim3(256), 0, s, x, w, bias, flow, nseg, H, W, segw);
+    else hipLaunchKernelGGL(flow_head2_kernel<false>, dim3((nseg + 7) / 8), dim3(256), 0, s, x, w, bias, flow, nseg, H, W, segw);
     LAUNCH_CHECK();
 }
 int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, int h8, int w8, int pad_l, int pad_t, int sh,

@@ -173,14 +173,16 @@ class DepthAnything(_Ctx):
     """
 
     def __init__(self, weights: Dict[str, np.ndarray], cfg: DepthCfg | str = "vitl", device: int = 0,
-                 max_batch: int = 1, metric: bool = False):
+                 max_batch: int = 1, metric: bool = False, precision: Optional[int] = None):
         super().__init__()
         self.cfg = DEPTH_CFGS[cfg] if isinstance(cfg, str) else cfg
         self.metric = bool(metric)
+        self.precision = _lib.default_precision() if precision is None else int(precision)
         if self.metric:      # ZoeDepth state dict: the core's tensors sit under `core.core.`
             weights = {(k[len("core.core."):] if k.startswith("core.core.") else k): v for k, v in weights.items()}
         c = _lib.pb_depth_cfg(self.cfg.embed_dim, self.cfg.depth, self.cfg.heads, self.cfg.features,
-                              (C.c_int32 * 4)(*self.cfg.out_channels), self.cfg.pos_grid, max_batch, int(self.metric))
+                              (C.c_int32 * 4)(*self.cfg.out_channels), self.cfg.pos_grid, max_batch, int(self.metric),
+                              self.precision)
         keep: List[np.ndarray] = []
         arr = (_lib.pb_tensor * len(weights))()
         for i, (name, w) in enumerate(weights.items()):
@@ -246,8 +248,10 @@ class FlowRaft(_Ctx):
     weights: reference checkpoint naming without the `module.` prefix (fnet.*, cnet.*, update_block.*).
     """
 
-    def __init__(self, weights: Dict[str, np.ndarray], device: int = 0):
+    def __init__(self, weights: Dict[str, np.ndarray], device: int = 0, precision: Optional[int] = None):
         super().__init__()
+        self.precision = _lib.default_precision() if precision is None else int(precision)
+        fc = _lib.pb_flow_cfg(self.precision)
         keep = {k: _f32(v) for k, v in weights.items() if np.asarray(v).dtype.kind == "f"}
         arr = (_lib.pb_tensor * len(keep))()
         for i, (name, w) in enumerate(keep.items()):
@@ -257,7 +261,7 @@ class FlowRaft(_Ctx):
             for j, s in enumerate(w.shape):
                 arr[i].shape[j] = s
             arr[i].data = w.ctypes.data
-        check(self.lib.pb_create(C.byref(self.ctx), device, b"flow_raft", arr, len(keep), None, 0))
+        check(self.lib.pb_create(C.byref(self.ctx), device, b"flow_raft", arr, len(keep), C.byref(fc), C.sizeof(fc)))
 
     def infer_sequence(self, frames: np.ndarray, scale: float = 0.75, iters: int = 12, backward: bool = False,
                        want_flow: bool = True, want_rgb: bool = True):
@@ -316,11 +320,11 @@ class FlowRaft(_Ctx):
         return out[:n].reshape(dims).copy()
 
 
-def _mask_cfg(cfg: MaskCfg, max_batch: int) -> "_lib.pb_mask_cfg":
+def _mask_cfg(cfg: MaskCfg, max_batch: int, precision: int = 0) -> "_lib.pb_mask_cfg":
     return _lib.pb_mask_cfg((C.c_int32 * 4)(*cfg.blocks), cfg.scale_long, cfg.scale_short, cfg.num_classes, cfg.feat_channels,
                             cfg.stacked_convs, (C.c_int32 * 5)(*cfg.num_grids), (C.c_int32 * 5)(*cfg.strides),
                             cfg.mask_feat_channels, cfg.mask_out_channels, cfg.nms_pre, cfg.max_per_img, cfg.score_thr,
-                            cfg.mask_thr, cfg.filter_thr, cfg.sigma, max_batch)
+                            cfg.mask_thr, cfg.filter_thr, cfg.sigma, max_batch, precision)
 
 
 def mask_net_size(cfg: MaskCfg | str, H: int, W: int) -> Tuple[int, int, int, int]:
@@ -338,10 +342,12 @@ class MaskMMDet(_Ctx):
     weights: mmdet state_dict naming (backbone.*, neck.*, mask_head.*) -> float32 ndarray.
     """
 
-    def __init__(self, weights: Dict[str, np.ndarray], cfg: MaskCfg | str = "r101", device: int = 0, max_batch: int = 4):
+    def __init__(self, weights: Dict[str, np.ndarray], cfg: MaskCfg | str = "r101", device: int = 0, max_batch: int = 4,
+                 precision: Optional[int] = None):
         super().__init__()
         self.cfg = MASK_CFGS[cfg] if isinstance(cfg, str) else cfg
-        c = _mask_cfg(self.cfg, max_batch)
+        self.precision = _lib.default_precision() if precision is None else int(precision)
+        c = _mask_cfg(self.cfg, max_batch, self.precision)
         keep = {k: _f32(v) for k, v in weights.items() if np.asarray(v).dtype.kind == "f"}
         arr = (_lib.pb_tensor * len(keep))()
         for i, (name, w) in enumerate(keep.items()):

@@ -27,13 +27,6 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, name)
 
 
-def test_struct_layout_matches_header():
-    assert C.sizeof(_lib.pb_depth_cfg) == 11 * 4            # ... max_batch, metric
-    assert C.sizeof(_lib.pb_mask_cfg) == 28 * 4             # 23 int32 + 4 float + max_batch
-    assert C.sizeof(_lib.pb_tensor) == 8 + 4 + 4 + 6 * 8 + 8
-    assert C.sizeof(_lib.pb_kernel_stat) == 8 + 3 * 8 + 8
-
-
 def test_net_size_matches_oracle(lib):
     for (w, h) in [(1280, 720), (1920, 1080), (934, 440), (518, 518), (128, 96), (120, 90), (640, 481), (333, 777)]:
         nh, nw = C.c_int(), C.c_int()

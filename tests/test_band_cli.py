@@ -173,8 +173,8 @@ def test_mask_cli_video_and_image(tmp_path):
     Image.fromarray(frames[0]).save(tmp_path / "img.png")
     band.main(["-i", str(tmp_path / "img.png"), "--arch", "tiny"])
     png = np.asarray(Image.open(tmp_path / "mask.png"))
-    # batch of 3 vs batch of 1: GroupNorm statistics are fp32 atomics and tile shapes differ, so threshold-edge pixels may flip
-    assert png.shape == (180, 300, 3) and (png[..., 0] != out[0, ..., 0]).mean() < 0.01
+    # batch of 3 vs batch of 1: the mask ids of a frame do not depend on the frames it shares a launch with
+    assert png.shape == (180, 300, 3) and np.array_equal(png[..., 0], out[0, ..., 0])
     band.model.close()
     band.model = None
 

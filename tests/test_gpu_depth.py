@@ -1,19 +1,20 @@
 """GPU: the depth_anything band end to end through the C ABI vs the oracle and the committed
 reference vectors.  Tolerance: BASELINE.json asks for 1e-3 relative on float depth; the
 metric used here is max|d - ref| / max|ref| (error relative to the depth range, which is what
-the min/max-normalised heat encoding sees) plus the relative L2 error."""
+the min/max-normalised heat encoding sees) plus the relative L2 error.  Both are asserted < 1e-3 in the engine's
+default precision (PB_PREC_SPLIT); the single-pass fp16 mode has its own documented bounds (conftest.TOL)."""
 import os
 
 import numpy as np
 import pytest
 
+from conftest import TOL
 from oracle import depth_oracle as O
 from prisma_amd import engine, synth
 
 pytestmark = pytest.mark.gpu
 
-TOL_RANGE = 2e-3      # max abs error / depth range   (fp16 MFMA operands, fp32 accumulate)
-TOL_L2 = 1e-3         # ||d - ref|| / ||ref||
+TOL_RANGE, TOL_L2 = TOL[1]      # max abs error / depth range, ||d - ref|| / ||ref||: 1e-3 each (split-fp16, the default)
 
 
 def relmax(a, b):
@@ -30,17 +31,18 @@ def report(tag, a, b):
     print(f"  {tag:14s} relmax {relmax(a, b):.3e}  relL2 {rell2(a, b):.3e}")
 
 
+@pytest.mark.parametrize("prec", [1, 0])
 @pytest.mark.parametrize("cfg,hw,seed", [("vits", (96, 128), 11), ("vitl_d4", (90, 120), 12)])
-def test_small_models_stagewise(cfg, hw, seed, golden_dir):
+def test_small_models_stagewise(cfg, hw, seed, prec, golden_dir):
     c = synth.DEPTH_CFGS[cfg]
     w = synth.depth_anything_weights(c, seed=1234)
     frame = synth.frames(1, hw[0], hw[1], seed=seed)[0]
-    net = engine.DepthAnything(w, c, device=0, max_batch=2)
+    net = engine.DepthAnything(w, c, device=0, max_batch=2, precision=prec)
     net.set_profiling(timing=False, debug_stages=True)
     depth, rgb, mn, mx = net.infer_batch(frame[None])
     x = O.preprocess(frame)[None]
     d_net, st = O.model_forward(w, x, c.depth, c.heads, return_stages=True)
-    print(f"\n[{cfg}] stage errors vs oracle")
+    print(f"\n[{cfg}, precision {prec}] stage errors vs oracle")
     worst = 0.0
     for name, key in [("tokens", "tokens"), ("block0", "block0"), (f"block{c.depth - 1}", f"block{c.depth - 1}"),
                       ("feat0", "feat0"), ("feat3", "feat3"), ("layer1_rn", "layer1_rn"), ("layer4_rn", "layer4_rn"),
@@ -55,7 +57,7 @@ def test_small_models_stagewise(cfg, hw, seed, golden_dir):
     report("depth", depth[0], ref)
     z = np.load(os.path.join(golden_dir, f"depth_{cfg}_{hw[0]}x{hw[1]}.npz"))
     report("depth/golden", depth[0], z["depth"])
-    assert relmax(depth[0], z["depth"]) < TOL_RANGE and rell2(depth[0], z["depth"]) < TOL_L2
+    assert relmax(depth[0], z["depth"]) < TOL[prec][0] and rell2(depth[0], z["depth"]) < TOL[prec][1]
     assert worst < 1e-2
     assert abs(mn[0] - depth[0].min()) == 0 and abs(mx[0] - depth[0].max()) == 0
     ref_rgb, _, _ = O.encode_depth_video(depth[0], flip=True)
@@ -77,21 +79,43 @@ def test_batch_matches_single():
     net.close()
 
 
-def test_vitl_720p_against_reference_vectors(golden_dir):
+@pytest.mark.parametrize("prec", [1, 0])
+def test_vitl_720p_against_reference_vectors(golden_dir, prec):
+    """BASELINE configs[1]: one 1280x720 frame, ViT-L, batch 1, against the reference's own output."""
     z = np.load(os.path.join(golden_dir, "depth_vitl_720p.npz"))
     c = synth.DEPTH_CFGS["vitl"]
     w = synth.depth_anything_weights(c, seed=1234)
     frame = synth.frames(1, 720, 1280, seed=int(z["frame_seed"]))[0]
-    net = engine.DepthAnything(w, c, device=0, max_batch=1)
+    net = engine.DepthAnything(w, c, device=0, max_batch=1, precision=prec)
     depth, rgb, mn, mx = net.infer_batch(frame[None])
     print()
-    report("vitl 720p", depth[0][::8, ::8], z["depth_s8"])
-    assert relmax(depth[0][::8, ::8], z["depth_s8"]) < TOL_RANGE
-    assert rell2(depth[0][::8, ::8], z["depth_s8"]) < TOL_L2
-    assert abs(mx[0] - z["minmax"][1]) < TOL_RANGE * z["minmax"][1]
+    report(f"vitl 720p p{prec}", depth[0][::8, ::8], z["depth_s8"])
+    assert relmax(depth[0][::8, ::8], z["depth_s8"]) < TOL[prec][0]
+    assert rell2(depth[0][::8, ::8], z["depth_s8"]) < TOL[prec][1]
+    assert abs(mx[0] - z["minmax"][1]) < TOL[prec][0] * z["minmax"][1]
     # size-independent properties at full size: encode is a pure function of (depth, min, max)
     ref_rgb, lo, hi = O.encode_depth_video(depth[0], flip=True)
     assert np.array_equal(rgb[0], ref_rgb) and lo == mn[0] and hi == mx[0]
+    net.close()
+
+
+@pytest.mark.parametrize("prec", [1, 0])
+def test_vitl_batch_32_at_1080p_equals_single_frames(prec):
+    """BASELINE configs[3]: ViT-L on a batch of 32 1920x1080 frames (one engine call, max_batch 32 - the bench's shape).  Frame i
+    of the batch equals the same frame run alone, bit for bit: depth, encoded bytes, min and max; and the frame that has a
+    reference golden-sized sibling stays within tolerance of the oracle."""
+    c = synth.DEPTH_CFGS["vitl"]
+    w = synth.depth_anything_weights(c, seed=1234)
+    frames = synth.frames(32, 1080, 1920, seed=77)
+    net = engine.DepthAnything(w, c, device=0, max_batch=32, precision=prec)
+    d, rgb, mn, mx = net.infer_batch(frames)
+    assert d.shape == (32, 1080, 1920) and np.isfinite(d).all() and (mx > mn).all()
+    for i in (0, 13, 31):
+        d1, rgb1, mn1, mx1 = net.infer_batch(frames[i:i + 1])
+        assert np.array_equal(d1[0], d[i]) and np.array_equal(rgb1[0], rgb[i]) and mn1[0] == mn[i] and mx1[0] == mx[i], i
+    ref = O.infer(w, frames[13], c.depth, c.heads)
+    report(f"b32[13] p{prec}", d[13], ref)
+    assert relmax(d[13], ref) < TOL[prec][0] and rell2(d[13], ref) < TOL[prec][1]
     net.close()
 
 

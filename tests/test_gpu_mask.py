@@ -102,6 +102,18 @@ def test_end_to_end_mask_image_close_to_oracle(tiny):
     assert mism < 0.03          # discrete decisions on fp16-perturbed scores: instance boundaries and near-threshold cells
 
 
+def test_mask_ids_do_not_depend_on_the_batch(tiny):
+    """GroupNorm statistics are fixed-order sums over fixed 256-pixel chunks (no atomics): frame i of a batch of 3 equals the
+    same frame alone, bit for bit, and a repeated call reproduces itself."""
+    cfg, w, net = tiny
+    frames = synth.frames(3, 180, 300, seed=21)
+    out3 = net.infer_batch(frames, 0.5, KEEP)
+    again = net.infer_batch(frames, 0.5, KEEP)
+    assert np.array_equal(out3, again)
+    for i in range(3):
+        assert np.array_equal(net.infer_batch(frames[i:i + 1], 0.5, KEEP)[0], out3[i]), i
+
+
 def test_keep_classes_and_confidence(tiny):
     cfg, w, net = tiny
     frames = synth.frames(1, 180, 300, seed=5)
@@ -143,4 +155,32 @@ def test_r101_720p_against_oracle():
     assert (out[1] != ref_img).mean() < 5e-4 and out[1].any()
     st = {s["name"]: s for s in net.kernel_stats()}
     print("  kernel ms (2 frames):", {k: round(v["ms"], 2) for k, v in st.items()})
+    net.close()
+
+
+def test_r101_1080p_batch_against_oracle():
+    """BASELINE configs[4] (mask part): ResNet-101 on 1920x1080 frames -> 1333x750 -> 768x1344, a batch of 3 with max_batch 2;
+    the frame checked against the oracle sits in the second chunk, and its mask image equals the same frame run alone."""
+    cfg = synth.MASK_CFGS["r101"]
+    w = synth.solov2_weights(cfg)
+    net = engine.MaskMMDet(w, cfg, max_batch=2)
+    net.set_profiling(True, True)
+    frames = synth.frames(3, 1080, 1920, seed=4)
+    out = net.infer_batch(frames, 0.5, KEEP)
+    assert engine.mask_net_size(cfg, 1080, 1920) == (750, 1333, 768, 1344)
+    x, meta = SO.preprocess(frames[2], cfg)
+    assert np.array_equal(net.stage("input")[0], x[0])                 # last chunk holds frame 2 alone
+    kps, cps, mf = SO.network(w, cfg, x)
+    for name, ref in (("mask_feats", mf), ("kernel_pred0", kps[0]), ("cls_logit0", cps[0]), ("cls_logit4", cps[4])):
+        got = net.stage(name)[0:1]
+        a, b = relmax(got, ref.numpy()), rell2(got, ref.numpy())
+        print("  %-13s relmax %.3e relL2 %.3e" % (name, a, b))
+        assert a < 2 * TOL_RANGE and b < 2 * TOL_L2, name
+    sc, lb, mk, dbg = _oracle_post_from_engine(cfg, net, 1, meta, 0)
+    g_sc, g_lb, g_mk, g_cand = net.instances(2, with_masks=True)      # instance records are indexed by frame of the call
+    assert g_cand == dbg["n_candidates"] and np.array_equal(g_lb, lb.numpy())
+    assert (g_mk != mk.numpy()).mean() < 2e-4
+    ref_img = SO.band_mask(sc, lb, mk, synth.COCO_CLASSES, synth.BAND_CLASSES, 0.5, meta["ori_shape"])
+    assert (out[2] != ref_img).mean() < 5e-4 and out[2].any()
+    assert np.array_equal(net.infer_batch(frames[2:3], 0.5, KEEP)[0], out[2])
     net.close()

@@ -1,15 +1,18 @@
 """GPU: the flow_raft band through the C ABI vs the oracle and the committed reference vectors.
-Flow tolerance: BASELINE.json asks for 1e-3 relative; metric = max|f - ref| / max|ref| and relative L2."""
+Flow tolerance: BASELINE.json asks for 1e-3 relative; metric = max|f - ref| / max|ref| and relative L2, both < 1e-3 in the
+default precision (PB_PREC_SPLIT); the single-pass fp16 mode is checked against its documented bounds (FAST_TOL)."""
 import os
 
 import numpy as np
 import pytest
 
+from conftest import TOL
 from oracle import raft_oracle as R
 from prisma_amd import engine, synth
 
 pytestmark = pytest.mark.gpu
-TOL_RANGE, TOL_L2 = 3e-3, 2e-3
+TOL_RANGE, TOL_L2 = TOL[1]
+FAST_TOL = (3e-3, 2e-3)       # PB_PREC_F16: 12 recurrent iterations on fp16 operands (measured 1.1-1.5e-3 / 0.8-1.1e-3)
 
 
 def relmax(a, b):
@@ -24,8 +27,21 @@ def rell2(a, b):
 
 @pytest.fixture(scope="module")
 def net():
-    n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0)
+    n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0, precision=1)
     yield n
+    n.close()
+
+
+def test_fast_mode_against_reference_vectors(golden_dir):
+    n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0, precision=0)
+    for name in ("raft_125x157.npz", "raft_131x181.npz"):
+        z = np.load(os.path.join(golden_dir, name))
+        h, w = [int(v) for v in z["hw"]]
+        fr = synth.frame_pair_sequence(2, h, w, seed=int(z["frame_seed"]))
+        flow, _, _ = n.infer_sequence(fr, scale=1.0, iters=int(z["iters"]), backward=True)
+        for k, got, ref in (("fwd", flow[0, 0], z["fwd"]), ("bwd", flow[0, 1], z["bwd"])):
+            print("\n  fp16 %s %s relmax %.3e relL2 %.3e" % (name, k, relmax(got, ref), rell2(got, ref)))
+            assert relmax(got, ref) < FAST_TOL[0] and rell2(got, ref) < FAST_TOL[1]
     n.close()
 
 
@@ -52,9 +68,13 @@ def test_pair_against_reference_vectors(net, golden_dir):
         print("  %s/golden relmax %.3e relL2 %.3e  max|flow| %.2f" % (name, relmax(got, ref), rell2(got, ref), np.abs(ref).max()))
         assert relmax(got, ref) < TOL_RANGE and rell2(got, ref) < TOL_L2
     # encode: max displacement and colours are functions of the engine's own flow
-    ref_rgb, ref_mx = R.process_flow(flow[0, 0])
-    assert abs(mx[0, 0] - ref_mx) <= 1e-6 * ref_mx
-    assert (np.abs(rgb[0, 0].astype(int) - ref_rgb.astype(int)) > 1).mean() < 1e-3     # atan2f vs numpy: off-by-one bytes only
+    ref_rgb, ref_mx = R.process_flow(flow[0, 0], exact_atan2=True)
+    assert mx[0, 0] == ref_mx
+    assert np.array_equal(rgb[0, 0], ref_rgb)          # byte exact (correctly rounded float32 arctan2 on both sides)
+    host_rgb, _ = R.process_flow(flow[0, 0])           # numpy's own float32 arctan2 (SVML or libm, depends on this host's CPU)
+    d = np.abs(rgb[0, 0].astype(int) - host_rgb.astype(int))
+    print("  bytes differing from this host's np.arctan2(float32) path: %.2e (max |diff| %d)" % ((d > 0).mean(), d.max()))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
 
 
 def test_odd_feature_grid_against_reference_vectors(net, golden_dir):
@@ -66,6 +86,48 @@ def test_odd_feature_grid_against_reference_vectors(net, golden_dir):
     for name, got, ref in (("fwd", flow[0, 0], z["fwd"]), ("bwd", flow[0, 1], z["bwd"])):
         print("\n  %s/golden relmax %.3e relL2 %.3e  max|flow| %.2f" % (name, relmax(got, ref), rell2(got, ref), np.abs(ref).max()))
         assert relmax(got, ref) < TOL_RANGE and rell2(got, ref) < TOL_L2
+
+
+@pytest.mark.parametrize("prec", [1, 0])
+def test_720p_batch_of_8_pairs_against_reference_vectors(golden_dir, prec):
+    """BASELINE configs[2]: 8 consecutive pairs of 1280x720 frames, 12 GRU iterations, no --scale, one engine call
+    (14 400^2 correlation volumes, 8-pair batching, 32-bit-offset guards) against the REAL reference's output on the same
+    frames (tests/golden/raft_full.npz: 1/8-strided samples + float64 sums per pair)."""
+    z = np.load(os.path.join(golden_dir, "raft_full.npz"))
+    fr = synth.frame_pair_sequence(9, 720, 1280, seed=int(z["frame_seed"]))
+    n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0, precision=prec)
+    flow, rgb, mx = n.infer_sequence(fr, scale=1.0, iters=int(z["iters"]), backward=False)
+    n.close()
+    assert flow.shape == (8, 1, 720, 1280, 2)
+    tol = TOL[1] if prec == 1 else FAST_TOL
+    for i in range(8):
+        got, ref = flow[i, 0][::8, ::8], z["fwd720_s8"][i]
+        print("\n  p%d pair %d relmax %.3e relL2 %.3e" % (prec, i, relmax(got, ref), rell2(got, ref)), end="")
+        assert relmax(got, ref) < tol[0] and rell2(got, ref) < tol[1], i
+        f64 = flow[i, 0].astype(np.float64)
+        sums = np.array([f64[..., 0].sum(), f64[..., 1].sum(), np.abs(f64).sum()])
+        assert np.all(np.abs(sums - z["sums720"][i]) < tol[1] * z["sums720"][i][2])       # whole-frame sums (every pixel counted)
+        ref_rgb, ref_mx = R.process_flow(flow[i, 0], exact_atan2=True)
+        assert mx[i, 0] == ref_mx and np.array_equal(rgb[i, 0], ref_rgb)                  # encode byte exact at full size
+
+
+@pytest.mark.parametrize("prec", [1, 0])
+def test_1080p_scaled_pair_against_reference_vectors(golden_dir, prec):
+    """BASELINE configs[4] (flow part): a 1920x1080 pair at the band's default --scale 0.75 -> 810x1440 -> network 816x1440
+    (18 360^2 volume), 12 iterations, against the reference network fed the same 8-bit cubic resize."""
+    z = np.load(os.path.join(golden_dir, "raft_full.npz"))
+    big = synth.frame_pair_sequence(2, 1080, 1920, seed=int(z["frame_seed"]) + 1)
+    n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0, precision=prec)
+    flow, rgb, mx = n.infer_sequence(big, scale=0.75, iters=int(z["iters"]), backward=False)
+    n.close()
+    assert flow.shape == (1, 1, 810, 1440, 2)
+    tol = TOL[1] if prec == 1 else FAST_TOL
+    got, ref = flow[0, 0][::8, ::8], z["fwd1080_s8"]
+    print("\n  p%d 1080p x0.75 relmax %.3e relL2 %.3e" % (prec, relmax(got, ref), rell2(got, ref)))
+    assert relmax(got, ref) < tol[0] and rell2(got, ref) < tol[1]
+    f64 = flow[0, 0].astype(np.float64)
+    sums = np.array([f64[..., 0].sum(), f64[..., 1].sum(), np.abs(f64).sum()])
+    assert np.all(np.abs(sums - z["sums1080"]) < tol[1] * z["sums1080"][2])
 
 
 def test_scaled_sequence_matches_oracle(net):

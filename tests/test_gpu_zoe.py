@@ -1,5 +1,6 @@
 """GPU: `depth_anything --metric` (ZoeDepth head over the ViT-L core) through the C ABI vs oracle/zoe_oracle.py.
-Tolerance: north_star's 1e-3 relative is the target; measured errors are printed, bounds as for the relative model."""
+Tolerance: north_star's 1e-3 relative on the band's output (metric depth, at network and at frame resolution), asserted in the
+default precision (PB_PREC_SPLIT); intermediate stages (relative depth of the core, bin centres) are printed and bounded at 2e-3."""
 import numpy as np
 import pytest
 
@@ -7,7 +8,8 @@ from oracle import zoe_oracle as Z
 from prisma_amd import engine, synth
 
 pytestmark = pytest.mark.gpu
-TOL_RANGE, TOL_L2 = 3e-3, 1.5e-3
+TOL_RANGE, TOL_L2 = 1e-3, 1e-3
+STAGE_RANGE, STAGE_L2 = 2e-3, 1e-3
 
 
 def relmax(a, b):
@@ -35,7 +37,10 @@ def test_metric_depth_matches_oracle():
             ref = ref.reshape(64, -1).T                      # oracle NCHW -> engine [pixels, 64]
         a, b = relmax(got, ref), rell2(got, ref)
         print("  %-10s relmax %.3e relL2 %.3e" % (name, a, b))
-        assert a < TOL_RANGE and b < TOL_L2, name
+        if name == "metric_net":
+            assert a < TOL_RANGE and b < TOL_L2, name
+        else:
+            assert a < STAGE_RANGE and b < STAGE_L2, name
     # the Pillow resize of the engine's own network output is exact (double accumulation, float32 passes)
     from PIL import Image
     pil = np.asarray(Image.fromarray(net.stage("metric_net")[1]).resize((640, 360)))

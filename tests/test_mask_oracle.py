@@ -54,6 +54,25 @@ def test_points_nms_hand_case():
     assert s[2, 0] == torch.sigmoid(torch.tensor(-3.0))      # window {(1,0), (2,0)}: a tie keeps the cell
 
 
+def test_matrix_nms_against_reference_vectors(golden_dir):
+    """tests/golden/matrix_nms.npz: inputs and outputs of the REAL mask_matrix_nms (reference bands/mmdet/core/post_processing/
+    matrix_nms.py:5-121, loaded by oracle/make_golden.py `nms` - the file imports only torch).  PINS the oracle's Matrix NMS."""
+    import dataclasses
+    import os
+    z = np.load(os.path.join(golden_dir, "matrix_nms.npz"))
+    for case in range(3):
+        n, h, w = [int(v) for v in z[f"shape{case}"]]
+        masks = np.unpackbits(z[f"masks{case}"], axis=-1)[..., :w].astype(bool)
+        nms_pre, max_num, filter_thr, sigma = z[f"cfg{case}"]
+        cfg = dataclasses.replace(synth.MASK_CFGS["tiny"], nms_pre=int(nms_pre), max_per_img=int(max_num), filter_thr=float(filter_thr),
+                                  sigma=float(sigma))
+        sc, lb, keep = SO.matrix_nms(torch.from_numpy(masks), torch.from_numpy(z[f"labels{case}"]), torch.from_numpy(z[f"scores{case}"]),
+                                     torch.from_numpy(z[f"areas{case}"]), cfg)
+        assert np.array_equal(sc.numpy(), z[f"out_scores{case}"]) and np.array_equal(lb.numpy(), z[f"out_labels{case}"])
+        assert np.array_equal(keep.numpy(), z[f"out_keep{case}"])
+        assert len(keep) == min(int(max_num), int((sc.numpy() >= filter_thr).sum()))
+
+
 def _matrix_nms_loops(masks, labels, scores, areas, cfg):
     """Independent restatement of core/post_processing/matrix_nms.py:52-121 with explicit loops."""
     order = sorted(range(len(scores)), key=lambda i: -scores[i])[:cfg.nms_pre]
