@@ -34,6 +34,20 @@ def write_rgb(path, rgb_u8):
     Image.fromarray(rgb_u8).save(path)
 
 
+def get_image_size(path):
+    """(width, height) of an image file (io.py:57-60)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return im.size[0], im.size[1]
+
+
+def get_video_data(path):
+    """(width, height, fps, total_frames) of a video (io.py:63-67)."""
+    v = FrameReader(path)
+    f0 = v[0]
+    return f0.shape[1], f0.shape[0], v.fps, len(v)
+
+
 class FrameReader:
     """len() / [i] -> uint8 HxWx3 RGB; fps.  decord for .mp4 (reference), numpy memmap for .npy."""
 
@@ -73,10 +87,17 @@ class VideoWriter:
                 import av
             except ImportError as e:
                 raise RuntimeError("writing .mp4 needs PyAV (reference dependency); write a .npy stack here") from e
+            # reference io.py:262-289: sides clamped to 3840 keeping the aspect, made even; rate as '%.2f' (29.97 stays 29.97, so the
+            # band videos stay frame-aligned with rgba.mp4); libx264 crf 15, frame threading AUTO
+            max_size = 3840
+            if width > max_size or height > max_size:
+                aspect = height / width
+                width, height = (max_size, round(max_size * aspect)) if aspect < 1 else (round(max_size / aspect), max_size)
             self._av = av.open(filename, mode="w")
-            self._st = self._av.add_stream("libx264", rate=int(round(frame_rate)), options={"crf": "15"})
+            self._st = self._av.add_stream("libx264", rate="%.2f" % frame_rate, options={"crf": "15"})
             self._w, self._h = 2 * round(width / 2), 2 * round(height / 2)
             self._st.width, self._st.height, self._st.pix_fmt = self._w, self._h, "yuv420p"
+            self._st.thread_type = "AUTO"
 
     def write(self, rgb):
         if self._frames is not None:

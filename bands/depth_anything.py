@@ -41,7 +41,8 @@ def heat_to_rgb(heat):
 def load_weights(encoder, path=""):
     """{reference state_dict name: float32 ndarray}.  The reference pulls LiheYoung/depth_anything_*14
     from the HF hub (:60); offline we read models/depth_anything_<enc>14.{npz,pth} if present and fall
-    back to the seeded synthetic weights with a warning."""
+    back to the seeded synthetic weights ONLY with --synthetic / PRISMA_SYNTH=1 (tests, benchmarks); otherwise a missing
+    checkpoint is an error."""
     cands = [path] if path else [os.path.join("models", f"depth_anything_{encoder}14.npz"),
                                  os.path.join("models", f"depth_anything_{encoder}14.pth")]
     for c in cands:
@@ -52,7 +53,9 @@ def load_weights(encoder, path=""):
             import torch
             sd = torch.load(c, map_location="cpu")
             return {k: v.float().numpy() for k, v in sd.items()}
-    print(f"[{BAND}] no checkpoint found ({cands}); using seeded synthetic weights", file=sys.stderr)
+    if not shard.synthetic_allowed(getattr(args, "synthetic", False)):
+        raise SystemExit(f"[{BAND}] no checkpoint found ({cands}); pass --weights, or --synthetic / PRISMA_SYNTH=1 for seeded synthetic weights")
+    print(f"[{BAND}] no checkpoint found ({cands}); using seeded synthetic weights (--synthetic)", file=sys.stderr)
     return synth.depth_anything_weights(encoder, seed=1234)
 
 
@@ -79,7 +82,9 @@ def load_metric_weights(path):
         sd = torch.load(path, map_location="cpu")
         sd = sd.get("model", sd)
         return {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "numpy")}
-    print(f"[{BAND}] metric checkpoint {path!r} not found; using seeded synthetic weights", file=sys.stderr)
+    if not shard.synthetic_allowed(getattr(args, "synthetic", False)):
+        raise SystemExit(f"[{BAND}] metric checkpoint {path!r} not found; pass --weights, or --synthetic / PRISMA_SYNTH=1")
+    print(f"[{BAND}] metric checkpoint {path!r} not found; using seeded synthetic weights (--synthetic)", file=sys.stderr)
     return synth.zoe_weights()
 
 
@@ -96,6 +101,8 @@ def infer(img, normalize=False):
 
 
 def process_image(a):
+    if getattr(a, "ply", False):       # reference :168-174 write_pcl (camera intrinsics + plyfile): geometry export, SURVEY section 2 out of scope
+        raise NotImplementedError("--ply (point cloud export of a still image) is not built: SURVEY.md section 2.1 geom")
     img = open_rgb(a.input)
     out_folder = os.path.dirname(a.output)
     pred = infer(img)
@@ -108,9 +115,12 @@ def process_image(a):
 
 
 def process_video(a):
-    """Frames shard by rank: every rank encodes its contiguous block on its own GPU; the encoded frames and
-    the per-frame (min, max) are gathered so rank 0 writes the video, the CSVs and the metadata in frame order."""
+    """Frames shard by rank: every rank encodes its contiguous block on its own GPU.  Rank 0 writes its own
+    chunks to the video as they finish and then muxes the other ranks' chunks in frame order (shard.Relay: one chunk in
+    memory at a time, nothing gathered); only the per-frame (min, max) scalars go through a collective."""
     rk = ranks or shard.Ranks()
+    if getattr(a, "ply", False):
+        print(f"[{BAND}] --ply only applies to still images (reference :168-174); ignored for video", file=sys.stderr)
     src = FrameReader(a.input)
     n = len(src)
     h, w = src[0].shape[:2]
@@ -124,16 +134,17 @@ def process_video(a):
     if model is None:
         init_model(device=rk.device)
     first, last = rk.frames(n)
-    lo, hi, held = [], [], []
+    lo, hi = [], []
     want_depth = bool(a.npy or a.subpath)
+    relay = shard.Relay(rk, a.output)
 
     def emit(s, depth, rgb):
         # runs on the sink thread, chunk after chunk in order: video frames, .npy / .png dumps (reference :215-225)
+        if not rk.main:
+            relay.put(s, {"rgb": rgb})
         for j in range(len(rgb)):
-            if rk.world == 1:
+            if rk.main:
                 out.write(rgb[j])
-            else:
-                held.append(rgb[j])
             if a.npy and a.subpath:
                 np.save(os.path.join(a.subpath, "{:05d}.npy".format(s + j)), depth[j])
             if a.subpath:
@@ -150,12 +161,12 @@ def process_video(a):
         hi += [float(v) for v in mx]
     sink.close()
     if rk.world > 1:
-        every = rk.gather(np.stack(held) if held else np.zeros((0, h, w, 3), np.uint8), n)
+        if rk.main:
+            relay.drain(n, BATCH, lambda s, c: [out.write(f) for f in c["rgb"]])
         mm = rk.gather(np.asarray([lo, hi], np.float32).T.reshape(-1, 2), n)
         if rk.main:
-            for f in every:
-                out.write(f)
             lo, hi = [float(v) for v in mm[:, 0]], [float(v) for v in mm[:, 1]]
+    relay.close()
     if not rk.main:
         return
     out.close()
@@ -178,10 +189,9 @@ def main(argv=None):
     ap.add_argument("--subpath", "-d", help="subpath to frames", type=str, default="")
     ap.add_argument("--encoder", type=str, default="vitl", choices=["vits", "vitb", "vitl"])
     ap.add_argument("--metric", help="Use a metric model", type=str, default="none", choices=["none", "indoor", "outdoor"])
-    ap.add_argument("--weights", help="checkpoint (.npz / .pth state dict); default models/ or synthetic", default="")
+    ap.add_argument("--weights", help="checkpoint (.npz / .pth state dict); default models/depth_anything_<encoder>14.*", default="")
+    ap.add_argument("--synthetic", help="seeded synthetic weights when no checkpoint is found (tests / benchmarks)", action="store_true")
     args = ap.parse_args(argv)
-    if args.ply:
-        raise NotImplementedError("--ply (point cloud export) is out of scope: SURVEY.md section 2.1 geom/colmap")
     data = load_metadata(args.input)
     if data:
         print("PRISMA metadata found and loaded")

@@ -19,16 +19,17 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 from common.io import FrameReader, VideoWriter, check_overwrite, write_flo, write_flow_png  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
-from common.pipe import prefetch  # noqa: E402
+from common.pipe import AsyncSink, prefetch  # noqa: E402
 from prisma_amd import engine, shard, synth  # noqa: E402
 
 BAND = "flow_raft"
-MODEL = "models/raft-things.pth"
+MODEL = "models/raft-sintel.pth"            # reference :31
 ITERATIONS = 20
 CHUNK = int(os.environ.get("PRISMA_BATCH", "16"))
 
 model = None
 data = None
+_SYNTH = [False]      # --synthetic
 ranks = None          # shard.Ranks(): one process per GPU under torchrun, world 1 otherwise
 
 
@@ -42,7 +43,9 @@ def load_weights(path):
             import torch
             sd = {k: v.numpy() for k, v in torch.load(path, map_location="cpu").items()}
         return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
-    print(f"[{BAND}] checkpoint {path!r} not found; using seeded synthetic weights", file=sys.stderr)
+    if not shard.synthetic_allowed(_SYNTH[0]):
+        raise SystemExit(f"[{BAND}] checkpoint {path!r} not found; pass --model, or --synthetic / PRISMA_SYNTH=1 for seeded synthetic weights")
+    print(f"[{BAND}] checkpoint {path!r} not found; using seeded synthetic weights (--synthetic)", file=sys.stderr)
     return synth.raft_weights(seed=4321)
 
 
@@ -50,6 +53,7 @@ def init_model(args=None, device=0):
     global model
     if args is not None and (getattr(args, "small", False) or getattr(args, "alternate_corr", False)):
         raise NotImplementedError("--small / --alternate_corr select other RAFT variants; only the basic model is built")
+    _SYNTH[0] = bool(getattr(args, "synthetic", False))
     model = engine.FlowRaft(load_weights(getattr(args, "model", MODEL) if args else MODEL), device=device)
     return model
 
@@ -74,8 +78,10 @@ def _mask_rgb(mask):
 
 
 def process_video(args):
-    """Pairs (i, i+1) shard by rank in contiguous blocks with a one-frame halo; the encoded frames, masks
-    and max displacements are gathered so rank 0 writes every output in frame order."""
+    """Pairs (i, i+1) shard by rank in contiguous blocks with a one-frame halo.  Every chunk is written as soon
+    as it is done: rank 0 feeds its own chunks to the VideoWriters from a sink thread (the next chunk is already on the
+    GPU) and then muxes the other ranks' chunks in frame order through shard.Relay; only the per-pair max displacements
+    (4 bytes each) go through a collective.  No list or tensor ever holds the whole video."""
     rk = ranks or shard.Ranks()
     src = FrameReader(args.input)
     n = len(src)
@@ -89,25 +95,41 @@ def process_video(args):
         init_model(args, device=rk.device)
     sh, sw = engine.flow_out_size(h, w, args.scale)
     first, last = rk.frames(n - 1)                       # pair indices owned by this rank
-    cols = {"rgb_f": [], "rgb_b": [], "mask_f": [], "mask_b": [], "mx": []}
-    load = lambda s: np.stack([src[i] for i in range(s, min(last, s + CHUNK) + 1)])  # noqa: E731  (1-frame halo)
-    for s, frames in prefetch(load, range(first, last, CHUNK)):     # the next chunk decodes while this one is on the GPU (SURVEY 8 f-4)
-        e = min(last, s + CHUNK)
-        mask = None
-        if want_mask:
-            flow, rgb, mx, mask = model.infer_sequence_masks(frames, scale=args.scale, iters=args.iterations,
-                                                             want_flow=want_flow, want_rgb=True)
+    fwd_video = bwd_video = fwd_mask_video = bwd_mask_video = None
+    if rk.main:
+        fwd_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output)
+        bwd_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=base + "_bwd." + ext) if args.backwards else None
+        if args.output_mask:
+            mbase, mext = args.output_mask.rsplit(".", 1)
+            fwd_mask_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output_mask)
+            if args.backwards:
+                bwd_mask_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=mbase + "_bwd." + mext)
+    relay = shard.Relay(rk, args.output)
+    mxs = []
+
+    def write_chunk(_s, c):          # rank 0 only: one chunk of encoded pairs into every open video, in order
+        for j in range(len(c["rgb_f"])):
+            fwd_video.write(c["rgb_f"][j])
+            if bwd_video:
+                bwd_video.write(c["rgb_b"][j])
+            if fwd_mask_video:
+                fwd_mask_video.write(_mask_rgb(c["mask_f"][j]))
+            if bwd_mask_video:
+                bwd_mask_video.write(_mask_rgb(c["mask_b"][j]))
+
+    def emit(s, flow, rgb, mask):    # sink thread, chunks in order
+        c = {"rgb_f": rgb[:, 0]}
+        if args.backwards:
+            c["rgb_b"] = rgb[:, 1]
+        if args.output_mask:
+            c["mask_f"] = mask[:, 0]
+            if args.backwards:
+                c["mask_b"] = mask[:, 1]
+        if rk.main:
+            write_chunk(s, c)
         else:
-            flow, rgb, mx = model.infer_sequence(frames, scale=args.scale, iters=args.iterations, backward=both,
-                                                 want_flow=want_flow, want_rgb=True)
-        for j in range(e - s):
-            cols["rgb_f"].append(rgb[j, 0])
-            cols["mx"].append(np.float32(mx[j, 0]))
-            if both:
-                cols["rgb_b"].append(rgb[j, 1])
-            if want_mask:
-                cols["mask_f"].append(mask[j, 0])
-                cols["mask_b"].append(mask[j, 1])
+            relay.put(s, c)
+        for j in range(len(rgb)):
             if args.subpath:    # the reference crashes here (common/flow.py:91 shadows io.write_flow); write the .flo it meant to
                 write_flo(os.path.join(args.subpath + "_fwd", "%04d.flo" % (s + j)), flow[j, 0])
                 if args.backwards:
@@ -116,34 +138,35 @@ def process_video(args):
                 write_flow_png(os.path.join(args.subpath_mask + "_fwd", "%04d.png" % (s + j)), flow[j, 0], mask[j, 0])
                 if args.backwards:
                     write_flow_png(os.path.join(args.subpath_mask + "_bwd", "%04d.png" % (s + j)), flow[j, 1], mask[j, 1])
-    shapes = {"rgb_f": (sh, sw, 3), "rgb_b": (sh, sw, 3), "mask_f": (sh, sw), "mask_b": (sh, sw), "mx": ()}
-    dtypes = {"rgb_f": np.uint8, "rgb_b": np.uint8, "mask_f": np.uint8, "mask_b": np.uint8, "mx": np.float32}
-    used = ["rgb_f", "mx"] + (["rgb_b"] if both else []) + (["mask_f", "mask_b"] if want_mask else [])
-    got = {}
-    for k in used:
-        local = np.asarray(cols[k], dtypes[k]).reshape((len(cols[k]),) + shapes[k])
-        got[k] = rk.gather(local, n - 1) if rk.world > 1 else local
+
+    sink = AsyncSink(depth=2)
+    load = lambda s: np.stack([src[i] for i in range(s, min(last, s + CHUNK) + 1)])  # noqa: E731  (1-frame halo)
+    for s, frames in prefetch(load, range(first, last, CHUNK)):     # the next chunk decodes while this one is on the GPU (SURVEY 8 f-4)
+        mask = None
+        if want_mask:
+            flow, rgb, mx, mask = model.infer_sequence_masks(frames, scale=args.scale, iters=args.iterations,
+                                                             want_flow=want_flow, want_rgb=True)
+        else:
+            flow, rgb, mx = model.infer_sequence(frames, scale=args.scale, iters=args.iterations, backward=both,
+                                                 want_flow=want_flow, want_rgb=True)
+        sink.submit(emit, s, flow, rgb, mask)
+        mxs += [np.float32(v) for v in mx[:, 0]]
+    sink.close()
+    mx_all = np.asarray(mxs, np.float32)
+    if rk.world > 1:
+        if rk.main:
+            relay.drain(n - 1, CHUNK, write_chunk)
+        mx_all = rk.gather(mx_all, n - 1)
+    relay.close()
     if not rk.main:
         return
-    fwd_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output)
-    bwd_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=base + "_bwd." + ext) if args.backwards else None
-    fwd_mask_video = bwd_mask_video = None
-    if args.output_mask:
-        mbase, mext = args.output_mask.rsplit(".", 1)
-        fwd_mask_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output_mask)
-        if args.backwards:
-            bwd_mask_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=mbase + "_bwd." + mext)
     zero = np.zeros((sh, sw, 3), np.uint8)
-    for i in range(n):      # last frame: zero flow -> 0/0 -> NaN -> uint8 0, max displacement 0.0, all-False masks (reference :116-131)
-        tail = i == n - 1
-        fwd_video.write(zero if tail else got["rgb_f"][i])
-        if bwd_video:
-            bwd_video.write(zero if tail else got["rgb_b"][i])
-        if fwd_mask_video:
-            fwd_mask_video.write(zero if tail else _mask_rgb(got["mask_f"][i]))
-        if bwd_mask_video:
-            bwd_mask_video.write(zero if tail else _mask_rgb(got["mask_b"][i]))
-    max_disps = [float(v) for v in got["mx"].reshape(-1)] + [0.0]
+    # last frame: zero flow -> 0/0 -> NaN -> uint8 0, max displacement 0.0, all-False masks (reference :116-131)
+    for v in (fwd_video, bwd_video, fwd_mask_video, bwd_mask_video):
+        if v:
+            v.write(zero)
+    # the reference appends np.float32 scalars and formats them with "{}" (:138-141): '12.148', not the float64 repr
+    max_disps = [np.float32(v) for v in np.asarray(mx_all).reshape(-1)] + [np.float32(0.0)]
     zf = np.zeros((sh, sw, 2), np.float32)
     if args.subpath:
         write_flo(os.path.join(args.subpath + "_fwd", "%04d.flo" % (n - 1)), zf)
@@ -189,6 +212,7 @@ def main(argv=None):
     ap.add_argument("--small", action="store_true", help="use small model")
     ap.add_argument("--mixed_precision", action="store_true", help="use mixed precision")
     ap.add_argument("--alternate_corr", action="store_true", help="use efficent correlation implementation")
+    ap.add_argument("--synthetic", action="store_true", help="seeded synthetic weights when the checkpoint is missing (tests / benchmarks)")
     args = ap.parse_args(argv)
     data = load_metadata(args.input)
     if data:

@@ -20,7 +20,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_rgb  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
-from common.pipe import prefetch  # noqa: E402
+from common.pipe import AsyncSink, prefetch  # noqa: E402
 from prisma_amd import engine, shard, synth  # noqa: E402
 
 BAND = "mask"
@@ -31,6 +31,7 @@ BATCH = int(os.environ.get("PRISMA_BATCH", "32"))
 
 model = None
 data = None
+_SYNTH = [False]      # --synthetic
 ranks = None          # shard.Ranks(): one process per GPU under torchrun, world 1 otherwise
 
 
@@ -44,7 +45,9 @@ def load_weights(path, cfg):
         sd = torch.load(path, map_location="cpu")
         sd = sd.get("state_dict", sd)
         return {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "numpy")}
-    print(f"[{BAND}] checkpoint {path!r} not found; using seeded synthetic weights", file=sys.stderr)
+    if not shard.synthetic_allowed(_SYNTH[0]):
+        raise SystemExit(f"[{BAND}] checkpoint {path!r} not found; pass --weights, or --synthetic / PRISMA_SYNTH=1 for seeded synthetic weights")
+    print(f"[{BAND}] checkpoint {path!r} not found; using seeded synthetic weights (--synthetic)", file=sys.stderr)
     return synth.solov2_weights(cfg)
 
 
@@ -86,7 +89,9 @@ def process_image(args):
 
 
 def process_video(args):
-    """Frames shard by rank (no cross-frame state, reference :131-154); rank 0 gathers and writes the video."""
+    """Frames shard by rank (no cross-frame state, reference :131-154).  Rank 0 writes its own chunks to the video as they
+    finish (sink thread) and then muxes the other ranks' chunks in frame order through shard.Relay; nothing is gathered
+    and no list holds the whole video."""
     rk = ranks or shard.Ranks()
     src = FrameReader(args.input)
     n = len(src)
@@ -95,21 +100,30 @@ def process_video(args):
         args.subpath = os.path.join(os.path.dirname(args.output), args.subpath)
         create_folder(args.subpath)
     first, last = rk.frames(n)
-    held = []
+    out = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output) if rk.main else None
+    relay = shard.Relay(rk, args.output)
+
+    def emit(s, masks):              # sink thread, chunks in order
+        done = np.stack([_finish(m_, args) for m_ in masks])
+        if rk.main:
+            for f in done:
+                out.write(f)
+        else:
+            relay.put(s, {"mask": done})
+        if args.subpath:            # COLMAP wants black objects on white (reference :149-150)
+            for j in range(len(masks)):
+                write_rgb(os.path.join(args.subpath, "{:05d}.png".format(s + j)), 255 - masks[j])
+
+    sink = AsyncSink(depth=2)
     load = lambda s: np.stack([src[i] for i in range(s, min(last, s + BATCH))])      # noqa: E731
     for s, frames in prefetch(load, range(first, last, BATCH)):      # the next chunk decodes while this one is on the GPU
-        masks = model.infer_batch(frames, args.confidence, keep_ids())
-        for j in range(len(frames)):
-            if args.subpath:        # COLMAP wants black objects on white (reference :149-150)
-                write_rgb(os.path.join(args.subpath, "{:05d}.png".format(s + j)), 255 - masks[j])
-            held.append(_finish(masks[j], args))
-    local = np.stack(held) if held else np.zeros((0, h, w, 3), np.uint8)
-    every = rk.gather(local, n) if rk.world > 1 else local
+        sink.submit(emit, s, model.infer_batch(frames, args.confidence, keep_ids()))
+    sink.close()
+    if rk.world > 1 and rk.main:
+        relay.drain(n, BATCH, lambda s, c: [out.write(f) for f in c["mask"]])
+    relay.close()
     if not rk.main:
         return
-    out = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output)
-    for f in every:
-        out.write(f)
     out.close()
     # the reference replaces the whole entry here, which also drops the `folder` key it set earlier (:127-129,158-161)
     data["bands"][BAND] = {"url": os.path.basename(args.output), "ids": CLASSES}
@@ -125,7 +139,9 @@ def main(argv=None):
     ap.add_argument("--subpath", help="Mask Subpath to frames", type=str, default="")
     ap.add_argument("--arch", help="backbone / geometry preset (prisma_amd.synth.MASK_CFGS)", default="r101")
     ap.add_argument("--weights", help="mmdet checkpoint (.pth) or .npz state dict", default=MODEL)
+    ap.add_argument("--synthetic", action="store_true", help="seeded synthetic weights when the checkpoint is missing (tests / benchmarks)")
     args = ap.parse_args(argv)
+    _SYNTH[0] = args.synthetic
     data = load_metadata(args.input)
     meta_path = args.input
     if data:

@@ -221,6 +221,33 @@ def infer_pair(w, prev_u8: np.ndarray, curr_u8: np.ndarray, scale: float = 0.75,
     return np.ascontiguousarray(up[0].transpose(1, 2, 0)), np.ascontiguousarray(up[1].transpose(1, 2, 0))
 
 
+_ATAN_C = np.array([0.0, 0.24497866312686414, 0.4636476090008061, 0.6435011087932844, 0.7853981633974483])
+_ATAN_COEF = [(-1.0) ** i / (2 * i + 1) for i in range(9)]
+
+
+def atan2_rn(y: np.ndarray, x: np.ndarray) -> np.ndarray:
+    """arctan2 in float64 from IEEE +, -, *, / only - the operation sequence of csrc/raft_kernels.hip atan2_rn, so the HIP
+    kernel reproduces it bit for bit.  |error| < 5e-16: its float32 rounding is the correctly rounded float32 arctan2
+    (tests/test_raft_oracle.py checks it against np.arctan2 in float64 and long double)."""
+    y, x = np.asarray(y, np.float64), np.asarray(x, np.float64)
+    ax, ay = np.abs(x), np.abs(y)
+    hi, lo = np.maximum(ax, ay), np.minimum(ax, ay)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        t = np.where(hi == 0.0, 0.0, lo / hi)
+        k = np.floor(t * 4.0 + 0.5)
+        c = k * 0.25
+        u = (t - c) / (1.0 + t * c)
+        u2 = u * u
+        p = np.full_like(u, _ATAN_COEF[8])
+        for i in range(7, -1, -1):
+            p = p * u2 + _ATAN_COEF[i]
+        r = _ATAN_C[np.where(np.isnan(k), 0, k).astype(np.int64)] + u * p
+        r = np.where(ay > ax, 1.5707963267948966 - r, r)
+        r = np.where(x < 0.0, 3.141592653589793 - r, r)
+        r = np.where(y < 0.0, -r, r)
+    return np.where(np.isnan(t), np.nan, r)
+
+
 def process_flow(flow: np.ndarray, exact_atan2: bool = False):
     """bands/common/encode.py:98-126 (+ hue_to_rgb :13-28, saturation :73-78): polar HSV-style encode.
     dtypes follow numpy's promotion in the reference: distances / angle / hue*6 in the flow's float32,
@@ -228,7 +255,7 @@ def process_flow(flow: np.ndarray, exact_atan2: bool = False):
     exact_atan2: np.arctan2 on float32 is host dependent (SVML, <= 4 ULP, on AVX512 builds; libm elsewhere - 38 % of random
     inputs differ in the last bit between the two), so the reference's bytes are only defined up to that.  False follows
     numpy on this host (bit-identical to the reference run on the same host: tests/golden/encode.npz); True is the
-    correctly rounded float32 arctan2 (double evaluation, rounded once) - the definition the HIP kernel implements."""
+    correctly rounded float32 arctan2 (atan2_rn in double, rounded once) - the definition the HIP kernel implements."""
     flow = np.asarray(flow, np.float32)
     dist = np.sqrt(np.square(flow[..., 0]) + np.square(flow[..., 1]))
     mx = dist.max()
@@ -236,7 +263,7 @@ def process_flow(flow: np.ndarray, exact_atan2: bool = False):
         dx = flow[..., 0] / float(mx)
         dy = flow[..., 1] / float(mx)
         rad = np.sqrt(np.square(dx) + np.square(dy))
-        at = np.arctan2(dy.astype(np.float64), dx.astype(np.float64)).astype(np.float32) if exact_atan2 else np.arctan2(dy, dx)
+        at = atan2_rn(dy, dx).astype(np.float32) if exact_atan2 else np.arctan2(dy, dx)
         a = (at / np.pi + 1.0) * 0.5                                       # float32
         rgb = np.zeros(a.shape + (3,), np.float64)
         rgb[..., 0] = a * 6.0

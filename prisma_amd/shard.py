@@ -1,4 +1,5 @@
-"""Multi-GPU plumbing of the bands: static contiguous frame shards + one scalar all-gather.
+"""Multi-GPU plumbing of the bands: static contiguous frame shards, one scalar all-gather, and an ordered per-chunk
+relay of the encoded frames to rank 0 (the ranks of ONE node share a filesystem; no whole-video tensor exists anywhere).
 
 The reference processes one frame at a time in one process (bands/depth_anything.py:203-225) and
 carries no cross-frame state for depth (min/max normalisation is per frame, :215-217), so frames
@@ -31,10 +32,9 @@ def shard_range(n_frames: int, rank: int, world: int, halo: int = 0) -> Tuple[in
 def gather_rows(local: np.ndarray, n_frames: int, device=None) -> np.ndarray | None:
     """All-gather per-frame rows ([n_local, ...], any dtype torch knows) into frame order; rank 0 gets [n_frames, ...].
 
-    Used for the per-frame scalars (float32 min / max / max-displacement, 4-8 bytes per frame) and, by the band scripts,
-    for the encoded uint8 frames rank 0 muxes into the output video (6.2 MB per 1080p frame over xGMI).  Shards have
-    ceil(n/world) frames except the tail; every rank pads to that length so one fixed-size all_gather_into_tensor
-    suffices.
+    Used for the per-frame scalars only (float32 min / max / max-displacement, 4-12 bytes per frame); the encoded frames
+    reach rank 0 through Relay.  Shards have ceil(n/world) frames except the tail; every rank pads to that length so one
+    fixed-size all_gather_into_tensor suffices.
     """
     import torch
     import torch.distributed as dist
@@ -64,6 +64,75 @@ def gather_rows(local: np.ndarray, n_frames: int, device=None) -> np.ndarray | N
 def gather_frame_scalars(local: np.ndarray, n_frames: int, device=None) -> np.ndarray | None:
     """float32 rows ([n_local, k]): the (min, max) / max-displacement columns of the CSV files."""
     return gather_rows(np.asarray(local, np.float32), n_frames, device)
+
+
+def synthetic_allowed(flag: bool = False) -> bool:
+    """Seeded synthetic weights are for tests and benchmarks only: a band falls back to them only when asked to
+    (`--synthetic` or PRISMA_SYNTH=1); otherwise a missing checkpoint is an error, never silent garbage in a PRISMA folder."""
+    import os
+    return bool(flag) or os.environ.get("PRISMA_SYNTH", "") == "1"
+
+
+class Relay:
+    """Ordered delivery of encoded chunks from every rank to rank 0, which muxes the output video(s).
+
+    north_star allows a collective only for the per-frame scalars, so the frames do not travel through torch.distributed at
+    all: the ranks are the GPUs of one node, and a rank > 0 drops each finished chunk ({name: array}, typically 16-32 encoded
+    frames) as one file into a spool directory next to the output (write to a temporary name, then rename: the consumer
+    never sees a partial file).  Rank 0 writes its own chunks straight to the video as they finish and then walks the other
+    ranks' chunk plans in frame order, waiting for each file, muxing it and deleting it.  Memory is bounded by one chunk per
+    rank; the spool holds, at most, the other ranks' encoded shards until rank 0 gets to them.  PRISMA_SPOOL overrides the
+    directory (e.g. a tmpfs)."""
+
+    def __init__(self, ranks: "Ranks", out_path: str, timeout_s: float = 900.0):
+        import os
+        self.rk, self.timeout = ranks, timeout_s
+        self.dir = os.environ.get("PRISMA_SPOOL") or (out_path + ".spool")
+        if ranks.world > 1:
+            import torch.distributed as dist
+            os.makedirs(self.dir, exist_ok=True)
+            if ranks.main:                   # leftovers of an aborted run must not be mistaken for this run's chunks
+                for f in os.listdir(self.dir):
+                    if f.startswith("chunk_"):
+                        os.remove(os.path.join(self.dir, f))
+            dist.barrier()
+
+    def _path(self, start: int) -> str:
+        import os
+        return os.path.join(self.dir, "chunk_%09d.npz" % start)
+
+    def put(self, start: int, arrays: dict):
+        """rank > 0: publish the chunk whose first unit (frame / pair index) is `start`."""
+        import os
+        tmp = self._path(start) + ".tmp.%d" % self.rk.rank
+        with open(tmp, "wb") as f:
+            np.savez(f, **{k: np.ascontiguousarray(v) for k, v in arrays.items()})
+        os.replace(tmp, self._path(start))
+
+    def drain(self, n_units: int, chunk: int, write):
+        """rank 0: for every other rank, in rank (= frame) order, for every chunk start of its shard: wait for the file, call
+        write(start, {name: array}), delete it."""
+        import os
+        import time
+        for r in range(1, self.rk.world):
+            first, last = shard_range(n_units, r, self.rk.world)
+            for s in range(first, last, chunk):
+                p, t0 = self._path(s), time.time()
+                while not os.path.exists(p):
+                    if time.time() - t0 > self.timeout:
+                        raise TimeoutError(f"rank {r} did not deliver chunk {s} within {self.timeout:.0f} s")
+                    time.sleep(0.005)
+                with np.load(p) as z:
+                    write(s, {k: z[k] for k in z.files})
+                os.remove(p)
+
+    def close(self):
+        import os
+        if self.rk.world > 1 and self.rk.main:
+            try:
+                os.rmdir(self.dir)
+            except OSError:
+                pass
 
 
 class Ranks:

@@ -23,3 +23,6 @@ def golden_dir():
 # mode bench.py also reports) is held to what an 11-bit-mantissa operand rounding delivers on these models.
 TOL = {1: (1e-3, 1e-3),       # precision -> (max / range, L2)
        0: (2e-3, 1.1e-3)}
+
+# the band scripts refuse to run without a checkpoint unless seeded synthetic weights are asked for; tests ask
+os.environ.setdefault("PRISMA_SYNTH", "1")
