@@ -163,7 +163,7 @@ def process_video(a):
     if rk.world > 1:
         if rk.main:
             relay.drain(n, BATCH, lambda s, c: [out.write(f) for f in c["rgb"]])
-        mm = rk.gather(np.asarray([lo, hi], np.float32).T.reshape(-1, 2), n)
+        mm = rk.gather(np.asarray([lo, hi], np.float32).T.reshape(-1, 2), n, ctx=model)
         if rk.main:
             lo, hi = [float(v) for v in mm[:, 0]], [float(v) for v in mm[:, 1]]
     relay.close()

@@ -156,7 +156,7 @@ def process_video(args):
     if rk.world > 1:
         if rk.main:
             relay.drain(n - 1, CHUNK, write_chunk)
-        mx_all = rk.gather(mx_all, n - 1)
+        mx_all = rk.gather(mx_all, n - 1, ctx=model)
     relay.close()
     if not rk.main:
         return

@@ -130,6 +130,18 @@ int pb_depth_infer_batch_dev(pb_ctx *ctx, const uint8_t *frames, int n, int H, i
                              float *depth_out, uint8_t *rgb_out, float *min_out, float *max_out, int flip);
 int pb_sync(pb_ctx *ctx);
 
+/* Multi-GPU: one process and one pb_ctx per GPU; frames shard by rank and never cross GPUs.  The only
+ * exchange is the all-gather of the per-frame scalars the CSV files need in frame order - depth (min, max), flow max
+ * displacement: 4-12 bytes per frame - over RCCL (xGMI inside a node).  Rank 0 calls pb_comm_unique_id and hands the 128
+ * bytes to the other ranks by any host channel (a file, torch.distributed's store); every rank then calls pb_comm_init on
+ * its ctx (collective), and pb_gather_scalars (collective): `local` n_local floats of this rank -> `global`
+ * [world x n_local] on every rank, rank-major.  Ranks with fewer frames pad to a common n_local.  Replaces the implicit
+ * single-process ordering of bands/depth_anything.py:215-238 and bands/flow_raft.py:138-141. */
+typedef struct { char internal[128]; } pb_comm_id;       /* = ncclUniqueId */
+int pb_comm_unique_id(pb_comm_id *id_out);
+int pb_comm_init(pb_ctx *ctx, const pb_comm_id *id, int rank, int world);
+int pb_gather_scalars(pb_ctx *ctx, const float *local, int n_local, float *global);
+
 /* Network input size for an H x W frame: keep-aspect lower-bound resize to 518, each side a
  * multiple of 14 (bands/d_anything/util/transform.py:100-166). */
 int pb_depth_net_size(int H, int W, int *net_h, int *net_w);

@@ -183,6 +183,43 @@ def encode_case():
     print("[encode] oracle == reference (bit exact)")
 
 
+def write_depth_case(seed=9):
+    """The REAL reference write_depth (bands/common/io.py:138-172) + float_to_edge / saturation / float_to_rgb (encode.py:73-95,
+    141-146) on a seeded float32 depth map, in the three ways the band scripts call it (relative: flip, metric: no flip, 16-bit).
+    cv2 is absent, so the reference runs on a stand-in module: imwrite records the array, cvtColor swaps channels, and Sobel is
+    the restatement this repo uses (bands/common/io.py _sobel_mag_u8: [-1, 0, 1] central differences, BORDER_REFLECT_101) -
+    the golden pins every byte of the PNG except the Sobel taps themselves (opencv-python 4.8.1.78, third party, unpinned)."""
+    written = {}
+    cv2 = types.ModuleType("cv2")
+    cv2.CV_64F, cv2.COLOR_RGB2BGR, cv2.INTER_AREA = 6, 4, 3
+
+    def sobel(img, ddepth, dx, dy, ksize=1):
+        assert ddepth == 6 and ksize == 1
+        p = np.pad(img.astype(np.float64), 1, mode="reflect")
+        return p[1:-1, 2:] - p[1:-1, :-2] if dx == 1 else p[2:, 1:-1] - p[:-2, 1:-1]
+    cv2.Sobel = sobel
+    cv2.cvtColor = lambda a, code: a[..., ::-1]
+    cv2.imwrite = lambda path, a: written.__setitem__(path, np.array(a))
+    for k in [k for k in sys.modules if k == "cv2" or k.startswith("common")]:
+        del sys.modules[k]
+    sys.modules["cv2"] = cv2
+    for name in ("decord", "av", "plyfile"):        # imported at module level by common/io.py and common/geom.py, unused here
+        m = sys.modules.setdefault(name, types.ModuleType(name))
+        if name == "plyfile":
+            m.PlyData = m.PlyElement = object
+    from common import io as RIO
+    g = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:60, 0:96].astype(np.float32)
+    depth = (3.0 + 2.0 * np.sin(xx / 11.0) * np.cos(yy / 7.0) + 0.05 * g.standard_normal((60, 96))).astype(np.float32)
+    depth[20:40, 30:60] += 4.0                                        # a step edge: saturation drops along it
+    RIO.write_depth("rel", depth.copy(), normalize=True, flip=True, heatmap=True, encode_range=True)
+    RIO.write_depth("met", depth.copy(), normalize=True, flip=False, heatmap=True, encode_range=True)
+    RIO.write_depth("u16", depth.copy(), normalize=True, flip=False, heatmap=False)
+    np.savez_compressed(os.path.join(GOLD, "write_depth.npz"), depth=depth, rel_rgb=written["rel"][..., ::-1].copy(),
+                        met_rgb=written["met"][..., ::-1].copy(), u16=written["u16"])
+    print("[write_depth] reference io.write_depth on a stand-in cv2: 3 images recorded; pixel (0,0)/(0,1) =", written["rel"][0, 0, ::-1], written["rel"][0, 1, ::-1])
+
+
 def raft_case(hgt=125, wid=157, seed=21, iters=12):
     """Reference RAFT (bands/raft/raft.py) + InputPadder (bands/common/flow.py) on a seeded frame pair,
     fwd and bwd in one batch exactly like bands/flow_raft.py:105-107 (scale = 1: cv2 is absent here)."""
@@ -372,7 +409,7 @@ def zoe_layers_case(seed=31):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full", "raft", "mask", "nms", "zoe"]
+    which = sys.argv[1:] or ["encode", "vits", "vitl_d4", "full", "raft", "mask", "nms", "zoe", "write_depth"]
     if "mask" in which:
         mask_case()
     if "nms" in which:
@@ -381,6 +418,8 @@ if __name__ == "__main__":
         zoe_layers_case()
     if "encode" in which:
         encode_case()
+    if "write_depth" in which:
+        write_depth_case()
     if "vits" in which:
         small_case("vits", 96, 128, 11)
     if "vitl_d4" in which:

@@ -205,20 +205,22 @@ def raft_forward(w: Dict[str, np.ndarray], image1: np.ndarray, image2: np.ndarra
     return flow_lo.numpy(), flow_up.numpy()
 
 
-def infer_pair(w, prev_u8: np.ndarray, curr_u8: np.ndarray, scale: float = 0.75, iters: int = 12):
+def infer_pair(w, prev_u8: np.ndarray, curr_u8: np.ndarray, scale: float = 0.75, iters: int = 12, backward: bool = True):
     """bands/flow_raft.py:99-107 + infer (:51-62): two uint8 frames -> (fwd, bwd) float32 [H', W', 2] at the
-    scaled resolution.  Index 0 of the reference's batch is prev->curr, index 1 curr->prev."""
+    scaled resolution.  Index 0 of the reference's batch is prev->curr, index 1 curr->prev.
+    backward=False evaluates the forward direction only (batch of 1; bwd is None) - what the engine computes without
+    --backwards / --mask, and what bench.py's cpu_baseline times beside it."""
     a = cv_resize_cubic_u8(prev_u8, scale) if scale != 1.0 else prev_u8
     c = cv_resize_cubic_u8(curr_u8, scale) if scale != 1.0 else curr_u8
     ta = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1).float()[None]
     tc = torch.from_numpy(np.ascontiguousarray(c)).permute(2, 0, 1).float()[None]
-    i1, i2 = torch.cat([ta, tc], 0), torch.cat([tc, ta], 0)
+    i1, i2 = (torch.cat([ta, tc], 0), torch.cat([tc, ta], 0)) if backward else (ta, tc)
     pad = pad_amounts(i1.shape[2], i1.shape[3])
     i1p, i2p = F.pad(i1, pad, mode="replicate"), F.pad(i2, pad, mode="replicate")
     _, up = raft_forward(w, i1p.numpy(), i2p.numpy(), iters)
     H, W = up.shape[2:]
     up = up[:, :, pad[2]:H - pad[3], pad[0]:W - pad[1]]
-    return np.ascontiguousarray(up[0].transpose(1, 2, 0)), np.ascontiguousarray(up[1].transpose(1, 2, 0))
+    return np.ascontiguousarray(up[0].transpose(1, 2, 0)), (np.ascontiguousarray(up[1].transpose(1, 2, 0)) if backward else None)
 
 
 _ATAN_C = np.array([0.0, 0.24497866312686414, 0.4636476090008061, 0.6435011087932844, 0.7853981633974483])

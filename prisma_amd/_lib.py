@@ -63,6 +63,9 @@ SYMBOLS = {
     "pb_depth_infer_batch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int]),
     "pb_depth_infer_batch_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int]),
     "pb_sync": (C.c_int, [_P]),
+    "pb_comm_unique_id": (C.c_int, [_P]),
+    "pb_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "pb_gather_scalars": (C.c_int, [_P, _P, C.c_int, _P]),
     "pb_depth_net_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_depth_get_stage": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "pb_mask_infer_batch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, _P]),

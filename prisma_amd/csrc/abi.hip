@@ -1,4 +1,5 @@
 // C ABI of libprisma_bands.so (include/prisma_bands.h).
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -83,6 +84,11 @@ struct pb_ctx {
     bool own_stream = false;
     int gemm_tile = TILE_AUTO, conv_tile = TILE_AUTO;
     HostPipe pipe;
+    // pb_comm_init: RCCL communicator of the ranks (one process per GPU) for pb_gather_scalars
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    float *comm_buf = nullptr;
+    size_t comm_cap = 0;
 };
 
 namespace {
@@ -194,9 +200,75 @@ int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *we
     return 0;
 }
 
+// ---- RCCL (the per-frame scalar all-gather of SURVEY 8(e)) -------------------------------------------------
+// librccl is opened lazily and privately (dlopen, RTLD_LOCAL): the library carries no link-time dependency on it and does
+// not interpose the copy a host framework (torch.distributed's "nccl" backend) may have loaded.
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, pb_comm_id, int) = nullptr;      // ncclUniqueId is passed by value: 128 bytes
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (h) return true;
+        for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return false;
+        GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+        AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        return GetUniqueId && CommInitRank && AllGather && CommDestroy && GetErrorString;
+    }
+} g_rccl;
+}  // namespace
+
+int pb_comm_unique_id(pb_comm_id *id_out) {
+    PB_CHECK(id_out, PB_ERR_ARG, "comm_unique_id: null");
+    PB_CHECK(g_rccl.load(), PB_ERR_DEVICE, "librccl could not be loaded: %s", dlerror());
+    const int rc = g_rccl.GetUniqueId(id_out);
+    PB_CHECK(rc == 0, PB_ERR_DEVICE, "ncclGetUniqueId: %s", g_rccl.GetErrorString(rc));
+    return 0;
+}
+
+int pb_comm_init(pb_ctx *c, const pb_comm_id *id, int rank, int world) {
+    PB_CHECK(c && id && world >= 1 && rank >= 0 && rank < world, PB_ERR_ARG, "comm_init: bad arguments");
+    PB_CHECK(!c->comm, PB_ERR_STATE, "comm_init: the ctx already has a communicator");
+    PB_CHECK(g_rccl.load(), PB_ERR_DEVICE, "librccl could not be loaded: %s", dlerror());
+    PB_HIP(hipSetDevice(c->device));
+    const int rc = g_rccl.CommInitRank(&c->comm, world, *id, rank);
+    PB_CHECK(rc == 0, PB_ERR_DEVICE, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(rc));
+    c->comm_rank = rank; c->comm_world = world;
+    return 0;
+}
+
+int pb_gather_scalars(pb_ctx *c, const float *local, int n_local, float *global) {
+    PB_CHECK(c && c->comm && local && global && n_local > 0, PB_ERR_ARG, "gather_scalars: needs pb_comm_init and non-empty buffers");
+    PB_HIP(hipSetDevice(c->device));
+    const size_t need = (size_t)(c->comm_world + 1) * n_local;
+    if (need > c->comm_cap) {
+        if (c->comm_buf) PB_HIP(hipFree(c->comm_buf));
+        c->comm_buf = nullptr; c->comm_cap = 0;
+        PB_HIP(hipMalloc((void **)&c->comm_buf, need * 4));
+        c->comm_cap = need;
+    }
+    float *send = c->comm_buf, *recv = c->comm_buf + n_local;
+    PB_HIP(hipMemcpyAsync(send, local, (size_t)n_local * 4, hipMemcpyHostToDevice, c->stream));
+    const int rc = g_rccl.AllGather(send, recv, (size_t)n_local, 7 /* ncclFloat32 */, c->comm, c->stream);
+    PB_CHECK(rc == 0, PB_ERR_DEVICE, "ncclAllGather: %s", g_rccl.GetErrorString(rc));
+    PB_HIP(hipMemcpyAsync(global, recv, (size_t)c->comm_world * n_local * 4, hipMemcpyDeviceToHost, c->stream));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 void pb_destroy(pb_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->comm) { hipStreamSynchronize(c->stream); g_rccl.CommDestroy(c->comm); }
+    if (c->comm_buf) hipFree(c->comm_buf);
     c->pipe.release();
     if (c->depth) delete c->depth;
     if (c->raft) delete c->raft;

@@ -50,6 +50,25 @@ class _Ctx:
         except Exception:
             pass
 
+    # RCCL all-gather of per-frame scalars through the C ABI (pb_comm_*, pb_gather_scalars)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(_lib.load().pb_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, comm_id: bytes, rank: int, world: int):
+        assert len(comm_id) == 128
+        check(self.lib.pb_comm_init(self.ctx, C.create_string_buffer(comm_id, 128), rank, world))
+        self._comm_world = world
+
+    def gather_scalars(self, local: np.ndarray) -> np.ndarray:
+        """float32 [n_local, ...] of this rank -> [world, n_local, ...] on every rank (same n_local everywhere)."""
+        local = _f32(local)
+        out = np.empty((self._comm_world,) + local.shape, np.float32)
+        check(self.lib.pb_gather_scalars(self.ctx, _ptr(local), local.size, _ptr(out)))
+        return out
+
     # device memory helpers (frames resident in HBM for bench / pipelines)
     def dev_alloc(self, nbytes: int) -> int:
         p = C.c_void_p()

@@ -167,7 +167,26 @@ class Ranks:
     def frames(self, n: int, halo: int = 0) -> Tuple[int, int]:
         return shard_range(n, self.rank, self.world, halo)
 
-    def gather(self, local: np.ndarray, n: int):
+    def gather(self, local: np.ndarray, n: int, ctx=None):
+        """Per-frame float32 scalars of every rank in frame order (rank 0 gets [n, k], the others None).  With a band ctx and
+        the "nccl" backend the exchange is the library's own RCCL all-gather (pb_gather_scalars; the 128-byte communicator id
+        travels through torch.distributed's object broadcast once); otherwise torch.distributed carries it (gloo in tests)."""
+        import os
+        if ctx is not None and self.world > 1 and self.backend == "nccl" and os.environ.get("PRISMA_NATIVE_GATHER", "1") != "0":
+            import torch.distributed as dist
+            if not getattr(ctx, "_comm_world", 0):
+                box = [ctx.comm_unique_id() if self.main else None]
+                dist.broadcast_object_list(box, src=0)
+                ctx.comm_init(box[0], self.rank, self.world)
+            local = np.ascontiguousarray(local, np.float32)
+            local = local[:, None] if local.ndim == 1 else local
+            per = -(-n // self.world)
+            pad = np.zeros((per,) + local.shape[1:], np.float32)
+            pad[: local.shape[0]] = local
+            every = ctx.gather_scalars(pad)
+            if not self.main:
+                return None
+            return np.concatenate([every[r][: shard_range(n, r, self.world)[1] - shard_range(n, r, self.world)[0]] for r in range(self.world)], 0)
         return gather_rows(local, n)
 
     def close(self):

@@ -75,3 +75,43 @@ def test_mask_small_frame_and_no_detection():
     with pytest.raises(Err):
         net.infer_batch(np.zeros((0, 8, 8, 3), np.uint8))
     net.close()
+
+
+@pytest.mark.gpu
+def test_rccl_gather_scalars_through_the_c_abi():
+    """pb_comm_unique_id / pb_comm_init / pb_gather_scalars on a one-rank RCCL communicator: the library opens
+    librccl itself, builds the communicator on the ctx's GPU and runs ncclAllGather on the ctx stream (with one rank the
+    gathered block is the local block).  The N > 1 ordering logic around it is covered on CPU (tests/test_shard_cpu.py)."""
+    from prisma_amd import engine
+    ops = engine.Ops()
+    cid = ops.comm_unique_id()
+    assert len(cid) == 128 and any(cid)
+    ops.comm_init(cid, 0, 1)
+    x = np.arange(24, dtype=np.float32).reshape(12, 2) * 0.5
+    g = ops.gather_scalars(x)
+    assert g.shape == (1, 12, 2) and np.array_equal(g[0], x)
+    g2 = ops.gather_scalars(np.float32([[3.0, 4.0, 5.0]]))           # a smaller payload afterwards reuses the buffer
+    assert np.array_equal(g2[0], np.float32([[3.0, 4.0, 5.0]]))
+    with pytest.raises(engine._lib.PrismaBandsError, match="already has a communicator"):
+        ops.comm_init(cid, 0, 1)
+    ops.close()
+
+
+@pytest.mark.gpu
+def test_bench_nccl_path_under_torch_distributed_run():
+    """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with one rank
+    and PRISMA_FORCE_DIST=1 so that the "nccl" (= RCCL) process group, its barrier, the max all-reduce and the scalar
+    all_gather_into_tensor really execute on this single-GPU box; tiny sizes."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PRISMA_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "3",
+           "--height", "270", "--width", "480", "--encoder", "vits", "--no-cpu-baseline", "--one-precision"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and "roofline" in line

@@ -68,3 +68,31 @@ def test_full_vitl_720p_matches_reference(golden_dir):
     assert abs(lo - z["minmax"][0]) < 1e-4 and abs(hi - z["minmax"][1]) < 1e-4
     # heat bytes may flip by one count where fp32 round-off crosses a truncation edge
     assert (np.abs(rgb[::8, ::8].astype(int) - z["rgb_s8"].astype(int)) > 1).mean() < 1e-3
+
+
+def test_write_depth_png_bytes_match_the_reference(golden_dir, tmp_path):
+    """the still-image / --subpath encode.  tests/golden/write_depth.npz holds what the REAL reference
+    write_depth (bands/common/io.py:138-172, encode.py:73-95,141-146) hands to cv2.imwrite for a seeded depth map (relative:
+    flipped; metric: not flipped; 16-bit); the band's writer must produce PNGs with exactly those pixels - heat ramp, Sobel-edge
+    saturation, min / max packed in pixels (0,0), (0,1), uint8 truncation.  (cv2.Sobel itself is the one unpinned step.)"""
+    import os
+    import sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "bands"))
+    from common import io as IO
+    z = np.load(os.path.join(golden_dir, "write_depth.npz"))
+    depth = z["depth"]
+    heat = lambda h: O.heat_to_rgb(h)
+    for name, flip in (("rel_rgb", True), ("met_rgb", False)):
+        p = str(tmp_path / (name + ".png"))
+        IO.write_depth(p, depth.copy(), heat, normalize=True, flip=flip, heatmap=True, encode_range=True)
+        got = np.asarray(Image.open(p))
+        assert got.shape == z[name].shape and np.array_equal(got, z[name]), name
+    # the range pixels decode back to min / max (viewer contract, view.py:186-210)
+    rgb = z["rel_rgb"].astype(np.float64)
+    dec = lambda px: (px[0] + px[1] * 256 + px[2] * 65536) / (256 ** 3 - 1) * 1000.0
+    assert abs(dec(rgb[0, 0]) - depth.min()) < 1e-4 and abs(dec(rgb[0, 1]) - depth.max()) < 1e-4
+    p = str(tmp_path / "u16.png")
+    IO.write_depth(p, depth.copy(), heat, normalize=True, flip=False, heatmap=False)
+    assert np.array_equal(np.asarray(Image.open(p)), z["u16"])
