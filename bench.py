@@ -271,7 +271,8 @@ SYMBOLS = {"depth/gemm_f16": "gemm8_kernel<0,0,0,true> (depth: fc1 + DPT 1x1/con
            "depth/gemm_f16_qkv": "gemm8_kernel<0,2,0,true> (depth: qkv projection)",
            "depth/conv_igemm_f16": "gemm8_kernel<1,0,0,true> (depth: implicit-GEMM convs of the DPT head)",
            "depth/attention": "attnq_kernel<1,2,0,false,8> (depth: fused attention)",
-           "flow/conv_igemm_f16_tile128": "gemm_kernel<128,128,2,2,1,0,true,2> (flow: implicit-GEMM convs with N < 256 or < 256 tiles)",
+           "flow/conv_igemm_f16_tile128": "gemm_kernel<128,128,2,2,1,0,true,2> (flow: implicit-GEMM convs with 64 < N < 256 or < 256 tiles)",
+           "flow/conv_igemm_f16_tile256x64": "gemm_kernel<256,64,4,1,1,0,true,2> (flow: implicit-GEMM convs with N <= 64)",
            "flow/conv_igemm_f16": "gemm8_kernel<1,0,0,true> (flow: implicit-GEMM convs on the 256 x 256 ping-pong kernel)",
            "flow/gemm_f16": "gemm8_kernel<0,0,0,true> (flow: correlation volume + 1x1 GEMMs)"}
 PREC_NAME = {0: "f16", 1: "split-f16"}

@@ -59,6 +59,45 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
     return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
 }
 
+// Separately rounded IEEE operations for the byte-exact kernels (encodes, masks): numpy evaluates `a * b + c` as two rounded
+// operations, while hipcc contracts it into an FMA by default (-ffp-contract=fast) - and HIP's __fmul_rn / __fadd_rn / ... are
+// plain operators (contractable) and __fsqrt_rn is the NATIVE (approximate) square root unless OCML_BASIC_ROUNDED_OPERATIONS is
+// defined.  These helpers carry `fp contract(off)` (the instructions keep no `contract` flag after inlining) and use the
+// correctly rounded divide / sqrt (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).
+__device__ __forceinline__ float ex_fmul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float ex_fadd(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float ex_fsub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float ex_fdiv(float a, float b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
+__device__ __forceinline__ float ex_fsqrt(float a) { return __builtin_sqrtf(a); }
+__device__ __forceinline__ double ex_dmul(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double ex_dadd(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double ex_dsub(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ double ex_ddiv(double a, double b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

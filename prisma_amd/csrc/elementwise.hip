@@ -249,22 +249,22 @@ __global__ __launch_bounds__(256) void heat_encode_kernel(const float *__restric
         if (mx) mx[b] = dmax;
     }
     if (!rgb) return;
-    const float range = __fsub_rn(dmax, dmin);
+    const float range = ex_fsub(dmax, dmin);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
-        float d = __fdiv_rn(__fsub_rn(depth[(int64_t)b * per + i], dmin), range);
-        if (flip) d = __fsub_rn(1.0f, d);
-        const double hue = __dmul_rn(__dsub_rn(1.0, (double)d), 0.65);
-        const double h6 = __dmul_rn(hue, 6.0);
+        float d = ex_fdiv(ex_fsub(depth[(int64_t)b * per + i], dmin), range);
+        if (flip) d = ex_fsub(1.0f, d);
+        const double hue = ex_dmul(ex_dsub(1.0, (double)d), 0.65);
+        const double h6 = ex_dmul(hue, 6.0);
         const double off[3] = {0.0, 4.0, 2.0};
         uint8_t o[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            double v = __dadd_rn(h6, off[c]);
+            double v = ex_dadd(h6, off[c]);
             v = fmod(v, 6.0);
-            if (v < 0.0) v = __dadd_rn(v, 6.0);
-            v = __dsub_rn(fabs(__dsub_rn(v, 3.0)), 1.0);
+            if (v < 0.0) v = ex_dadd(v, 6.0);
+            v = ex_dsub(fabs(ex_dsub(v, 3.0)), 1.0);
             v = fmin(fmax(v, 0.0), 1.0);
-            v = __dmul_rn(v, 255.0);
+            v = ex_dmul(v, 255.0);
             o[c] = (v == v) ? (uint8_t)(int)v : (uint8_t)0;      // NaN (max == min) -> 0 like numpy on x86
         }
         uint8_t *dst = rgb + ((int64_t)b * per + i) * 3;

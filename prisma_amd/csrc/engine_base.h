@@ -23,18 +23,19 @@ class EngineBase {
 
   protected:
     // kernel families of the per-launch timer; convolutions are split by the GEMM kernel that runs them (launch_gemm's choice)
-    enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_CONV128 = 6, F_COUNT = 7 };
+    enum { F_GEMM = 0, F_CONV = 1, F_ATTN = 2, F_LN = 3, F_ELT = 4, F_PP = 5, F_CONV128 = 6, F_CONV64 = 7, F_COUNT = 8 };
 
     // create the ctx stream, index the float32 tensors by name, allocate the zero page
     int begin_load(const pb_tensor *w, int n);
     const pb_tensor *find(const std::string &name) const;
     // src: host fp32 [N, K] in GEMM order -> device fp16 [round_up(N, 256), Kpad] (+ fp32 bias, zero padded)
     // taps: src is [N][taps][K / taps] (only matters with split_w_: the hi / lo segments alternate per tap)
-    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias, int taps = 1);
+    // sa: the activation operand of this weight is a split-fp16 map [hi | lo] (per tap [w_hi | w_hi | w_lo]; only with split_w_)
+    int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias, int taps = 1, int sa = 0);
     // eval-mode BatchNorm2d (eps 1e-5) as a per-channel (scale, shift)
     int fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift);
     // conv weight [co, ci, kh, kw] (+ bias) -> rows [co][(ky * kw + kx) * round_up(ci, 64) + c], optional per-output affine
-    int pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out);
+    int pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out, int sa = 0);
 
     // direct launch_gemm callers: K, and with split-fp16 weights the K wrap / channel bookkeeping of gemm.h (a.cC, a.cLd of
     // ONE part must be set before the call for convolutions)
@@ -49,8 +50,9 @@ class EngineBase {
     void toc();
     // fusion hooks of one conv() call: a second (ReLU'd) copy of the output, and the SepConvGRU epilogues (gemm.h ACT_GRU_*)
     struct ConvFuse { f16 *out2 = nullptr; float *gru_h = nullptr; const f16 *gru_z = nullptr; f16 *gru_rh = nullptr; };
+    // lo_off != 0: out (and add1) are split-fp16 maps, the rounding residual of every output goes to +lo_off (gemm.h)
     int conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w, f16 *out, int ldo,
-             int act, int pre_relu = 0, const f16 *add1 = nullptr, const ConvFuse *fuse = nullptr);
+             int act, int pre_relu = 0, const f16 *add1 = nullptr, const ConvFuse *fuse = nullptr, int lo_off = 0);
     int dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1 = nullptr);
 
     std::map<std::string, const pb_tensor *> tmap_;

@@ -5,7 +5,8 @@
 #include <algorithm>
 
 namespace {
-const char *kFam[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost", "conv_igemm_f16_tile128"};
+const char *kFam[] = {"gemm_f16", "conv_igemm_f16", "attention", "layernorm", "elementwise", "prepost", "conv_igemm_f16_tile128",
+                      "conv_igemm_f16_tile256x64"};
 inline int cp64(int c) { return (int)round_up(c, 64); }
 }  // namespace
 
@@ -66,11 +67,11 @@ const pb_tensor *EngineBase::find(const std::string &name) const {
     return it == tmap_.end() ? nullptr : it->second;
 }
 
-int EngineBase::pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias, int taps) {
+int EngineBase::pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias, int taps, int sa_req) {
     const int64_t Np = round_up(N, 256);
     // split_w_ (PB_PREC_SPLIT): every tap's channels are followed by the fp16 rounding residuals of the same weights, and the
     // GEMM reads the activations twice (gemm.h kwrap): a w_hi + a w_lo in one accumulator
-    const int sw = split_w_ && Kpad % (64 * taps) == 0 && K % taps == 0 ? 1 : 0, segs = 1 + sw;
+    const int sw = split_w_ && Kpad % (64 * taps) == 0 && K % taps == 0 ? 1 : 0, sa = sw && sa_req ? 1 : 0, segs = 1 + sa + sw;
     const int Cin = sw ? K / taps : K, Cp = sw ? Kpad / taps : Kpad, tp = sw ? taps : 1;
     const int64_t Kt = (int64_t)tp * segs * Cp;
     std::vector<f16> h((size_t)Np * Kt, (f16)0.f);
@@ -81,14 +82,15 @@ int EngineBase::pack(const float *src, int N, int K, int Kpad, PackedW &out, con
                 const f16 hi = (f16)v;
                 f16 *d = h.data() + (size_t)n * Kt + (size_t)t * segs * Cp;
                 d[k] = hi;
-                if (sw) d[Cp + k] = (f16)(v - (float)hi);
+                if (sa) d[Cp + k] = hi;
+                if (sw) d[(1 + sa) * Cp + k] = (f16)(v - (float)hi);
             }
     void *p = nullptr;
     PB_HIP(hipMalloc(&p, h.size() * 2));
     owned_.push_back(p);
     PB_HIP(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     out.w = (f16 *)p; out.N = N; out.K = (int)Kt; out.Kreal = K; out.bias = nullptr;
-    out.sa = 0; out.sw = sw; out.Cseg = Cp;
+    out.sa = sa; out.sw = sw; out.Cseg = Cp;
     if (bias) {
         void *b = nullptr;
         PB_HIP(hipMalloc(&b, std::max<size_t>((size_t)Np * 4, 256)));
@@ -117,7 +119,7 @@ int EngineBase::fold_bn(const std::string &bn, int C, std::vector<float> &scale,
     return 0;
 }
 
-int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out) {
+int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out, int sa) {
     const pb_tensor *t = find(name + ".weight");
     PB_CHECK(t && t->ndim == 4, PB_ERR_ARG, "missing conv '%s'", name.c_str());
     const float *b = nullptr;
@@ -136,7 +138,7 @@ int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *s
             for (int tp = 0; tp < kh * kw; ++tp) g[(size_t)o * K + tp * cip + c] = w[((size_t)o * ci + c) * kh * kw + tp] * s;
         bb[o] = (b ? b[o] : 0.f) * s + (shift ? shift[o] : 0.f);
     }
-    int r = pack(g.data(), co, K, K, out, bb.data(), kh * kw);
+    int r = pack(g.data(), co, K, K, out, bb.data(), kh * kw, sa);
     out.Kreal = kh * kw * ci;
     return r;
 }
@@ -144,12 +146,12 @@ int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *s
 void EngineBase::set_weights(GemmArgs &a, const PackedW &w, bool is_conv) const {
     a.W = w.w; a.K = w.K; a.bias = w.bias; a.zero = zero_;
     if (!w.sw) return;
-    if (is_conv) {               // per tap [w_hi | w_lo]: the channel cursor re-reads the pixel
-        if (!a.cLd) a.cLd = a.cC;
-        a.kwrap = a.cC;
-        a.cC = 2 * a.cC;
+    if (is_conv) {               // per tap [w_hi | w_hi (if sa) | w_lo]: the channel cursor wraps back onto the pixel's hi part
+        if (!a.cLd) a.cLd = (1 + w.sa) * a.cC;
+        a.kwrap = (1 + w.sa) * a.cC;
+        a.cC = (2 + w.sa) * a.cC;
     } else {
-        a.kwrap = w.Cseg / 64;
+        a.kwrap = (1 + w.sa) * w.Cseg / 64;
     }
 }
 
@@ -173,13 +175,13 @@ int EngineBase::commit_arena(const char *what) {
 }
 
 int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w, f16 *out,
-                     int ldo, int act, int pre_relu, const f16 *add1, const ConvFuse *fuse) {
+                     int ldo, int act, int pre_relu, const f16 *add1, const ConvFuse *fuse, int lo_off) {
     GemmArgs a;
     a.A = in; a.N = w.N;
     a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = kw; a.cStride = stride; a.cPad = kh / 2; a.cPadX = kw / 2;
     a.cOH = (H + 2 * (kh / 2) - kh) / stride + 1; a.cOW = (W + 2 * (kw / 2) - kw) / stride + 1;
     a.M = n * a.cOH * a.cOW;
-    a.out = out; a.ldo = ldo; a.act = act; a.pre_relu = pre_relu; a.add1 = add1;
+    a.out = out; a.ldo = ldo; a.act = act; a.pre_relu = pre_relu; a.add1 = add1; a.lo_off = lo_off;
     if (fuse) { a.out2 = fuse->out2; a.gru_h = fuse->gru_h; a.gru_z = fuse->gru_z; a.gru_rh = fuse->gru_rh; }
     PB_CHECK(!w.sw || w.Cseg == cC, PB_ERR_STATE, "split conv: %d channels, weights packed for %d", cC, w.Cseg);
     set_weights(a, w, true);
@@ -187,7 +189,8 @@ int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh
     // same predicate as launch_gemm's TILE_AUTO: the 256 x 256 ping-pong kernel needs N % 256 == 0 and >= 256 tiles
     const bool wide = conv_tile == TILE_256 || (conv_tile == TILE_AUTO && a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256);
     // algorithmic bytes: the input map once, the weights once, the output once (fp16)
-    tic(wide ? F_CONV : F_CONV128, 2.0 * a.M * (double)a.N * w.Kreal, 2.0 * ((double)n * H * W * cC + (double)a.N * w.Kreal + (double)a.M * a.N));
+    // one family per kernel symbol launch_gemm picks: 256 x 256 ping-pong, 256 x 64 (N <= 64), 128 x 128
+    tic(wide ? F_CONV : (conv_tile == TILE_AUTO && a.N <= 64 ? F_CONV64 : F_CONV128), 2.0 * a.M * (double)a.N * w.Kreal, 2.0 * ((double)n * H * W * cC + (double)a.N * w.Kreal + (double)a.M * a.N));
     int r = launch_gemm(cur_, A_CONV, EPI_STD, conv_tile, a);
     toc();
     return r;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(const uint8_t *__restric
             const int h1 = r1[tx.x * 3 + c] * tx.z + r1[tx.y * 3 + c] * tx.w;
             int q = (((ty.z * (h0 >> 4)) >> 16) + ((ty.w * (h1 >> 4)) >> 16) + 2) >> 2;
             q = q < 0 ? 0 : (q > 255 ? 255 : q);
-            v[c] = __fmul_rn(__fsub_rn((float)q, mean[c]), istd[c]);
+            v[c] = ex_fmul(ex_fsub((float)q, mean[c]), istd[c]);
             o[c] = (f16)v[c];
         }
     }

@@ -83,7 +83,7 @@ int RaftEngine::load(const pb_tensor *w, int n) {
                                             g[(size_t)n * 576 + (ty * 3 + tx) * 64 + (dy * 4 + dx) * 4 + c] = wt[((size_t)o * 3 + c) * 49 + ky * 7 + kx] * s;
                                     }
                     }
-            if ((r = pack(g.data(), 256, 576, 576, E.stem, bb.data(), 9))) return r;
+            if ((r = pack(g.data(), 256, 576, 576, E.stem, bb.data(), 9, 1))) return r;
             E.stem.Kreal = 147;
         }
         for (int li = 0; li < 3; ++li)
@@ -92,15 +92,15 @@ int RaftEngine::load(const pb_tensor *w, int n) {
                 for (int c = 0; c < 2; ++c) {
                     if (bnf && (r = fold_bn(p + ".norm" + std::to_string(c + 1), dims[li], sc, sf))) return r;
                     if ((r = pack_conv(p + ".conv" + std::to_string(c + 1), true, bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr,
-                                       E.l[li][bi][c])))
+                                       E.l[li][bi][c], 1)))
                         return r;
                 }
                 if (bi == 0 && li > 0) {
                     if (bnf && (r = fold_bn(p + ".norm3", dims[li], sc, sf))) return r;
-                    if ((r = pack_conv(p + ".downsample.0", true, bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr, E.ds[li]))) return r;
+                    if ((r = pack_conv(p + ".downsample.0", true, bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr, E.ds[li], 1))) return r;
                 }
             }
-        if ((r = pack_conv(en + ".conv2", true, nullptr, nullptr, E.out))) return r;
+        if ((r = pack_conv(en + ".conv2", true, nullptr, nullptr, E.out, 1))) return r;
     }
     const std::string u = "update_block.";
     if ((r = pack_conv(u + "encoder.convc1", true, nullptr, nullptr, convc1_))) return r;
@@ -171,10 +171,12 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         arena_off_ = 0;
         xi_ = (int *)carve((size_t)sw_ * 16); xc_ = (int *)carve((size_t)sw_ * 16);
         yi_ = (int *)carve((size_t)sh_ * 16); yc_ = (int *)carve((size_t)sh_ * 16);
-        img_ = (f16 *)carve((size_t)F * Hp_ * Wp_ * 8);
-        for (auto &b : r1_) b = (f16 *)carve((size_t)round_up((int64_t)F * h2 * w2, 256) * 64 * 2);
-        for (auto &b : r2_) b = (f16 *)carve((size_t)round_up((int64_t)F * h4 * w4, 256) * 128 * 2);
-        for (auto &b : r3_) b = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 128 * 2);
+        // split-fp16 mode: the encoders' maps (image included) are [hi | lo] per pixel (es = 2)
+        const size_t es = split_w_ ? 2 : 1;
+        img_ = (f16 *)carve((size_t)F * Hp_ * Wp_ * 8 * es);
+        for (auto &b : r1_) b = (f16 *)carve((size_t)round_up((int64_t)F * h2 * w2, 256) * 64 * 2 * es);
+        for (auto &b : r2_) b = (f16 *)carve((size_t)round_up((int64_t)F * h4 * w4, 256) * 128 * 2 * es);
+        for (auto &b : r3_) b = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 128 * 2 * es);
         for (auto &b : st_) b = (float *)carve((size_t)F * 256 * 2 * 4);
         stp_ = (float *)carve((size_t)in_stats_chunks(h2 * w2) * F * 256 * 2 * 4);     // per-chunk partial sums of the largest map
         fmap_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2 + slack);
@@ -234,7 +236,9 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
 
     // ---- frame prep + stem im2col (shared by fnet and cnet) ----
     tic(F_PP, 0, (double)F * H * W * 3);
-    r = launch_raft_prep(stream, frames, F, H, W, sh_, sw_, Hp_, Wp_, padl_, padt_, scale != 1.f, xi_, xc_, yi_, yc_, img_, nullptr, 1);
+    const int es = split_w_ ? 2 : 1;                         // encoder maps are [hi | lo] in split-fp16 mode
+    auto lo = [&](int c) { return split_w_ ? c : 0; };
+    r = launch_raft_prep(stream, frames, F, H, W, sh_, sw_, Hp_, Wp_, padl_, padt_, scale != 1.f, xi_, xc_, yi_, yc_, img_, nullptr, 1, lo(64));
     toc();
     if (r) return r;
 
@@ -244,13 +248,13 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         const bool inorm = e == 0;
         auto norm_relu = [&](const f16 *t, float *st, f16 *y, int HW, int C, const f16 *b, const float *sb) -> int {
             tic(F_ELT, 0, 0);
-            int rr = launch_in_apply(stream, t, st, b, sb, y, F, HW, C, C);
+            int rr = launch_in_apply(stream, t, st, b, sb, y, F, HW, C, es * C, lo(C));
             toc();
             return rr;
         };
         auto stats = [&](const f16 *t, float *st, int HW, int C) -> int {
             tic(F_ELT, 0, 0);
-            int rr = launch_in_stats(stream, t, F, HW, C, C, stp_, st);
+            int rr = launch_in_stats(stream, t, F, HW, C, es * C, stp_, st, lo(C));
             toc();
             return rr;
         };
@@ -258,10 +262,10 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         {
             GemmArgs a;
             a.A = img_; a.N = 256;
-            a.cH = Hp_ / 4; a.cW = Wp_ / 4; a.cC = 64; a.cLd = 64; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1;
+            a.cH = Hp_ / 4; a.cW = Wp_ / 4; a.cC = 64; a.cLd = es * 64; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1;
             set_weights(a, E.stem, true);
             a.cOH = a.cH; a.cOW = a.cW; a.M = F * a.cH * a.cW;
-            a.out = r1_[5]; a.ldo = 64; a.act = inorm ? ACT_NONE : ACT_RELU;
+            a.out = r1_[5]; a.ldo = es * 64; a.lo_off = lo(64); a.act = inorm ? ACT_NONE : ACT_RELU;
             a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
             tic(F_CONV, 2.0 * F * h2 * w2 * 64.0 * 147, 0);
             r = launch_gemm(stream, A_CONV, EPI_PIXSHUF, TILE_AUTO, a);
@@ -285,31 +289,31 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
                 const int Cin = bi == 0 ? C_ : Cn;
                 f16 *t1 = R[0], *t2 = R[1], *t3 = R[2], *outb = R[3 + bi];
                 if (inorm) {
-                    if ((r = conv(x, Cin, Cin, F, H_, W_, 3, 3, s, E.l[li][bi][0], t1, Cn, ACT_NONE))) return r;
+                    if ((r = conv(x, Cin, es * Cin, F, H_, W_, 3, 3, s, E.l[li][bi][0], t1, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
                     if ((r = stats(t1, st_[0], OH * OW, Cn))) return r;
                     if ((r = norm_relu(t1, st_[0], t1, OH * OW, Cn, nullptr, nullptr))) return r;
-                    if ((r = conv(t1, Cn, Cn, F, OH, OW, 3, 3, 1, E.l[li][bi][1], t2, Cn, ACT_NONE))) return r;
+                    if ((r = conv(t1, Cn, es * Cn, F, OH, OW, 3, 3, 1, E.l[li][bi][1], t2, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
                     if ((r = stats(t2, st_[1], OH * OW, Cn))) return r;
                     if (s != 1) {
-                        if ((r = conv(x, Cin, Cin, F, H_, W_, 1, 1, s, E.ds[li], t3, Cn, ACT_NONE))) return r;
+                        if ((r = conv(x, Cin, es * Cin, F, H_, W_, 1, 1, s, E.ds[li], t3, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
                         if ((r = stats(t3, st_[2], OH * OW, Cn))) return r;
                         if ((r = norm_relu(t2, st_[1], outb, OH * OW, Cn, t3, st_[2]))) return r;
                     } else {
                         if ((r = norm_relu(t2, st_[1], outb, OH * OW, Cn, x, nullptr))) return r;
                     }
                 } else {
-                    if ((r = conv(x, Cin, Cin, F, H_, W_, 3, 3, s, E.l[li][bi][0], t1, Cn, ACT_RELU))) return r;
+                    if ((r = conv(x, Cin, es * Cin, F, H_, W_, 3, 3, s, E.l[li][bi][0], t1, es * Cn, ACT_RELU, 0, nullptr, nullptr, lo(Cn)))) return r;
                     const f16 *xs = x;
                     if (s != 1) {
-                        if ((r = conv(x, Cin, Cin, F, H_, W_, 1, 1, s, E.ds[li], t3, Cn, ACT_NONE))) return r;
+                        if ((r = conv(x, Cin, es * Cin, F, H_, W_, 1, 1, s, E.ds[li], t3, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
                         xs = t3;
                     }
-                    if ((r = conv(t1, Cn, Cn, F, OH, OW, 3, 3, 1, E.l[li][bi][1], outb, Cn, ACT_RELU, 1, xs))) return r;
+                    if ((r = conv(t1, Cn, es * Cn, F, OH, OW, 3, 3, 1, E.l[li][bi][1], outb, es * Cn, ACT_RELU, 1, xs, nullptr, lo(Cn)))) return r;
                 }
                 x = outb; H_ = OH; W_ = OW; C_ = Cn;
             }
         }
-        if ((r = dense(x, 128, (int64_t)F * P_, E.out, e == 0 ? fmap_ : ctx_, 256, ACT_NONE))) return r;
+        if ((r = dense(x, es * 128, (int64_t)F * P_, E.out, e == 0 ? fmap_ : ctx_, 256, ACT_NONE))) return r;
     }
     stages_["fmap"] = Stage{fmap_, 1, 0, 256, h8_, w8_, 256, 0};
 

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
                                                         int sw, int Hp, int Wp, int pad_l, int pad_t, int resize,
                                                         const int *__restrict__ xi, const int *__restrict__ xc,
                                                         const int *__restrict__ yi, const int *__restrict__ yc,
-                                                        f16 *__restrict__ out, uint8_t *__restrict__ scaled_out, int s2d) {
+                                                        f16 *__restrict__ out, uint8_t *__restrict__ scaled_out, int s2d, int lo_off) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)F * Hp * Wp) return;
     const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), f = (int)(i / ((int64_t)Wp * Hp));
@@ -50,14 +50,24 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
         const uint8_t *px = img + ((int64_t)sy * W + sx) * 3;
         v[0] = px[0]; v[1] = px[1]; v[2] = px[2];
     }
-    f16x4 o;
+    f16x4 o, l;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = (f16)(2.f * ((float)v[c] / 255.f) - 1.f);
-    o[3] = (f16)0.f;
+    for (int c = 0; c < 3; ++c) {
+        const float t = 2.f * ((float)v[c] / 255.f) - 1.f;
+        o[c] = (f16)t;
+        l[c] = (f16)(t - (float)o[c]);
+    }
+    o[3] = (f16)0.f; l[3] = (f16)0.f;
     // s2d: 4 x 4 pixel blocks become the 64 channels ((dy * 4 + dx) * 4 + c) of a [F, Hp / 4, Wp / 4] map - the layout in which the
     // 7x7 / stride-2 stem is a 3x3 convolution with 4 x 64 output channels (raft_engine.hip)
-    const int64_t oi = s2d ? ((((int64_t)f * (Hp >> 2) + (y >> 2)) * (Wp >> 2) + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)) : i;
-    *(f16x4 *)(out + oi * 4) = o;
+    if (s2d && lo_off) {        // split-fp16 encoder input: [hi (64) | lo (64)] per space-to-depth pixel
+        const int64_t px = (((int64_t)f * (Hp >> 2) + (y >> 2)) * (Wp >> 2) + (x >> 2)) * (2 * lo_off) + ((y & 3) * 4 + (x & 3)) * 4;
+        *(f16x4 *)(out + px) = o;
+        *(f16x4 *)(out + px + lo_off) = l;
+    } else {
+        const int64_t oi = s2d ? ((((int64_t)f * (Hp >> 2) + (y >> 2)) * (Wp >> 2) + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)) : i;
+        *(f16x4 *)(out + oi * 4) = o;
+    }
     if (scaled_out && y >= pad_t && y < pad_t + sh && x >= pad_l && x < pad_l + sw) {
         uint8_t *d = scaled_out + (((int64_t)f * sh + (y - pad_t)) * sw + (x - pad_l)) * 3;
         d[0] = (uint8_t)v[0]; d[1] = (uint8_t)v[1]; d[2] = (uint8_t)v[2];
@@ -91,8 +101,9 @@ __global__ __launch_bounds__(256) void im2col7_kernel(const T *__restrict__ x, i
 // - no atomics, so the result does not depend on block scheduling.  Pass 2: one thread per (b, c) adds the chunks in order and
 // stores {mean, 1 / sqrt(var + eps)}.  Threads cover (pixel lane, 8 channels).
 // ------------------------------------------------------------------------------------------------
+// lo_off != 0: x is a split-fp16 map [hi | lo] and the statistics are those of hi + lo.
 __global__ __launch_bounds__(256) void in_stats_kernel(const f16 *__restrict__ x, int HW, int C8, int ldc,
-                                                        float *__restrict__ part, int chunk) {
+                                                        float *__restrict__ part, int chunk, int lo_off) {
     __shared__ float red[256 * 16];
     const int b = blockIdx.y;
     const int c8 = threadIdx.x % C8, pl = threadIdx.x / C8, npl = blockDim.x / C8;
@@ -103,8 +114,14 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const f16 *__restrict__ x
     if (pl < npl) {
         for (int p = p0 + pl; p < p1; p += npl) {
             const f16x8 v = *(const f16x8 *)(x + ((int64_t)b * HW + p) * ldc + c8 * 8);
+            if (lo_off) {
+                const f16x8 l = *(const f16x8 *)(x + ((int64_t)b * HW + p) * ldc + c8 * 8 + lo_off);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[j] + (float)l[j]; s[j] += f; q[j] += f * f; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+            }
         }
     }
 #pragma unroll
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float *__restric
 // out = relu( relu(IN(a)) + (b ? (sb ? IN(b) : b) : 0) )   [second relu only when b is given];  sa / sb = {mean, rstd}
 __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a, const float *__restrict__ sa,
                                                         const f16 *__restrict__ bsrc, const float *__restrict__ sb,
-                                                        f16 *__restrict__ out, int B, int HW, int C8, int ldc) {
+                                                        f16 *__restrict__ out, int B, int HW, int C8, int ldc, int lo_off) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * HW * C8) return;
     const int c8 = (int)(i % C8);
@@ -146,8 +163,12 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a
     const int b = (int)(pix / HW);
     const int64_t o = pix * ldc + c8 * 8;
     const f16x8 va = *(const f16x8 *)(a + o);
-    f16x8 vb;
+    f16x8 vb, la, lb;
     if (bsrc) vb = *(const f16x8 *)(bsrc + o);
+    if (lo_off) {                   // split-fp16 maps [hi | lo]
+        la = *(const f16x8 *)(a + o + lo_off);
+        if (bsrc) lb = *(const f16x8 *)(bsrc + o + lo_off);
+    }
     const f32x4 *st = (const f32x4 *)(sa + ((int64_t)b * C8 * 8 + c8 * 8) * 2);
     f32x4 ms[4], ms2[4];
 #pragma unroll
@@ -157,19 +178,22 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a
 #pragma unroll
         for (int j = 0; j < 4; ++j) ms2[j] = s2[j];
     }
-    f16x8 r;
+    f16x8 r, rl;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float mean = ms[j >> 1][(j & 1) * 2], rstd = ms[j >> 1][(j & 1) * 2 + 1];
-        float v = fmaxf(((float)va[j] - mean) * rstd, 0.f);
+        const float xa = lo_off ? (float)va[j] + (float)la[j] : (float)va[j];
+        float v = fmaxf((xa - mean) * rstd, 0.f);
         if (bsrc) {
-            float w = (float)vb[j];
+            float w = lo_off ? (float)vb[j] + (float)lb[j] : (float)vb[j];
             if (sb) w = (w - ms2[j >> 1][(j & 1) * 2]) * ms2[j >> 1][(j & 1) * 2 + 1];
             v = fmaxf(v + w, 0.f);
         }
         r[j] = (f16)v;
+        rl[j] = (f16)(v - (float)r[j]);
     }
     *(f16x8 *)(out + o) = r;
+    if (lo_off) *(f16x8 *)(out + o + lo_off) = rl;
 }
 
 // cnet output [rows][256] fp16 -> net = tanh(c[:128]) (fp32 master + fp16 copy in HX[:, 0:128]),
@@ -452,7 +476,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float *__restrict__
         if ((unsigned)oy < (unsigned)sh && (unsigned)ox < (unsigned)sw) {
             float *o = out + (((int64_t)n * sh + oy) * sw + ox) * 2;
             o[0] = u; o[1] = v;
-            dmax = fmaxf(dmax, __fsqrt_rn(__fadd_rn(__fmul_rn(u, u), __fmul_rn(v, v))));
+            dmax = fmaxf(dmax, ex_fsqrt(ex_fadd(ex_fmul(u, u), ex_fmul(v, v))));
         }
     }
 #pragma unroll
@@ -471,24 +495,24 @@ __device__ __forceinline__ double atan2_rn(double y, double x) {
     const double ATAN_C[5] = {0.0, 0.24497866312686414, 0.4636476090008061, 0.6435011087932844, 0.7853981633974483};
     const double ax = fabs(x), ay = fabs(y);
     const double hi = fmax(ax, ay), lo = fmin(ax, ay);
-    const double t = hi == 0.0 ? 0.0 : __ddiv_rn(lo, hi);
+    const double t = hi == 0.0 ? 0.0 : ex_ddiv(lo, hi);
     if (t != t) return t;                                   // NaN in -> NaN out (0 / 0 flow: the last frame of a video)
-    const double k = floor(__dadd_rn(__dmul_rn(t, 4.0), 0.5));
-    const double c = __dmul_rn(k, 0.25);
-    const double u = __ddiv_rn(__dsub_rn(t, c), __dadd_rn(1.0, __dmul_rn(t, c)));
-    const double u2 = __dmul_rn(u, u);
+    const double k = floor(ex_dadd(ex_dmul(t, 4.0), 0.5));
+    const double c = ex_dmul(k, 0.25);
+    const double u = ex_ddiv(ex_dsub(t, c), ex_dadd(1.0, ex_dmul(t, c)));
+    const double u2 = ex_dmul(u, u);
     double p = 1.0 / 17.0;
-    p = __dadd_rn(__dmul_rn(p, u2), -1.0 / 15.0);
-    p = __dadd_rn(__dmul_rn(p, u2), 1.0 / 13.0);
-    p = __dadd_rn(__dmul_rn(p, u2), -1.0 / 11.0);
-    p = __dadd_rn(__dmul_rn(p, u2), 1.0 / 9.0);
-    p = __dadd_rn(__dmul_rn(p, u2), -1.0 / 7.0);
-    p = __dadd_rn(__dmul_rn(p, u2), 1.0 / 5.0);
-    p = __dadd_rn(__dmul_rn(p, u2), -1.0 / 3.0);
-    p = __dadd_rn(__dmul_rn(p, u2), 1.0);
-    double r = __dadd_rn(ATAN_C[(int)k], __dmul_rn(u, p));
-    if (ay > ax) r = __dsub_rn(1.5707963267948966, r);
-    if (x < 0.0) r = __dsub_rn(3.141592653589793, r);
+    p = ex_dadd(ex_dmul(p, u2), -1.0 / 15.0);
+    p = ex_dadd(ex_dmul(p, u2), 1.0 / 13.0);
+    p = ex_dadd(ex_dmul(p, u2), -1.0 / 11.0);
+    p = ex_dadd(ex_dmul(p, u2), 1.0 / 9.0);
+    p = ex_dadd(ex_dmul(p, u2), -1.0 / 7.0);
+    p = ex_dadd(ex_dmul(p, u2), 1.0 / 5.0);
+    p = ex_dadd(ex_dmul(p, u2), -1.0 / 3.0);
+    p = ex_dadd(ex_dmul(p, u2), 1.0);
+    double r = ex_dadd(ATAN_C[(int)k], ex_dmul(u, p));
+    if (ay > ax) r = ex_dsub(1.5707963267948966, r);
+    if (x < 0.0) r = ex_dsub(3.141592653589793, r);
     if (y < 0.0) r = -r;
     return r;
 }
@@ -503,25 +527,25 @@ __global__ __launch_bounds__(256) void flow_encode_kernel(const float *__restric
     if (!rgb) return;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
         const float *f = flow + ((int64_t)n * per + i) * 2;
-        const float dx = __fdiv_rn(f[0], mx), dy = __fdiv_rn(f[1], mx);
-        const float rad = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+        const float dx = ex_fdiv(f[0], mx), dy = ex_fdiv(f[1], mx);
+        const float rad = ex_fsqrt(ex_fadd(ex_fmul(dx, dx), ex_fmul(dy, dy)));
         // np.arctan2 on float32 is not one function: numpy dispatches to SVML (<= 4 ULP) on AVX512 hosts and to libm elsewhere, so
         // the reference's last bit depends on its CPU.  The engine (and oracle.process_flow(exact_atan2=True)) take the
         // correctly rounded float32 value, from a double evaluation made of IEEE +, -, *, / only (atan2_rn).
         const float at = (float)atan2_rn((double)dy, (double)dx);
-        const float a = __fmul_rn(__fadd_rn(__fdiv_rn(at, 3.14159265358979323846f), 1.0f), 0.5f);
-        const float h6 = __fmul_rn(a, 6.0f);
+        const float a = ex_fmul(ex_fadd(ex_fdiv(at, 3.14159265358979323846f), 1.0f), 0.5f);
+        const float h6 = ex_fmul(a, 6.0f);
         const float offs[3] = {0.f, 4.f, 2.f};
         uint8_t o[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            double v = (double)(c == 0 ? h6 : __fadd_rn(h6, offs[c]));
+            double v = (double)(c == 0 ? h6 : ex_fadd(h6, offs[c]));
             v = fmod(v, 6.0);
-            if (v < 0.0) v = __dadd_rn(v, 6.0);
-            v = __dsub_rn(fabs(__dsub_rn(v, 3.0)), 1.0);
+            if (v < 0.0) v = ex_dadd(v, 6.0);
+            v = ex_dsub(fabs(ex_dsub(v, 3.0)), 1.0);
             v = fmin(fmax(v, 0.0), 1.0);
-            v = __dadd_rn(__dmul_rn(v, (double)rad), (double)__fsub_rn(1.0f, rad));
-            v = __dmul_rn(v, 255.0);
+            v = ex_dadd(ex_dmul(v, (double)rad), (double)ex_fsub(1.0f, rad));
+            v = ex_dmul(v, 255.0);
             o[c] = (v == v) ? (uint8_t)(int)v : (uint8_t)0;
         }
         uint8_t *d = rgb + ((int64_t)n * per + i) * 3;
@@ -540,9 +564,9 @@ __global__ void fill_u32_kernel(unsigned *p, unsigned v, int n) {
 
 int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, int sh, int sw, int Hp, int Wp, int pad_l,
                      int pad_t, int resize, const int *xi, const int *xc, const int *yi, const int *yc, f16 *out,
-                     uint8_t *scaled_out, int s2d) {
+                     uint8_t *scaled_out, int s2d, int lo_off) {
     hipLaunchKernelGGL(raft_prep_kernel, dim3(nblk((int64_t)F * Hp * Wp)), dim3(256), 0, s, frames, F, H, W, sh, sw, Hp, Wp,
-                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d);
+                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d, lo_off);
     LAUNCH_CHECK();
 }
 int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp) {
@@ -551,16 +575,16 @@ int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 
     LAUNCH_CHECK();
 }
 int in_stats_chunks(int HW) { return (HW + 2047) / 2048; }
-int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *part, float *stats) {
+int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *part, float *stats, int lo_off) {
     PB_CHECK(C % 8 == 0 && C <= 256 && 256 % (C / 8) == 0, -1, "instance norm: C=%d unsupported", C);
     const int chunk = 2048, nchunk = in_stats_chunks(HW);
-    hipLaunchKernelGGL(in_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, HW, C / 8, ldc, part, chunk);
+    hipLaunchKernelGGL(in_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, HW, C / 8, ldc, part, chunk, lo_off);
     hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, nchunk, B * C, 1.f / (float)HW, stats);
     LAUNCH_CHECK();
 }
 int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, const float *sb, f16 *out, int B, int HW,
-                    int C, int ldc) {
-    hipLaunchKernelGGL(in_apply_kernel, dim3(nblk((int64_t)B * HW * (C / 8))), dim3(256), 0, s, a, sa, b, sb, out, B, HW, C / 8, ldc);
+                    int C, int ldc, int lo_off) {
+    hipLaunchKernelGGL(in_apply_kernel, dim3(nblk((int64_t)B * HW * (C / 8))), dim3(256), 0, s, a, sa, b, sb, out, B, HW, C / 8, ldc, lo_off);
     LAUNCH_CHECK();
 }
 int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows) {
@@ -616,7 +640,7 @@ int launch_flow_encode(hipStream_t s, const float *flow, int N, int sh, int sw, 
 // flows: [n, 2, h, w, 2]; mask: [n, 2, h, w] bytes of 0 / 1.
 namespace {
 __device__ __forceinline__ float norm2_rn(float x, float y) {
-    return __fsqrt_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)));
+    return ex_fsqrt(ex_fadd(ex_fmul(x, x), ex_fmul(y, y)));
 }
 
 __global__ __launch_bounds__(256) void fwdbwd_mask_kernel(const float2 *__restrict__ flow, int h, int w, float a1, float a2,
@@ -628,11 +652,11 @@ __global__ __launch_bounds__(256) void fwdbwd_mask_kernel(const float2 *__restri
     const float2 *self = flow + (int64_t)nd * hw, *other = flow + (int64_t)(nd ^ 1) * hw;
     const int y = (int)(p / w), x = (int)(p - (int64_t)y * w);
     const float2 f = self[p];
-    const int qx = __float2int_rn(__fmul_rn(__fadd_rn(f.x, (float)x), 32.f));
-    const int qy = __float2int_rn(__fmul_rn(__fadd_rn(f.y, (float)y), 32.f));
+    const int qx = __float2int_rn(ex_fmul(ex_fadd(f.x, (float)x), 32.f));
+    const int qy = __float2int_rn(ex_fmul(ex_fadd(f.y, (float)y), 32.f));
     const int ix = qx >> 5, iy = qy >> 5;
-    const float fx = __fmul_rn((float)(qx & 31), 1.f / 32), fy = __fmul_rn((float)(qy & 31), 1.f / 32);
-    const float tx[2] = {__fsub_rn(1.f, fx), fx}, ty[2] = {__fsub_rn(1.f, fy), fy};
+    const float fx = ex_fmul((float)(qx & 31), 1.f / 32), fy = ex_fmul((float)(qy & 31), 1.f / 32);
+    const float tx[2] = {ex_fsub(1.f, fx), fx}, ty[2] = {ex_fsub(1.f, fy), fy};
     float wx = 0.f, wy = 0.f;
 #pragma unroll
     for (int k1 = 0; k1 < 2; ++k1)
@@ -641,13 +665,13 @@ __global__ __launch_bounds__(256) void fwdbwd_mask_kernel(const float2 *__restri
             const int yy = iy + k1, xx = ix + k2;
             float2 v = make_float2(0.f, 0.f);
             if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = other[(int64_t)yy * w + xx];
-            const float wt = __fmul_rn(ty[k1], tx[k2]);
-            const float tx_ = __fmul_rn(v.x, wt), ty_ = __fmul_rn(v.y, wt);
-            wx = (k1 | k2) ? __fadd_rn(wx, tx_) : tx_;
-            wy = (k1 | k2) ? __fadd_rn(wy, ty_) : ty_;
+            const float wt = ex_fmul(ty[k1], tx[k2]);
+            const float tx_ = ex_fmul(v.x, wt), ty_ = ex_fmul(v.y, wt);
+            wx = (k1 | k2) ? ex_fadd(wx, tx_) : tx_;
+            wy = (k1 | k2) ? ex_fadd(wy, ty_) : ty_;
         }
-    const float err = norm2_rn(__fadd_rn(f.x, wx), __fadd_rn(f.y, wy));
-    const float thr = __fadd_rn(__fmul_rn(a1, __fadd_rn(norm2_rn(f.x, f.y), norm2_rn(wx, wy))), a2);
+    const float err = norm2_rn(ex_fadd(f.x, wx), ex_fadd(f.y, wy));
+    const float thr = ex_fadd(ex_fmul(a1, ex_fadd(norm2_rn(f.x, f.y), norm2_rn(wx, wy))), a2);
     mask[(int64_t)nd * hw + p] = err < thr ? 1 : 0;
 }
 }  // namespace

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void pil_h_kernel(const float *__restrict__ in
     const float *src = in + row * w + xb[2 * X];
     const double *k = xk + (int64_t)X * ks;
     double ss = 0.0;
-    for (int t = 0; t < xb[2 * X + 1]; ++t) ss = __dadd_rn(ss, __dmul_rn((double)src[t], k[t]));
+    for (int t = 0; t < xb[2 * X + 1]; ++t) ss = ex_dadd(ss, ex_dmul((double)src[t], k[t]));
     out[i] = (float)ss;
 }
 __global__ __launch_bounds__(256) void pil_v_kernel(const float *__restrict__ in, float *__restrict__ out, int n, int h, int H, int W,
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void pil_v_kernel(const float *__restrict__ in
     const float *src = in + ((int64_t)b * h + yb[2 * Y]) * W + X;
     const double *k = yk + (int64_t)Y * ks;
     double ss = 0.0;
-    for (int t = 0; t < yb[2 * Y + 1]; ++t) ss = __dadd_rn(ss, __dmul_rn((double)src[(int64_t)t * W], k[t]));
+    for (int t = 0; t < yb[2 * Y + 1]; ++t) ss = ex_dadd(ss, ex_dmul((double)src[(int64_t)t * W], k[t]));
     out[i] = (float)ss;
 }
 }  // namespace

@@ -108,4 +108,3 @@ def test_relay_delivers_chunks_in_frame_order_with_bounded_memory(tmp_path):
     assert peak <= chunk * 270 * 480 * 3
     assert not spool_left
     assert mx == list(map(float, range(n)))
-    assert rss_kb * 1024 < 78e6 + 600e6        # the process never materialised the 78 MB video on top of its ~0.4 GB python / torch baseline
