@@ -289,9 +289,10 @@ def main():
     ap.add_argument("--encoder", default="vitl")
     ap.add_argument("--flow-scale", type=float, default=0.75, help="flow_raft --scale (the band's default)")
     ap.add_argument("--flow-iters", type=int, default=12, help="GRU iterations (BASELINE.json configs[2])")
-    ap.add_argument("--precision", type=int, default=0, choices=(0, 1),
-                    help="pb_precision of the timed `value`: 0 = one fp16 MFMA pass per GEMM (dtype f16), 1 = split-fp16 (meets the 1e-3 "
-                         "max-norm bound the parity tests assert); the other mode is timed too and reported under `other_precision`")
+    ap.add_argument("--precision", type=int, default=1, choices=(0, 1),
+                    help="pb_precision of the timed `value`: 1 (default) = split-fp16, the mode that meets north_star's 1e-3 tolerance on every "
+                         "reference vector (what the parity tests assert and the band scripts use); 0 = one fp16 MFMA pass per GEMM (faster, "
+                         "1.3-2.2e-3 max-norm error).  The other mode is timed too (child process) and reported under `other_precision`")
     ap.add_argument("--one-precision", action="store_true", help="skip the second precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256, 4 simple 256")
@@ -374,7 +375,7 @@ def main():
         fam = {}
         for band, net_ in (("depth", dn), ("flow", fn)):
             for s in net_.kernel_stats():
-                fam[band + "/" + s["name"]] = {k: s[k] for k in ("ms", "flops", "bytes", "launches")}
+                fam[band + "/" + s["name"]] = {k: s[k] for k in ("ms", "flops", "exec_flops", "bytes", "launches")}
             net_.set_profiling(timing=False)
         dt = R.max_over_ranks(dt)
         sc = scal.cpu().numpy()
@@ -432,6 +433,7 @@ def main():
         dom_name, g = max(((k, v) for k, v in fam.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic(SYMBOLS.get(dom_name, dom_name).split(" ")[0])
+        exec_mult = g["exec_flops"] / g["flops"] if g["flops"] > 0 else 1.0     # MFMA passes issued per algorithmic pass (split-fp16: 2 - 3)
         tot_fl = sum(v["flops"] for v in fam.values())
         band_fl = {b: sum(v["flops"] for k, v in fam.items() if k.startswith(b + "/")) for b in ("depth", "flow")}
 
@@ -453,8 +455,10 @@ def main():
                        "precision": PREC_NAME[args.precision],
                        "parallelism": f"one clip per GPU on {world} GPU(s); per-frame scalars all-gathered (12 bytes per frame), nothing else crosses GPUs"},
             "precision_modes": {
-                "f16": "one fp16 MFMA pass per GEMM / conv, fp32 accumulate; vs the fp32 reference: L2 < 1e-3, max-norm up to 1.6e-3 (tests: conftest.TOL[0])",
-                "split-f16": "hi + lo fp16 operands where the error budget needs them (2-3 passes over K); max-norm and L2 < 1e-3 on every reference vector (the tests' default)"},
+                "split-f16": "hi + lo fp16 operands where the error budget needs them (2-3 MFMA passes over K, one fp32 accumulator); max-norm and L2 error "
+                             "< 1e-3 against every reference vector (depth <= 4.0e-4, flow <= 6.1e-4 measured) - north_star's tolerance; the band scripts' mode",
+                "f16": "one fp16 MFMA pass per GEMM / conv, fp32 accumulate; against the fp32 reference depth 1.3e-3 max / 8e-4 L2, flow up to 2.2e-3 / 1.5e-3 "
+                       "at 1280x720 - outside the tolerance, reported for comparison with round 1"},
             "roofline": {"bound": "mfma", "kernel": SYMBOLS.get(dom_name, dom_name), "family": dom_name,
                          "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
@@ -466,9 +470,12 @@ def main():
                          "step_frac": round(tot_fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
                          "depth_frac_alone": round(band_fl["depth"] / main_res["depth_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
                          "flow_frac_alone": round(band_fl["flow"] / main_res["flow_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
-                         "note": "flops are algorithmic multiply-adds (2 M N K of the layer, padding and split-fp16 passes not counted); *_frac_alone = a "
+                         "executed_frac": round(ach * exec_mult / PEAK_F16_TFLOPS, 4),
+                         "note": "flops are algorithmic multiply-adds (2 M N K of the layer; padding and the extra split-fp16 passes not counted) - executed_frac "
+                                 "counts the MFMA work actually issued (x2 for weight-split, x3 for weight+activation-split layers); *_frac_alone = a "
                                  "band's flops / its wall time inside the step / peak; step_frac = all launches' flops / step wall time / peak"},
             "model_tflops": round(tot_fl / dt / 1e12, 2),
+            "executed_tflops": round(sum(v["exec_flops"] for v in fam.values()) / dt / 1e12, 2),
             "depth_anything": {"metric": f"frames/sec (depth_anything ViT-L, 1080p, batch {B} per GPU, inside the step)",
                                "value": round(world * B * args.steps / main_res["depth_s"], 3), "unit": "frames/s",
                                "ms_per_step": round(main_res["depth_s"] / args.steps * 1e3, 3),

@@ -221,7 +221,8 @@ int pb_memcpy_d2h(pb_ctx *ctx, void *dst, const void *src, size_t bytes);
 typedef struct {
     const char *name;     /* kernel family, e.g. "gemm_f16", "attention", "conv3x3"      */
     double ms;            /* summed event time of that family in the last call            */
-    double flops;         /* algorithmic FLOPs those launches performed                   */
+    double flops;         /* algorithmic FLOPs those launches performed (2 M N K of the layers) */
+    double exec_flops;    /* MFMA FLOPs actually issued: x2 / x3 for split-fp16 layers (PB_PREC_SPLIT) */
     double bytes;         /* algorithmic HBM bytes (compulsory traffic) of those launches */
     int32_t launches;
 } pb_kernel_stat;

@@ -46,7 +46,7 @@ class pb_mask_cfg(C.Structure):
 
 
 class pb_kernel_stat(C.Structure):
-    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double),
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("flops", C.c_double), ("exec_flops", C.c_double), ("bytes", C.c_double),
                 ("launches", C.c_int32)]
 
 

@@ -26,7 +26,7 @@ struct Stage {
 };
 
 struct KernelTimer {
-    struct Rec { int fam; hipEvent_t a, b; double flops, bytes; };
+    struct Rec { int fam; hipEvent_t a, b; double flops, bytes, exec; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
@@ -77,7 +77,7 @@ class DepthEngine {
     // taps > 1: src is [N][taps][K / taps] and every tap is padded to Kpad / taps; sa / sw: split-fp16 segments (PackedW)
     int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias, int taps = 1, int sa = 0, int sw = 0);
     const pb_tensor *find(const std::string &name) const;
-    void tic(int fam, double flops, double bytes);
+    void tic(int fam, double flops, double bytes, double passes = 1.0);
     void toc();
     void snapshot(const std::string &name);
 

@@ -32,9 +32,9 @@ KernelTimer::~KernelTimer() {
     for (auto e : pool) hipEventDestroy(e);
 }
 
-void DepthEngine::tic(int fam, double flops, double bytes) {
+void DepthEngine::tic(int fam, double flops, double bytes, double passes) {
     if (!timer.enabled) return;
-    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes};
+    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes, flops * passes};
     hipEventRecord(r.a, stream);
     timer.recs.push_back(r);
 }
@@ -46,12 +46,13 @@ void DepthEngine::toc() {
 int DepthEngine::stats(pb_kernel_stat *out, int cap) {
     if (hipStreamSynchronize(stream) != hipSuccess) return -2;
     pb_kernel_stat acc[F_COUNT];
-    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFam[i], 0, 0, 0, 0};
+    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFam[i], 0, 0, 0, 0, 0};
     for (auto &r : timer.recs) {
         float ms = 0;
         hipEventElapsedTime(&ms, r.a, r.b);
         acc[r.fam].ms += ms;
         acc[r.fam].flops += r.flops;
+        acc[r.fam].exec_flops += r.exec;
         acc[r.fam].bytes += r.bytes;
         acc[r.fam].launches++;
     }
@@ -490,7 +491,7 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
     a.zero = zero_;
     const double flops = 2.0 * a.M * (double)a.N * w.Kreal;
     const double bytes = 2.0 * ((double)a.M * w.Kreal + (double)a.N * w.Kreal + (double)a.M * a.N);
-    tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes);
+    tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes, 1.0 + w.sa + w.sw);
     if (tile == TILE_AUTO) tile = amode == A_CONV ? conv_tile : gemm_tile;
     int r = launch_gemm(stream, amode, epi, tile, a);
     toc();

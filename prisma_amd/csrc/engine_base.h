@@ -46,7 +46,7 @@ class EngineBase {
     int commit_arena(const char *what);
 
     // helpers launch on cur_ (the ctx stream unless a derived engine forks work onto side streams)
-    void tic(int fam, double flops, double bytes);
+    void tic(int fam, double flops, double bytes, double passes = 1.0);
     void toc();
     // fusion hooks of one conv() call: a second (ReLU'd) copy of the output, and the SepConvGRU epilogues (gemm.h ACT_GRU_*)
     struct ConvFuse { f16 *out2 = nullptr; float *gru_h = nullptr; const f16 *gru_z = nullptr; f16 *gru_rh = nullptr; };

@@ -18,9 +18,9 @@ EngineBase::~EngineBase() {
     if (stream) hipStreamDestroy(stream);
 }
 
-void EngineBase::tic(int fam, double flops, double bytes) {
+void EngineBase::tic(int fam, double flops, double bytes, double passes) {
     if (!timer.enabled) return;
-    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes};
+    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes, flops * passes};
     hipEventRecord(r.a, cur_);
     timer.recs.push_back(r);
     open_.push_back(timer.recs.size() - 1);
@@ -34,11 +34,11 @@ void EngineBase::toc() {
 int EngineBase::stats(pb_kernel_stat *out, int cap) {
     if (hipStreamSynchronize(stream) != hipSuccess) return -2;
     pb_kernel_stat acc[F_COUNT];
-    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFam[i], 0, 0, 0, 0};
+    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFam[i], 0, 0, 0, 0, 0};
     for (auto &r : timer.recs) {
         float ms = 0;
         hipEventElapsedTime(&ms, r.a, r.b);
-        acc[r.fam].ms += ms; acc[r.fam].flops += r.flops; acc[r.fam].bytes += r.bytes; acc[r.fam].launches++;
+        acc[r.fam].ms += ms; acc[r.fam].flops += r.flops; acc[r.fam].exec_flops += r.exec; acc[r.fam].bytes += r.bytes; acc[r.fam].launches++;
     }
     int n = 0;
     for (int i = 0; i < F_COUNT && n < cap; ++i)
@@ -190,7 +190,7 @@ int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh
     const bool wide = conv_tile == TILE_256 || (conv_tile == TILE_AUTO && a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256);
     // algorithmic bytes: the input map once, the weights once, the output once (fp16)
     // one family per kernel symbol launch_gemm picks: 256 x 256 ping-pong, 256 x 64 (N <= 64), 128 x 128
-    tic(wide ? F_CONV : (conv_tile == TILE_AUTO && a.N <= 64 ? F_CONV64 : F_CONV128), 2.0 * a.M * (double)a.N * w.Kreal, 2.0 * ((double)n * H * W * cC + (double)a.N * w.Kreal + (double)a.M * a.N));
+    tic(wide ? F_CONV : (conv_tile == TILE_AUTO && a.N <= 64 ? F_CONV64 : F_CONV128), 2.0 * a.M * (double)a.N * w.Kreal, 2.0 * ((double)n * H * W * cC + (double)a.N * w.Kreal + (double)a.M * a.N), 1.0 + w.sa + w.sw);
     int r = launch_gemm(cur_, A_CONV, EPI_STD, conv_tile, a);
     toc();
     return r;
@@ -201,7 +201,7 @@ int EngineBase::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *o
     a.A = A; a.lda = lda; a.N = w.N; a.M = (int)M;
     set_weights(a, w, false);
     a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
-    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 2.0 * ((double)M * w.Kreal + (double)a.N * w.Kreal + (double)M * a.N));
+    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 2.0 * ((double)M * w.Kreal + (double)a.N * w.Kreal + (double)M * a.N), 1.0 + w.sa + w.sw);
     int r = launch_gemm(cur_, A_DENSE, EPI_STD, TILE_AUTO, a);
     toc();
     return r;

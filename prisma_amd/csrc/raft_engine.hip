@@ -267,7 +267,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
             a.cOH = a.cH; a.cOW = a.cW; a.M = F * a.cH * a.cW;
             a.out = r1_[5]; a.ldo = es * 64; a.lo_off = lo(64); a.act = inorm ? ACT_NONE : ACT_RELU;
             a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
-            tic(F_CONV, 2.0 * F * h2 * w2 * 64.0 * 147, 0);
+            tic(F_CONV, 2.0 * F * h2 * w2 * 64.0 * 147, 0, 1.0 + E.stem.sa + E.stem.sw);
             r = launch_gemm(stream, A_CONV, EPI_PIXSHUF, TILE_AUTO, a);
             toc();
             if (r) return r;
@@ -395,7 +395,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         a.A = m0_; a.lda = 256; a.N = 576; a.M = (int)rows;
         set_weights(a, mk2_, false);
         a.out32 = mask_; a.ldo = 576; a.scale = 0.25f;
-        tic(F_GEMM, 2.0 * rows * 576.0 * 256, 0);
+        tic(F_GEMM, 2.0 * rows * 576.0 * 256, 0, 1.0 + mk2_.sw);
         r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
         toc();
         if (r) return r;

@@ -101,7 +101,7 @@ class _Ctx:
     def kernel_stats(self) -> List[dict]:
         arr = (_lib.pb_kernel_stat * 16)()
         n = check(self.lib.pb_get_kernel_stats(self.ctx, arr, 16))
-        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes,
+        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, exec_flops=arr[i].exec_flops, bytes=arr[i].bytes,
                      launches=arr[i].launches) for i in range(n)]
 
 
