@@ -33,6 +33,8 @@ struct AttnArgs {
     const f16 *q, *k, *vt;
     f16 *o;
     int ntp, ntok, heads, ldo, nq, nb;
+    int o8_off;
+    float o8_scale;
 };
 
 // NQB query blocks of 32 rows per wave: with NQB = 2 a K / Vt fragment feeds two MFMAs on independent accumulators and
@@ -257,6 +259,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void attnq_kernel(const AttnArgs p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) r[j] = (f16)(oacc[qb][d][g * 4 + j] * inv);
                     *(f16x4 *)(orow + d * 32 + 8 * g + 4 * lh) = r;
+                    if (p.o8_off)       // fp8 copy of the row after its fp16 part: the A operand of proj's MX correction segment
+                        *(int *)((char *)(orow - head * 64) + p.o8_off + head * 64 + d * 32 + 8 * g + 4 * lh) =
+                            pb_fp8x4((float)r[0] * p.o8_scale, (float)r[1] * p.o8_scale, (float)r[2] * p.o8_scale, (float)r[3] * p.o8_scale);
                 }
         }
     }
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attnq_kernel(const AttnArgs p) {
 }  // namespace
 
 int launch_attention(hipStream_t stream, const f16 *q, const f16 *k, const f16 *vt, f16 *o, int B, int heads,
-                     int ntp, int ntok, int ldo, int variant) {
+                     int ntp, int ntok, int ldo, int variant, int o8_off, float o8_scale) {
     static int env_variant = -1;
     if (env_variant < 0) { const char *e = getenv("PB_ATTN_VARIANT"); env_variant = e ? atoi(e) : 0; }
     if (variant <= 0) variant = env_variant;
@@ -274,7 +279,7 @@ int launch_attention(hipStream_t stream, const f16 *q, const f16 *k, const f16 *
     const int nqb = variant == 3 || variant == 5 ? 2 : 1;
     const int nw = variant == 0 || variant == 1 || variant == 5 ? 8 : 4;
     const int nq = (ntok + 32 * nw * nqb - 1) / (32 * nw * nqb);
-    AttnArgs a{q, k, vt, o, ntp, ntok, heads, ldo, nq, B};
+    AttnArgs a{q, k, vt, o, ntp, ntok, heads, ldo, nq, B, o8_off, o8_scale};
     dim3 grid(8 * nq * ((B * heads + 7) / 8));
     // template arguments: NQB, minimum workgroups per CU the register allocation must allow, ablation, prefetch, NW
     switch (variant) {

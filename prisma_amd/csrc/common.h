@@ -98,6 +98,18 @@ __device__ __forceinline__ double ex_ddiv(double a, double b) {
     return a / b;
 }
 
+// two / four floats -> OCP e4m3 bytes (saturating at +-448), for the fp8 copies the MX correction segments read (gemm.h nk16)
+__device__ __forceinline__ unsigned short pb_fp8x2(float a, float b) {
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    return (unsigned short)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+}
+__device__ __forceinline__ int pb_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

@@ -13,7 +13,7 @@ namespace {
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                         const float *__restrict__ bt, f16 *__restrict__ y, int B,
                                                         int ntp, int ntok, int D, float eps, int drop_cls, int ldy,
-                                                        int lo_off) {
+                                                        int lo_off, int o8_off, float o8_scale) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= (int64_t)B * ntok) return;
@@ -59,6 +59,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             }
             *(f16x4 *)(yr + c) = o;
             if (lo_off) *(f16x4 *)(yr + c + lo_off) = l;       // split-fp16 consumers read [hi | lo] (gemm.h)
+            if (o8_off)                                        // fp8 copy after the row's fp16 part (gemm.h nk16)
+                *(int *)((char *)yr + o8_off + c) = pb_fp8x4((float)o[0] * o8_scale, (float)o[1] * o8_scale, (float)o[2] * o8_scale, (float)o[3] * o8_scale);
         }
     }
 }
@@ -324,10 +326,10 @@ inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t
 }  // namespace
 
 int launch_layernorm(hipStream_t s, const float *x, const float *g, const float *b, f16 *y, int B, int ntp, int ntok,
-                     int D, float eps, int drop_cls, int ldy, int lo_off) {
+                     int D, float eps, int drop_cls, int ldy, int lo_off, int o8_off, float o8_scale) {
     PB_CHECK(D % 4 == 0 && D <= 1024, -1, "layernorm: D=%d unsupported", D);
     hipLaunchKernelGGL(layernorm_kernel, dim3(nblk((int64_t)B * ntok, 4)), dim3(256), 0, s, x, g, b, y, B, ntp, ntok,
-                       D, eps, drop_cls, ldy ? ldy : D, lo_off);
+                       D, eps, drop_cls, ldy ? ldy : D, lo_off, o8_off, o8_scale);
     PB_HIP(hipGetLastError());
     return 0;
 }

@@ -17,7 +17,10 @@ struct PackedW {
     // split-fp16 packing (gemm.h kwrap): per tap the K axis holds the segments [w_hi | w_hi (if sa) | w_lo (if sw)] of Cseg
     // channels each; the activation operand must then be [hi | lo (if sa)] with Cseg channels per part
     int sa = 0, sw = 0, Cseg = 0;
+    // MX-fp8 correction (gemm.h nk16): rows are [w_hi fp16 (Kin) | w_lo e4m3 (Kin bytes, scaled by 2^mx_pw)]; K counts 64-half units of the row
+    int nk16 = 0, mx_pw = 0;
 };
+unsigned char pb_f32_to_e4m3(float x);     // OCP e4m3fn, round to nearest even, saturating (engine.hip)
 
 struct Stage {
     const void *ptr;
@@ -76,6 +79,8 @@ class DepthEngine {
     int upload_f32(const float *src, size_t n, float **dst);
     // taps > 1: src is [N][taps][K / taps] and every tap is padded to Kpad / taps; sa / sw: split-fp16 segments (PackedW)
     int pack(const float *src, int N, int K, int Kpad, PackedW &out, const float *bias, int taps = 1, int sa = 0, int sw = 0);
+    // dense weights with the split residual as an MX-fp8 segment (K % 128 == 0): PackedW::nk16
+    int pack_mx(const float *src, int N, int K, PackedW &out, const float *bias);
     const pb_tensor *find(const std::string &name) const;
     void tic(int fam, double flops, double bytes, double passes = 1.0);
     void toc();
@@ -85,6 +90,10 @@ class DepthEngine {
     // PB_PREC_SPLIT (tools/precision_budget.py): ViT linears and the metric head keep their weights as hi + lo (2 passes);
     // the DPT head keeps weights AND feature maps as hi + lo (3 passes; maps are [hi | lo] per pixel, hs_ = 2)
     int vit_sw_ = 0, head_sa_ = 0, head_sw_ = 0, hs_ = 1;
+    // vit_mx_: the ViT linears' weight residual runs as an MX-fp8 segment (half the matrix-pipe time of an fp16 pass); their A
+    // operands (LayerNorm out, attention out, GELU out) then carry an fp8 copy after the fp16 part of each row (row stride 1.5 K)
+    int vit_mx_ = 0;
+    static constexpr int kMxPa = 4;             // fp8 activation copies are stored scaled by 2^4 (|a| up to 28 before saturation)
     int batch_cap(int H, int W) const;          // frames per chunk the 32-bit tensor offsets allow for this frame size
     std::map<std::string, const pb_tensor *> tmap_;
     std::vector<void *> owned_;                 // permanent device allocations (weights)

@@ -64,6 +64,57 @@ int DepthEngine::stats(pb_kernel_stat *out, int cap) {
 
 DepthEngine::DepthEngine(int dev, const pb_depth_cfg &cfg) : device(dev), cfg_(cfg) {}
 
+unsigned char pb_f32_to_e4m3(float x) {
+    const unsigned char s = x < 0.f ? 0x80 : 0x00;
+    const float a = fabsf(x);
+    if (!(a == a)) return 0x7F;
+    if (a >= 448.f) return s | 0x7E;
+    int e;
+    const float m = frexpf(a, &e);                  // a = m 2^e, m in [0.5, 1)
+    int E = e - 1;                                  // a = (2 m) 2^E
+    if (a == 0.f || E < -6) {                       // subnormal range: multiples of 2^-9
+        const int q = (int)nearbyintf(a * 512.f);
+        return s | (unsigned char)(q >= 8 ? 0x08 : q);
+    }
+    int q = (int)nearbyintf((2.f * m - 1.f) * 8.f);
+    if (q == 8) { q = 0; ++E; }
+    unsigned char code = (unsigned char)(((E + 7) << 3) | q);
+    if (E > 8 || code > 0x7E) code = 0x7E;
+    return s | code;
+}
+
+int DepthEngine::pack_mx(const float *src, int N, int K, PackedW &out, const float *bias) {
+    PB_CHECK(K % 128 == 0, PB_ERR_ARG, "pack_mx: K %d", K);
+    const int64_t Np = round_up(N, 256), ld = K + K / 2;           // halfs per row: K fp16 + K fp8 bytes
+    float mlo = 0.f;
+    for (int64_t i = 0; i < (int64_t)N * K; ++i) {
+        const float v = src[i];
+        mlo = fmaxf(mlo, fabsf(v - (float)(f16)v));
+    }
+    int pw = 0;
+    if (mlo > 0.f) { int e; frexpf(mlo, &e); pw = 8 - e; }          // max |w_lo| 2^pw in [128, 256)
+    std::vector<f16> h((size_t)Np * ld, (f16)0.f);
+    for (int n = 0; n < N; ++n) {
+        f16 *d = h.data() + (int64_t)n * ld;
+        unsigned char *d8 = (unsigned char *)(d + K);
+        for (int k = 0; k < K; ++k) {
+            const float v = src[(int64_t)n * K + k];
+            const f16 hi = (f16)v;
+            d[k] = hi;
+            d8[k] = pb_f32_to_e4m3(ldexpf(v - (float)hi, pw));
+        }
+    }
+    void *p = nullptr;
+    PB_HIP(hipMalloc(&p, h.size() * 2));
+    owned_.push_back(p);
+    PB_HIP(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    out.w = (f16 *)p; out.N = N; out.K = (int)ld; out.Kreal = K; out.sa = 0; out.sw = 0; out.Cseg = K;
+    out.nk16 = K / 64; out.mx_pw = pw;
+    out.bias = nullptr;
+    if (bias) return upload_f32(bias, N, &out.bias);
+    return 0;
+}
+
 DepthEngine::~DepthEngine() {
     hipSetDevice(device);
     if (stream) hipStreamSynchronize(stream);
@@ -141,6 +192,8 @@ int DepthEngine::load(const pb_tensor *w, int n) {
             if (strlen(e) == 3) { vit_sw_ = e[0] == '1'; head_sa_ = e[1] == '1'; head_sw_ = e[2] == '1'; }
         }
         hs_ = head_sa_ ? 2 : 1;
+        const char *mx = getenv("PB_MX");
+        vit_mx_ = vit_sw_ && D % 128 == 0 && !(mx && mx[0] == '0');
     }
     PB_CHECK(D % 128 == 0 && D <= 1024 && D / cfg_.heads == 64, PB_ERR_ARG, "embed_dim %d / heads %d unsupported", D,
              cfg_.heads);
@@ -183,7 +236,7 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         UP(B.ls1, b + "ls1.gamma", D);     UP(B.ls2, b + "ls2.gamma", D);
         int r;
         { NEED(wt, b + "attn.qkv.weight", (int64_t)3 * D * D); NEED(bs, b + "attn.qkv.bias", 3 * D);
-          if ((r = pack(wt, 3 * D, D, D, B.qkv, bs, 1, 0, vit_sw_))) return r; }
+          if ((r = vit_mx_ ? pack_mx(wt, 3 * D, D, B.qkv, bs) : pack(wt, 3 * D, D, D, B.qkv, bs, 1, 0, vit_sw_))) return r; }
         // LayerScale (layer_scale.py:27-28) is folded into the weights: x + g*(W y + b) = x + (g.W) y + g.b, so the GEMM
         // can accumulate straight onto the residual stream
         auto pack_scaled = [&](const float *wt, const float *bs, const float *g, int N, int K, PackedW &out) -> int {
@@ -192,12 +245,12 @@ int DepthEngine::load(const pb_tensor *w, int n) {
                 for (int k = 0; k < K; ++k) ws[(size_t)n * K + k] = wt[(size_t)n * K + k] * g[n];
                 bb[n] = bs[n] * g[n];
             }
-            return pack(ws.data(), N, K, K, out, bb.data(), 1, 0, vit_sw_);
+            return vit_mx_ ? pack_mx(ws.data(), N, K, out, bb.data()) : pack(ws.data(), N, K, K, out, bb.data(), 1, 0, vit_sw_);
         };
         { NEED(wt, b + "attn.proj.weight", (int64_t)D * D); NEED(bs, b + "attn.proj.bias", D); NEED(g1, b + "ls1.gamma", D);
           if ((r = pack_scaled(wt, bs, g1, D, D, B.proj))) return r; }
         { NEED(wt, b + "mlp.fc1.weight", (int64_t)Hd * D); NEED(bs, b + "mlp.fc1.bias", Hd);
-          if ((r = pack(wt, Hd, D, D, B.fc1, bs, 1, 0, vit_sw_))) return r; }
+          if ((r = vit_mx_ ? pack_mx(wt, Hd, D, B.fc1, bs) : pack(wt, Hd, D, D, B.fc1, bs, 1, 0, vit_sw_))) return r; }
         { NEED(wt, b + "mlp.fc2.weight", (int64_t)D * Hd); NEED(bs, b + "mlp.fc2.bias", D); NEED(g2, b + "ls2.gamma", D);
           if ((r = pack_scaled(wt, bs, g2, D, Hd, B.fc2))) return r; }
     }
@@ -411,11 +464,12 @@ int DepthEngine::prepare(int B, int H, int W) {
         pos_ = (float *)carve((size_t)ntok_ * D * 4);
         patchA_ = (f16 *)carve((size_t)round_up((int64_t)B * P_, 256) * 640 * 2);
         X_ = (float *)carve((size_t)rows * D * 4);
-        Y_ = (f16 *)carve((size_t)rows * D * 2);
+        const size_t mxs = vit_mx_ ? 3 : 2;          // bytes per element of a GEMM-input row: fp16 (+ an fp8 copy, gemm.h nk16)
+        Y_ = (f16 *)carve((size_t)rows * D * mxs);
         const size_t qkb = (size_t)B * cfg_.heads * ntp_ * 64 * 2 + slack;
         Q_ = (f16 *)carve(qkb); K_ = (f16 *)carve(qkb); Vt_ = (f16 *)carve(qkb);
-        AO_ = (f16 *)carve((size_t)rows * D * 2);
-        Hd_ = (f16 *)carve((size_t)rows * 4 * D * 2);
+        AO_ = (f16 *)carve((size_t)rows * D * mxs);
+        Hd_ = (f16 *)carve((size_t)rows * 4 * D * mxs);
         // split-fp16 head (hs_ = 2): every head map holds [hi | lo] per pixel / token
         for (int i = 0; i < 4; ++i) feat_[i] = (f16 *)carve((size_t)round_up((int64_t)B * P_, 256) * D * 2 * hs_);
         for (int i = 0; i < 4; ++i) {
@@ -486,12 +540,13 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
             a.kwrap = w.sw ? (1 + w.sa) * w.Cseg / 64 : 0;
         }
     }
+    if (w.nk16) { a.nk16 = w.nk16; a.mx_scale_a = 127 - kMxPa; a.mx_scale_b = 127 - w.mx_pw; }
     if (!a.N) a.N = w.N;
     if (!a.bias) a.bias = w.bias;
     a.zero = zero_;
     const double flops = 2.0 * a.M * (double)a.N * w.Kreal;
     const double bytes = 2.0 * ((double)a.M * w.Kreal + (double)a.N * w.Kreal + (double)a.M * a.N);
-    tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes, 1.0 + w.sa + w.sw);
+    tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes, 1.0 + w.sa + w.sw + (w.nk16 ? 0.5 : 0.0));
     if (tile == TILE_AUTO) tile = amode == A_CONV ? conv_tile : gemm_tile;
     int r = launch_gemm(stream, amode, epi, tile, a);
     toc();
@@ -534,39 +589,43 @@ int DepthEngine::vit(int n) {
     }
     snapshot("tokens");
     const double ln_bytes = (double)n * ntok_ * D * 6.0;
+    // MX mode: rows of Y_ / AO_ / Hd_ are [fp16 (K) | fp8 (K bytes)], i.e. 1.5 K halfs apart; the fp8 copy is stored x 2^kMxPa
+    const int ldy = vit_mx_ ? D + D / 2 : D, o8 = vit_mx_ ? 2 * D : 0;
+    const float o8s = (float)(1 << kMxPa);
     for (int i = 0; i < cfg_.depth; ++i) {
         const Block &b = blocks_[i];
         tic(F_LN, 0, ln_bytes);
-        r = launch_layernorm(stream, X_, b.ln1g, b.ln1b, Y_, n, ntp_, ntok_, D, 1e-6f, 0);
+        r = launch_layernorm(stream, X_, b.ln1g, b.ln1b, Y_, n, ntp_, ntok_, D, 1e-6f, 0, ldy, 0, o8, o8s);
         toc();
         if (r) return r;
         {
             GemmArgs a;
-            a.A = Y_; a.lda = D; a.M = M;
+            a.A = Y_; a.lda = ldy; a.M = M;
             a.q = Q_; a.k = K_; a.vt = Vt_; a.ntp = ntp_; a.heads = cfg_.heads; a.D = D; a.qscale = PB_QSCALE;
             if ((r = gemm(A_DENSE, EPI_QKV, a, b.qkv))) return r;
         }
         tic(F_ATTN, 4.0 * n * cfg_.heads * (double)ntok_ * ntok_ * 64.0, (double)n * ntok_ * D * 2.0 * 4.0);
-        r = launch_attention(stream, Q_, K_, Vt_, AO_, n, cfg_.heads, ntp_, ntok_, D);
+        r = launch_attention(stream, Q_, K_, Vt_, AO_, n, cfg_.heads, ntp_, ntok_, ldy, 0, o8, o8s);
         toc();
         if (r) return r;
         {
             GemmArgs a;
-            a.A = AO_; a.lda = D; a.M = M; a.resid = X_; a.ldr = D; a.gamma = b.ls1;
+            a.A = AO_; a.lda = ldy; a.M = M; a.resid = X_; a.ldr = D; a.gamma = b.ls1;
             if ((r = gemm(A_DENSE, EPI_RESID, a, b.proj))) return r;
         }
         tic(F_LN, 0, ln_bytes);
-        r = launch_layernorm(stream, X_, b.ln2g, b.ln2b, Y_, n, ntp_, ntok_, D, 1e-6f, 0);
+        r = launch_layernorm(stream, X_, b.ln2g, b.ln2b, Y_, n, ntp_, ntok_, D, 1e-6f, 0, ldy, 0, o8, o8s);
         toc();
         if (r) return r;
         {
             GemmArgs a;
-            a.A = Y_; a.lda = D; a.M = M; a.out = Hd_; a.ldo = 4 * D; a.act = ACT_GELU;
+            a.A = Y_; a.lda = ldy; a.M = M; a.out = Hd_; a.ldo = 4 * ldy; a.act = ACT_GELU;
+            if (vit_mx_) { a.o8_off = 4 * D * 2; a.o8_scale = o8s; }
             if ((r = gemm(A_DENSE, EPI_STD, a, b.fc1))) return r;
         }
         {
             GemmArgs a;
-            a.A = Hd_; a.lda = 4 * D; a.M = M; a.resid = X_; a.ldr = D; a.gamma = b.ls2;
+            a.A = Hd_; a.lda = 4 * ldy; a.M = M; a.resid = X_; a.ldr = D; a.gamma = b.ls2;
             if ((r = gemm(A_DENSE, EPI_RESID, a, b.fc2))) return r;
         }
         if (debug) snapshot("block" + std::to_string(i));

@@ -26,6 +26,16 @@ struct GemmArgs {
     // dense: K tile kt reads A tile (kt >= kwrap ? kt - kwrap : kt); conv: channel cursor c reads channel (c >= kwrap ? c - kwrap : c)
     // of a pixel (cC = channels per tap of the concatenated K axis, cLd = pixel stride of the [hi | lo] image).  0 = off.
     int kwrap = 0;
+    // MX-fp8 correction segments (split-fp16 mode on shapes that allow it): the operand rows are [fp16 part | fp8 part] in memory - K tiles
+    // [0, nk16) hold 64 halfs, tiles [nk16, K / 64) hold 128 OCP e4m3 bytes (same 128 bytes per row and tile, so the staging does
+    // not change) and are multiplied with v_mfma_scale_f32_32x32x64_f8f6f4 into the SAME accumulators; the two E8M0 scale bytes undo
+    // the power-of-two scalings the fp8 copies were stored with (a_hi 2^pa x w_lo 2^pw, a_lo 2^(pa + 12) x w_hi 2^(pw - 12)).
+    // `K` counts 64-half units of the whole row.  nk16 = 0: every tile is fp16.
+    int nk16 = 0, mx_scale_a = 127, mx_scale_b = 127;
+    // EPI_STD direct epilogue: also store fp8(v * o8_scale) - the A operand of a consumer's fp8 segment - at byte offset o8_off of
+    // the output row (after its fp16 part); 0 = off
+    int o8_off = 0;
+    float o8_scale = 16.f;
     // fp16 outputs (out, out2) also store the rounding residual (f16)(v - (float)(f16)v) at element offset +lo_off, and the
     // skip tensors add1 / add2 are read as hi + lo.  0 = off.
     int lo_off = 0;

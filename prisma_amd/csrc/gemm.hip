@@ -21,6 +21,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 // All CUs start their first tile together and every tile of a launch takes the same time, so without help every
@@ -42,6 +44,18 @@ __device__ __forceinline__ void stagger_start(int stagger, int first_wave) {
 // rows before the first store: the compiler cannot hoist a load above a store that may alias it, and
 // a load -> use -> store chain per row costs one full memory latency each (measured 23k-53k
 // cycles per 256x256 tile before this restructuring, 2-3x the MFMA main loop's share).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// two 16-byte fragments (the ones the fp16 path feeds to k-steps 2q and 2q + 1) as the 32-byte operand of one fp8 MFMA: any
+// assignment of the tile's bytes to (lane half, byte slot) is valid as long as A and B use the same one (tools/probe/mx_probe.hip)
+__device__ __forceinline__ i32x8 cat_frag(f16x8 a, f16x8 b) {
+    union { f16x8 h[2]; i32x8 v; } u;
+    u.h[0] = a; u.h[1] = b;
+    return u.v;
+}
+__device__ __forceinline__ f32x16 mfma_mx8(f16x8 a0, f16x8 a1, f16x8 b0, f16x8 b1, f32x16 c, int sa, int sb) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat_frag(a0, a1), cat_frag(b0, b1), c, 0, 0, 0, sa, 0, sb);
+}
+
 struct EpiAux {
     f16x8 a1, a2;       // EPI_STD skip tensors
     f32x4 r0, r1;       // EPI_RESID residual / EPI_PATCH pos-embed
@@ -463,6 +477,15 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 o[0] = (f16)(v0[q] * qs); o[1] = (f16)(v1[q] * qs);
                 if (!CHECK || ok[q]) *(f16x2 *)(dst + off[q]) = o;
             }
+            if constexpr (EPI == EPI_STD && !LO) {
+                if (p.o8_off) {                  // fp8 copy for a consumer's MX correction segment (gemm.h)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned short o8 = pb_fp8x2(v0[q] * p.o8_scale, v1[q] * p.o8_scale);
+                        if (!CHECK || ok[q]) *(unsigned short *)((char *)p.out + (off[q] - nc) * 2 + p.o8_off + nc) = o8;
+                    }
+                }
+            }
             if constexpr (EPI != EPI_QKV) {
                 if constexpr (LO) {              // split-fp16 consumers read [hi | lo]
 #pragma unroll
@@ -751,6 +774,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
         for (int t = 0; t < TN; ++t) bf[buf][t] = *(const f16x8 *)(sb + b_off[t] + c);
     };
     static_assert(NS == 2 || (NS == 3 && (NA + NB == 8 || NA + NB == 6 || NA + NB == 4)), "stage count / DMAs per stage");
+    constexpr bool MXOK = TM * TN <= 4;          // the single-barrier 256 x 256 A/B variant has no registers to spare for the fp8 operands
+    const int n16 = MXOK && p.nk16 > 0 && p.nk16 < nk ? p.nk16 : nk;
+    const int mxa = p.mx_scale_a * 0x01010101, mxb = p.mx_scale_b * 0x01010101;
     stage(0, 0);
     if constexpr (NS == 3) { if (nk > 1) stage(1, 1); }
     int cbuf = 0;                                           // buffer of tile kt
@@ -767,6 +793,22 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
         } else {
             if (kt + 1 < nk) stage(cbuf ^ 1, kt + 1);
             cbuf ^= 1;
+        }
+        if (MXOK && kt >= n16) {
+            // MX-fp8 tile (gemm.h nk16): the fragments of k-steps 2q, 2q + 1 are the 32-byte operands of one scaled MFMA
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                if (q2) load_frags(0, sb, 2);
+                load_frags(1, sb, 2 * q2 + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = mfma_mx8(af[0][i], af[1][i], bf[0][j], bf[1][j], acc[i][j], mxa, mxb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            continue;
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -1003,7 +1045,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     if (wr == 1) PB_BAR();                               // stagger the second wave group by one barrier
     if (p.dbg) ts1 = __builtin_readcyclecounter();
 
-    for (int t = 0; t < nk; ++t) {
+    const int mxa = p.mx_scale_a * 0x01010101, mxb = p.mx_scale_b * 0x01010101;
+    // one K tile; FP8 tiles hold 128 e4m3 bytes per row and go through the MX-scaled MFMA (gemm.h nk16): same staging, same fragment
+    // reads, 4 MFMAs of 64 cycles instead of 8 of 32 per phase - twice the K per tile at the same matrix-pipe time
+    auto tile = [&](auto fp8_tag, int t) {
+        constexpr bool FP8 = decltype(fp8_tag)::value;
         const char *sb = smem + (t & 1) * BUF;
         // ================= p0 =================
         if ((VAR != 3 && VAR != 5 && VAR != 6) || t == 0) {
@@ -1018,12 +1064,21 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
-        if (VAR != 5)
+        if (VAR != 5) {
+            if constexpr (FP8) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+                for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[rt][0], 0, 0, 0);
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[rt][0] = mfma_mx8(fa[rt][2 * q2], fa[rt][2 * q2 + 1], fb0[2 * q2], fb0[2 * q2 + 1], acc[rt][0], mxa, mxb);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[rt][0], 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
         // ================= p1 =================
@@ -1035,12 +1090,21 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
-        if (VAR != 5)
+        if (VAR != 5) {
+            if constexpr (FP8) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+                for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[rt][1], 0, 0, 0);
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[rt][1] = mfma_mx8(fa[rt][2 * q2], fa[rt][2 * q2 + 1], fb1[2 * q2], fb1[2 * q2 + 1], acc[rt][1], mxa, mxb);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[rt][1], 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
         // ================= p2 =================
@@ -1054,12 +1118,21 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
-        if (VAR != 5)
+        if (VAR != 5) {
+            if constexpr (FP8) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+                for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[2 + rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[2 + rt][1], 0, 0, 0);
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[2 + rt][1] = mfma_mx8(fa[rt][2 * q2], fa[rt][2 * q2 + 1], fb1[2 * q2], fb1[2 * q2 + 1], acc[2 + rt][1], mxa, mxb);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[2 + rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[2 + rt][1], 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
         // ================= p3 =================
@@ -1067,14 +1140,30 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
-        if (VAR != 5)
+        if (VAR != 5) {
+            if constexpr (FP8) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+                for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                acc[2 + rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[2 + rt][0], 0, 0, 0);
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[2 + rt][0] = mfma_mx8(fa[rt][2 * q2], fa[rt][2 * q2 + 1], fb0[2 * q2], fb0[2 * q2 + 1], acc[2 + rt][0], mxa, mxb);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[2 + rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[2 + rt][0], 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
+    };
+    {
+        const int n16 = p.nk16 > 0 && p.nk16 < nk ? p.nk16 : nk;
+        for (int t = 0; t < n16; ++t) tile(std::false_type{}, t);
+        if constexpr (VAR == 0) {
+            for (int t = n16; t < nk; ++t) tile(std::true_type{}, t);
+        }
     }
     if (wr == 0) PB_BAR();                               // re-align the two wave groups
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

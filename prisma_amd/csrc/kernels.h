@@ -2,15 +2,16 @@
 #pragma once
 #include "common.h"
 
+// o8_off != 0: also store fp8(o * o8_scale) at byte offset o8_off of every output row (gemm.h nk16)
 int launch_attention(hipStream_t s, const f16 *q, const f16 *k, const f16 *vt, f16 *o, int B, int heads, int ntp,
-                     int ntok, int ldo, int variant = 0);
+                     int ntok, int ldo, int variant = 0, int o8_off = 0, float o8_scale = 16.f);
 
 // LayerNorm(eps) of fp32 rows -> fp16 rows.  Input row r = (b, t) of [B, ntp, D]; only t < ntok are
 // normalised.  drop_cls = 0: output row = input row (same [B, ntp] indexing, ld = D).
 // drop_cls = 1: output is compact [B, ntok-1, D] without the class token (DPT taps).
 // ldy = output row stride (0 = D); lo_off != 0: also store the rounding residual of every output at +lo_off (split fp16).
 int launch_layernorm(hipStream_t s, const float *x, const float *g, const float *b, f16 *y, int B, int ntp, int ntok,
-                     int D, float eps, int drop_cls, int ldy = 0, int lo_off = 0);
+                     int D, float eps, int drop_cls, int ldy = 0, int lo_off = 0, int o8_off = 0, float o8_scale = 16.f);
 
 // resid[b, 0, :] = cls + pos[0]
 int launch_cls_rows(hipStream_t s, float *resid, const float *cls, const float *pos, int B, int ntp, int D);
