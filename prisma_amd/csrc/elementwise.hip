@@ -13,7 +13,7 @@ namespace {
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                         const float *__restrict__ bt, f16 *__restrict__ y, int B,
                                                         int ntp, int ntok, int D, float eps, int drop_cls, int ldy,
-                                                        int lo_off, int o8_off, float o8_scale) {
+                                                        int lo_off, int o8_off, float o8_scale, int lo8_pa) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= (int64_t)B * ntok) return;
@@ -58,7 +58,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
                 l[e] = (f16)(t - (float)o[e]);
             }
             *(f16x4 *)(yr + c) = o;
-            if (lo_off) *(f16x4 *)(yr + c + lo_off) = l;       // split-fp16 consumers read [hi | lo] (gemm.h)
+            if (lo_off && lo8_pa >= 0) {                       // split map with e4m3 residual parts: [hi | hi8 | lo8] (gemm.h lo8)
+                const float shi = __builtin_ldexpf(1.f, lo8_pa), slo = __builtin_ldexpf(1.f, lo8_pa + 12);
+                float tv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tv[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+                *(int *)((char *)yr + 2 * lo_off + c) = pb_fp8x4((float)o[0] * shi, (float)o[1] * shi, (float)o[2] * shi, (float)o[3] * shi);
+                *(int *)((char *)yr + 3 * lo_off + c) = pb_fp8x4((tv[0] - (float)o[0]) * slo, (tv[1] - (float)o[1]) * slo, (tv[2] - (float)o[2]) * slo,
+                                                                 (tv[3] - (float)o[3]) * slo);
+            } else if (lo_off) *(f16x4 *)(yr + c + lo_off) = l;       // split-fp16 consumers read [hi | lo] (gemm.h)
             if (o8_off)                                        // fp8 copy after the row's fp16 part (gemm.h nk16)
                 *(int *)((char *)yr + o8_off + c) = pb_fp8x4((float)o[0] * o8_scale, (float)o[1] * o8_scale, (float)o[2] * o8_scale, (float)o[3] * o8_scale);
         }
@@ -133,7 +141,7 @@ __host__ __device__ inline float bilerp_scale(int in, int out, int align) {
 
 __global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int B,
                                                             int H, int W, int OH, int OW, int C8, int ldc, int align,
-                                                            float sy, float sx, int lo_off) {
+                                                            float sy, float sx, int lo_off, int lo8_pa) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * OH * OW * C8) return;
     const int c = (int)(i % C8);
@@ -150,6 +158,41 @@ __global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const f16 *__restric
     const f16x8 v11 = *(const f16x8 *)(base + ((int64_t)y1 * W + x1) * ldc);
     const float hy = 1.f - ly, hx = 1.f - lx;
     f16x8 o;
+    if (lo_off && lo8_pa >= 0) {     // split maps with e4m3 residual parts [hi | hi8 | lo8] (gemm.h lo8)
+        const float shi = __builtin_ldexpf(1.f, lo8_pa), slo = __builtin_ldexpf(1.f, lo8_pa + 12), inv = __builtin_ldexpf(1.f, -(lo8_pa + 12));
+        const int64_t o00 = ((int64_t)y0 * W + x0) * ldc, o01 = ((int64_t)y0 * W + x1) * ldc, o10 = ((int64_t)y1 * W + x0) * ldc,
+                      o11 = ((int64_t)y1 * W + x1) * ldc;
+        const char *bb = (const char *)(x + (int64_t)b * H * W * ldc) + 3 * lo_off + c * 8;
+        const int64_t po[4] = {o00, o01, o10, o11};
+        float lo[4][8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int2 u = *(const int2 *)(bb + po[t] * 2);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int wv = h ? u.y : u.x;
+                const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(wv, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(wv, true);
+                lo[t][4 * h + 0] = a[0] * inv; lo[t][4 * h + 1] = a[1] * inv; lo[t][4 * h + 2] = d[0] * inv; lo[t][4 * h + 3] = d[1] * inv;
+            }
+        }
+        float tv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = (float)v00[j] + lo[0][j], b2 = (float)v01[j] + lo[1][j], c2 = (float)v10[j] + lo[2][j], d = (float)v11[j] + lo[3][j];
+            tv[j] = hy * (hx * a + lx * b2) + ly * (hx * c2 + lx * d);
+            o[j] = (f16)tv[j];
+        }
+        f16 *dst = y + pix * ldc;
+        *(f16x8 *)(dst + c * 8) = o;
+        int2 h8, l8;
+        h8.x = pb_fp8x4((float)o[0] * shi, (float)o[1] * shi, (float)o[2] * shi, (float)o[3] * shi);
+        h8.y = pb_fp8x4((float)o[4] * shi, (float)o[5] * shi, (float)o[6] * shi, (float)o[7] * shi);
+        l8.x = pb_fp8x4((tv[0] - (float)o[0]) * slo, (tv[1] - (float)o[1]) * slo, (tv[2] - (float)o[2]) * slo, (tv[3] - (float)o[3]) * slo);
+        l8.y = pb_fp8x4((tv[4] - (float)o[4]) * slo, (tv[5] - (float)o[5]) * slo, (tv[6] - (float)o[6]) * slo, (tv[7] - (float)o[7]) * slo);
+        *(int2 *)((char *)dst + 2 * lo_off + c * 8) = h8;
+        *(int2 *)((char *)dst + 3 * lo_off + c * 8) = l8;
+        return;
+    }
     if (lo_off) {        // split-fp16 maps [hi | lo]: interpolate hi + lo, store the result's hi and lo
         const f16x8 l00 = *(const f16x8 *)(base + ((int64_t)y0 * W + x0) * ldc + lo_off);
         const f16x8 l01 = *(const f16x8 *)(base + ((int64_t)y0 * W + x1) * ldc + lo_off);
@@ -326,10 +369,10 @@ inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t
 }  // namespace
 
 int launch_layernorm(hipStream_t s, const float *x, const float *g, const float *b, f16 *y, int B, int ntp, int ntok,
-                     int D, float eps, int drop_cls, int ldy, int lo_off, int o8_off, float o8_scale) {
+                     int D, float eps, int drop_cls, int ldy, int lo_off, int o8_off, float o8_scale, int lo8_pa) {
     PB_CHECK(D % 4 == 0 && D <= 1024, -1, "layernorm: D=%d unsupported", D);
     hipLaunchKernelGGL(layernorm_kernel, dim3(nblk((int64_t)B * ntok, 4)), dim3(256), 0, s, x, g, b, y, B, ntp, ntok,
-                       D, eps, drop_cls, ldy ? ldy : D, lo_off, o8_off, o8_scale);
+                       D, eps, drop_cls, ldy ? ldy : D, lo_off, o8_off, o8_scale, lo8_pa);
     PB_HIP(hipGetLastError());
     return 0;
 }
@@ -349,11 +392,11 @@ int launch_preprocess(hipStream_t s, const uint8_t *frames, int B, int H, int W,
 }
 
 int launch_bilinear_nhwc(hipStream_t s, const f16 *x, f16 *y, int B, int H, int W, int OH, int OW, int C, int ldc,
-                         int align, int lo_off) {
+                         int align, int lo_off, int lo8_pa) {
     PB_CHECK(C % 8 == 0 && ldc % 8 == 0, -1, "bilinear: C=%d ldc=%d must be multiples of 8", C, ldc);
     const float sy = bilerp_scale(H, OH, align), sx = bilerp_scale(W, OW, align);
     hipLaunchKernelGGL(bilinear_nhwc_kernel, dim3(nblk((int64_t)B * OH * OW * (C / 8))), dim3(256), 0, s, x, y, B, H,
-                       W, OH, OW, C / 8, ldc, align, sy, sx, lo_off);
+                       W, OH, OW, C / 8, ldc, align, sy, sx, lo_off, lo8_pa);
     PB_HIP(hipGetLastError());
     return 0;
 }

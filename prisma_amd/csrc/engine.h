@@ -19,6 +19,9 @@ struct PackedW {
     int sa = 0, sw = 0, Cseg = 0;
     // MX-fp8 correction (gemm.h nk16): rows are [w_hi fp16 (Kin) | w_lo e4m3 (Kin bytes, scaled by 2^mx_pw)]; K counts 64-half units of the row
     int nk16 = 0, mx_pw = 0;
+    // mx3: weights AND activations split with e4m3 residual parts: per tap [w_hi fp16 (Cseg) | w_lo8 (Cseg bytes) | w_hi8 (Cseg bytes)]
+    // = 2 Cseg halfs, meeting a split map's [hi | hi8 | lo8] pixel (gemm.h mx_period, lo8); K = taps x 2 Cseg
+    int mx3 = 0;
 };
 unsigned char pb_f32_to_e4m3(float x);     // OCP e4m3fn, round to nearest even, saturating (engine.hip)
 
@@ -92,7 +95,8 @@ class DepthEngine {
     int vit_sw_ = 0, head_sa_ = 0, head_sw_ = 0, hs_ = 1;
     // vit_mx_: the ViT linears' weight residual runs as an MX-fp8 segment (half the matrix-pipe time of an fp16 pass); their A
     // operands (LayerNorm out, attention out, GELU out) then carry an fp8 copy after the fp16 part of each row (row stride 1.5 K)
-    int vit_mx_ = 0;
+    int vit_mx_ = 0, head_mx_ = 0;              // head_mx_: the DPT head's maps / weights carry e4m3 residual parts (PackedW::mx3)
+    static constexpr int kLo8Pa = 3;            // ... stored as hi 2^3 and lo 2^15 (|x| up to 56 before the copy saturates)
     static constexpr int kMxPa = 4;             // fp8 activation copies are stored scaled by 2^4 (|a| up to 28 before saturation)
     int batch_cap(int H, int W) const;          // frames per chunk the 32-bit tensor offsets allow for this frame size
     std::map<std::string, const pb_tensor *> tmap_;

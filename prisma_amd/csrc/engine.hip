@@ -149,6 +149,40 @@ int DepthEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, co
     const int64_t Np = round_up(N, 256);
     const int segs = 1 + sa + sw, Cin = K / taps, Cp = Kpad / taps;
     PB_CHECK(K % taps == 0 && Kpad % taps == 0 && Cp >= Cin && (segs == 1 || Cp % 64 == 0), PB_ERR_ARG, "pack: K %d / Kpad %d / taps %d", K, Kpad, taps);
+    if (head_mx_ && sa && sw) {        // mx3 layout: per tap [w_hi fp16 | w_lo e4m3 2^pw | w_hi e4m3 2^(pw - 12)]
+        float mlo = 0.f, mhi = 0.f;
+        for (int64_t i = 0; i < (int64_t)N * K; ++i) {
+            const float v = src[i];
+            mhi = fmaxf(mhi, fabsf(v));
+            mlo = fmaxf(mlo, fabsf(v - (float)(f16)v));
+        }
+        int pw = 0, e = 0;
+        if (mlo > 0.f) { frexpf(mlo, &e); pw = 8 - e; }
+        if (mhi > 0.f) { frexpf(mhi, &e); pw = std::min(pw, 20 - e); }     // max |w_hi| 2^(pw - 12) < 256 too
+        const int64_t Kt = (int64_t)taps * 2 * Cp;
+        std::vector<f16> h((size_t)Np * Kt, (f16)0.f);
+        for (int n = 0; n < N; ++n)
+            for (int t = 0; t < taps; ++t) {
+                const float *s = src + (int64_t)n * K + (int64_t)t * Cin;
+                f16 *d = h.data() + (int64_t)n * Kt + (int64_t)t * 2 * Cp;
+                unsigned char *d8 = (unsigned char *)(d + Cp);
+                for (int k = 0; k < Cin; ++k) {
+                    const f16 hi = (f16)s[k];
+                    d[k] = hi;
+                    d8[k] = pb_f32_to_e4m3(ldexpf(s[k] - (float)hi, pw));
+                    d8[Cp + k] = pb_f32_to_e4m3(ldexpf((float)hi, pw - 12));
+                }
+            }
+        void *p = nullptr;
+        PB_HIP(hipMalloc(&p, h.size() * 2));
+        owned_.push_back(p);
+        PB_HIP(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        out.w = (f16 *)p; out.N = N; out.K = (int)Kt; out.Kreal = K; out.sa = 1; out.sw = 1; out.Cseg = Cp; out.mx3 = 1; out.mx_pw = pw;
+        out.nk16 = Cp / 64;
+        out.bias = nullptr;
+        if (bias) return upload_f32(bias, N, &out.bias);
+        return 0;
+    }
     const int64_t Kt = (int64_t)taps * segs * Cp;
     std::vector<f16> h((size_t)Np * Kt, (f16)0.f);
     for (int n = 0; n < N; ++n)
@@ -194,6 +228,7 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         hs_ = head_sa_ ? 2 : 1;
         const char *mx = getenv("PB_MX");
         vit_mx_ = vit_sw_ && D % 128 == 0 && !(mx && mx[0] == '0');
+        head_mx_ = head_sa_ && head_sw_ && !(mx && (mx[0] == '0' || mx[1] == '0'));      // PB_MX=10: MX in the ViT only
     }
     PB_CHECK(D % 128 == 0 && D <= 1024 && D / cfg_.heads == 64, PB_ERR_ARG, "embed_dim %d / heads %d unsupported", D,
              cfg_.heads);
@@ -530,7 +565,15 @@ int DepthEngine::prepare(int B, int H, int W) {
 int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int tile) {
     a.W = w.w;
     a.K = w.K;
-    if (w.sa || w.sw) {          // split-fp16 segments along K (gemm.h): the callers pass cC / lda of ONE part
+    if (w.mx3) {                 // [hi | hi8 | lo8] maps x [w_hi | w_lo8 | w_hi8] weights: fp16 tiles then fp8 tiles, per tap (gemm.h)
+        a.nk16 = w.nk16; a.mx_scale_a = 127 - kLo8Pa; a.mx_scale_b = 127 - w.mx_pw;
+        if (amode == A_CONV) {
+            PB_CHECK(a.cC == w.Cseg, PB_ERR_STATE, "mx conv: %d channels per part, weights packed for %d", a.cC, w.Cseg);
+            if (!a.cLd) a.cLd = 2 * a.cC;
+            a.cC = 2 * w.Cseg;
+            a.mx_period = 2 * w.Cseg / 64;
+        }
+    } else if (w.sa || w.sw) {          // split-fp16 segments along K (gemm.h): the callers pass cC / lda of ONE part
         if (amode == A_CONV) {
             PB_CHECK(a.cC == w.Cseg, PB_ERR_STATE, "split conv: %d channels per part, weights packed for %d", a.cC, w.Cseg);
             if (!a.cLd) a.cLd = (1 + w.sa) * a.cC;
@@ -540,13 +583,14 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
             a.kwrap = w.sw ? (1 + w.sa) * w.Cseg / 64 : 0;
         }
     }
-    if (w.nk16) { a.nk16 = w.nk16; a.mx_scale_a = 127 - kMxPa; a.mx_scale_b = 127 - w.mx_pw; }
+    if (w.nk16 && !w.mx3) { a.nk16 = w.nk16; a.mx_scale_a = 127 - kMxPa; a.mx_scale_b = 127 - w.mx_pw; }
+    if (a.lo_off && head_mx_) { a.lo8 = 1; a.lo8_pa = kLo8Pa; }
     if (!a.N) a.N = w.N;
     if (!a.bias) a.bias = w.bias;
     a.zero = zero_;
     const double flops = 2.0 * a.M * (double)a.N * w.Kreal;
     const double bytes = 2.0 * ((double)a.M * w.Kreal + (double)a.N * w.Kreal + (double)a.M * a.N);
-    tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes, 1.0 + w.sa + w.sw + (w.nk16 ? 0.5 : 0.0));
+    tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes, w.mx3 ? 2.0 : 1.0 + w.sa + w.sw + (w.nk16 ? 0.5 : 0.0));
     if (tile == TILE_AUTO) tile = amode == A_CONV ? conv_tile : gemm_tile;
     int r = launch_gemm(stream, amode, epi, tile, a);
     toc();
@@ -632,7 +676,8 @@ int DepthEngine::vit(int n) {
         const int tap = i - (cfg_.depth - 4);
         if (tap >= 0) {
             tic(F_LN, 0, ln_bytes);
-            r = launch_layernorm(stream, X_, normg_, normb_, feat_[tap], n, ntp_, ntok_, D, 1e-6f, 1, hs_ * D, head_sa_ ? D : 0);
+            r = launch_layernorm(stream, X_, normg_, normb_, feat_[tap], n, ntp_, ntok_, D, 1e-6f, 1, hs_ * D, head_sa_ ? D : 0, 0, 16.f,
+                                 head_mx_ ? kLo8Pa : -1);
             toc();
             if (r) return r;
             stages_["feat" + std::to_string(tap)] = Stage{feat_[tap], 3, 0, P_, 1, D, hs_ * D, (int64_t)P_ * D};
@@ -652,7 +697,7 @@ int DepthEngine::head(int n) {
     };
     auto bil = [&](const f16 *x, f16 *y, int h, int w, int oh, int ow, int c, int ld) -> int {
         tic(F_ELT, 0, (double)n * ((double)h * w + (double)oh * ow) * c * 2.0 * hs);
-        int rr = launch_bilinear_nhwc(stream, x, y, n, h, w, oh, ow, c, hs * ld, 1, lo(ld));
+        int rr = launch_bilinear_nhwc(stream, x, y, n, h, w, oh, ow, c, hs * ld, 1, lo(ld), head_mx_ ? kLo8Pa : -1);
         toc();
         return rr;
     };

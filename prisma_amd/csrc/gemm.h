@@ -7,7 +7,7 @@ enum { EPI_STD = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_PIXSHUF = 3, EPI_PATCH = 4, 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4,
        ACT_GRU_ZR = 5,     // N = 256 = [z | r]: z = sigmoid -> out; r = sigmoid, r * gru_h -> gru_rh (ld 384), nothing to out
        ACT_GRU_Q = 6 };    // N = 128: q = tanh; h = (1 - z) h + z q with z from gru_z (ld 256), h in gru_h (fp32, ld 128); h -> out
-enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256_SIMPLE = 4, TILE_256x128 = 5, TILE_256x128_S3 = 7, TILE_128_S3 = 8, TILE_256x64 = 9 };
+enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256x64 = 9 };      // (4, 5, 7, 8, 10: round-1 variants, measured slower, removed)
 
 struct GemmArgs {
     // operands: A row-major fp16 [M, lda] (dense) or NHWC image (conv); W fp16 [Npad, K], K % 64 == 0
@@ -30,8 +30,13 @@ struct GemmArgs {
     // [0, nk16) hold 64 halfs, tiles [nk16, K / 64) hold 128 OCP e4m3 bytes (same 128 bytes per row and tile, so the staging does
     // not change) and are multiplied with v_mfma_scale_f32_32x32x64_f8f6f4 into the SAME accumulators; the two E8M0 scale bytes undo
     // the power-of-two scalings the fp8 copies were stored with (a_hi 2^pa x w_lo 2^pw, a_lo 2^(pa + 12) x w_hi 2^(pw - 12)).
-    // `K` counts 64-half units of the whole row.  nk16 = 0: every tile is fp16.
-    int nk16 = 0, mx_scale_a = 127, mx_scale_b = 127;
+    // `K` counts 64-half units of the whole row.  nk16 = 0: every tile is fp16.  The pattern repeats every mx_period tiles
+    // (0 = the whole K axis): a convolution over split maps [hi fp16 (C) | hi e4m3 (C bytes) | lo e4m3 (C bytes)] per pixel has, per
+    // tap, C / 64 fp16 tiles followed by C / 64 fp8 tiles whose bytes [a_hi8 | a_lo8] meet the weights' [w_lo8 | w_hi8].
+    int nk16 = 0, mx_period = 0, mx_scale_a = 127, mx_scale_b = 127;
+    // with lo_off: the residual parts of split maps are e4m3 - outputs store fp8(hi 2^lo8_pa) at byte lo_off * 2 + n and
+    // fp8(lo 2^(lo8_pa + 12)) at byte lo_off * 3 + n of the pixel (lo_off = padded channels), skip tensors are read as hi + lo8
+    int lo8 = 0, lo8_pa = 3;
     // EPI_STD direct epilogue: also store fp8(v * o8_scale) - the A operand of a consumer's fp8 segment - at byte offset o8_off of
     // the output row (after its fp16 part); 0 = off
     int o8_off = 0;

@@ -56,6 +56,20 @@ __device__ __forceinline__ f32x16 mfma_mx8(f16x8 a0, f16x8 a1, f16x8 b0, f16x8 b
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat_frag(a0, a1), cat_frag(b0, b1), c, 0, 0, 0, sa, 0, sb);
 }
 
+// split maps with e4m3 residual parts (gemm.h lo8): per pixel [hi fp16 (C) | hi8 (C bytes) | lo8 (C bytes)], C = lo_off.
+// `pix` = element offset of the pixel's first half, `col` = channel.
+__device__ __forceinline__ void lo8_store2(f16 *base, int64_t pix, int col, int C, float v0, float v1, float s_hi, float s_lo) {
+    const f16 h0 = (f16)v0, h1 = (f16)v1;
+    char *b = (char *)(base + pix);
+    *(unsigned short *)(b + 2 * C + col) = pb_fp8x2((float)h0 * s_hi, (float)h1 * s_hi);
+    *(unsigned short *)(b + 3 * C + col) = pb_fp8x2((v0 - (float)h0) * s_lo, (v1 - (float)h1) * s_lo);
+}
+__device__ __forceinline__ f32x2 lo8_load2(const f16 *base, int64_t pix, int col, int C, float inv_lo) {
+    const unsigned short u = *(const unsigned short *)((const char *)(base + pix) + 3 * C + col);
+    const f32x2 f = __builtin_amdgcn_cvt_pk_f32_fp8((int)u, false);
+    return f * inv_lo;
+}
+
 struct EpiAux {
     f16x8 a1, a2;       // EPI_STD skip tensors
     f32x4 r0, r1;       // EPI_RESID residual / EPI_PATCH pos-embed
@@ -249,7 +263,11 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = (f16)(v[j] + cb[j]);
         *(f16x8 *)(p.out + row * p.ldo + co) = r;
-        if (p.lo_off) {
+        if (p.lo_off && p.lo8) {
+            const float shi = __builtin_ldexpf(1.f, p.lo8_pa), slo = __builtin_ldexpf(1.f, p.lo8_pa + 12);
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) lo8_store2(p.out, row * p.ldo, co + j, p.lo_off, v[j] + cb[j], v[j + 1] + cb[j + 1], shi, slo);
+        } else if (p.lo_off) {
             f16x8 l;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float t = v[j] + cb[j]; l[j] = (f16)(t - (float)(f16)t); }
@@ -314,7 +332,9 @@ __device__ __forceinline__ int col_map(int r, bool il) {        // tile-local B 
     return il ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;
 }
 
-template <int EPI, int TM, bool CHECK, bool LO>
+// LOM: 0 plain outputs, 1 split maps with fp16 residuals ([hi | lo]), 2 split maps with e4m3 residual parts (gemm.h lo8); each mode
+// is its own copy of the code so that the plain path keeps its register allocation
+template <int EPI, int TM, bool CHECK, int LOM>
 __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     const int n = wave_n0 + 2 * li;
@@ -339,6 +359,9 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
         co = wave_n0 - tap * p.ps_co + 2 * li;
         tap_dy = tap / p.ps_s; tap_dx = tap - tap_dy * p.ps_s;
     }
+    // lo8 (LO only): this lane's channel inside the pixel and the power-of-two scalings of the e4m3 parts
+    const int pcol = EPI == EPI_PIXSHUF ? co : nc;
+    const float lo8_shi = __builtin_ldexpf(1.f, p.lo8_pa), lo8_slo = __builtin_ldexpf(1.f, p.lo8_pa + 12), lo8_inv = __builtin_ldexpf(1.f, -(p.lo8_pa + 12));
 #pragma unroll
     for (int th = 0; th < TM * 2; ++th) {                   // 8 accumulator registers (= 16 rows) per pass
         const int tm = th >> 1, r0 = (th & 1) * 8;
@@ -380,11 +403,16 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add1 + off[q]);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
-                if constexpr (LO) {
+                if constexpr (LOM != 0) {
+                    if constexpr (LOM == 2) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add1 + off[q] + p.lo_off);
+                        for (int q = 0; q < 8; ++q) { const f32x2 l = lo8_load2(p.add1, off[q] - pcol, pcol, p.lo_off, lo8_inv); v0[q] += l[0]; v1[q] += l[1]; }
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                        for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add1 + off[q] + p.lo_off);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                    }
                 }
             }
             if (p.add2) {
@@ -393,11 +421,16 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add2 + off[q]);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
-                if constexpr (LO) {
+                if constexpr (LOM != 0) {
+                    if constexpr (LOM == 2) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add2 + off[q] + p.lo_off);
+                        for (int q = 0; q < 8; ++q) { const f32x2 l = lo8_load2(p.add2, off[q] - pcol, pcol, p.lo_off, lo8_inv); v0[q] += l[0]; v1[q] += l[1]; }
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                        for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add2 + off[q] + p.lo_off);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                    }
                 }
             }
             if (p.out2) {
@@ -407,13 +440,17 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                     o2[0] = (f16)fmaxf(v0[q], 0.f); o2[1] = (f16)fmaxf(v1[q], 0.f);
                     if (!CHECK || ok[q]) *(f16x2 *)(p.out2 + off[q]) = o2;
                 }
-                if constexpr (LO) {
+                if constexpr (LOM != 0) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const float r0 = fmaxf(v0[q], 0.f), r1 = fmaxf(v1[q], 0.f);
-                        f16x2 o2;
-                        o2[0] = (f16)(r0 - (float)(f16)r0); o2[1] = (f16)(r1 - (float)(f16)r1);
-                        if (!CHECK || ok[q]) *(f16x2 *)(p.out2 + off[q] + p.lo_off) = o2;
+                        if constexpr (LOM == 2) {
+                            if (!CHECK || ok[q]) lo8_store2(p.out2, off[q] - pcol, pcol, p.lo_off, r0, r1, lo8_shi, lo8_slo);
+                        } else {
+                            f16x2 o2;
+                            o2[0] = (f16)(r0 - (float)(f16)r0); o2[1] = (f16)(r1 - (float)(f16)r1);
+                            if (!CHECK || ok[q]) *(f16x2 *)(p.out2 + off[q] + p.lo_off) = o2;
+                        }
                     }
                 }
             }
@@ -477,7 +514,7 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 o[0] = (f16)(v0[q] * qs); o[1] = (f16)(v1[q] * qs);
                 if (!CHECK || ok[q]) *(f16x2 *)(dst + off[q]) = o;
             }
-            if constexpr (EPI == EPI_STD && !LO) {
+            if constexpr (EPI == EPI_STD && LOM == 0) {
                 if (p.o8_off) {                  // fp8 copy for a consumer's MX correction segment (gemm.h)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -487,12 +524,16 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 }
             }
             if constexpr (EPI != EPI_QKV) {
-                if constexpr (LO) {              // split-fp16 consumers read [hi | lo]
+                if constexpr (LOM != 0) {              // split-fp16 consumers read [hi | lo] (or [hi | hi8 | lo8], gemm.h lo8)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        f16x2 o;
-                        o[0] = (f16)(v0[q] - (float)(f16)v0[q]); o[1] = (f16)(v1[q] - (float)(f16)v1[q]);
-                        if (!CHECK || ok[q]) *(f16x2 *)(dst + off[q] + p.lo_off) = o;
+                        if constexpr (LOM == 2) {
+                            if (!CHECK || ok[q]) lo8_store2(dst, off[q] - pcol, pcol, p.lo_off, v0[q], v1[q], lo8_shi, lo8_slo);
+                        } else {
+                            f16x2 o;
+                            o[0] = (f16)(v0[q] - (float)(f16)v0[q]); o[1] = (f16)(v1[q] - (float)(f16)v1[q]);
+                            if (!CHECK || ok[q]) *(f16x2 *)(dst + off[q] + p.lo_off) = o;
+                        }
                     }
                 }
             }
@@ -506,13 +547,19 @@ __device__ __forceinline__ void direct_epilogue_f16(const GemmArgs &p, f32x16 (&
     // split-fp16 outputs (p.lo_off) take their own copy of the code: the plain path keeps its register allocation
     if constexpr (EPI == EPI_STD || EPI == EPI_PIXSHUF) {
         if (p.lo_off) {
-            if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false, true>(p, acc, wave_m0, wave_n0, lane);
-            else direct_epilogue_f16_impl<EPI, TM, true, true>(p, acc, wave_m0, wave_n0, lane);
+            const bool inner = wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N;
+            if (p.lo8) {
+                if (inner) direct_epilogue_f16_impl<EPI, TM, false, 2>(p, acc, wave_m0, wave_n0, lane);
+                else direct_epilogue_f16_impl<EPI, TM, true, 2>(p, acc, wave_m0, wave_n0, lane);
+            } else {
+                if (inner) direct_epilogue_f16_impl<EPI, TM, false, 1>(p, acc, wave_m0, wave_n0, lane);
+                else direct_epilogue_f16_impl<EPI, TM, true, 1>(p, acc, wave_m0, wave_n0, lane);
+            }
             return;
         }
     }
-    if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false, false>(p, acc, wave_m0, wave_n0, lane);
-    else direct_epilogue_f16_impl<EPI, TM, true, false>(p, acc, wave_m0, wave_n0, lane);
+    if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false, 0>(p, acc, wave_m0, wave_n0, lane);
+    else direct_epilogue_f16_impl<EPI, TM, true, 0>(p, acc, wave_m0, wave_n0, lane);
 }
 
 // Accumulators -> per-wave LDS patch -> 8-column chunks -> fused store.  `smem` must be free of live
@@ -775,7 +822,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     };
     static_assert(NS == 2 || (NS == 3 && (NA + NB == 8 || NA + NB == 6 || NA + NB == 4)), "stage count / DMAs per stage");
     constexpr bool MXOK = TM * TN <= 4;          // the single-barrier 256 x 256 A/B variant has no registers to spare for the fp8 operands
-    const int n16 = MXOK && p.nk16 > 0 && p.nk16 < nk ? p.nk16 : nk;
+    const int mxper = p.mx_period > 0 ? p.mx_period : nk;
+    const int n16 = MXOK && p.nk16 > 0 && p.nk16 < mxper ? p.nk16 : mxper;
+    int kphase = 0;                              // kt % mxper
     const int mxa = p.mx_scale_a * 0x01010101, mxb = p.mx_scale_b * 0x01010101;
     stage(0, 0);
     if constexpr (NS == 3) { if (nk > 1) stage(1, 1); }
@@ -794,7 +843,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             if (kt + 1 < nk) stage(cbuf ^ 1, kt + 1);
             cbuf ^= 1;
         }
-        if (MXOK && kt >= n16) {
+        const bool is8 = MXOK && kphase >= n16;
+        kphase = kphase + 1 == mxper ? 0 : kphase + 1;
+        if (is8) {
             // MX-fp8 tile (gemm.h nk16): the fragments of k-steps 2q, 2q + 1 are the 32-byte operands of one scaled MFMA
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
@@ -1158,11 +1209,18 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
     };
-    {
+    if constexpr (AMODE == A_DENSE) {            // [fp16 tiles | fp8 tiles] once
         const int n16 = p.nk16 > 0 && p.nk16 < nk ? p.nk16 : nk;
         for (int t = 0; t < n16; ++t) tile(std::false_type{}, t);
         if constexpr (VAR == 0) {
             for (int t = n16; t < nk; ++t) tile(std::true_type{}, t);
+        }
+    } else {                                     // per tap (mx_period tiles): fp16 tiles, then fp8 tiles
+        const int per = p.mx_period > 0 ? p.mx_period : nk;
+        const int n16 = p.nk16 > 0 && p.nk16 < per ? p.nk16 : per;
+        for (int t0 = 0; t0 < nk; t0 += per) {
+            for (int t = t0; t < t0 + n16; ++t) tile(std::false_type{}, t);
+            for (int t = t0 + n16; t < t0 + per; ++t) tile(std::true_type{}, t);
         }
     }
     if (wr == 0) PB_BAR();                               // re-align the two wave groups
@@ -1251,14 +1309,8 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
         return launch_t<256, 32, 4, 1, AMODE, EPI>(s, a);
     } else {
         if (tile == TILE_256) return launch_g8<AMODE, EPI>(s, a);
-        if (tile == TILE_256_SIMPLE) return launch_t<256, 256, 2, 4, AMODE, EPI>(s, a);
-        if (tile == TILE_256x128) return launch_t<256, 128, 4, 2, AMODE, EPI>(s, a);
         if constexpr (EPI == EPI_STD) {
             if (tile == TILE_256x64) return launch_t<256, 64, 4, 1, AMODE, EPI>(s, a);
-        }
-        if constexpr (EPI == EPI_STD || EPI == EPI_F32) {
-            if (tile == TILE_256x128_S3) return launch_t<256, 128, 4, 2, AMODE, EPI, false, 3>(s, a);
-            if (tile == TILE_128_S3) return launch_t<128, 128, 2, 2, AMODE, EPI, false, 3>(s, a);
         }
         return launch_t<128, 128, 2, 2, AMODE, EPI>(s, a);
     }
@@ -1291,13 +1343,6 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         if (tile == TILE_128 && (epi == EPI_STD || epi == EPI_F32) && small_tile != TILE_128) tile = small_tile;
     }
     if (epi == EPI_QKV) PB_CHECK(a.D % (tile == TILE_128 ? 128 : 256) == 0 && a.ntp % 8 == 0, -1, "qkv epilogue: D=%d ntp=%d", a.D, a.ntp);
-    if (amode == A_DENSE && epi == EPI_STD && tile > 16) {      // timing-only ablations of the ping-pong kernel
-        if (tile == 18) return launch_g8<A_DENSE, EPI_STD, 1>(stream, a);
-        if (tile == 34) return launch_g8<A_DENSE, EPI_STD, 2>(stream, a);
-        if (tile == 50) return launch_g8<A_DENSE, EPI_STD, 3>(stream, a);
-        if (tile == 82) return launch_g8<A_DENSE, EPI_STD, 5>(stream, a);
-        if (tile == 98) return launch_g8<A_DENSE, EPI_STD, 6>(stream, a);
-    }
 #define PB_CASE(AM, EP) \
     if (amode == AM && epi == EP) return launch_tile<AM, EP>(stream, tile, a)
     PB_CASE(A_DENSE, EPI_STD);

@@ -11,7 +11,7 @@ int launch_attention(hipStream_t s, const f16 *q, const f16 *k, const f16 *vt, f
 // drop_cls = 1: output is compact [B, ntok-1, D] without the class token (DPT taps).
 // ldy = output row stride (0 = D); lo_off != 0: also store the rounding residual of every output at +lo_off (split fp16).
 int launch_layernorm(hipStream_t s, const float *x, const float *g, const float *b, f16 *y, int B, int ntp, int ntok,
-                     int D, float eps, int drop_cls, int ldy = 0, int lo_off = 0, int o8_off = 0, float o8_scale = 16.f);
+                     int D, float eps, int drop_cls, int ldy = 0, int lo_off = 0, int o8_off = 0, float o8_scale = 16.f, int lo8_pa = -1);
 
 // resid[b, 0, :] = cls + pos[0]
 int launch_cls_rows(hipStream_t s, float *resid, const float *cls, const float *pos, int B, int ntp, int D);
@@ -24,7 +24,7 @@ int launch_preprocess(hipStream_t s, const uint8_t *frames, int B, int H, int W,
 // NHWC fp16 bilinear resize (torch F.interpolate semantics), C % 8 == 0 with channel stride ldc.
 // lo_off != 0: x and y are split-fp16 maps [hi | lo] (lo at element offset +lo_off inside a pixel).
 int launch_bilinear_nhwc(hipStream_t s, const f16 *x, f16 *y, int B, int H, int W, int OH, int OW, int C, int ldc,
-                         int align_corners, int lo_off = 0);
+                         int align_corners, int lo_off = 0, int lo8_pa = -1);
 
 // net depth [B, nh, nw] fp32 -> bilinear(align_corners=False) -> [B, H, W] fp32 (optional) and
 // per-frame min/max (ordered-uint atomics in mm[2*B]); then heat encode to uint8 RGB.

@@ -12,9 +12,10 @@ w = synth.depth_anything_weights("vitl", seed=1234)
 frame = synth.frames(1, 720, 1280, seed=int(z["frame_seed"]))
 clip = synth.frames(B, 1080, 1920, seed=3)
 ref = z["depth_s8"].astype(np.float64)
-rows = (("f16", 0, None, "1"), ("split 111 + MX-fp8 ViT (default)", 1, "111", "1"), ("split 111, fp16 passes only", 1, "111", "0"),
+rows = (("f16", 0, None, "1"), ("split 111, MX-fp8 ViT + head (default)", 1, "111", "1"), ("split 111, MX-fp8 ViT only", 1, "111", "10"),
+        ("split 111, fp16 passes only", 1, "111", "0"),
         ("split 110", 1, "110", "0"), ("split 100", 1, "100", "0"), ("split 011", 1, "011", "0"), ("split 101", 1, "101", "0"))
-if len(sys.argv) > 2: rows = rows[:3]
+if len(sys.argv) > 2: rows = rows[:4]
 for name, prec, split, mx in rows:
     os.environ["PB_MX"] = mx
     if split: os.environ["PB_SPLIT"] = split
@@ -29,5 +30,5 @@ for name, prec, split, mx in rows:
     net.set_profiling(timing=True)
     net.infer_batch(clip, want_depth=False)
     st = {s["name"]: round(s["ms"], 1) for s in net.kernel_stats()}
-    print("%-34s relmax %.3e relL2 %.3e | %d x 1080p through the host API %.1f ms | kernel ms %s" % (name, emax, el2, B, dt * 1e3, st), flush=True)
+    print("%-40s relmax %.3e relL2 %.3e | %d x 1080p through the host API %.1f ms | kernel ms %s" % (name, emax, el2, B, dt * 1e3, st), flush=True)
     net.close()
