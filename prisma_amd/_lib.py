@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprisma_bands.so")
+LIB_PATH = os.environ.get("PRISMA_BANDS_LIB") or os.path.join(_HERE, "libprisma_bands.so")      # the override is for A/B timing of two builds
 
 
 class pb_tensor(C.Structure):

@@ -156,6 +156,10 @@ int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *we
         }
         c->raft = new RaftEngine(device_id);
         c->raft->split_w_ = prec == PB_PREC_SPLIT;
+        {
+            const char *mx = getenv("PB_MX");
+            c->raft->mx_ = c->raft->split_w_ && !(mx && mx[0] == '0');
+        }
         int r = c->raft->load(weights, n_weights);
         if (r) {
             delete c->raft;

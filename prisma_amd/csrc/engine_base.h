@@ -19,6 +19,9 @@ class EngineBase {
     KernelTimer timer;
     int conv_tile = TILE_AUTO;
     int split_w_ = 0;            // PB_PREC_SPLIT: weights packed as hi + lo fp16, two passes over K (set before load)
+    int mx_ = 0;                 // ... and where activations are split too (sa) the residual parts are e4m3: maps [hi | hi8 | lo8],
+                                 // weights [w_hi | w_lo8 | w_hi8] per tap, fp8 tiles through the MX-scaled MFMA (PackedW::mx3)
+    static constexpr int kLo8Pa = 3;
     const f16 *zero_page() const { return zero_; }
 
   protected:

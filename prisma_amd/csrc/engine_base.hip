@@ -73,6 +73,37 @@ int EngineBase::pack(const float *src, int N, int K, int Kpad, PackedW &out, con
     // GEMM reads the activations twice (gemm.h kwrap): a w_hi + a w_lo in one accumulator
     const int sw = split_w_ && Kpad % (64 * taps) == 0 && K % taps == 0 ? 1 : 0, sa = sw && sa_req ? 1 : 0, segs = 1 + sa + sw;
     const int Cin = sw ? K / taps : K, Cp = sw ? Kpad / taps : Kpad, tp = sw ? taps : 1;
+    if (sa && mx_) {             // mx3 layout (engine.hip DepthEngine::pack has the same one)
+        float mlo = 0.f, mhi = 0.f;
+        for (int64_t i = 0; i < (int64_t)N * K; ++i) {
+            const float v = src[i];
+            mhi = fmaxf(mhi, fabsf(v));
+            mlo = fmaxf(mlo, fabsf(v - (float)(f16)v));
+        }
+        int pw = 0, e = 0;
+        if (mlo > 0.f) { frexpf(mlo, &e); pw = 8 - e; }
+        if (mhi > 0.f) { frexpf(mhi, &e); pw = std::min(pw, 20 - e); }
+        const int64_t K3 = (int64_t)tp * 2 * Cp;
+        std::vector<f16> h3((size_t)Np * K3, (f16)0.f);
+        for (int n = 0; n < N; ++n)
+            for (int t = 0; t < tp; ++t) {
+                f16 *d = h3.data() + (size_t)n * K3 + (size_t)t * 2 * Cp;
+                unsigned char *d8 = (unsigned char *)(d + Cp);
+                for (int k = 0; k < Cin; ++k) {
+                    const float v = src[(size_t)n * K + (size_t)t * Cin + k];
+                    const f16 hi = (f16)v;
+                    d[k] = hi;
+                    d8[k] = pb_f32_to_e4m3(ldexpf(v - (float)hi, pw));
+                    d8[Cp + k] = pb_f32_to_e4m3(ldexpf((float)hi, pw - 12));
+                }
+            }
+        void *p3 = nullptr;
+        PB_HIP(hipMalloc(&p3, h3.size() * 2));
+        owned_.push_back(p3);
+        PB_HIP(hipMemcpy(p3, h3.data(), h3.size() * 2, hipMemcpyHostToDevice));
+        out.w = (f16 *)p3; out.N = N; out.K = (int)K3; out.Kreal = K; out.bias = nullptr;
+        out.sa = 1; out.sw = 1; out.Cseg = Cp; out.mx3 = 1; out.mx_pw = pw; out.nk16 = Cp / 64;
+    } else {
     const int64_t Kt = (int64_t)tp * segs * Cp;
     std::vector<f16> h((size_t)Np * Kt, (f16)0.f);
     for (int n = 0; n < N; ++n)
@@ -91,6 +122,7 @@ int EngineBase::pack(const float *src, int N, int K, int Kpad, PackedW &out, con
     PB_HIP(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     out.w = (f16 *)p; out.N = N; out.K = (int)Kt; out.Kreal = K; out.bias = nullptr;
     out.sa = sa; out.sw = sw; out.Cseg = Cp;
+    }
     if (bias) {
         void *b = nullptr;
         PB_HIP(hipMalloc(&b, std::max<size_t>((size_t)Np * 4, 256)));
@@ -145,6 +177,15 @@ int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *s
 
 void EngineBase::set_weights(GemmArgs &a, const PackedW &w, bool is_conv) const {
     a.W = w.w; a.K = w.K; a.bias = w.bias; a.zero = zero_;
+    if (w.mx3) {                 // [hi | hi8 | lo8] maps: per tap fp16 tiles then fp8 tiles (gemm.h mx_period)
+        a.nk16 = w.nk16; a.mx_scale_a = 127 - kLo8Pa; a.mx_scale_b = 127 - w.mx_pw;
+        if (is_conv) {
+            if (!a.cLd) a.cLd = 2 * a.cC;
+            a.cC = 2 * w.Cseg;
+            a.mx_period = 2 * w.Cseg / 64;
+        }
+        return;
+    }
     if (!w.sw) return;
     if (is_conv) {               // per tap [w_hi | w_hi (if sa) | w_lo]: the channel cursor wraps back onto the pixel's hi part
         if (!a.cLd) a.cLd = (1 + w.sa) * a.cC;
@@ -182,6 +223,7 @@ int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh
     a.cOH = (H + 2 * (kh / 2) - kh) / stride + 1; a.cOW = (W + 2 * (kw / 2) - kw) / stride + 1;
     a.M = n * a.cOH * a.cOW;
     a.out = out; a.ldo = ldo; a.act = act; a.pre_relu = pre_relu; a.add1 = add1; a.lo_off = lo_off;
+    if (lo_off && mx_) { a.lo8 = 1; a.lo8_pa = kLo8Pa; }
     if (fuse) { a.out2 = fuse->out2; a.gru_h = fuse->gru_h; a.gru_z = fuse->gru_z; a.gru_rh = fuse->gru_rh; }
     PB_CHECK(!w.sw || w.Cseg == cC, PB_ERR_STATE, "split conv: %d channels, weights packed for %d", cC, w.Cseg);
     set_weights(a, w, true);
@@ -190,7 +232,7 @@ int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh
     const bool wide = conv_tile == TILE_256 || (conv_tile == TILE_AUTO && a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256);
     // algorithmic bytes: the input map once, the weights once, the output once (fp16)
     // one family per kernel symbol launch_gemm picks: 256 x 256 ping-pong, 256 x 64 (N <= 64), 128 x 128
-    tic(wide ? F_CONV : (conv_tile == TILE_AUTO && a.N <= 64 ? F_CONV64 : F_CONV128), 2.0 * a.M * (double)a.N * w.Kreal, 2.0 * ((double)n * H * W * cC + (double)a.N * w.Kreal + (double)a.M * a.N), 1.0 + w.sa + w.sw);
+    tic(wide ? F_CONV : (conv_tile == TILE_AUTO && a.N <= 64 ? F_CONV64 : F_CONV128), 2.0 * a.M * (double)a.N * w.Kreal, 2.0 * ((double)n * H * W * cC + (double)a.N * w.Kreal + (double)a.M * a.N), w.mx3 ? 2.0 : 1.0 + w.sa + w.sw);
     int r = launch_gemm(cur_, A_CONV, EPI_STD, conv_tile, a);
     toc();
     return r;
@@ -201,7 +243,7 @@ int EngineBase::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *o
     a.A = A; a.lda = lda; a.N = w.N; a.M = (int)M;
     set_weights(a, w, false);
     a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
-    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 2.0 * ((double)M * w.Kreal + (double)a.N * w.Kreal + (double)M * a.N), 1.0 + w.sa + w.sw);
+    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 2.0 * ((double)M * w.Kreal + (double)a.N * w.Kreal + (double)M * a.N), w.mx3 ? 2.0 : 1.0 + w.sa + w.sw);
     int r = launch_gemm(cur_, A_DENSE, EPI_STD, TILE_AUTO, a);
     toc();
     return r;

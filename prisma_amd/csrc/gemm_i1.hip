@@ -1,0 +1,7 @@
+// One translation unit of the GEMM kernel instantiations (the templates live in gemm_kernels.h; split so that make -j compiles them in parallel).
+#include "gemm_kernels.h"
+
+int pb_gemm_dense_resid_f16(hipStream_t s, int tile, const GemmArgs &a) { return launch_tile<A_DENSE, EPI_RESID, false>(s, tile, a); }
+int pb_gemm_dense_resid_mx(hipStream_t s, int tile, const GemmArgs &a) { return launch_tile<A_DENSE, EPI_RESID, true>(s, tile, a); }
+int pb_gemm_dense_qkv_f16(hipStream_t s, int tile, const GemmArgs &a) { return launch_tile<A_DENSE, EPI_QKV, false>(s, tile, a); }
+int pb_gemm_dense_qkv_mx(hipStream_t s, int tile, const GemmArgs &a) { return launch_tile<A_DENSE, EPI_QKV, true>(s, tile, a); }

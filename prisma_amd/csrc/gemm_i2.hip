@@ -1,0 +1,8 @@
+// One translation unit of the GEMM kernel instantiations (the templates live in gemm_kernels.h; split so that make -j compiles them in parallel).
+#include "gemm_kernels.h"
+
+int pb_gemm_dense_pixshuf_f16(hipStream_t s, int tile, const GemmArgs &a) { return launch_tile<A_DENSE, EPI_PIXSHUF, false>(s, tile, a); }
+int pb_gemm_dense_pixshuf_mx(hipStream_t s, int tile, const GemmArgs &a) { return launch_tile<A_DENSE, EPI_PIXSHUF, true>(s, tile, a); }
+int pb_gemm_dense_patch_f16(hipStream_t s, int tile, const GemmArgs &a) { return launch_tile<A_DENSE, EPI_PATCH, false>(s, tile, a); }
+int pb_gemm_dense_f32_f16(hipStream_t s, int tile, const GemmArgs &a) { return launch_tile<A_DENSE, EPI_F32, false>(s, tile, a); }
+int pb_gemm_conv_f32_f16(hipStream_t s, int tile, const GemmArgs &a) { return launch_tile<A_CONV, EPI_F32, false>(s, tile, a); }

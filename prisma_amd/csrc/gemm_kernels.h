@@ -1,0 +1,1332 @@
+// fp16 MFMA GEMM and implicit-GEMM convolution kernels for gfx950 (CDNA4).
+//
+// One kernel template serves every matmul-shaped op of the bands engine: the ViT linears
+// (qkv / proj / fc1 / fc2, reference dinov2/layers/attention.py:49-62, mlp.py:35-41), the patch
+// embedding (patch_embed.py:66-82), and the DPT head's 1x1 / 3x3 / transposed convolutions
+// (bands/d_anything/dpt.py:103-136, blocks.py:69-153) as NHWC implicit GEMM.
+//
+// Structure (per workgroup): BM x BN output tile, K in steps of 64 halfs.
+//   * A and W tiles go HBM -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR round
+//     trip), double buffered, one barrier per K step; the next step's loads are issued before
+//     the current step's MFMAs.
+//   * LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7, applied
+//     on the global SOURCE address (the LDS image of a DMA is lane-linear) and again on the
+//     ds_read_b128 fragment reads, which makes those reads bank-conflict free.
+//   * v_mfma_f32_32x32x16_f16, fp32 accumulators; wave tile (BM/WM) x (BN/WN).
+//   * Epilogue: accumulators -> per-wave LDS patch -> each lane owns 8 consecutive columns of
+//     one row (16-byte stores), with the op-specific fusion (bias, GELU, ReLU, LayerScale +
+//     residual, q/k/v split with V transposed, pixel-shuffle for transposed convs, ...).
+//   * blockIdx is remapped so that each XCD (private L2) works on a contiguous range of tiles.
+#pragma once
+#include "gemm.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace {
+
+// All CUs start their first tile together and every tile of a launch takes the same time, so without help every
+// CU reaches its epilogue at the same moment: the whole chip writes 256 x (128..512 KB) at once and each epilogue
+// lasts as long as that HBM burst (measured 14k-38k cycles against a 51k-cycle main loop), while HBM idles during
+// the main loops.  Delaying the first-wave workgroups by eighths of a tile period de-phases the CUs for the rest
+// of the launch; stores then drain under other CUs' MFMA time.
+__device__ __forceinline__ void stagger_start(int stagger, int first_wave) {
+    if (stagger > 0 && (int)blockIdx.x < first_wave) {
+        const int n = ((blockIdx.x >> 3) & 7) * stagger;     // units of 64 cycles
+        for (int i = 0; i < n; i += 100) __builtin_amdgcn_s_sleep(100);
+    }
+}
+
+// ---- fused epilogues ---------------------------------------------------------------------------
+// A lane owns the same 8 output columns (n .. n+7) for every row it stores, so everything that
+// depends only on the column (bias, LayerScale gamma, head weights) is loaded ONCE per lane.  Row
+// dependent operands (residual stream, skip tensors, pos-embed) are fetched for all of a pass's
+// rows before the first store: the compiler cannot hoist a load above a store that may alias it, and
+// a load -> use -> store chain per row costs one full memory latency each (measured 23k-53k
+// cycles per 256x256 tile before this restructuring, 2-3x the MFMA main loop's share).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// two 16-byte fragments (the ones the fp16 path feeds to k-steps 2q and 2q + 1) as the 32-byte operand of one fp8 MFMA: any
+// assignment of the tile's bytes to (lane half, byte slot) is valid as long as A and B use the same one (tools/probe/mx_probe.hip)
+__device__ __forceinline__ i32x8 cat_frag(f16x8 a, f16x8 b) {
+    union { f16x8 h[2]; i32x8 v; } u;
+    u.h[0] = a; u.h[1] = b;
+    return u.v;
+}
+__device__ __forceinline__ f32x16 mfma_mx8(f16x8 a0, f16x8 a1, f16x8 b0, f16x8 b1, f32x16 c, int sa, int sb) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat_frag(a0, a1), cat_frag(b0, b1), c, 0, 0, 0, sa, 0, sb);
+}
+
+// split maps with e4m3 residual parts (gemm.h lo8): per pixel [hi fp16 (C) | hi8 (C bytes) | lo8 (C bytes)], C = lo_off.
+// `pix` = element offset of the pixel's first half, `col` = channel.
+__device__ __forceinline__ void lo8_store2(f16 *base, int64_t pix, int col, int C, float v0, float v1, float s_hi, float s_lo) {
+    const f16 h0 = (f16)v0, h1 = (f16)v1;
+    char *b = (char *)(base + pix);
+    *(unsigned short *)(b + 2 * C + col) = pb_fp8x2((float)h0 * s_hi, (float)h1 * s_hi);
+    *(unsigned short *)(b + 3 * C + col) = pb_fp8x2((v0 - (float)h0) * s_lo, (v1 - (float)h1) * s_lo);
+}
+__device__ __forceinline__ f32x2 lo8_load2(const f16 *base, int64_t pix, int col, int C, float inv_lo) {
+    const unsigned short u = *(const unsigned short *)((const char *)(base + pix) + 3 * C + col);
+    const f32x2 f = __builtin_amdgcn_cvt_pk_f32_fp8((int)u, false);
+    return f * inv_lo;
+}
+
+struct EpiAux {
+    f16x8 a1, a2;       // EPI_STD skip tensors
+    f32x4 r0, r1;       // EPI_RESID residual / EPI_PATCH pos-embed
+};
+
+__device__ __forceinline__ float fast_gelu(float x) {
+    // exact-erf GELU as  max(x, 0) - |x| * Q(|x|),  Q(a) = 0.5 erfc(a / sqrt 2) = 2^P(a): a degree-5 minimax fit of
+    // log2 Q on [0, 6.5] weighted by a Q(a) (tools: numpy lstsq, max |error| of the whole expression 6.4e-7 in fp32
+    // Horner arithmetic, i.e. below fp32 round-off of the result for |x| > 4).  5 FMAs + one v_exp_f32; the A&S
+    // 7.1.26 form needed an rcp and an exp and twice the VALU work (14k of a 75k-cycle fc1 tile).
+    const float a = fminf(fabsf(x), 6.5f);
+    float p = fmaf(a, -0.00047330817324109375f, 0.007084541954100132f);
+    p = fmaf(a, p, -0.051827322691679f);
+    p = fmaf(a, p, -0.45999252796173096f);
+    p = fmaf(a, p, -1.1507878303527832f);
+    p = fmaf(a, p, -1.000037670135498f);
+    return fmaxf(x, 0.f) - a * __builtin_amdgcn_exp2f(p);
+}
+
+// two values per instruction where the ISA has a packed form (v_pk_fma_f32): the fc1 epilogue is VALU bound
+__device__ __forceinline__ void fast_gelu2(float &x0, float &x1) {
+    // v_med3_f32 clamps without the canonicalising v_max that fminf / fmaxf put in front of every operand
+    const f32x2 a = {__builtin_amdgcn_fmed3f(fabsf(x0), 0.f, 6.5f), __builtin_amdgcn_fmed3f(fabsf(x1), 0.f, 6.5f)};
+    const f32x2 c5 = {-0.00047330817324109375f, -0.00047330817324109375f}, c4 = {0.007084541954100132f, 0.007084541954100132f},
+                c3 = {-0.051827322691679f, -0.051827322691679f}, c2 = {-0.45999252796173096f, -0.45999252796173096f},
+                c1 = {-1.1507878303527832f, -1.1507878303527832f}, c0 = {-1.000037670135498f, -1.000037670135498f};
+    f32x2 p = __builtin_elementwise_fma(a, c5, c4);
+    p = __builtin_elementwise_fma(a, p, c3);
+    p = __builtin_elementwise_fma(a, p, c2);
+    p = __builtin_elementwise_fma(a, p, c1);
+    p = __builtin_elementwise_fma(a, p, c0);
+    const f32x2 e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+    const f32x2 r = {__builtin_amdgcn_fmed3f(x0, 0.f, 3.0e38f), __builtin_amdgcn_fmed3f(x1, 0.f, 3.0e38f)};
+    const f32x2 o = __builtin_elementwise_fma(-a, e, r);
+    x0 = o[0]; x1 = o[1];
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_cols(const GemmArgs &p, int n, bool nok, float (&cb)[8], float (&cg)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cb[j] = 0.f; cg[j] = 0.f; }
+    if (!nok) return;
+    if constexpr (EPI == EPI_PIXSHUF) {
+        const int co = n % p.ps_co;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cb[j] = p.bias[co + j];
+    } else {
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cb[j] = p.bias[n + j];
+        }
+    }
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cg[j] = p.gamma[n + j];
+    }
+    if constexpr (EPI == EPI_HEAD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cg[j] = p.w2[n + j];
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_prefetch(const GemmArgs &p, int m, int n, EpiAux &x) {
+    if constexpr (EPI == EPI_STD) {
+        const int64_t o = (int64_t)m * p.ldo + n;
+        if (p.add1) x.a1 = *(const f16x8 *)(p.add1 + o);
+        if (p.add2) x.a2 = *(const f16x8 *)(p.add2 + o);
+    } else if constexpr (EPI == EPI_RESID) {
+        const float *r = p.resid + (int64_t)m * p.ldr + n;
+        x.r0 = *(const f32x4 *)r;
+        x.r1 = *(const f32x4 *)(r + 4);
+    } else if constexpr (EPI == EPI_PATCH) {
+        const int b = m / p.ppi, pi = m - b * p.ppi;
+        const float *pe = p.pos + (int64_t)(1 + pi) * p.D + n;
+        x.r0 = *(const f32x4 *)pe;
+        x.r1 = *(const f32x4 *)(pe + 4);
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, float (&v)[8], const EpiAux &x,
+                                           const float (&cb)[8], const float (&cg)[8]) {
+    if constexpr (EPI == EPI_STD) {
+        const int64_t o = (int64_t)m * p.ldo + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += cb[j];
+        if (p.pre_relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (p.add1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)x.a1[j];
+            if (p.lo_off) {
+                const f16x8 l = *(const f16x8 *)(p.add1 + o + p.lo_off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
+            }
+        }
+        if (p.add2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)x.a2[j];
+            if (p.lo_off) {
+                const f16x8 l = *(const f16x8 *)(p.add2 + o + p.lo_off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
+            }
+        }
+        if (p.out) {
+            f16x8 r;
+            if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (f16)fast_gelu(v[j]);
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (f16)fmaxf(v[j], 0.f);
+            } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (f16)(1.f / (1.f + __expf(-v[j])));
+            } else if (p.act == ACT_TANH) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (f16)tanhf(v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (f16)v[j];
+            }
+            *(f16x8 *)(p.out + o) = r;
+            if (p.lo_off) {                  // (only the linear / ReLU activations are used with split outputs)
+                f16x8 l;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = p.act == ACT_RELU ? fmaxf(v[j], 0.f) : v[j];
+                    l[j] = (f16)(t - (float)(f16)t);
+                }
+                *(f16x8 *)(p.out + o + p.lo_off) = l;
+            }
+        }
+        if (p.out2) {
+            f16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (f16)fmaxf(v[j], 0.f);
+            *(f16x8 *)(p.out2 + o) = r;
+            if (p.lo_off) {
+                f16x8 l;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float t = fmaxf(v[j], 0.f); l[j] = (f16)(t - (float)(f16)t); }
+                *(f16x8 *)(p.out2 + o + p.lo_off) = l;
+            }
+        }
+    } else if constexpr (EPI == EPI_F32) {
+        float *r = p.out32 + (int64_t)m * p.ldo + n;
+        f32x4 r0, r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r0[j] = (v[j] + cb[j]) * p.scale;
+            r1[j] = (v[4 + j] + cb[4 + j]) * p.scale;
+        }
+        *(f32x4 *)r = r0;
+        *(f32x4 *)(r + 4) = r1;
+    } else if constexpr (EPI == EPI_RESID) {
+        float *r = p.resid + (int64_t)m * p.ldr + n;
+        f32x4 r0 = x.r0, r1 = x.r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r0[j] += cg[j] * (v[j] + cb[j]);
+            r1[j] += cg[4 + j] * (v[4 + j] + cb[4 + j]);
+        }
+        *(f32x4 *)r = r0;
+        *(f32x4 *)(r + 4) = r1;
+    } else if constexpr (EPI == EPI_QKV) {
+        // q / k rows only; the V third is handled by the transposed path below
+        const int which = n / p.D;
+        const int hn = n - which * p.D;
+        const int head = hn >> 6, d = hn & 63;
+        const int b = m / p.ntp, t = m - b * p.ntp;
+        const float s = which == 0 ? p.qscale : 1.f;
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (f16)((v[j] + cb[j]) * s);
+        f16 *dst = (which == 0 ? p.q : p.k) + (((int64_t)b * p.heads + head) * p.ntp + t) * 64 + d;
+        *(f16x8 *)dst = r;
+    } else if constexpr (EPI == EPI_PIXSHUF) {
+        const int hw = p.ps_h * p.ps_w;
+        const int b = m / hw, rem = m - b * hw;
+        const int y = rem / p.ps_w, xx = rem - y * p.ps_w;
+        const int tap = n / p.ps_co, co = n - tap * p.ps_co;
+        const int dy = tap / p.ps_s, dx = tap - dy * p.ps_s;
+        const int64_t row = ((int64_t)b * p.ps_h * p.ps_s + (y * p.ps_s + dy)) * (p.ps_w * p.ps_s) + (xx * p.ps_s + dx);
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (f16)(v[j] + cb[j]);
+        *(f16x8 *)(p.out + row * p.ldo + co) = r;
+        if (p.lo_off && p.lo8) {
+            const float shi = __builtin_ldexpf(1.f, p.lo8_pa), slo = __builtin_ldexpf(1.f, p.lo8_pa + 12);
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) lo8_store2(p.out, row * p.ldo, co + j, p.lo_off, v[j] + cb[j], v[j + 1] + cb[j + 1], shi, slo);
+        } else if (p.lo_off) {
+            f16x8 l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t = v[j] + cb[j]; l[j] = (f16)(t - (float)(f16)t); }
+            *(f16x8 *)(p.out + row * p.ldo + co + p.lo_off) = l;
+        }
+    } else if constexpr (EPI == EPI_PATCH) {
+        const int b = m / p.ppi, pi = m - b * p.ppi;
+        float *r = p.resid + ((int64_t)b * p.ntp + 1 + pi) * p.ldr + n;
+        f32x4 r0, r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r0[j] = v[j] + cb[j] + x.r0[j];
+            r1[j] = v[4 + j] + cb[4 + j] + x.r1[j];
+        }
+        *(f32x4 *)r = r0;
+        *(f32x4 *)(r + 4) = r1;
+    }
+}
+
+// EPI_RESID: X += A W'^T + b' with LayerScale pre-folded into W' and b'.  The accumulators START from the fp32
+// residual tile (loaded in the prologue, under the first DMAs' latency) and are stored straight back from the
+// MFMA layout (32 consecutive columns per half wave = 128-byte segments): no LDS transpose, no read in the epilogue.
+template <int TM, int TN, bool STORE>
+__device__ __forceinline__ void resid_io(const GemmArgs &p, f32x16 (&acc)[TM][TN], int wave_m0, int wave_n0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = wave_n0 + tn * 32 + li;
+        const bool nok = n < p.N;
+        const int nc = nok ? n : p.N - 1;                   // loads are unconditional (clamped address): a per-element
+        const float b = STORE ? 0.f : p.bias[nc];           // conditional load would serialise on vmcnt(0) each
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wave_m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (STORE) {
+                    if (nok && m < p.M) p.resid[(int64_t)m * p.ldr + n] = acc[tm][tn][r];
+                } else {
+                    // clamped row: keeps the load addresses distinct from the epilogue's store addresses - if the
+                    // compiler CSEs the two it keeps 128 address pairs live across the main loop and spills
+                    const int mc = m < p.M ? m : p.M - 1;
+                    acc[tm][tn][r] = p.resid[(int64_t)mc * p.ldr + nc] + b;
+                }
+            }
+    }
+}
+
+// ---- interleaved output columns (fp16 epilogues, TN == 2) -----------------------------------------
+// A global store instruction is cheapest when each half wave writes ONE contiguous 128-byte line (measured:
+// ~11 cycles per instruction and CU for 2 x 128 B against ~140 for the 8 x 128 B pattern of the LDS-transposed
+// epilogue, which made a 256 x 256 fp16 tile cost 18-22k cycles).  In the MFMA layout a lane owns column `li`
+// of each 32-wide tile, so the two tiles of a wave are fed weight rows in the order  LDS row (tn*32 + j) <-
+// column 2j + tn : lane li then holds columns 2 li and 2 li + 1 of a row in acc[.][0] / acc[.][1], packs them
+// into one dword, and 32 lanes cover 64 consecutive fp16 columns = 128 bytes.  Only the DMA source rows of
+// the weight operand change; nothing moves between lanes.
+template <int EPI, int TN>
+__host__ __device__ constexpr bool epi_interleaved() {
+    return TN == 2 && (EPI == EPI_STD || EPI == EPI_QKV || EPI == EPI_PIXSHUF);
+}
+__device__ __forceinline__ int col_map(int r, bool il) {        // tile-local B row -> tile-local output column
+    return il ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;
+}
+
+// LOM: 0 plain outputs, 1 split maps with fp16 residuals ([hi | lo]), 2 split maps with e4m3 residual parts (gemm.h lo8); each mode
+// is its own copy of the code so that the plain path keeps its register allocation
+template <int EPI, int TM, bool CHECK, int LOM>
+__device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int n = wave_n0 + 2 * li;
+    const bool nok = n < p.N;
+    const int nc = nok ? n : 0;
+    float b0 = 0.f, b1 = 0.f;
+    if (p.bias) {
+        const int bi = EPI == EPI_PIXSHUF ? nc % p.ps_co : nc;
+        b0 = p.bias[bi]; b1 = p.bias[bi + 1];
+    }
+    // per-wave constants of the split / shuffle epilogues (a wave's 64 columns never straddle a head or a tap)
+    f16 *qk_base = nullptr;
+    float qs = 1.f;
+    int tap_dy = 0, tap_dx = 0, co = 0;
+    if constexpr (EPI == EPI_QKV) {
+        const int which = wave_n0 / p.D, hn = wave_n0 - which * p.D;
+        qk_base = (which == 0 ? p.q : p.k) + (int64_t)(hn >> 6) * p.ntp * 64 + 2 * li;
+        qs = which == 0 ? p.qscale : 1.f;
+    }
+    if constexpr (EPI == EPI_PIXSHUF) {
+        const int tap = wave_n0 / p.ps_co;
+        co = wave_n0 - tap * p.ps_co + 2 * li;
+        tap_dy = tap / p.ps_s; tap_dx = tap - tap_dy * p.ps_s;
+    }
+    // lo8 (LO only): this lane's channel inside the pixel and the power-of-two scalings of the e4m3 parts
+    const int pcol = EPI == EPI_PIXSHUF ? co : nc;
+    const float lo8_shi = __builtin_ldexpf(1.f, p.lo8_pa), lo8_slo = __builtin_ldexpf(1.f, p.lo8_pa + 12), lo8_inv = __builtin_ldexpf(1.f, -(p.lo8_pa + 12));
+#pragma unroll
+    for (int th = 0; th < TM * 2; ++th) {                   // 8 accumulator registers (= 16 rows) per pass
+        const int tm = th >> 1, r0 = (th & 1) * 8;
+        int64_t off[8];
+        int mr[8];
+        bool ok[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = r0 + q;
+            const int m = wave_m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            ok[q] = !CHECK || (nok && m < p.M);
+            const int mc = (!CHECK || m < p.M) ? m : p.M - 1;
+            mr[q] = mc;
+            if constexpr (EPI == EPI_QKV) {
+                const int b = mc / p.ntp, t = mc - b * p.ntp;
+                off[q] = ((int64_t)b * p.heads * p.ntp + t) * 64;
+            } else if constexpr (EPI == EPI_PIXSHUF) {
+                const int hw = p.ps_h * p.ps_w;
+                const int b = mc / hw, rem = mc - b * hw;
+                const int y = rem / p.ps_w, x = rem - y * p.ps_w;
+                off[q] = (((int64_t)b * p.ps_h * p.ps_s + (y * p.ps_s + tap_dy)) * (p.ps_w * p.ps_s) + (x * p.ps_s + tap_dx)) * p.ldo + co;
+            } else {
+                off[q] = (int64_t)mc * p.ldo + nc;
+            }
+        }
+        // every runtime switch (skip tensors, ReLU'd copy, activation) wraps a whole 8-register loop, never a
+        // single element: per-element branches on kernel arguments explode into hundreds of exec-mask branches
+        float v0[8], v1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { v0[q] = acc[tm][0][r0 + q] + b0; v1[q] = acc[tm][1][r0 + q] + b1; }
+        if constexpr (EPI == EPI_STD) {
+            if (p.pre_relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            }
+            if (p.add1) {
+                f16x2 a[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add1 + off[q]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                if constexpr (LOM == 1 || LOM == 2) {
+                    if constexpr (LOM == 2) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { const f32x2 l = lo8_load2(p.add1, off[q] - pcol, pcol, p.lo_off, lo8_inv); v0[q] += l[0]; v1[q] += l[1]; }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add1 + off[q] + p.lo_off);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                    }
+                }
+            }
+            if (p.add2) {
+                f16x2 a[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add2 + off[q]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                if constexpr (LOM == 1 || LOM == 2) {
+                    if constexpr (LOM == 2) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { const f32x2 l = lo8_load2(p.add2, off[q] - pcol, pcol, p.lo_off, lo8_inv); v0[q] += l[0]; v1[q] += l[1]; }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) a[q] = *(const f16x2 *)(p.add2 + off[q] + p.lo_off);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                    }
+                }
+            }
+            if (p.out2) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    f16x2 o2;
+                    o2[0] = (f16)fmaxf(v0[q], 0.f); o2[1] = (f16)fmaxf(v1[q], 0.f);
+                    if (!CHECK || ok[q]) *(f16x2 *)(p.out2 + off[q]) = o2;
+                }
+                if constexpr (LOM == 1 || LOM == 2) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float r0 = fmaxf(v0[q], 0.f), r1 = fmaxf(v1[q], 0.f);
+                        if constexpr (LOM == 2) {
+                            if (!CHECK || ok[q]) lo8_store2(p.out2, off[q] - pcol, pcol, p.lo_off, r0, r1, lo8_shi, lo8_slo);
+                        } else {
+                            f16x2 o2;
+                            o2[0] = (f16)(r0 - (float)(f16)r0); o2[1] = (f16)(r1 - (float)(f16)r1);
+                            if (!CHECK || ok[q]) *(f16x2 *)(p.out2 + off[q] + p.lo_off) = o2;
+                        }
+                    }
+                }
+            }
+            if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) fast_gelu2(v0[q], v1[q]);
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
+            } else if (p.act == ACT_TANH) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = tanhf(v0[q]); v1[q] = tanhf(v1[q]); }
+            } else if (p.act == ACT_GRU_ZR) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
+                if (wave_n0 >= 128) {            // r columns (a wave's 64 columns are all z or all r): r * h -> gru_rh
+                    f32x2 h[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) h[q] = *(const f32x2 *)(p.gru_h + (int64_t)mr[q] * 128 + (nc - 128));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        f16x2 o;
+                        o[0] = (f16)(v0[q] * h[q][0]); o[1] = (f16)(v1[q] * h[q][1]);
+                        if (!CHECK || ok[q]) *(f16x2 *)(p.gru_rh + (int64_t)mr[q] * 384 + (nc - 128)) = o;
+                    }
+                    continue;
+                }
+            } else if (p.act == ACT_GRU_Q) {
+                f32x2 h[8];
+                f16x2 z[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    h[q] = *(const f32x2 *)(p.gru_h + (int64_t)mr[q] * 128 + nc);
+                    z[q] = *(const f16x2 *)(p.gru_z + (int64_t)mr[q] * 256 + nc);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float z0 = (float)z[q][0], z1 = (float)z[q][1];
+                    f32x2 hn;
+                    hn[0] = (1.f - z0) * h[q][0] + z0 * tanhf(v0[q]);
+                    hn[1] = (1.f - z1) * h[q][1] + z1 * tanhf(v1[q]);
+                    if (!CHECK || ok[q]) *(f32x2 *)(p.gru_h + (int64_t)mr[q] * 128 + nc) = hn;
+                    v0[q] = hn[0]; v1[q] = hn[1];
+                }
+            }
+        }
+        if constexpr (EPI == EPI_PIXSHUF) {
+            if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            }
+        }
+        f16 *dst = EPI == EPI_QKV ? qk_base : p.out;
+        if (EPI != EPI_STD || p.out) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f16x2 o;
+                o[0] = (f16)(v0[q] * qs); o[1] = (f16)(v1[q] * qs);
+                if (!CHECK || ok[q]) *(f16x2 *)(dst + off[q]) = o;
+            }
+            if constexpr (EPI == EPI_STD && LOM == 3) {
+                {                                // fp8 copy for a consumer's MX correction segment (gemm.h o8_off)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned short o8 = pb_fp8x2(v0[q] * p.o8_scale, v1[q] * p.o8_scale);
+                        if (!CHECK || ok[q]) *(unsigned short *)((char *)p.out + (off[q] - nc) * 2 + p.o8_off + nc) = o8;
+                    }
+                }
+            }
+            if constexpr (EPI != EPI_QKV) {
+                if constexpr (LOM == 1 || LOM == 2) {              // split-fp16 consumers read [hi | lo] (or [hi | hi8 | lo8], gemm.h lo8)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if constexpr (LOM == 2) {
+                            if (!CHECK || ok[q]) lo8_store2(dst, off[q] - pcol, pcol, p.lo_off, v0[q], v1[q], lo8_shi, lo8_slo);
+                        } else {
+                            f16x2 o;
+                            o[0] = (f16)(v0[q] - (float)(f16)v0[q]); o[1] = (f16)(v1[q] - (float)(f16)v1[q]);
+                            if (!CHECK || ok[q]) *(f16x2 *)(dst + off[q] + p.lo_off) = o;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, int TM, bool MX>
+__device__ __forceinline__ void direct_epilogue_f16(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
+    // interior tiles (the common case) store without per-lane predicates: each predicate costs an exec-mask branch
+    // split-fp16 outputs (p.lo_off) take their own copy of the code: the plain path keeps its register allocation
+    if constexpr (EPI == EPI_STD || EPI == EPI_PIXSHUF) {
+        if (p.lo_off) {
+            // MX builds serve the e4m3-residual maps (lo8), fp16-only builds the fp16-residual maps
+            const bool inner = wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N;
+            if (inner) direct_epilogue_f16_impl<EPI, TM, false, MX ? 2 : 1>(p, acc, wave_m0, wave_n0, lane);
+            else direct_epilogue_f16_impl<EPI, TM, true, MX ? 2 : 1>(p, acc, wave_m0, wave_n0, lane);
+            return;
+        }
+    }
+    if constexpr (MX && EPI == EPI_STD) {
+        if (p.o8_off) {
+            if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false, 3>(p, acc, wave_m0, wave_n0, lane);
+            else direct_epilogue_f16_impl<EPI, TM, true, 3>(p, acc, wave_m0, wave_n0, lane);
+            return;
+        }
+    }
+    if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false, 0>(p, acc, wave_m0, wave_n0, lane);
+    else direct_epilogue_f16_impl<EPI, TM, true, 0>(p, acc, wave_m0, wave_n0, lane);
+}
+
+// Accumulators -> per-wave LDS patch -> 8-column chunks -> fused store.  `smem` must be free of live
+// staging data (callers barrier first).  TM x TN = 32x32 MFMA tiles per wave.
+template <int EPI, int TM, int TN, bool MX>
+__device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM][TN], char *smem, int wave, int lane,
+                                             int wave_m0, int wave_n0, int n0) {
+    constexpr int ES = TN * 32 + 4;
+    constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * ES * 4;
+    constexpr bool IL = epi_interleaved<EPI, TN>();
+    const int li = lane & 31, lh = lane >> 5;
+    float *es = (float *)(smem + wave * EPIB);
+
+    if constexpr (EPI == EPI_QKV) {
+        if (n0 >= 2 * p.D) {
+            // V third: transpose through LDS so that stores run along the token axis of Vt.
+            float bb[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bb[tn] = p.bias[wave_n0 + (IL ? 2 * li + tn : tn * 32 + li)];
+#pragma unroll
+            for (int tmi = 0; tmi < TM; ++tmi) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 w4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w4[j] = acc[tmi][tn][g * 4 + j] + bb[tn];
+                        *(f32x4 *)(es + (IL ? 2 * li + tn : tn * 32 + li) * 36 + 8 * g + 4 * lh) = w4;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < TN * 2; ++it) {
+                    const int item = it * 64 + lane;
+                    const int nr = item >> 2, mc = item & 3;
+                    const f32x4 x0 = *(const f32x4 *)(es + nr * 36 + mc * 8);
+                    const f32x4 x1 = *(const f32x4 *)(es + nr * 36 + mc * 8 + 4);
+                    const int m = wave_m0 + tmi * 32 + mc * 8;
+                    const int n = wave_n0 + nr - 2 * p.D;
+                    if (m < p.M) {
+                        const int b = m / p.ntp, t = m - b * p.ntp;
+                        f16x8 r;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { r[j] = (f16)x0[j]; r[4 + j] = (f16)x1[j]; }
+                        *(f16x8 *)(p.vt + (((int64_t)b * p.heads + (n >> 6)) * 64 + (n & 63)) * p.ntp + t) = r;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            return;
+        }
+    }
+
+    if constexpr (IL) {
+        const bool direct = EPI != EPI_PIXSHUF || (p.ps_co & 63) == 0;
+        if (direct) {
+            direct_epilogue_f16<EPI, TM, MX>(p, acc, wave_m0, wave_n0, lane);
+            return;
+        }
+    }
+    constexpr int CPR = TN * 4;                             // 8-column chunks per patch row
+    constexpr int NIT = 32 * CPR / 64;                      // rows per lane per pass
+    constexpr int RSTEP = 64 / CPR;
+    const int ch = lane % CPR, row0 = lane / CPR;
+    const int n = wave_n0 + ch * 8;
+    const bool nok = n < p.N;
+    float cb[8], cg[8];
+    epi_cols<EPI>(p, n, nok, cb, cg);
+
+#pragma unroll
+    for (int tmi = 0; tmi < TM; ++tmi) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + (IL ? 2 * li + tn : tn * 32 + li)] = acc[tmi][tn][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float v[NIT][8];
+        EpiAux aux[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RSTEP + row0;
+            const f32x4 x0 = *(const f32x4 *)(es + row * ES + ch * 8);
+            const f32x4 x1 = *(const f32x4 *)(es + row * ES + ch * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[it][j] = x0[j]; v[it][4 + j] = x1[j]; }
+            const int m = wave_m0 + tmi * 32 + row;
+            if (m < p.M && nok) epi_prefetch<EPI>(p, m, n, aux[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int m = wave_m0 + tmi * 32 + it * RSTEP + row0;
+            if constexpr (EPI == EPI_HEAD) {
+                // N == 32: the 4 lanes of a row hold its 32 channels
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += fmaxf(v[it][j] + cb[j], 0.f) * cg[j];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                if (ch == 0 && m < p.M) p.depth[m] = fmaxf(s + p.b2, 0.f);
+            } else {
+                if (m < p.M && nok) epi_finish<EPI>(p, m, n, v[it], aux[it], cb, cg);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+__device__ __forceinline__ void vm_wait_halftiles(int n) {
+    if (n >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// NS LDS stages (2 or 3).  With 2 the DMA of tile kt+1 has one tile of MFMAs (~0.5k cycles) to land; with 3 the loads run
+// two tiles ahead and the wait before the barrier leaves the newest stage in flight (counted vmcnt, never drained).
+// MX: the launch has MX-fp8 tiles (gemm.h nk16); the fp16-only build of every kernel keeps the plain K loop
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool BUFP = false, int NS = 2, bool MX = false>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;       // 16-byte chunks per thread per stage
+    static_assert(NA >= 1 && NB >= 1, "tile too small for the block");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    stagger_start(p.stagger, BM == 128 ? 512 : 256);
+
+    // ---- tile id with XCD-contiguous remap (bijective for any grid size) ----
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int tile_m = swz / tilesN, tile_n = swz - tile_m * tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread staging addresses ----
+    const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
+    const int srow = tid >> 3;                              // + i * (NT/8)
+    const int cg = (tid & 7) ^ ((tid >> 4) & 7);            // swizzled global chunk for this LDS slot
+    const f16 *a_ptr[NA];
+    int a_iy0[NA], a_ix0[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + srow + i * (NT / 8);
+        if constexpr (AMODE == A_DENSE) {
+            const int mc = m < p.M ? m : p.M - 1;
+            a_ptr[i] = p.A + (int64_t)mc * p.lda + cg * 8;
+            a_ok[i] = true;
+            a_iy0[i] = a_ix0[i] = 0;
+        } else {
+            const int ohw = p.cOH * p.cOW;
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+            a_ok[i] = m < p.M;
+            a_ptr[i] = p.A + (int64_t)b * p.cH * p.cW * cld + cg * 8;
+            a_iy0[i] = oy * p.cStride - p.cPad;
+            a_ix0[i] = ox * p.cStride - padx;
+        }
+    }
+    const f16 *b_ptr[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        b_ptr[i] = p.W + (int64_t)(n0 + col_map(srow + i * (NT / 8), epi_interleaved<EPI, TN>())) * p.K + cg * 8;
+
+    int c_ky = 0, c_kx = 0, c_c0 = 0;                       // conv tap state of the NEXT stage call
+    const int nk = p.K >> 6;
+    // BUFP: LDS-DMA through the buffer path (see gemm8_kernel); p.bufmode 1 = whole operand, 2 = two-image window (conv)
+    __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, 0u), rsW = make_rsrc(p.W, 0u);
+    unsigned a_voff[NA], b_voff[NB];
+    if constexpr (BUFP) {
+        rsW = make_rsrc(p.W, (unsigned)((int64_t)((p.N + 255) / 256 * 256) * p.K * 2));
+        int b0 = 0;
+        if constexpr (AMODE == A_DENSE) {
+            rsA = make_rsrc(p.A, (unsigned)((int64_t)p.M * p.lda * 2));
+        } else {
+            const int ohw = p.cOH * p.cOW, nimg = p.M / ohw;
+            const int64_t img = (int64_t)p.cH * p.cW * cld;
+            int cnt = nimg;
+            if (p.bufmode == 2) { b0 = m0 / ohw; cnt = nimg - b0 < 2 ? nimg - b0 : 2; }
+            rsA = make_rsrc(p.A + b0 * img, (unsigned)(cnt * img * 2));
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if constexpr (AMODE == A_DENSE) a_voff[i] = (unsigned)((a_ptr[i] - p.A) * 2);
+            else a_voff[i] = (unsigned)((int64_t)((m0 + srow + i * (NT / 8)) / (p.cOH * p.cOW) - b0) * p.cH * p.cW * cld * 2) + cg * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) b_voff[i] = (unsigned)((b_ptr[i] - p.W) * 2);
+    }
+
+    auto stage = [&](int buf, int kt) {
+        char *sA = smem + buf * STAGE + wave * 1024;
+        char *sB = smem + buf * STAGE + A_BYTES + wave * 1024;
+        const int ka = (p.kwrap && kt >= p.kwrap) ? kt - p.kwrap : kt;            // split-fp16 segments re-read A (gemm.h)
+        const int cs = (p.kwrap && c_c0 >= p.kwrap) ? c_c0 - p.kwrap : c_c0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if constexpr (AMODE == A_DENSE) {
+                if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[i], ka * 128, sA + i * (NT * 16));
+                else glds16(a_ptr[i] + ka * 64, sA + i * (NT * 16));
+            } else {
+                const int iy = a_iy0[i] + c_ky, ix = a_ix0[i] + c_kx;
+                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+                if constexpr (BUFP) {      // branch-free: OR-ing all ones into the offset makes it out of range -> the load returns zeros
+                    const unsigned oob = ok ? 0u : 0xFFFFFF00u;
+                    glds16_buf(rsA, (int)((a_voff[i] + (unsigned)(((iy * p.cW + ix) * cld + cs) * 2)) | oob), 0, sA + i * (NT * 16));
+                } else {
+                    glds16(ok ? a_ptr[i] + ((iy * p.cW + ix) * cld + cs) : p.zero, sA + i * (NT * 16));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if constexpr (BUFP) glds16_buf(rsW, (int)b_voff[i], kt * 128, sB + i * (NT * 16));
+            else glds16(b_ptr[i] + kt * 64, sB + i * (NT * 16));
+        }
+        if constexpr (AMODE == A_CONV) {
+            c_c0 += 64;
+            if (c_c0 >= p.cC) {
+                c_c0 = 0;
+                if (++c_kx == p.cKW) { c_kx = 0; ++c_ky; }
+            }
+        }
+    };
+
+    // ---- fragment read offsets ----
+    const int li = lane & 31, lh = lane >> 5;
+    const int fsw = (li >> 1) & 7;
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) a_off[t] = ((wm * TM + t) * 32 + li) * 128;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) b_off[t] = A_BYTES + ((wn * TN + t) * 32 + li) * 128;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (EPI == EPI_RESID) resid_io<TM, TN, false>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
+
+    // K loop: one barrier per K tile; inside a tile the fragments of k-step ks+1 are read from LDS while the
+    // MFMAs of k-step ks run (register double buffer), and the next tile's DMAs are issued behind the first reads.
+    f16x8 af[MX ? 4 : 2][TM], bf[MX ? 4 : 2][TN];           // MX tiles keep all four k-steps' fragments in flight
+    auto load_frags = [&](int buf, const char *sb, int ks) {
+        const int c = ((2 * ks + lh) ^ fsw) * 16;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[buf][t] = *(const f16x8 *)(sb + a_off[t] + c);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bf[buf][t] = *(const f16x8 *)(sb + b_off[t] + c);
+    };
+    static_assert(NS == 2 || (NS == 3 && (NA + NB == 8 || NA + NB == 6 || NA + NB == 4)), "stage count / DMAs per stage");
+    const int mxper = MX && p.mx_period > 0 ? p.mx_period : nk;
+    const int n16 = MX && p.nk16 > 0 && p.nk16 < mxper ? p.nk16 : mxper;
+    int kphase = 0;                              // kt % mxper
+    const int mxa = p.mx_scale_a * 0x01010101, mxb = p.mx_scale_b * 0x01010101;
+    stage(0, 0);
+    if constexpr (NS == 3) { if (nk > 1) stage(1, 1); }
+    int cbuf = 0;                                           // buffer of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        if (NS == 3 && kt + 1 < nk) vm_wait_halftiles((NA + NB) / 2);   // all but the newest stage (NA + NB DMAs) landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char *sb = smem + cbuf * STAGE;
+        load_frags(0, sb, 0);
+        if constexpr (NS == 3) {
+            int nb = cbuf + 2; nb = nb >= 3 ? nb - 3 : nb;
+            if (kt + 2 < nk) stage(nb, kt + 2);
+            cbuf = cbuf == 2 ? 0 : cbuf + 1;
+        } else {
+            if (kt + 1 < nk) stage(cbuf ^ 1, kt + 1);
+            cbuf ^= 1;
+        }
+        bool is8 = false;
+        if constexpr (MX) {
+            is8 = kphase >= n16;
+            kphase = kphase + 1 == mxper ? 0 : kphase + 1;
+        }
+        if (MX && is8) {
+            // MX-fp8 tile (gemm.h nk16): the fragments of k-steps 2q, 2q + 1 are the 32-byte operands of one scaled MFMA
+            // the second MFMA group's fragments are read from the LDS under the first group's MFMAs
+            constexpr int FB = MX ? 2 : 0;
+            load_frags(1, sb, 1);
+            load_frags(FB, sb, 2);
+            load_frags(FB + 1, sb, 3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = mfma_mx8(af[0][i], af[1][i], bf[0][j], bf[1][j], acc[i][j], mxa, mxb);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = mfma_mx8(af[FB][i], af[FB + 1][i], bf[FB][j], bf[FB + 1][j], acc[i][j], mxa, mxb);
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) load_frags((ks + 1) & 1, sb, ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();            // staging buffers are dead; reuse LDS for the epilogue patches
+
+    if constexpr (EPI == EPI_RESID) resid_io<TM, TN, true>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
+    else run_epilogue<EPI, TM, TN, MX>(p, acc, smem, wave, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 "ping-pong" kernel: 8 waves = 2 wave groups (rows 0-127 / 128-255) staggered by
+// one barrier, so on every SIMD one wave runs its 8-MFMA cluster while its partner issues the
+// ds_reads and LDS-DMA of its next cluster.  Per K tile each wave walks its 128 x 64 output in four
+// 64 x 32 quadrants (phases p0..p3):
+//     p0: read B(j0)[4] + A(i0)[8] | mfma (i0,j0)      p1: read B(j1)[4] | mfma (i0,j1)
+//     p2: read A(i1)[8]            | mfma (i1,j1)      p3: -              | mfma (i1,j0)
+// LDS: 2 K-tile buffers x {A 32 KB, B 32 KB}; each buffer is staged as four 16 KB "half tiles"
+// A_i = rows {64 i .. +64} of both wave groups, B_j = rows {64 wc + 32 j .. +32} of the four wave
+// columns, one half tile (2 global_load_lds per thread) per phase, in consumption order and 5-6
+// phases ahead of first use:
+//     p0: B_1(t+1)   p1: A_1(t+1)   p2: A_0(t+2)   p3: B_0(t+2)
+// A region is re-staged >= 2 phases after its last ds_read (WAR) and read >= 1 phase after the
+// issuing waves' counted s_waitcnt vmcnt + barrier (RAW); vmcnt never drains to 0 in steady state
+// (8 DMAs = 4 half tiles stay in flight).
+// ------------------------------------------------------------------------------------------------
+
+#define PB_BAR()                                  \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        asm volatile("s_barrier" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+
+// VAR != 0 are timing-only ablations (wrong results): 1 no DMA in the loop, 2 no vmcnt waits, 3 no ds_reads,
+// 5 DMA + barriers only (no ds_reads, no MFMAs), 6 MFMAs + barriers only.
+template <int AMODE, int EPI, int VAR = 0, bool BUFP = false, bool MX = false>
+__global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int BUF = 65536, BOFF = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wr = wave >> 2, wc = wave & 3;
+    long long ts0 = 0, ts1 = 0, ts2 = 0, tr0 = 0;
+    stagger_start(p.stagger, 256);
+    if (p.dbg) { ts0 = __builtin_readcyclecounter(); tr0 = wall_clock64(); }
+
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    // Within an XCD's contiguous range, walk 8 (M) x GN (N) super-tiles so that the ~32 tiles in flight on
+    // the XCD share few A and W panels (fewer L2 misses -> less MALL/HBM traffic; loop time is unchanged).
+    int tile_m, tile_n;
+    {
+        const int GN = tilesN < 4 ? tilesN : 4;
+        const int per_band = 8 * tilesN;                 // tiles in a band of 8 M-panels
+        const int band = swz / per_band, rem = swz - band * per_band;
+        const int tilesM = nwg / tilesN;
+        const int bh = (tilesM - band * 8) < 8 ? (tilesM - band * 8) : 8;   // M-panels in this band
+        const int grp = rem / (bh * GN), r2 = rem - grp * bh * GN;
+        const int gw = (tilesN - grp * GN) < GN ? (tilesN - grp * GN) : GN; // N-panels in this group
+        tile_m = band * 8 + r2 / gw;
+        tile_n = grp * GN + r2 % gw;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging geometry: half tile h in {A_0, A_1, B_0, B_1}, two DMAs (u = 0, 1) per thread ----
+    // DMA (wave, u) covers the 8 LDS rows starting at row0; lane -> row0 + (lane >> 3), chunk lane & 7.
+    const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
+    const int lrow = lane >> 3;
+    int a_row0[2][2], b_row0[2][2];                  // [half][u], tile-local row of the DMA's first row
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = wave * 2 + u;
+            a_row0[hf][u] = (g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8;
+            b_row0[hf][u] = (g >> 2) * 64 + hf * 32 + (g & 3) * 8;
+        }
+    // swizzled global chunk of this lane's LDS slot: row0 is a multiple of 8 with (row0 >> 3) & 1 == u
+    int cgu[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) cgu[u] = (lane & 7) ^ ((4 * u + (lane >> 4)) & 7);
+
+    const f16 *a_ptr[2][2];
+    int a_iy0[2][2], a_ix0[2][2];
+    bool a_ok[2][2];
+    const f16 *b_ptr[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int m = m0 + a_row0[hf][u] + lrow;
+            if constexpr (AMODE == A_DENSE) {
+                const int mc = m < p.M ? m : p.M - 1;
+                a_ptr[hf][u] = p.A + (int64_t)mc * p.lda + cgu[u] * 8;
+                a_ok[hf][u] = true;
+                a_iy0[hf][u] = a_ix0[hf][u] = 0;
+            } else {
+                const int ohw = p.cOH * p.cOW;
+                const int b = m / ohw, rem = m - b * ohw;
+                const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+                a_ok[hf][u] = m < p.M;
+                a_ptr[hf][u] = p.A + (int64_t)b * p.cH * p.cW * cld + cgu[u] * 8;
+                a_iy0[hf][u] = oy * p.cStride - p.cPad;
+                a_ix0[hf][u] = ox * p.cStride - padx;
+            }
+            b_ptr[hf][u] = p.W + (int64_t)(n0 + col_map(b_row0[hf][u] + lrow, epi_interleaved<EPI, 2>())) * p.K + cgu[u] * 8;
+        }
+    const int nk = p.K >> 6;
+    // BUFP: stage through the buffer path (`buffer_load_dwordx4 ... lds`) - measurably cheaper to issue than the flat
+    // `global_load_lds` (8192^3: 1145 -> 1245 TF, qkv / fc1 shapes +14 ... +17 %).  The resource covers the whole operand
+    // (dense, weights) or the one or two images this tile's rows fall into (conv: a whole DPT map batch exceeds 4 GB);
+    // the launcher only picks this variant when those spans fit 32-bit byte offsets.  Out-of-range offsets read zeros,
+    // which is how padded taps and rows >= M are fed.
+    __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, 0u), rsW = make_rsrc(p.W, 0u);
+    unsigned a_voff[2][2], b_voff[2][2];
+    if constexpr (BUFP) {
+        rsW = make_rsrc(p.W, (unsigned)((int64_t)((p.N + 255) / 256 * 256) * p.K * 2));
+        if constexpr (AMODE == A_DENSE) {
+            rsA = make_rsrc(p.A, (unsigned)((int64_t)p.M * p.lda * 2));
+        } else {
+            const int ohw = p.cOH * p.cOW, nimg = p.M / ohw, b0 = p.bufmode == 2 ? m0 / ohw : 0;
+            const int64_t img = (int64_t)p.cH * p.cW * cld;
+            rsA = make_rsrc(p.A + b0 * img, (unsigned)((p.bufmode == 2 ? (nimg - b0 < 2 ? nimg - b0 : 2) : nimg) * img * 2));
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if constexpr (AMODE == A_DENSE) {
+                    a_voff[hf][u] = (unsigned)((a_ptr[hf][u] - p.A) * 2);
+                } else {
+                    const int ohw = p.cOH * p.cOW, b0 = p.bufmode == 2 ? m0 / ohw : 0;
+                    const int m = m0 + a_row0[hf][u] + lrow;
+                    a_voff[hf][u] = (unsigned)((int64_t)(m / ohw - b0) * p.cH * p.cW * cld * 2) + cgu[u] * 16;
+                }
+                b_voff[hf][u] = (unsigned)((b_ptr[hf][u] - p.W) * 2);
+            }
+    }
+
+    // staging past the last K tile re-reads the last one into a slot nobody reads any more: the loop stays branch free
+    // and every phase can use the same counted wait
+    // conv: each A half has its own tap cursor (ky, kx, c0) that steps one K tile per call - no divisions in the loop - and
+    // the per-lane pixel offset of tap (0, 0) is precomputed, so a DMA costs one add, two range tests and a select
+    int cur_ky[2] = {0, 0}, cur_kx[2] = {0, 0}, cur_c0[2] = {0, 0}, cur_kt[2] = {0, 0};
+    int a_pix0[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) a_pix0[hf][u] = AMODE == A_CONV ? (a_iy0[hf][u] * p.cW + a_ix0[hf][u]) * cld : 0;
+    auto stage_a = [&](int hf, int kt_) {
+        const int ktc = kt_ < nk ? kt_ : nk - 1;
+        const int kt = (p.kwrap && ktc >= p.kwrap) ? ktc - p.kwrap : ktc;         // split-fp16 segments re-read A (gemm.h)
+        char *base = smem + (kt_ & 1) * BUF;
+        const int ky = cur_ky[hf], kx = cur_kx[hf], c0 = cur_c0[hf];
+        const int tapoff = (ky * p.cW + kx) * cld + ((p.kwrap && c0 >= p.kwrap) ? c0 - p.kwrap : c0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = wave * 2 + u;
+            char *dst = base + ((g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8) * 128;
+            if constexpr (AMODE == A_DENSE) {
+                if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[hf][u], kt * 128, dst);
+                else glds16(a_ptr[hf][u] + kt * 64, dst);
+            } else {
+                const bool ok = a_ok[hf][u] && (unsigned)(a_iy0[hf][u] + ky) < (unsigned)p.cH && (unsigned)(a_ix0[hf][u] + kx) < (unsigned)p.cW;
+                const int eo = a_pix0[hf][u] + tapoff;                      // element offset inside the image
+                if constexpr (BUFP) {
+                    const unsigned oob = ok ? 0u : 0xFFFFFF00u;            // any out-of-range offset reads zeros
+                    glds16_buf(rsA, (int)((a_voff[hf][u] + (unsigned)(eo * 2)) | oob), 0, dst);
+                } else {
+                    glds16(ok ? a_ptr[hf][u] + eo : p.zero, dst);
+                }
+            }
+        }
+        if constexpr (AMODE == A_CONV) {
+            // branch-free step; past the end the cursor stays on the last K tile
+            const int adv = cur_kt[hf] < nk - 1 ? 1 : 0;
+            cur_kt[hf] += adv;
+            const int c1 = cur_c0[hf] + 64 * adv;
+            const int w1 = c1 >= p.cC ? 1 : 0;
+            cur_c0[hf] = w1 ? 0 : c1;
+            const int x1 = cur_kx[hf] + w1;
+            const int w2 = x1 == p.cKW ? 1 : 0;
+            cur_kx[hf] = w2 ? 0 : x1;
+            cur_ky[hf] += w2;
+        }
+    };
+    auto stage_b = [&](int hf, int kt_) {
+        const int kt = kt_ < nk ? kt_ : nk - 1;
+        char *base = smem + (kt_ & 1) * BUF + BOFF;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = wave * 2 + u;
+            if constexpr (BUFP) glds16_buf(rsW, b_voff[hf][u], kt * 128, base + ((g >> 2) * 64 + hf * 32 + (g & 3) * 8) * 128);
+            else glds16(b_ptr[hf][u] + kt * 64, base + ((g >> 2) * 64 + hf * 32 + (g & 3) * 8) * 128);
+        }
+    };
+
+    // ---- fragment addressing: chunk(ks) = (lh ^ fsw) ^ 2 ks  ->  byte offset = c0 ^ (32 ks) ----
+    const int li = lane & 31, lh = lane >> 5;
+    const int c0 = (lh ^ ((li >> 1) & 7)) * 16;
+    const int a_base = (wr * 128 + li) * 128;            // + i*8192 + rt*4096
+    const int b_base = BOFF + (wc * 64 + li) * 128;      // + j*4096
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f16x8 fa[2][4], fb0[4], fb1[4];
+    if constexpr (EPI == EPI_RESID) resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+
+    // prologue: A_0(0) B_0(0) B_1(0) A_1(0) A_0(1) B_0(1)   (issuing these BEFORE the residual loads measured 5 % slower on proj)
+    stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+    stage_a(0, 1); stage_b(0, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A_0(0), B_0(0) landed (this wave's share)
+    PB_BAR();
+    if (wr == 1) PB_BAR();                               // stagger the second wave group by one barrier
+    if (p.dbg) ts1 = __builtin_readcyclecounter();
+
+    const int mxa = p.mx_scale_a * 0x01010101, mxb = p.mx_scale_b * 0x01010101;
+    // one K tile; FP8 tiles hold 128 e4m3 bytes per row and go through the MX-scaled MFMA (gemm.h nk16): same staging, same fragment
+    // reads, 4 MFMAs of 64 cycles instead of 8 of 32 per phase - twice the K per tile at the same matrix-pipe time
+    auto tile = [&](auto fp8_tag, int t) {
+        constexpr bool FP8 = decltype(fp8_tag)::value;
+        const char *sb = smem + (t & 1) * BUF;
+        // ================= p0 =================
+        if ((VAR != 3 && VAR != 5 && VAR != 6) || t == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb0[ks] = *(const f16x8 *)(sb + b_base + (c0 ^ (ks * 32)));
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const f16x8 *)(sb + a_base + rt * 4096 + (c0 ^ (ks * 32)));
+        }
+        if (VAR != 1 && VAR != 6) stage_b(1, t + 1);
+        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+        if (VAR != 5) {
+            if constexpr (FP8) {
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[rt][0] = mfma_mx8(fa[rt][2 * q2], fa[rt][2 * q2 + 1], fb0[2 * q2], fb0[2 * q2 + 1], acc[rt][0], mxa, mxb);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[rt][0], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
+        // ================= p1 =================
+        if ((VAR != 3 && VAR != 5 && VAR != 6) || t == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb1[ks] = *(const f16x8 *)(sb + b_base + 4096 + (c0 ^ (ks * 32)));
+        }
+        if (VAR != 1 && VAR != 6) stage_a(1, t + 1);
+        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+        if (VAR != 5) {
+            if constexpr (FP8) {
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[rt][1] = mfma_mx8(fa[rt][2 * q2], fa[rt][2 * q2 + 1], fb1[2 * q2], fb1[2 * q2 + 1], acc[rt][1], mxa, mxb);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[rt][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
+        // ================= p2 =================
+        if (VAR != 3 && VAR != 5 && VAR != 6)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                fa[rt][ks] = *(const f16x8 *)(sb + a_base + 8192 + rt * 4096 + (c0 ^ (ks * 32)));
+        if (VAR != 1 && VAR != 6) stage_a(0, t + 2);
+        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+        if (VAR != 5) {
+            if constexpr (FP8) {
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[2 + rt][1] = mfma_mx8(fa[rt][2 * q2], fa[rt][2 * q2 + 1], fb1[2 * q2], fb1[2 * q2 + 1], acc[2 + rt][1], mxa, mxb);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[2 + rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[2 + rt][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
+        // ================= p3 =================
+        if (VAR != 1 && VAR != 6) stage_b(0, t + 2);
+        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        PB_BAR();
+        __builtin_amdgcn_s_setprio(1);
+        if (VAR != 5) {
+            if constexpr (FP8) {
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[2 + rt][0] = mfma_mx8(fa[rt][2 * q2], fa[rt][2 * q2 + 1], fb0[2 * q2], fb0[2 * q2 + 1], acc[2 + rt][0], mxa, mxb);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[2 + rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[2 + rt][0], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        PB_BAR();
+    };
+    if constexpr (!MX) {
+        for (int t = 0; t < nk; ++t) tile(std::false_type{}, t);
+    } else if constexpr (AMODE == A_DENSE) {     // [fp16 tiles | fp8 tiles] once
+        const int n16 = p.nk16 > 0 && p.nk16 < nk ? p.nk16 : nk;
+        for (int t = 0; t < n16; ++t) tile(std::false_type{}, t);
+        if constexpr (VAR == 0) {
+            for (int t = n16; t < nk; ++t) tile(std::true_type{}, t);
+        }
+    } else {                                     // per tap (mx_period tiles): fp16 tiles, then fp8 tiles
+        const int per = p.mx_period > 0 ? p.mx_period : nk;
+        const int n16 = p.nk16 > 0 && p.nk16 < per ? p.nk16 : per;
+        for (int t0 = 0; t0 < nk; t0 += per) {
+            for (int t = t0; t < t0 + n16; ++t) tile(std::false_type{}, t);
+            for (int t = t0 + n16; t < t0 + per; ++t) tile(std::true_type{}, t);
+        }
+    }
+    if (wr == 0) PB_BAR();                               // re-align the two wave groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.dbg) ts2 = __builtin_readcyclecounter();
+    if constexpr (EPI == EPI_RESID) resid_io<4, 2, true>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+    else run_epilogue<EPI, 4, 2, MX>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, n0);
+    if (p.dbg && tid == 0) {
+        const long long t_issue = __builtin_readcyclecounter();      // all epilogue stores issued, none waited for
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long *d = p.dbg + (long long)blockIdx.x * 8;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter(); d[4] = tr0; d[5] = wall_clock64();
+        d[6] = t_issue; d[7] = swz;
+    }
+}
+
+template <int AMODE, int EPI, bool MX, bool BUFP>
+int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
+    constexpr int SMEM = 131072;
+    auto kern = gemm8_kernel<AMODE, EPI, 0, BUFP, MX>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), SMEM, stream, a);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+// The buffer-path variants need every DMA offset to fit an unsigned 32-bit byte count: 1 = the whole A operand does,
+// 2 = (conv) any two consecutive images do and a BM-row tile never spans more than two, 0 = neither (flat path).
+inline int buffer_mode(int amode, const GemmArgs &a, int BM) {
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("PB_GEMM_BUFFER"); env = e ? atoi(e) : 1; }
+    if (!env) return 0;
+    const int64_t lim = (1LL << 32) - (1 << 20);
+    if ((int64_t)((a.N + 255) / 256 * 256) * a.K * 2 >= lim) return 0;
+    if (amode == A_DENSE) return (int64_t)a.M * a.lda * 2 < lim ? 1 : 0;
+    const int cld = a.cLd ? a.cLd : a.cC;
+    const int64_t ohw = (int64_t)a.cOH * a.cOW, img = (int64_t)a.cH * a.cW * cld * 2;
+    if (ohw <= 0 || a.M % ohw != 0) return 0;
+    if ((a.M / ohw) * img < lim) return 1;
+    return ohw >= BM && 2 * img < lim ? 2 : 0;
+}
+
+template <int AMODE, int EPI, bool MX>
+int launch_g8(hipStream_t stream, const GemmArgs &a) {
+    GemmArgs b = a;
+    b.bufmode = buffer_mode(AMODE, a, 256);
+    if (b.bufmode) return launch_g8_impl<AMODE, EPI, MX, true>(stream, b);
+    return launch_g8_impl<AMODE, EPI, MX, false>(stream, a);
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool MX, bool BUFP = false, int NS = 2>
+int launch_t(hipStream_t stream, const GemmArgs &a) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TN = BN / WN / 32;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * (TN * 32 + 4) * 4;
+    constexpr int SMEM = NS * STAGE > WM * WN * EPIB ? NS * STAGE : WM * WN * EPIB;
+    if constexpr (!BUFP && ((BM == 128 && BN == 128) || NS == 3 || BN == 64)) {       // the small tiles also have a buffer-path build
+        GemmArgs b = a;
+        b.bufmode = buffer_mode(AMODE, a, BM);
+        if (b.bufmode) return launch_t<BM, BN, WM, WN, AMODE, EPI, MX, true, NS>(stream, b);
+    }
+    auto kern = gemm_kernel<BM, BN, WM, WN, AMODE, EPI, BUFP, NS, MX>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(NT), SMEM, stream, a);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int AMODE, int EPI, bool MX>
+int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
+    if constexpr (EPI == EPI_HEAD) {
+        return launch_t<256, 32, 4, 1, AMODE, EPI, MX>(s, a);
+    } else {
+        if (tile == TILE_256) return launch_g8<AMODE, EPI, MX>(s, a);
+        if constexpr (EPI == EPI_STD) {
+            if (tile == TILE_256x64) return launch_t<256, 64, 4, 1, AMODE, EPI, MX>(s, a);
+        }
+        return launch_t<128, 128, 2, 2, AMODE, EPI, MX>(s, a);
+    }
+}
+
+}  // namespace
+

@@ -238,7 +238,8 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     tic(F_PP, 0, (double)F * H * W * 3);
     const int es = split_w_ ? 2 : 1;                         // encoder maps are [hi | lo] in split-fp16 mode
     auto lo = [&](int c) { return split_w_ ? c : 0; };
-    r = launch_raft_prep(stream, frames, F, H, W, sh_, sw_, Hp_, Wp_, padl_, padt_, scale != 1.f, xi_, xc_, yi_, yc_, img_, nullptr, 1, lo(64));
+    const int l8 = split_w_ && mx_ ? kLo8Pa : -1;            // the residual parts of the encoder maps are e4m3 ([hi | hi8 | lo8])
+    r = launch_raft_prep(stream, frames, F, H, W, sh_, sw_, Hp_, Wp_, padl_, padt_, scale != 1.f, xi_, xc_, yi_, yc_, img_, nullptr, 1, lo(64), l8);
     toc();
     if (r) return r;
 
@@ -248,13 +249,13 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         const bool inorm = e == 0;
         auto norm_relu = [&](const f16 *t, float *st, f16 *y, int HW, int C, const f16 *b, const float *sb) -> int {
             tic(F_ELT, 0, 0);
-            int rr = launch_in_apply(stream, t, st, b, sb, y, F, HW, C, es * C, lo(C));
+            int rr = launch_in_apply(stream, t, st, b, sb, y, F, HW, C, es * C, lo(C), l8);
             toc();
             return rr;
         };
         auto stats = [&](const f16 *t, float *st, int HW, int C) -> int {
             tic(F_ELT, 0, 0);
-            int rr = launch_in_stats(stream, t, F, HW, C, es * C, stp_, st, lo(C));
+            int rr = launch_in_stats(stream, t, F, HW, C, es * C, stp_, st, lo(C), l8);
             toc();
             return rr;
         };
@@ -266,8 +267,9 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
             set_weights(a, E.stem, true);
             a.cOH = a.cH; a.cOW = a.cW; a.M = F * a.cH * a.cW;
             a.out = r1_[5]; a.ldo = es * 64; a.lo_off = lo(64); a.act = inorm ? ACT_NONE : ACT_RELU;
+            if (l8 >= 0) { a.lo8 = 1; a.lo8_pa = l8; }
             a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
-            tic(F_CONV, 2.0 * F * h2 * w2 * 64.0 * 147, 0, 1.0 + E.stem.sa + E.stem.sw);
+            tic(F_CONV, 2.0 * F * h2 * w2 * 64.0 * 147, 0, E.stem.mx3 ? 2.0 : 1.0 + E.stem.sa + E.stem.sw);
             r = launch_gemm(stream, A_CONV, EPI_PIXSHUF, TILE_AUTO, a);
             toc();
             if (r) return r;

@@ -18,7 +18,8 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
                                                         int sw, int Hp, int Wp, int pad_l, int pad_t, int resize,
                                                         const int *__restrict__ xi, const int *__restrict__ xc,
                                                         const int *__restrict__ yi, const int *__restrict__ yc,
-                                                        f16 *__restrict__ out, uint8_t *__restrict__ scaled_out, int s2d, int lo_off) {
+                                                        f16 *__restrict__ out, uint8_t *__restrict__ scaled_out, int s2d, int lo_off,
+                                                        int lo8_pa) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)F * Hp * Wp) return;
     const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), f = (int)(i / ((int64_t)Wp * Hp));
@@ -63,7 +64,18 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
     if (s2d && lo_off) {        // split-fp16 encoder input: [hi (64) | lo (64)] per space-to-depth pixel
         const int64_t px = (((int64_t)f * (Hp >> 2) + (y >> 2)) * (Wp >> 2) + (x >> 2)) * (2 * lo_off) + ((y & 3) * 4 + (x & 3)) * 4;
         *(f16x4 *)(out + px) = o;
-        *(f16x4 *)(out + px + lo_off) = l;
+        if (lo8_pa >= 0) {      // e4m3 residual parts: [hi | hi8 | lo8] per pixel (gemm.h lo8)
+            const float shi = __builtin_ldexpf(1.f, lo8_pa), slo = __builtin_ldexpf(1.f, lo8_pa + 12);
+            float t[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t[c] = 2.f * ((float)v[c] / 255.f) - 1.f;
+            char *pb = (char *)(out + px - ((y & 3) * 4 + (x & 3)) * 4);
+            const int col = ((y & 3) * 4 + (x & 3)) * 4;
+            *(int *)(pb + 2 * lo_off + col) = pb_fp8x4((float)o[0] * shi, (float)o[1] * shi, (float)o[2] * shi, 0.f);
+            *(int *)(pb + 3 * lo_off + col) = pb_fp8x4((t[0] - (float)o[0]) * slo, (t[1] - (float)o[1]) * slo, (t[2] - (float)o[2]) * slo, 0.f);
+        } else {
+            *(f16x4 *)(out + px + lo_off) = l;
+        }
     } else {
         const int64_t oi = s2d ? ((((int64_t)f * (Hp >> 2) + (y >> 2)) * (Wp >> 2) + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)) : i;
         *(f16x4 *)(out + oi * 4) = o;
@@ -101,9 +113,20 @@ __global__ __launch_bounds__(256) void im2col7_kernel(const T *__restrict__ x, i
 // - no atomics, so the result does not depend on block scheduling.  Pass 2: one thread per (b, c) adds the chunks in order and
 // stores {mean, 1 / sqrt(var + eps)}.  Threads cover (pixel lane, 8 channels).
 // ------------------------------------------------------------------------------------------------
+// 8 e4m3 residuals of a split map's pixel ([hi | hi8 | lo8], gemm.h lo8) -> float
+__device__ __forceinline__ void lo8_load8(const char *p, float inv, float (&l)[8]) {
+    const int2 u = *(const int2 *)p;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int wv = h ? u.y : u.x;
+        const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(wv, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(wv, true);
+        l[4 * h + 0] = a[0] * inv; l[4 * h + 1] = a[1] * inv; l[4 * h + 2] = d[0] * inv; l[4 * h + 3] = d[1] * inv;
+    }
+}
+
 // lo_off != 0: x is a split-fp16 map [hi | lo] and the statistics are those of hi + lo.
 __global__ __launch_bounds__(256) void in_stats_kernel(const f16 *__restrict__ x, int HW, int C8, int ldc,
-                                                        float *__restrict__ part, int chunk, int lo_off) {
+                                                        float *__restrict__ part, int chunk, int lo_off, int lo8_pa) {
     __shared__ float red[256 * 16];
     const int b = blockIdx.y;
     const int c8 = threadIdx.x % C8, pl = threadIdx.x / C8, npl = blockDim.x / C8;
@@ -114,7 +137,12 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const f16 *__restrict__ x
     if (pl < npl) {
         for (int p = p0 + pl; p < p1; p += npl) {
             const f16x8 v = *(const f16x8 *)(x + ((int64_t)b * HW + p) * ldc + c8 * 8);
-            if (lo_off) {
+            if (lo_off && lo8_pa >= 0) {
+                float l[8];
+                lo8_load8((const char *)(x + ((int64_t)b * HW + p) * ldc) + 3 * lo_off + c8 * 8, __builtin_ldexpf(1.f, -(lo8_pa + 12)), l);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[j] + l[j]; s[j] += f; q[j] += f * f; }
+            } else if (lo_off) {
                 const f16x8 l = *(const f16x8 *)(x + ((int64_t)b * HW + p) * ldc + c8 * 8 + lo_off);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = (float)v[j] + (float)l[j]; s[j] += f; q[j] += f * f; }
@@ -155,7 +183,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float *__restric
 // out = relu( relu(IN(a)) + (b ? (sb ? IN(b) : b) : 0) )   [second relu only when b is given];  sa / sb = {mean, rstd}
 __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a, const float *__restrict__ sa,
                                                         const f16 *__restrict__ bsrc, const float *__restrict__ sb,
-                                                        f16 *__restrict__ out, int B, int HW, int C8, int ldc, int lo_off) {
+                                                        f16 *__restrict__ out, int B, int HW, int C8, int ldc, int lo_off, int lo8_pa) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * HW * C8) return;
     const int c8 = (int)(i % C8);
@@ -163,11 +191,22 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a
     const int b = (int)(pix / HW);
     const int64_t o = pix * ldc + c8 * 8;
     const f16x8 va = *(const f16x8 *)(a + o);
-    f16x8 vb, la, lb;
+    f16x8 vb;
+    float la[8], lb[8];
     if (bsrc) vb = *(const f16x8 *)(bsrc + o);
-    if (lo_off) {                   // split-fp16 maps [hi | lo]
-        la = *(const f16x8 *)(a + o + lo_off);
-        if (bsrc) lb = *(const f16x8 *)(bsrc + o + lo_off);
+    if (lo_off && lo8_pa >= 0) {    // split maps with e4m3 residual parts [hi | hi8 | lo8]
+        const float inv = __builtin_ldexpf(1.f, -(lo8_pa + 12));
+        lo8_load8((const char *)(a + pix * ldc) + 3 * lo_off + c8 * 8, inv, la);
+        if (bsrc) lo8_load8((const char *)(bsrc + pix * ldc) + 3 * lo_off + c8 * 8, inv, lb);
+    } else if (lo_off) {            // split-fp16 maps [hi | lo]
+        const f16x8 ta = *(const f16x8 *)(a + o + lo_off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) la[j] = (float)ta[j];
+        if (bsrc) {
+            const f16x8 tb = *(const f16x8 *)(bsrc + o + lo_off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lb[j] = (float)tb[j];
+        }
     }
     const f32x4 *st = (const f32x4 *)(sa + ((int64_t)b * C8 * 8 + c8 * 8) * 2);
     f32x4 ms[4], ms2[4];
@@ -179,21 +218,33 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a
         for (int j = 0; j < 4; ++j) ms2[j] = s2[j];
     }
     f16x8 r, rl;
+    float rv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float mean = ms[j >> 1][(j & 1) * 2], rstd = ms[j >> 1][(j & 1) * 2 + 1];
-        const float xa = lo_off ? (float)va[j] + (float)la[j] : (float)va[j];
+        const float xa = lo_off ? (float)va[j] + la[j] : (float)va[j];
         float v = fmaxf((xa - mean) * rstd, 0.f);
         if (bsrc) {
-            float w = lo_off ? (float)vb[j] + (float)lb[j] : (float)vb[j];
+            float w = lo_off ? (float)vb[j] + lb[j] : (float)vb[j];
             if (sb) w = (w - ms2[j >> 1][(j & 1) * 2]) * ms2[j >> 1][(j & 1) * 2 + 1];
             v = fmaxf(v + w, 0.f);
         }
         r[j] = (f16)v;
         rl[j] = (f16)(v - (float)r[j]);
+        rv[j] = v;
     }
     *(f16x8 *)(out + o) = r;
-    if (lo_off) *(f16x8 *)(out + o + lo_off) = rl;
+    if (lo_off && lo8_pa >= 0) {
+        const float shi = __builtin_ldexpf(1.f, lo8_pa), slo = __builtin_ldexpf(1.f, lo8_pa + 12);
+        int2 h8, l8;
+        h8.x = pb_fp8x4((float)r[0] * shi, (float)r[1] * shi, (float)r[2] * shi, (float)r[3] * shi);
+        h8.y = pb_fp8x4((float)r[4] * shi, (float)r[5] * shi, (float)r[6] * shi, (float)r[7] * shi);
+        l8.x = pb_fp8x4((rv[0] - (float)r[0]) * slo, (rv[1] - (float)r[1]) * slo, (rv[2] - (float)r[2]) * slo, (rv[3] - (float)r[3]) * slo);
+        l8.y = pb_fp8x4((rv[4] - (float)r[4]) * slo, (rv[5] - (float)r[5]) * slo, (rv[6] - (float)r[6]) * slo, (rv[7] - (float)r[7]) * slo);
+        char *pb = (char *)(out + pix * ldc);
+        *(int2 *)(pb + 2 * lo_off + c8 * 8) = h8;
+        *(int2 *)(pb + 3 * lo_off + c8 * 8) = l8;
+    } else if (lo_off) *(f16x8 *)(out + o + lo_off) = rl;
 }
 
 // cnet output [rows][256] fp16 -> net = tanh(c[:128]) (fp32 master + fp16 copy in HX[:, 0:128]),
@@ -564,9 +615,9 @@ __global__ void fill_u32_kernel(unsigned *p, unsigned v, int n) {
 
 int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, int sh, int sw, int Hp, int Wp, int pad_l,
                      int pad_t, int resize, const int *xi, const int *xc, const int *yi, const int *yc, f16 *out,
-                     uint8_t *scaled_out, int s2d, int lo_off) {
+                     uint8_t *scaled_out, int s2d, int lo_off, int lo8_pa) {
     hipLaunchKernelGGL(raft_prep_kernel, dim3(nblk((int64_t)F * Hp * Wp)), dim3(256), 0, s, frames, F, H, W, sh, sw, Hp, Wp,
-                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d, lo_off);
+                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d, lo_off, lo8_pa);
     LAUNCH_CHECK();
 }
 int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp) {
@@ -575,16 +626,16 @@ int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 
     LAUNCH_CHECK();
 }
 int in_stats_chunks(int HW) { return (HW + 2047) / 2048; }
-int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *part, float *stats, int lo_off) {
+int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *part, float *stats, int lo_off, int lo8_pa) {
     PB_CHECK(C % 8 == 0 && C <= 256 && 256 % (C / 8) == 0, -1, "instance norm: C=%d unsupported", C);
     const int chunk = 2048, nchunk = in_stats_chunks(HW);
-    hipLaunchKernelGGL(in_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, HW, C / 8, ldc, part, chunk, lo_off);
+    hipLaunchKernelGGL(in_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, HW, C / 8, ldc, part, chunk, lo_off, lo8_pa);
     hipLaunchKernelGGL(in_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, nchunk, B * C, 1.f / (float)HW, stats);
     LAUNCH_CHECK();
 }
 int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, const float *sb, f16 *out, int B, int HW,
-                    int C, int ldc, int lo_off) {
-    hipLaunchKernelGGL(in_apply_kernel, dim3(nblk((int64_t)B * HW * (C / 8))), dim3(256), 0, s, a, sa, b, sb, out, B, HW, C / 8, ldc, lo_off);
+                    int C, int ldc, int lo_off, int lo8_pa) {
+    hipLaunchKernelGGL(in_apply_kernel, dim3(nblk((int64_t)B * HW * (C / 8))), dim3(256), 0, s, a, sa, b, sb, out, B, HW, C / 8, ldc, lo_off, lo8_pa);
     LAUNCH_CHECK();
 }
 int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows) {
