@@ -256,7 +256,7 @@ def pmc_traffic(symbol):
     timed bench, so the figure is read from profiles/ (newest round first)."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     want = symbol.replace(" ", "")
-    for name in ("r02_pmc_traffic.json", "r01k_pmc_traffic.json"):
+    for name in ("r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(here, name)
         if not os.path.exists(path):
             continue
@@ -266,15 +266,9 @@ def pmc_traffic(symbol):
     return None, None
 
 
-SYMBOLS = {"depth/gemm_f16": "gemm8_kernel<0,0,0,true> (depth: fc1 + DPT 1x1/convT GEMMs, fp16 out)",
-           "depth/gemm_f16_resid": "gemm8_kernel<0,1,0,true> (depth: proj + fc2, accumulating onto the fp32 residual)",
-           "depth/gemm_f16_qkv": "gemm8_kernel<0,2,0,true> (depth: qkv projection)",
-           "depth/conv_igemm_f16": "gemm8_kernel<1,0,0,true> (depth: implicit-GEMM convs of the DPT head)",
-           "depth/attention": "attnq_kernel<1,2,0,false,8> (depth: fused attention)",
-           "flow/conv_igemm_f16_tile128": "gemm_kernel<128,128,2,2,1,0,true,2> (flow: implicit-GEMM convs with 64 < N < 256 or < 256 tiles)",
-           "flow/conv_igemm_f16_tile256x64": "gemm_kernel<256,64,4,1,1,0,true,2> (flow: implicit-GEMM convs with N <= 64)",
-           "flow/conv_igemm_f16": "gemm8_kernel<1,0,0,true> (flow: implicit-GEMM convs on the 256 x 256 ping-pong kernel)",
-           "flow/gemm_f16": "gemm8_kernel<0,0,0,true> (flow: correlation volume + 1x1 GEMMs)"}
+# GEMM-shaped launches are keyed by the kernel symbol itself (pb_kernel_stat.name = what rocprofv3 prints); the other families:
+SYMBOLS = {"attention": "attnq_kernel<1, 2, 0, false, 8>", "layernorm": "layernorm_kernel", "elementwise": "(bilinear, instance-norm, lookup, ... kernels)",
+           "prepost": "(pre- / post-processing kernels)"}
 PREC_NAME = {0: "f16", 1: "split-f16"}
 
 
@@ -432,7 +426,9 @@ def main():
         # the kernel's own time - the criterion rocprofv3's per-symbol totals reproduce)
         dom_name, g = max(((k, v) for k, v in fam.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(SYMBOLS.get(dom_name, dom_name).split(" ")[0])
+        dom_sym = dom_name.split("/", 1)[1]
+        dom_sym = SYMBOLS.get(dom_sym, dom_sym)
+        traffic, traffic_src = pmc_traffic(dom_sym)
         exec_mult = g["exec_flops"] / g["flops"] if g["flops"] > 0 else 1.0     # MFMA passes issued per algorithmic pass (split-fp16: 2 - 3)
         tot_fl = sum(v["flops"] for v in fam.values())
         band_fl = {b: sum(v["flops"] for k, v in fam.items() if k.startswith(b + "/")) for b in ("depth", "flow")}
@@ -459,14 +455,15 @@ def main():
                              "< 1e-3 against every reference vector (depth <= 4.0e-4, flow <= 6.1e-4 measured) - north_star's tolerance; the band scripts' mode",
                 "f16": "one fp16 MFMA pass per GEMM / conv, fp32 accumulate; against the fp32 reference depth 1.3e-3 max / 8e-4 L2, flow up to 2.2e-3 / 1.5e-3 "
                        "at 1280x720 - outside the tolerance, reported for comparison with round 1"},
-            "roofline": {"bound": "mfma", "kernel": SYMBOLS.get(dom_name, dom_name), "family": dom_name,
+            "roofline": {"bound": "mfma", "kernel": dom_sym, "family": dom_name,
                          "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                          "algorithmic_bytes": round(g["bytes"] / max(g["launches"], 1)),
                          "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5), "launches_per_step": g["launches"] / args.steps,
                          "flop_per_launch": g["flops"] / max(g["launches"], 1),
-                         "selection": "family with the largest summed launch time in the timed region (bands run one after the other; HIP events on the band's stream)",
+                         "selection": "kernel symbol with the largest summed launch time in the timed region (bands run one after the other; HIP events on the "
+                                      "band's stream; `family` = <band>/<symbol as rocprofv3 prints it>)",
                          "step_frac": round(tot_fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
                          "depth_frac_alone": round(band_fl["depth"] / main_res["depth_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
                          "flow_frac_alone": round(band_fl["flow"] / main_res["flow_s"] / 1e12 / PEAK_F16_TFLOPS, 4),

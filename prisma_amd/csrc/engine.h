@@ -22,6 +22,9 @@ struct PackedW {
     // mx3: weights AND activations split with e4m3 residual parts: per tap [w_hi fp16 (Cseg) | w_lo8 (Cseg bytes) | w_hi8 (Cseg bytes)]
     // = 2 Cseg halfs, meeting a split map's [hi | hi8 | lo8] pixel (gemm.h mx_period, lo8); K = taps x 2 Cseg
     int mx3 = 0;
+    int mx2 = 0;             // weights-only split with the residual as e4m3: per tap [w_hi fp16 (Cseg) | w_lo8 (Cseg bytes)] = 1.5 Cseg halfs
+    // conv weights in slice-major K order (gemm.h cTapInner): the (taps x K / (64 taps)) grid of 128-byte blocks of every row, transposed
+    int tapin = 0, taps = 1;
 };
 unsigned char pb_f32_to_e4m3(float x);     // OCP e4m3fn, round to nearest even, saturating (engine.hip)
 
@@ -32,7 +35,9 @@ struct Stage {
 };
 
 struct KernelTimer {
-    struct Rec { int fam; hipEvent_t a, b; double flops, bytes, exec; };
+    struct Rec { int fam; hipEvent_t a, b; double flops, bytes, exec; const char *name; };   // name: GEMM launches, the kernel symbol (gemm.h)
+    // per family (non-GEMM kernels) / per GEMM kernel symbol sums of the records
+    int collect(const char *const *fam_names, int nfam, pb_kernel_stat *out, int cap);
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;

@@ -34,7 +34,7 @@ KernelTimer::~KernelTimer() {
 
 void DepthEngine::tic(int fam, double flops, double bytes, double passes) {
     if (!timer.enabled) return;
-    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes, flops * passes};
+    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes, flops * passes, nullptr};
     hipEventRecord(r.a, stream);
     timer.recs.push_back(r);
 }
@@ -43,23 +43,29 @@ void DepthEngine::toc() {
     hipEventRecord(timer.recs.back().b, stream);
 }
 
-int DepthEngine::stats(pb_kernel_stat *out, int cap) {
-    if (hipStreamSynchronize(stream) != hipSuccess) return -2;
-    pb_kernel_stat acc[F_COUNT];
-    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFam[i], 0, 0, 0, 0, 0};
-    for (auto &r : timer.recs) {
+int KernelTimer::collect(const char *const *fam_names, int nfam, pb_kernel_stat *out, int cap) {
+    std::vector<pb_kernel_stat> acc;
+    auto slot = [&](const char *name) -> pb_kernel_stat & {
+        for (auto &a : acc)
+            if (a.name == name || !strcmp(a.name, name)) return a;
+        acc.push_back(pb_kernel_stat{name, 0, 0, 0, 0, 0});
+        return acc.back();
+    };
+    for (auto &r : recs) {
         float ms = 0;
         hipEventElapsedTime(&ms, r.a, r.b);
-        acc[r.fam].ms += ms;
-        acc[r.fam].flops += r.flops;
-        acc[r.fam].exec_flops += r.exec;
-        acc[r.fam].bytes += r.bytes;
-        acc[r.fam].launches++;
+        pb_kernel_stat &a = slot(r.name && r.name[0] ? r.name : fam_names[r.fam < nfam ? r.fam : 0]);
+        a.ms += ms; a.flops += r.flops; a.exec_flops += r.exec; a.bytes += r.bytes; a.launches++;
     }
     int n = 0;
-    for (int i = 0; i < F_COUNT && n < cap; ++i)
-        if (acc[i].launches) out[n++] = acc[i];
+    for (auto &a : acc)
+        if (n < cap) out[n++] = a;
     return n;
+}
+
+int DepthEngine::stats(pb_kernel_stat *out, int cap) {
+    if (hipStreamSynchronize(stream) != hipSuccess) return -2;
+    return timer.collect(kFam, F_COUNT, out, cap);
 }
 
 DepthEngine::DepthEngine(int dev, const pb_depth_cfg &cfg) : device(dev), cfg_(cfg) {}
@@ -579,6 +585,7 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
             if (!a.cLd) a.cLd = (1 + w.sa) * a.cC;
             a.cC = (1 + w.sa + w.sw) * w.Cseg;
             a.kwrap = w.sw ? (1 + w.sa) * w.Cseg : 0;
+            a.kshift = -a.kwrap;
         } else {
             a.kwrap = w.sw ? (1 + w.sa) * w.Cseg / 64 : 0;
         }
@@ -593,6 +600,7 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
     tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes, w.mx3 ? 2.0 : 1.0 + w.sa + w.sw + (w.nk16 ? 0.5 : 0.0));
     if (tile == TILE_AUTO) tile = amode == A_CONV ? conv_tile : gemm_tile;
     int r = launch_gemm(stream, amode, epi, tile, a);
+    if (timer.enabled && !r) timer.recs.back().name = pb_gemm_last_kernel();
     toc();
     return r;
 }

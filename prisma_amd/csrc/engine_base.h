@@ -22,6 +22,10 @@ class EngineBase {
     int mx_ = 0;                 // ... and where activations are split too (sa) the residual parts are e4m3: maps [hi | hi8 | lo8],
                                  // weights [w_hi | w_lo8 | w_hi8] per tap, fp8 tiles through the MX-scaled MFMA (PackedW::mx3)
     static constexpr int kLo8Pa = 3;
+    int pack_mx2_ = 0;           // while set, pack() lays weights out as [w_hi fp16 | w_lo e4m3] per tap (PackedW::mx2): the layer's input
+                                 // map carries an fp8 copy after its fp16 part ([a16 (Ctot) | a8 (Ctot bytes)], scaled by 2^kMx2Pa)
+    static constexpr int kMx2Pa = 4;
+    int pack_tapin_ = 0;         // while set, pack() stores convolution weights (taps > 1) in slice-major K order (gemm.h cTapInner)
     const f16 *zero_page() const { return zero_; }
 
   protected:
@@ -52,11 +56,15 @@ class EngineBase {
     void tic(int fam, double flops, double bytes, double passes = 1.0);
     void toc();
     // fusion hooks of one conv() call: a second (ReLU'd) copy of the output, and the SepConvGRU epilogues (gemm.h ACT_GRU_*)
-    struct ConvFuse { f16 *out2 = nullptr; float *gru_h = nullptr; const f16 *gru_z = nullptr; f16 *gru_rh = nullptr; };
+    struct ConvFuse { f16 *out2 = nullptr; float *gru_h = nullptr; const f16 *gru_z = nullptr; f16 *gru_rh = nullptr; int gru_ld = 384; };
     // lo_off != 0: out (and add1) are split-fp16 maps, the rounding residual of every output goes to +lo_off (gemm.h)
     int conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w, f16 *out, int ldo,
-             int act, int pre_relu = 0, const f16 *add1 = nullptr, const ConvFuse *fuse = nullptr, int lo_off = 0);
-    int dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1 = nullptr);
+             int act, int pre_relu = 0, const f16 *add1 = nullptr, const ConvFuse *fuse = nullptr, int lo_off = 0, int a8_rel = 0,
+             int o8_off = 0);
+    // a8_rel (mx2 weights): half-offset from `in` to the fp8 copy of its channels (0 = right after the cC channels); o8_off: byte
+    // offset, from the output row, of the fp8 copy the epilogue also stores (0 = none)
+    int dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1 = nullptr, int o8_off = 0,
+              int a_pa = -1);          // a_pa: power-of-two scale the A operand's fp8 copy was stored with (default kMx2Pa)
 
     std::map<std::string, const pb_tensor *> tmap_;
     std::vector<void *> owned_;                 // permanent device allocations (weights), freed by the destructor

@@ -20,7 +20,7 @@ EngineBase::~EngineBase() {
 
 void EngineBase::tic(int fam, double flops, double bytes, double passes) {
     if (!timer.enabled) return;
-    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes, flops * passes};
+    KernelTimer::Rec r{fam, timer.get(), timer.get(), flops, bytes, flops * passes, nullptr};
     hipEventRecord(r.a, cur_);
     timer.recs.push_back(r);
     open_.push_back(timer.recs.size() - 1);
@@ -33,17 +33,7 @@ void EngineBase::toc() {
 
 int EngineBase::stats(pb_kernel_stat *out, int cap) {
     if (hipStreamSynchronize(stream) != hipSuccess) return -2;
-    pb_kernel_stat acc[F_COUNT];
-    for (int i = 0; i < F_COUNT; ++i) acc[i] = pb_kernel_stat{kFam[i], 0, 0, 0, 0, 0};
-    for (auto &r : timer.recs) {
-        float ms = 0;
-        hipEventElapsedTime(&ms, r.a, r.b);
-        acc[r.fam].ms += ms; acc[r.fam].flops += r.flops; acc[r.fam].exec_flops += r.exec; acc[r.fam].bytes += r.bytes; acc[r.fam].launches++;
-    }
-    int n = 0;
-    for (int i = 0; i < F_COUNT && n < cap; ++i)
-        if (acc[i].launches) out[n++] = acc[i];
-    return n;
+    return timer.collect(kFam, F_COUNT, out, cap);
 }
 
 int EngineBase::begin_load(const pb_tensor *w, int n) {
@@ -73,7 +63,47 @@ int EngineBase::pack(const float *src, int N, int K, int Kpad, PackedW &out, con
     // GEMM reads the activations twice (gemm.h kwrap): a w_hi + a w_lo in one accumulator
     const int sw = split_w_ && Kpad % (64 * taps) == 0 && K % taps == 0 ? 1 : 0, sa = sw && sa_req ? 1 : 0, segs = 1 + sa + sw;
     const int Cin = sw ? K / taps : K, Cp = sw ? Kpad / taps : Kpad, tp = sw ? taps : 1;
-    if (sa && mx_) {             // mx3 layout (engine.hip DepthEngine::pack has the same one)
+    // slice-major K order (gemm.h cTapInner): rows are (taps x S) grids of 128-byte blocks in every layout below - transpose them
+    const int tapin = pack_tapin_ && taps > 1 && Kpad % (64 * taps) == 0 ? 1 : 0;
+    auto to_slice_major = [&](std::vector<f16> &h, int64_t rowlen) {
+        if (!tapin) return;
+        const int64_t S = rowlen / (64 * (int64_t)taps);
+        std::vector<f16> row((size_t)rowlen);
+        for (int64_t n = 0; n < Np; ++n) {
+            f16 *r = h.data() + (size_t)n * rowlen;
+            for (int t = 0; t < taps; ++t)
+                for (int64_t sidx = 0; sidx < S; ++sidx)
+                    std::copy_n(r + ((int64_t)t * S + sidx) * 64, 64, row.data() + (sidx * taps + t) * 64);
+            std::copy_n(row.data(), (size_t)rowlen, r);
+        }
+    };
+    out.tapin = tapin; out.taps = taps;
+    if (!sa && sw && mx_ && pack_mx2_ && Cp % 128 == 0) {        // mx2 layout: per tap [w_hi fp16 | w_lo e4m3 2^pw]
+        float mlo = 0.f;
+        for (int64_t i = 0; i < (int64_t)N * K; ++i) mlo = fmaxf(mlo, fabsf(src[i] - (float)(f16)src[i]));
+        int pw = 0, e = 0;
+        if (mlo > 0.f) { frexpf(mlo, &e); pw = 8 - e; }
+        const int64_t K2 = (int64_t)tp * (Cp + Cp / 2);
+        std::vector<f16> h2((size_t)Np * K2, (f16)0.f);
+        for (int n = 0; n < N; ++n)
+            for (int t = 0; t < tp; ++t) {
+                f16 *d = h2.data() + (size_t)n * K2 + (size_t)t * (Cp + Cp / 2);
+                unsigned char *d8 = (unsigned char *)(d + Cp);
+                for (int k = 0; k < Cin; ++k) {
+                    const float v = src[(size_t)n * K + (size_t)t * Cin + k];
+                    const f16 hi = (f16)v;
+                    d[k] = hi;
+                    d8[k] = pb_f32_to_e4m3(ldexpf(v - (float)hi, pw));
+                }
+            }
+        to_slice_major(h2, K2);
+        void *p2 = nullptr;
+        PB_HIP(hipMalloc(&p2, h2.size() * 2));
+        owned_.push_back(p2);
+        PB_HIP(hipMemcpy(p2, h2.data(), h2.size() * 2, hipMemcpyHostToDevice));
+        out.w = (f16 *)p2; out.N = N; out.K = (int)K2; out.Kreal = K; out.bias = nullptr;
+        out.sa = 0; out.sw = 1; out.Cseg = Cp; out.mx2 = 1; out.mx_pw = pw; out.nk16 = Cp / 64;
+    } else if (sa && mx_) {             // mx3 layout (engine.hip DepthEngine::pack has the same one)
         float mlo = 0.f, mhi = 0.f;
         for (int64_t i = 0; i < (int64_t)N * K; ++i) {
             const float v = src[i];
@@ -97,6 +127,7 @@ int EngineBase::pack(const float *src, int N, int K, int Kpad, PackedW &out, con
                     d8[Cp + k] = pb_f32_to_e4m3(ldexpf((float)hi, pw - 12));
                 }
             }
+        to_slice_major(h3, K3);
         void *p3 = nullptr;
         PB_HIP(hipMalloc(&p3, h3.size() * 2));
         owned_.push_back(p3);
@@ -116,6 +147,7 @@ int EngineBase::pack(const float *src, int N, int K, int Kpad, PackedW &out, con
                 if (sa) d[Cp + k] = hi;
                 if (sw) d[(1 + sa) * Cp + k] = (f16)(v - (float)hi);
             }
+    to_slice_major(h, Kt);
     void *p = nullptr;
     PB_HIP(hipMalloc(&p, h.size() * 2));
     owned_.push_back(p);
@@ -177,12 +209,25 @@ int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *s
 
 void EngineBase::set_weights(GemmArgs &a, const PackedW &w, bool is_conv) const {
     a.W = w.w; a.K = w.K; a.bias = w.bias; a.zero = zero_;
+    const bool tapin = is_conv && w.tapin;
+    if (tapin) { a.cTapInner = 1; a.cKH = w.taps / a.cKW; }
+    if (w.mx2) {                 // [a16 | a8] maps x [w_hi | w_lo8] weights: per tap Cseg / 64 fp16 tiles then Cseg / 128 fp8 tiles
+        a.nk16 = w.nk16; a.mx_scale_a = 127 - kMx2Pa; a.mx_scale_b = 127 - w.mx_pw;
+        if (is_conv) {
+            const int c = a.cC;                   // channels of the slice; the caller set cLd and (conv()) a8_rel via kshift
+            a.cC = c + c / 2;
+            a.mx_period = a.cC / 64;
+            if (tapin) { a.mx_period = 0; a.nk16 = w.nk16 * w.taps; }      // slice-major: every fp16 slice of all taps, then the fp8 slices
+        }
+        return;
+    }
     if (w.mx3) {                 // [hi | hi8 | lo8] maps: per tap fp16 tiles then fp8 tiles (gemm.h mx_period)
         a.nk16 = w.nk16; a.mx_scale_a = 127 - kLo8Pa; a.mx_scale_b = 127 - w.mx_pw;
         if (is_conv) {
             if (!a.cLd) a.cLd = 2 * a.cC;
             a.cC = 2 * w.Cseg;
             a.mx_period = 2 * w.Cseg / 64;
+            if (tapin) { a.mx_period = 0; a.nk16 = w.nk16 * w.taps; }
         }
         return;
     }
@@ -190,6 +235,7 @@ void EngineBase::set_weights(GemmArgs &a, const PackedW &w, bool is_conv) const 
     if (is_conv) {               // per tap [w_hi | w_hi (if sa) | w_lo]: the channel cursor wraps back onto the pixel's hi part
         if (!a.cLd) a.cLd = (1 + w.sa) * a.cC;
         a.kwrap = (1 + w.sa) * a.cC;
+        a.kshift = -a.kwrap;
         a.cC = (2 + w.sa) * a.cC;
     } else {
         a.kwrap = (1 + w.sa) * w.Cseg / 64;
@@ -216,7 +262,7 @@ int EngineBase::commit_arena(const char *what) {
 }
 
 int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w, f16 *out,
-                     int ldo, int act, int pre_relu, const f16 *add1, const ConvFuse *fuse, int lo_off) {
+                     int ldo, int act, int pre_relu, const f16 *add1, const ConvFuse *fuse, int lo_off, int a8_rel, int o8_off) {
     GemmArgs a;
     a.A = in; a.N = w.N;
     a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = kw; a.cStride = stride; a.cPad = kh / 2; a.cPadX = kw / 2;
@@ -224,7 +270,9 @@ int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh
     a.M = n * a.cOH * a.cOW;
     a.out = out; a.ldo = ldo; a.act = act; a.pre_relu = pre_relu; a.add1 = add1; a.lo_off = lo_off;
     if (lo_off && mx_) { a.lo8 = 1; a.lo8_pa = kLo8Pa; }
-    if (fuse) { a.out2 = fuse->out2; a.gru_h = fuse->gru_h; a.gru_z = fuse->gru_z; a.gru_rh = fuse->gru_rh; }
+    if (fuse) { a.out2 = fuse->out2; a.gru_h = fuse->gru_h; a.gru_z = fuse->gru_z; a.gru_rh = fuse->gru_rh; a.gru_ld = fuse->gru_ld; }
+    if (w.mx2 && a8_rel && a8_rel != cC) { a.kwrap = cC; a.kshift = a8_rel - cC; }      // the fp8 copy of a channel slice is not adjacent
+    if (o8_off) { a.o8_off = o8_off; a.o8_scale = (float)(1 << kMx2Pa); }
     PB_CHECK(!w.sw || w.Cseg == cC, PB_ERR_STATE, "split conv: %d channels, weights packed for %d", cC, w.Cseg);
     set_weights(a, w, true);
     PB_CHECK(w.K == kh * kw * a.cC, PB_ERR_STATE, "conv: packed K %d != %d*%d*%d", w.K, kh, kw, a.cC);
@@ -232,19 +280,23 @@ int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh
     const bool wide = conv_tile == TILE_256 || (conv_tile == TILE_AUTO && a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256);
     // algorithmic bytes: the input map once, the weights once, the output once (fp16)
     // one family per kernel symbol launch_gemm picks: 256 x 256 ping-pong, 256 x 64 (N <= 64), 128 x 128
-    tic(wide ? F_CONV : (conv_tile == TILE_AUTO && a.N <= 64 ? F_CONV64 : F_CONV128), 2.0 * a.M * (double)a.N * w.Kreal, 2.0 * ((double)n * H * W * cC + (double)a.N * w.Kreal + (double)a.M * a.N), w.mx3 ? 2.0 : 1.0 + w.sa + w.sw);
+    tic(wide ? F_CONV : (conv_tile == TILE_AUTO && a.N <= 64 ? F_CONV64 : F_CONV128), 2.0 * a.M * (double)a.N * w.Kreal, 2.0 * ((double)n * H * W * cC + (double)a.N * w.Kreal + (double)a.M * a.N), w.mx3 ? 2.0 : (w.mx2 ? 1.5 : 1.0 + w.sa + w.sw));
     int r = launch_gemm(cur_, A_CONV, EPI_STD, conv_tile, a);
+    if (timer.enabled && !r) timer.recs[open_.back()].name = pb_gemm_last_kernel();
     toc();
     return r;
 }
 
-int EngineBase::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1) {
+int EngineBase::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1, int o8_off, int a_pa) {
     GemmArgs a;
     a.A = A; a.lda = lda; a.N = w.N; a.M = (int)M;
     set_weights(a, w, false);
     a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
-    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 2.0 * ((double)M * w.Kreal + (double)a.N * w.Kreal + (double)M * a.N), w.mx3 ? 2.0 : 1.0 + w.sa + w.sw);
+    if (o8_off) { a.o8_off = o8_off; a.o8_scale = (float)(1 << kMx2Pa); }
+    if (w.mx2 && a_pa >= 0) a.mx_scale_a = 127 - a_pa;
+    tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 2.0 * ((double)M * w.Kreal + (double)a.N * w.Kreal + (double)M * a.N), w.mx3 ? 2.0 : (w.mx2 ? 1.5 : 1.0 + w.sa + w.sw));
     int r = launch_gemm(cur_, A_DENSE, EPI_STD, TILE_AUTO, a);
+    if (timer.enabled && !r) timer.recs[open_.back()].name = pb_gemm_last_kernel();
     toc();
     return r;
 }

@@ -21,11 +21,21 @@ struct GemmArgs {
     // channel slice [0, cC) of a wider NHWC buffer can be convolved in place
     int cH = 0, cW = 0, cC = 0, cOH = 0, cOW = 0, cKW = 1, cStride = 1, cPad = 0, cPadX = -1, cLd = 0;
     const f16 *zero = nullptr;            // >= 16 bytes of zeros: source of padded taps / rows >= M
+    // conv K order.  0: tap-major - K index = (tap, c): every tap walks the pixel's whole channel extent (cC) before the next tap.
+    // 1 (cTapInner, needs cKH): slice-major - K index = (c / 64, tap, c % 64): the KH x KW taps of one 64-half slice run back to back,
+    // so the lines a workgroup (and its neighbours on the XCD) touch are re-used by the next 8 tiles while they still sit in the L2;
+    // with tap-major order a 384-channel map's per-tap footprint of the tiles in flight on an XCD (~6 MB) exceeds its 4 MB L2 and
+    // every tap re-fetches from the fabric.  The weights' K axis is permuted to match (engine_base.hip pack, 128-byte blocks).
+    int cTapInner = 0, cKH = 0;
     // split-fp16 operands (precision mode): the K axis is a concatenation of segments [a_hi w_hi | a_lo w_hi | a_hi w_lo]
     // (any subset after the first).  W holds the segments back to back; A holds [hi | lo] (or just hi) and its K index wraps:
     // dense: K tile kt reads A tile (kt >= kwrap ? kt - kwrap : kt); conv: channel cursor c reads channel (c >= kwrap ? c - kwrap : c)
     // of a pixel (cC = channels per tap of the concatenated K axis, cLd = pixel stride of the [hi | lo] image).  0 = off.
     int kwrap = 0;
+    // conv: what is added to the channel cursor past kwrap: -kwrap for the wrap above; a map whose fp8 copy sits after the whole
+    // pixel's fp16 part ([a16 (Ctot) | a8 (Ctot bytes)], nk16 below) convolved on a channel slice jumps forward instead.
+    int kshift = 0;
+    int gru_ld = 384;                     // pixel stride (halfs) of gru_rh (the GRU input buffer; 576 with an fp8 copy)
     // MX-fp8 correction segments (split-fp16 mode on shapes that allow it): the operand rows are [fp16 part | fp8 part] in memory - K tiles
     // [0, nk16) hold 64 halfs, tiles [nk16, K / 64) hold 128 OCP e4m3 bytes (same 128 bytes per row and tile, so the staging does
     // not change) and are multiplied with v_mfma_scale_f32_32x32x64_f8f6f4 into the SAME accumulators; the two E8M0 scale bytes undo
@@ -80,3 +90,8 @@ struct GemmArgs {
 
 // Launches the kernel on `stream`.  tile: TILE_AUTO picks from the shape.
 int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a);
+
+// Name of the kernel the last launch_gemm call of this thread launched, spelled like the symbol rocprofv3 reports
+// ("gemm8_kernel<1, 0, 0, true, false>"): the engines' per-launch timers are keyed by it, so a bench family IS one symbol.
+const char *pb_gemm_last_kernel();
+void pb_gemm_set_last_kernel(const char *name);

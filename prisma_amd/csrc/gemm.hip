@@ -22,6 +22,10 @@ int pb_gemm_conv_pixshuf_mx(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_head_f16(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_head_mx(hipStream_t s, int tile, const GemmArgs &a);
 
+static thread_local const char *g_last_kernel = "";
+const char *pb_gemm_last_kernel() { return g_last_kernel; }
+void pb_gemm_set_last_kernel(const char *name) { g_last_kernel = name; }
+
 int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a_in) {
     GemmArgs a = a_in;
     PB_CHECK(a.K > 0 && a.K % 64 == 0, -1, "gemm: K=%d must be a positive multiple of 64", a.K);

@@ -440,6 +440,10 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                     f16x2 o2;
                     o2[0] = (f16)fmaxf(v0[q], 0.f); o2[1] = (f16)fmaxf(v1[q], 0.f);
                     if (!CHECK || ok[q]) *(f16x2 *)(p.out2 + off[q]) = o2;
+                    if constexpr (LOM == 3) {
+                        if (!CHECK || ok[q])
+                            *(unsigned short *)((char *)p.out2 + (off[q] - nc) * 2 + p.o8_off + nc) = pb_fp8x2((float)o2[0] * p.o8_scale, (float)o2[1] * p.o8_scale);
+                    }
                 }
                 if constexpr (LOM == 1 || LOM == 2) {
 #pragma unroll
@@ -478,7 +482,12 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                     for (int q = 0; q < 8; ++q) {
                         f16x2 o;
                         o[0] = (f16)(v0[q] * h[q][0]); o[1] = (f16)(v1[q] * h[q][1]);
-                        if (!CHECK || ok[q]) *(f16x2 *)(p.gru_rh + (int64_t)mr[q] * 384 + (nc - 128)) = o;
+                        if (!CHECK || ok[q]) *(f16x2 *)(p.gru_rh + (int64_t)mr[q] * p.gru_ld + (nc - 128)) = o;
+                        if constexpr (LOM == 3) {       // fp8 twin of r * h for the q convolution's MX segment (o8_off = byte offset of the copy)
+                            if (!CHECK || ok[q])
+                                *(unsigned short *)((char *)(p.gru_rh + (int64_t)mr[q] * p.gru_ld) + p.o8_off + (nc - 128)) =
+                                    pb_fp8x2((float)o[0] * p.o8_scale, (float)o[1] * p.o8_scale);
+                        }
                     }
                     continue;
                 }
@@ -516,7 +525,7 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 if (!CHECK || ok[q]) *(f16x2 *)(dst + off[q]) = o;
             }
             if constexpr (EPI == EPI_STD && LOM == 3) {
-                {                                // fp8 copy for a consumer's MX correction segment (gemm.h o8_off)
+                if (p.act != ACT_GRU_ZR) {       // fp8 copy for a consumer's MX correction segment (gemm.h o8_off); z itself has none
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const unsigned short o8 = pb_fp8x2(v0[q] * p.o8_scale, v1[q] * p.o8_scale);
@@ -766,7 +775,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
         char *sA = smem + buf * STAGE + wave * 1024;
         char *sB = smem + buf * STAGE + A_BYTES + wave * 1024;
         const int ka = (p.kwrap && kt >= p.kwrap) ? kt - p.kwrap : kt;            // split-fp16 segments re-read A (gemm.h)
-        const int cs = (p.kwrap && c_c0 >= p.kwrap) ? c_c0 - p.kwrap : c_c0;
+        const int cs = (p.kwrap && c_c0 >= p.kwrap) ? c_c0 + p.kshift : c_c0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if constexpr (AMODE == A_DENSE) {
@@ -789,11 +798,18 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             else glds16(b_ptr[i] + kt * 64, sB + i * (NT * 16));
         }
         if constexpr (AMODE == A_CONV) {
-            c_c0 += 64;
-            if (c_c0 >= p.cC) {
-                c_c0 = 0;
-                if (++c_kx == p.cKW) { c_kx = 0; ++c_ky; }
-            }
+            // one branch-free step for both K orders (gemm.h cTapInner): tap-major walks (ky, kx, c), slice-major (c, ky, kx)
+            const int ti = p.cTapInner;
+            int c1 = c_c0 + (ti ? 0 : 64);
+            const int wc = (!ti && c1 >= p.cC) ? 1 : 0;
+            c1 = wc ? 0 : c1;
+            int x1 = c_kx + ti + wc;
+            const int wx = x1 == p.cKW ? 1 : 0;
+            c_kx = wx ? 0 : x1;
+            const int y1 = c_ky + wx;
+            const int wy = (ti && y1 == p.cKH) ? 1 : 0;
+            c_ky = wy ? 0 : y1;
+            c_c0 = c1 + 64 * wy;
         }
     };
 
@@ -1041,7 +1057,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         const int kt = (p.kwrap && ktc >= p.kwrap) ? ktc - p.kwrap : ktc;         // split-fp16 segments re-read A (gemm.h)
         char *base = smem + (kt_ & 1) * BUF;
         const int ky = cur_ky[hf], kx = cur_kx[hf], c0 = cur_c0[hf];
-        const int tapoff = (ky * p.cW + kx) * cld + ((p.kwrap && c0 >= p.kwrap) ? c0 - p.kwrap : c0);
+        const int tapoff = (ky * p.cW + kx) * cld + ((p.kwrap && c0 >= p.kwrap) ? c0 + p.kshift : c0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int g = wave * 2 + u;
@@ -1064,13 +1080,19 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             // branch-free step; past the end the cursor stays on the last K tile
             const int adv = cur_kt[hf] < nk - 1 ? 1 : 0;
             cur_kt[hf] += adv;
-            const int c1 = cur_c0[hf] + 64 * adv;
-            const int w1 = c1 >= p.cC ? 1 : 0;
-            cur_c0[hf] = w1 ? 0 : c1;
-            const int x1 = cur_kx[hf] + w1;
-            const int w2 = x1 == p.cKW ? 1 : 0;
-            cur_kx[hf] = w2 ? 0 : x1;
-            cur_ky[hf] += w2;
+            // one step for both K orders (gemm.h cTapInner): tap-major walks (ky, kx, c), slice-major (c, ky, kx); scalar selects only -
+            // a branch here costs the 256 x 256 MX kernel its register allocation (128 VGPRs spilled)
+            const int ti = p.cTapInner;
+            int c1 = cur_c0[hf] + (ti ? 0 : 64 * adv);
+            const int wc = (!ti && c1 >= p.cC) ? 1 : 0;
+            c1 = wc ? 0 : c1;
+            const int x1 = cur_kx[hf] + (ti ? adv : 0) + wc;
+            const int wx = x1 == p.cKW ? 1 : 0;
+            cur_kx[hf] = wx ? 0 : x1;
+            const int y1 = cur_ky[hf] + wx;
+            const int wy = (ti && y1 == p.cKH) ? 1 : 0;
+            cur_ky[hf] = wy ? 0 : y1;
+            cur_c0[hf] = c1 + 64 * wy;
         }
     };
     auto stage_b = [&](int hf, int kt_) {
@@ -1256,6 +1278,9 @@ template <int AMODE, int EPI, bool MX, bool BUFP>
 int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
     constexpr int SMEM = 131072;
     auto kern = gemm8_kernel<AMODE, EPI, 0, BUFP, MX>;
+    static char name[96];
+    if (!name[0]) snprintf(name, sizeof(name), "gemm8_kernel<%d, %d, 0, %s, %s>", AMODE, EPI, BUFP ? "true" : "false", MX ? "true" : "false");
+    pb_gemm_set_last_kernel(name);
     static bool attr_set = false;
     if (!attr_set) {
         PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1304,6 +1329,11 @@ int launch_t(hipStream_t stream, const GemmArgs &a) {
         if (b.bufmode) return launch_t<BM, BN, WM, WN, AMODE, EPI, MX, true, NS>(stream, b);
     }
     auto kern = gemm_kernel<BM, BN, WM, WN, AMODE, EPI, BUFP, NS, MX>;
+    static char name[112];
+    if (!name[0])
+        snprintf(name, sizeof(name), "gemm_kernel<%d, %d, %d, %d, %d, %d, %s, %d, %s>", BM, BN, WM, WN, AMODE, EPI, BUFP ? "true" : "false", NS,
+                 MX ? "true" : "false");
+    pb_gemm_set_last_kernel(name);
     static bool attr_set = false;
     if (!attr_set) {
         PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));

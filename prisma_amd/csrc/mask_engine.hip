@@ -265,6 +265,7 @@ int MaskEngine::conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, co
     PB_CHECK(w.K == 9 * a.cC, PB_ERR_STATE, "conv_f32: packed K %d != 9*%d", w.K, a.cC);
     tic(F_CONV, 2.0 * a.M * (double)a.N * w.Kreal, 0);
     int r = launch_gemm(cur_, A_CONV, EPI_F32, TILE_128, a);
+    if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
     toc();
     return r;
 }
@@ -292,6 +293,7 @@ int MaskEngine::backbone(int n) {
         a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
         tic(F_CONV, 2.0 * n * H2 * W2 * 64.0 * 147, 0);
         r = launch_gemm(cur_, A_CONV, EPI_PIXSHUF, TILE_AUTO, a);
+        if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
         toc();
         if (r) return r;
     }
@@ -521,6 +523,7 @@ int MaskEngine::post_chunk(int n, int first, float confidence, const std::vector
         a.out32 = plog_ + f.off * HW4; a.ldo = HW4; a.scale = 1.f; a.zero = zero_;
         tic(F_GEMM, 2.0 * K * (double)HW4 * 256, 0);
         r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
+        if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
         toc();
         if (r) return r;
         tic(F_PP, 0, (double)K * HW4 * 4);

@@ -48,5 +48,6 @@ class RaftEngine : public EngineBase {
         *zrb_ = nullptr, *fh_ = nullptr, *m0_ = nullptr;
     unsigned *maxd_ = nullptr;
     int last_nd_ = 0;
+    int upd8_ = 0;               // the update block's maps carry fp8 copies and its weights e4m3 residuals (MX segments; raft_engine.hip load)
     std::map<std::string, Stage> stages_;
 };

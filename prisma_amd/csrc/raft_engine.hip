@@ -53,6 +53,7 @@ int RaftEngine::load(const pb_tensor *w, int n) {
     if (r0) return r0;
     int r;
     const int dims[3] = {64, 96, 128};
+    pack_tapin_ = getenv("PB_TAPIN") && getenv("PB_TAPIN")[0] == '2';
     for (int e = 0; e < 2; ++e) {
         const std::string en = e == 0 ? "fnet" : "cnet";
         Enc &E = e == 0 ? fnet_ : cnet_;
@@ -103,6 +104,18 @@ int RaftEngine::load(const pb_tensor *w, int n) {
         if ((r = pack_conv(en + ".conv2", true, nullptr, nullptr, E.out, 1))) return r;
     }
     const std::string u = "update_block.";
+    // the update block's activations carry an fp8 copy ([a16 | a8] per pixel) and its weight residuals are e4m3 (PackedW::mx2)
+    // ... as an opt-in (PB_MX_UPD=1) only: measured on MI355X it buys 1 % of the band (1080p x 0.75, 31 pairs: 174.7 -> 172.9 ms; 720p:
+    // 177.8 -> 175.7 ms - these convolutions are not bound by the matrix pipe, and the fp8 copies add traffic) while the e4m3 copies of
+    // the recurrent state eat the parity margin (720p x 8 pairs, worst pair: 5.8e-4 -> 1.1e-3 max-norm).  The default keeps the two
+    // fp16 passes (w_hi, w_lo) here.
+    pack_mx2_ = mx_ && getenv("PB_MX_UPD") && getenv("PB_MX_UPD")[0] == '1';
+    upd8_ = pack_mx2_;
+    // slice-major K order (gemm.h cTapInner) for the 3x3 / 1x5 / 5x1 convolutions over the 128 ... 384-channel maps of the update block:
+    // tap-major order overflows the XCD L2 there.  PB_TAPIN=0 turns it off, 2 also applies it to the encoders (A/B runs).
+    const char *tin = getenv("PB_TAPIN");
+    const int tapin_all = pack_tapin_;
+    pack_tapin_ = !(tin && tin[0] == '0');
     if ((r = pack_conv(u + "encoder.convc1", true, nullptr, nullptr, convc1_))) return r;
     if ((r = pack_conv(u + "encoder.convc2", true, nullptr, nullptr, convc2_))) return r;
     if ((r = pack_conv(u + "encoder.convf2", true, nullptr, nullptr, convf2_))) return r;
@@ -142,9 +155,16 @@ int RaftEngine::load(const pb_tensor *w, int n) {
         if ((r = pack_conv(u + "gru.convq" + sfx, true, nullptr, nullptr, q_[half]))) return r;
     }
     if ((r = pack_conv(u + "flow_head.conv1", true, nullptr, nullptr, fh1_))) return r;
+    pack_mx2_ = 0;                                          // flow_head2 is a direct kernel, mask.2 an fp32-output GEMM: fp16 residuals
+    const int tapin_upd = pack_tapin_;
+    pack_tapin_ = 0;                                        // ... that walks its weights tap-major
     if ((r = pack_conv(u + "flow_head.conv2", true, nullptr, nullptr, fh2_))) return r;
     fh2_.N = 8;                                             // 2 real outputs, rows 2..7 are zero
+    pack_mx2_ = upd8_;
+    pack_tapin_ = tapin_upd;
     if ((r = pack_conv(u + "mask.0", true, nullptr, nullptr, mk0_))) return r;
+    pack_mx2_ = 0;
+    pack_tapin_ = tapin_all;
     if ((r = pack_conv(u + "mask.2", true, nullptr, nullptr, mk2_))) return r;
     tmap_.clear();
     PB_HIP(hipDeviceSynchronize());
@@ -192,10 +212,11 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         const int64_t rows = round_up(ND * P_, 256);
         h32_ = (float *)carve((size_t)rows * 128 * 4); flow_ = (float *)carve((size_t)rows * 2 * 4);
         mask_ = (float *)carve((size_t)rows * 576 * 4);
-        hx_ = (f16 *)carve((size_t)rows * 384 * 2); hx2_ = (f16 *)carve((size_t)rows * 384 * 2);
-        corr_ = (f16 *)carve((size_t)rows * 384 * 2); c1_ = (f16 *)carve((size_t)rows * 256 * 2);
-        corflo_ = (f16 *)carve((size_t)rows * 256 * 2); fa_ = (f16 *)carve((size_t)rows * 128 * 2);
-        f1_ = (f16 *)carve((size_t)rows * 128 * 2); zrb_ = (f16 *)carve((size_t)rows * 256 * 2);
+        const size_t u8 = upd8_ ? 3 : 2;                   // bytes per channel of an update-block map: fp16 (+ its fp8 copy after the pixel's fp16 part)
+        hx_ = (f16 *)carve((size_t)rows * 384 * u8); hx2_ = (f16 *)carve((size_t)rows * 384 * u8);
+        corr_ = (f16 *)carve((size_t)rows * 384 * u8); c1_ = (f16 *)carve((size_t)rows * 256 * u8);
+        corflo_ = (f16 *)carve((size_t)rows * 256 * u8); fa_ = (f16 *)carve((size_t)rows * 128 * u8);
+        f1_ = (f16 *)carve((size_t)rows * 128 * u8); zrb_ = (f16 *)carve((size_t)rows * 256 * 2);
         fh_ = (f16 *)carve((size_t)rows * 256 * 2);
         m0_ = (f16 *)carve((size_t)rows * 256 * 2);
         up_ = (float *)carve((size_t)ND * sh_ * sw_ * 2 * 4);
@@ -236,6 +257,8 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
 
     // ---- frame prep + stem im2col (shared by fnet and cnet) ----
     tic(F_PP, 0, (double)F * H * W * 3);
+    const int Lhx = upd8_ ? 576 : 384, L256 = upd8_ ? 384 : 256, L128 = upd8_ ? 192 : 128;    // pixel strides of the update block's maps
+    const float s8 = (float)(1 << kMx2Pa);
     const int es = split_w_ ? 2 : 1;                         // encoder maps are [hi | lo] in split-fp16 mode
     auto lo = [&](int c) { return split_w_ ? c : 0; };
     const int l8 = split_w_ && mx_ ? kLo8Pa : -1;            // the residual parts of the encoder maps are e4m3 ([hi | hi8 | lo8])
@@ -271,6 +294,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
             a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
             tic(F_CONV, 2.0 * F * h2 * w2 * 64.0 * 147, 0, E.stem.mx3 ? 2.0 : 1.0 + E.stem.sa + E.stem.sw);
             r = launch_gemm(stream, A_CONV, EPI_PIXSHUF, TILE_AUTO, a);
+            if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
             toc();
             if (r) return r;
         }
@@ -340,12 +364,13 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
                 a.out = pyr_[l] + (int64_t)n * P_ * pld_[l]; a.ldo = pld_[l]; a.zero = zero_;
                 tic(F_GEMM, 2.0 * P_ * (double)lh_[l] * lw_[l] * 256, 0);
                 r = launch_gemm(stream, A_DENSE, EPI_STD, TILE_AUTO, a);
+                if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
                 toc();
                 if (r) return r;
             }
             tic(F_ELT, 0, 0);
             r = launch_init_state(stream, ctx_ + (int64_t)(i + d) * P_ * 256, h32_ + (int64_t)n * P_ * 128,
-                                  hx_ + (int64_t)n * P_ * 384, hx2_ + (int64_t)n * P_ * 384, flow_ + (int64_t)n * P_ * 2, P_);
+                                  hx_ + (int64_t)n * P_ * Lhx, hx2_ + (int64_t)n * P_ * Lhx, flow_ + (int64_t)n * P_ * 2, P_, Lhx, upd8_ ? 768 : 0, s8);
             toc();
             if (r) return r;
         }
@@ -353,36 +378,37 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     // ---- GRU iterations (raft.py:124-144, update.py:122-136) ----
     for (int it = 0; it < iters; ++it) {
         tic(F_ELT, 0, 0);
-        r = launch_corr_lookup(stream, pyr_, lh_, lw_, lwp_, pld_, flow_, P_, w8_, corr_, rows);
+        r = launch_corr_lookup(stream, pyr_, lh_, lw_, lwp_, pld_, flow_, P_, w8_, corr_, rows, Lhx, upd8_ ? 768 : 0, s8);
         toc();
         if (r) return r;
-        // BasicMotionEncoder
-        if ((r = conv(corr_, 384, 384, ND, h8_, w8_, 1, 1, 1, convc1_, c1_, 256, ACT_RELU))) return r;
-        if ((r = conv(c1_, 256, 256, ND, h8_, w8_, 3, 3, 1, convc2_, corflo_, 256, ACT_RELU))) return r;
+        // BasicMotionEncoder.  With upd8_ every map is [a16 (C) | a8 (C bytes)] per pixel (pixel stride 1.5 C halfs): the conv epilogues
+        // store the fp8 copy too (o8 = its byte offset from the output row: 2 Ctot - slice offset) and the MX segments read it
+        if ((r = conv(corr_, 384, Lhx, ND, h8_, w8_, 1, 1, 1, convc1_, c1_, L256, ACT_RELU, 0, nullptr, nullptr, 0, 0, upd8_ ? 512 : 0))) return r;
+        if ((r = conv(c1_, 256, L256, ND, h8_, w8_, 3, 3, 1, convc2_, corflo_, L256, ACT_RELU, 0, nullptr, nullptr, 0, 0, upd8_ ? 512 : 0))) return r;
         tic(F_ELT, 0, 0);
-        r = launch_im2col7_flow(stream, flow_, ND, h8_, w8_, fa_, 128);
+        r = launch_im2col7_flow(stream, flow_, ND, h8_, w8_, fa_, 128, L128, upd8_);
         toc();
         if (r) return r;
-        if ((r = dense(fa_, 128, rows, convf1_, f1_, 128, ACT_RELU))) return r;
-        if ((r = conv(f1_, 128, 128, ND, h8_, w8_, 3, 3, 1, convf2_, corflo_ + 192, 256, ACT_RELU))) return r;
+        if ((r = dense(fa_, L128, rows, convf1_, f1_, L128, ACT_RELU, nullptr, upd8_ ? 256 : 0, 0))) return r;     // flow is in pixels: its fp8 copy is unscaled
+        if ((r = conv(f1_, 128, L128, ND, h8_, w8_, 3, 3, 1, convf2_, corflo_ + 192, L256, ACT_RELU, 0, nullptr, nullptr, 0, 0, upd8_ ? 512 - 192 : 0))) return r;
         // HX = [h | inp | motion] feeds the z / r convs, HX2 = [r * h | inp | motion] the q conv: the motion features are
         // written to both by the producing conv (its ReLU'd second output), r * h and the state update by the GRU epilogues
         ConvFuse dup; dup.out2 = hx2_ + 256;
-        if ((r = conv(corflo_, 256, 256, ND, h8_, w8_, 3, 3, 1, convm_, hx_ + 256, 384, ACT_RELU, 0, nullptr, &dup))) return r;
+        if ((r = conv(corflo_, 256, L256, ND, h8_, w8_, 3, 3, 1, convm_, hx_ + 256, Lhx, ACT_RELU, 0, nullptr, &dup, 0, 0, upd8_ ? 768 - 256 : 0))) return r;
         tic(F_ELT, 0, 0);
-        r = launch_put_flow(stream, flow_, hx_, hx2_, rows);
+        r = launch_put_flow(stream, flow_, hx_, hx2_, rows, Lhx, upd8_ ? 768 : 0, s8);
         toc();
         if (r) return r;
         // SepConvGRU: (1 x 5) then (5 x 1)
         for (int half = 0; half < 2; ++half) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1;
-            ConvFuse fz; fz.gru_h = h32_; fz.gru_rh = hx2_;
-            if ((r = conv(hx_, 384, 384, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_GRU_ZR, 0, nullptr, &fz))) return r;
+            ConvFuse fz; fz.gru_h = h32_; fz.gru_rh = hx2_; fz.gru_ld = Lhx;
+            if ((r = conv(hx_, 384, Lhx, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_GRU_ZR, 0, nullptr, &fz, 0, 0, upd8_ ? 768 : 0))) return r;
             ConvFuse fq; fq.gru_h = h32_; fq.gru_z = zrb_;
-            if ((r = conv(hx2_, 384, 384, ND, h8_, w8_, kh, kw, 1, q_[half], hx_, 384, ACT_GRU_Q, 0, nullptr, &fq))) return r;
+            if ((r = conv(hx2_, 384, Lhx, ND, h8_, w8_, kh, kw, 1, q_[half], hx_, Lhx, ACT_GRU_Q, 0, nullptr, &fq, 0, 0, upd8_ ? 768 : 0))) return r;
         }
-        // FlowHead -> delta_flow (fp32), coords1 += delta
-        if ((r = conv(hx_, 128, 384, ND, h8_, w8_, 3, 3, 1, fh1_, fh_, 256, ACT_RELU))) return r;
+        // FlowHead -> delta_flow (fp32), coords1 += delta (the h slice's fp8 copy sits 384 halfs after it)
+        if ((r = conv(hx_, 128, Lhx, ND, h8_, w8_, 3, 3, 1, fh1_, fh_, 256, ACT_RELU, 0, nullptr, nullptr, 0, upd8_ ? 384 : 0))) return r;
         tic(F_CONV, 2.0 * rows * 2.0 * fh2_.Kreal, 0);
         r = launch_flow_head2(stream, fh_, fh2_.w, fh2_.bias, flow_, ND, h8_, w8_, fh2_.sw);
         toc();
@@ -391,7 +417,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     stages_["flow_lo"] = Stage{flow_, 0, 0, P_, 1, 2, 2, (int64_t)P_ * 2};
 
     // ---- mask head (last iteration only) + convex upsample + unpad + encode ----
-    if ((r = conv(hx_, 128, 384, ND, h8_, w8_, 3, 3, 1, mk0_, m0_, 256, ACT_RELU))) return r;
+    if ((r = conv(hx_, 128, Lhx, ND, h8_, w8_, 3, 3, 1, mk0_, m0_, 256, ACT_RELU, 0, nullptr, nullptr, 0, upd8_ ? 384 : 0))) return r;
     {
         GemmArgs a;
         a.A = m0_; a.lda = 256; a.N = 576; a.M = (int)rows;
@@ -399,6 +425,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         a.out32 = mask_; a.ldo = 576; a.scale = 0.25f;
         tic(F_GEMM, 2.0 * rows * 576.0 * 256, 0, 1.0 + mk2_.sw);
         r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
+        if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
         toc();
         if (r) return r;
     }

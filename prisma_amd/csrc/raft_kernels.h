@@ -5,18 +5,21 @@
 int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, int sh, int sw, int Hp, int Wp, int pad_l,
                      int pad_t, int resize, const int *xi, const int *xc, const int *yi, const int *yc, f16 *out,
                      uint8_t *scaled_out, int s2d = 0, int lo_off = 0, int lo8_pa = -1);
-int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp);
+// ld: row stride of `out` in halfs (0 = Kp); o8: also store the row as e4m3 (unscaled) after its Kp halfs (gemm.h nk16)
+int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp, int ld = 0, int o8 = 0);
 int in_stats_chunks(int HW);
 int launch_in_stats(hipStream_t s, const f16 *x, int B, int HW, int C, int ldc, float *part, float *stats, int lo_off = 0, int lo8_pa = -1);
 int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, const float *sb, f16 *out, int B, int HW,
                     int C, int ldc, int lo_off = 0, int lo8_pa = -1);
-int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows);
+// ld: pixel stride of hx / hx2 (384, or 576 with the fp8 copy at byte o8_off = 768, scaled by o8_scale)
+int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows, int ld = 384, int o8_off = 0,
+                      float o8_scale = 16.f);
 int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C);
 int launch_corr_tile(hipStream_t s, const f16 *x, f16 *y, int F, int h, int w, int wp, int npad);
 int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], const int w[4], const int wp[4], const int ld[4],
-                       const float *flow, int P, int w8, f16 *out, int64_t rows);
+                       const float *flow, int P, int w8, f16 *out, int64_t rows, int ldo = 384, int o8_off = 0, float o8_scale = 16.f);
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W, int split = 0);
-int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows);
+int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows, int ld = 384, int o8_off = 0, float o8_scale = 16.f);
 int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, int h8, int w8, int pad_l, int pad_t, int sh,
                     int sw, float *out, unsigned *maxd);
 int launch_flow_encode(hipStream_t s, const float *flow, int N, int sh, int sw, const unsigned *maxd, uint8_t *rgb,

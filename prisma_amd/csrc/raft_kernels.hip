@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
 // ------------------------------------------------------------------------------------------------
 template <typename T, int CS>
 __global__ __launch_bounds__(256) void im2col7_kernel(const T *__restrict__ x, int B, int H, int W, int C, int stride,
-                                                       int OH, int OW, f16 *__restrict__ out, int Kp) {
+                                                       int OH, int OW, f16 *__restrict__ out, int Kp, int ld, int o8) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * OH * OW * 49) return;
     const int tap = (int)(i % 49);
@@ -102,8 +102,16 @@ __global__ __launch_bounds__(256) void im2col7_kernel(const T *__restrict__ x, i
     const int iy = oy * stride - 3 + ky, ix = ox * stride - 3 + kx;
     const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     const T *src = x + (((int64_t)b * H + iy) * W + ix) * CS;
-    f16 *dst = out + row * Kp + tap * C;
+    f16 *dst = out + row * ld + tap * C;
     for (int c = 0; c < C; ++c) dst[c] = ok ? (f16)(float)src[c] : (f16)0.f;
+    if (o8) {                // fp8 copy (unscaled: flow is in pixels) after the row's Kp halfs (gemm.h nk16)
+        unsigned char *d8 = (unsigned char *)(out + row * ld + Kp) + tap * C;
+        for (int c = 0; c < C; c += 2) {
+            const unsigned short u = pb_fp8x2(ok ? (float)dst[c] : 0.f, ok && c + 1 < C ? (float)dst[c + 1] : 0.f);
+            d8[c] = (unsigned char)(u & 0xFF);
+            if (c + 1 < C) d8[c + 1] = (unsigned char)(u >> 8);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -250,7 +258,8 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a
 // cnet output [rows][256] fp16 -> net = tanh(c[:128]) (fp32 master + fp16 copy in HX[:, 0:128]),
 // inp = relu(c[128:]) in HX[:, 128:256]; flow = 0.
 __global__ __launch_bounds__(256) void init_state_kernel(const f16 *__restrict__ c, float *__restrict__ h32,
-                                                          f16 *__restrict__ hx, f16 *__restrict__ hx2, float *__restrict__ flow, int64_t rows) {
+                                                          f16 *__restrict__ hx, f16 *__restrict__ hx2, float *__restrict__ flow, int64_t rows,
+                                                          int ld, int o8_off, float o8_scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * 32) return;
     const int c8 = (int)(i % 32);
@@ -268,8 +277,15 @@ __global__ __launch_bounds__(256) void init_state_kernel(const f16 *__restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (f16)fmaxf((float)v[j], 0.f);
     }
-    *(f16x8 *)(hx + r * 384 + c8 * 8) = o;
-    if (c8 >= 16) *(f16x8 *)(hx2 + r * 384 + c8 * 8) = o;      // the context half of the q conv's input [r * h | inp | motion]
+    *(f16x8 *)(hx + r * ld + c8 * 8) = o;
+    if (c8 >= 16) *(f16x8 *)(hx2 + r * ld + c8 * 8) = o;      // the context half of the q conv's input [r * h | inp | motion]
+    if (o8_off) {
+        int2 o8;
+        o8.x = pb_fp8x4((float)o[0] * o8_scale, (float)o[1] * o8_scale, (float)o[2] * o8_scale, (float)o[3] * o8_scale);
+        o8.y = pb_fp8x4((float)o[4] * o8_scale, (float)o[5] * o8_scale, (float)o[6] * o8_scale, (float)o[7] * o8_scale);
+        *(int2 *)((char *)(hx + r * ld) + o8_off + c8 * 8) = o8;
+        if (c8 >= 16) *(int2 *)((char *)(hx2 + r * ld) + o8_off + c8 * 8) = o8;
+    }
     if (c8 == 0) { flow[r * 2] = 0.f; flow[r * 2 + 1] = 0.f; }
 }
 
@@ -329,7 +345,7 @@ struct PyrPtrs { const f16 *lv[4]; int h[4], w[4], wp[4], ld[4]; };
 // (The scalar-gather version of step 3 - 36 two-byte global loads per thread - took 215 us per call at 720p x 8 pairs
 // whatever the volume layout; it was bound by the number of gather instructions.)
 __global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const float *__restrict__ flow, int P, int w8,
-                                                           f16 *__restrict__ out, int64_t rows) {
+                                                           f16 *__restrict__ out, int64_t rows, int ldo, int o8_off, float o8_scale) {
     __shared__ __attribute__((aligned(16))) f16 win[28 * 11 * 24];
     __shared__ __attribute__((aligned(8))) f16 tile[7 * 324];
     __shared__ int ci[28 * 18];
@@ -395,18 +411,29 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const floa
     for (int v = t; v < 7 * 81; v += 256) {
         const int pr = v / 81, c4 = v - pr * 81;
         const int64_t r = r0 + pr;
-        if (r < rows) *(f16x4 *)(out + r * 384 + c4 * 4) = *(const f16x4 *)(tile + pr * 324 + c4 * 4);
+        if (r < rows) {
+            const f16x4 o = *(const f16x4 *)(tile + pr * 324 + c4 * 4);
+            *(f16x4 *)(out + r * ldo + c4 * 4) = o;
+            if (o8_off)      // fp8 copy after the row's fp16 part: the A operand of convc1's MX segment (gemm.h nk16)
+                *(int *)((char *)(out + r * ldo) + o8_off + c4 * 4) = pb_fp8x4((float)o[0] * o8_scale, (float)o[1] * o8_scale, (float)o[2] * o8_scale, (float)o[3] * o8_scale);
+        }
     }
 }
 
 // flow (fp32 [rows][2]) -> HX[:, 382:384] (the last two input channels of the GRU, update.py:97)
-__global__ void put_flow_kernel(const float *__restrict__ flow, f16 *__restrict__ hx, f16 *__restrict__ hx2, int64_t rows) {
+__global__ void put_flow_kernel(const float *__restrict__ flow, f16 *__restrict__ hx, f16 *__restrict__ hx2, int64_t rows, int ld, int o8_off,
+                                float o8_scale) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     f16x2 o;
     o[0] = (f16)flow[r * 2]; o[1] = (f16)flow[r * 2 + 1];
-    *(f16x2 *)(hx + r * 384 + 382) = o;
-    *(f16x2 *)(hx2 + r * 384 + 382) = o;
+    *(f16x2 *)(hx + r * ld + 382) = o;
+    *(f16x2 *)(hx2 + r * ld + 382) = o;
+    if (o8_off) {
+        const unsigned short o8 = pb_fp8x2((float)o[0] * o8_scale, (float)o[1] * o8_scale);
+        *(unsigned short *)((char *)(hx + r * ld) + o8_off + 382) = o8;
+        *(unsigned short *)((char *)(hx2 + r * ld) + o8_off + 382) = o8;
+    }
 }
 
 // r * h and h = (1 - z) h + z q are epilogues of the z / r and q convolutions (gemm.h ACT_GRU_ZR / ACT_GRU_Q)
@@ -620,9 +647,9 @@ int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, 
                        pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d, lo_off, lo8_pa);
     LAUNCH_CHECK();
 }
-int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp) {
+int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp, int ld, int o8) {
     hipLaunchKernelGGL((im2col7_kernel<float, 2>), dim3(nblk((int64_t)B * H * W * 49)), dim3(256), 0, s, x, B, H, W, 2, 1, H, W,
-                       out, Kp);
+                       out, Kp, ld ? ld : Kp, o8);
     LAUNCH_CHECK();
 }
 int in_stats_chunks(int HW) { return (HW + 2047) / 2048; }
@@ -638,8 +665,8 @@ int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, 
     hipLaunchKernelGGL(in_apply_kernel, dim3(nblk((int64_t)B * HW * (C / 8))), dim3(256), 0, s, a, sa, b, sb, out, B, HW, C / 8, ldc, lo_off, lo8_pa);
     LAUNCH_CHECK();
 }
-int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows) {
-    hipLaunchKernelGGL(init_state_kernel, dim3(nblk(rows * 32)), dim3(256), 0, s, c, h32, hx, hx2, flow, rows);
+int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows, int ld, int o8_off, float o8_scale) {
+    hipLaunchKernelGGL(init_state_kernel, dim3(nblk(rows * 32)), dim3(256), 0, s, c, h32, hx, hx2, flow, rows, ld, o8_off, o8_scale);
     LAUNCH_CHECK();
 }
 int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C) {
@@ -652,14 +679,14 @@ int launch_corr_tile(hipStream_t s, const f16 *x, f16 *y, int F, int h, int w, i
     LAUNCH_CHECK();
 }
 int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], const int w[4], const int wp[4], const int ld[4],
-                       const float *flow, int P, int w8, f16 *out, int64_t rows) {
+                       const float *flow, int P, int w8, f16 *out, int64_t rows, int ldo, int o8_off, float o8_scale) {
     PyrPtrs py;
     for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; py.wp[i] = wp[i]; py.ld[i] = ld[i]; }
-    hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)((rows + 6) / 7)), dim3(256), 0, s, py, flow, P, w8, out, rows);
+    hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)((rows + 6) / 7)), dim3(256), 0, s, py, flow, P, w8, out, rows, ldo, o8_off, o8_scale);
     LAUNCH_CHECK();
 }
-int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows) {
-    hipLaunchKernelGGL(put_flow_kernel, dim3(nblk(rows)), dim3(256), 0, s, flow, hx, hx2, rows);
+int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows, int ld, int o8_off, float o8_scale) {
+    hipLaunchKernelGGL(put_flow_kernel, dim3(nblk(rows)), dim3(256), 0, s, flow, hx, hx2, rows, ld, o8_off, o8_scale);
     LAUNCH_CHECK();
 }
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W, int split) {

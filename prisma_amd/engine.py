@@ -99,8 +99,8 @@ class _Ctx:
         check(self.lib.pb_set_profiling(self.ctx, (1 if timing else 0) | (2 if debug_stages else 0) | (4 if accumulate else 0)))
 
     def kernel_stats(self) -> List[dict]:
-        arr = (_lib.pb_kernel_stat * 16)()
-        n = check(self.lib.pb_get_kernel_stats(self.ctx, arr, 16))
+        arr = (_lib.pb_kernel_stat * 64)()
+        n = check(self.lib.pb_get_kernel_stats(self.ctx, arr, 64))
         return [dict(name=arr[i].name.decode(), ms=arr[i].ms, flops=arr[i].flops, exec_flops=arr[i].exec_flops, bytes=arr[i].bytes,
                      launches=arr[i].launches) for i in range(n)]
 

@@ -1,0 +1,32 @@
+"""Reads the -Rpass-analysis=kernel-resource-usage remarks the Makefile keeps per translation unit (prisma_amd/csrc/build/*.log), prints
+one line per kernel and fails when a GEMM kernel spills vector registers: a spill in the K loop of the 256 x 256 kernel costs 2-3x
+(round 2: a two-sided `if` in the conv tap cursor spilled 128 VGPRs in gemm8_kernel<1, 0, 0, *, true> and tripled the DPT head's time).
+python tools/check_spills.py [build_dir]"""
+import glob, os, re, subprocess, sys
+
+bdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "prisma_amd", "csrc", "build")
+rows, cur = [], None
+for f in sorted(glob.glob(os.path.join(bdir, "*.log"))):
+    for line in open(f, errors="replace"):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = {"sym": m.group(1), "tu": os.path.basename(f)[:-4]}
+            rows.append(cur)
+            continue
+        for key, tag in (("vgpr", "VGPRs:"), ("agpr", "AGPRs:"), ("scratch", "ScratchSize [bytes/lane]:"), ("occ", "Occupancy [waves/SIMD]:"),
+                         ("vspill", "VGPRs Spill:"), ("lds", "LDS Size [bytes/block]:")):
+            if cur is not None and tag in line:
+                cur[key] = int(re.search(r"(\d+)", line.split(tag)[1]).group(1))
+if not rows:
+    sys.exit("no resource-usage remarks under %s (run make in prisma_amd/csrc first)" % bdir)
+names = subprocess.run(["c++filt"] + [r["sym"] for r in rows], capture_output=True, text=True).stdout.split("\n")
+bad = []
+for r, n in zip(rows, names):
+    n = n.replace("(anonymous namespace)::", "").replace("(GemmArgs)", "").replace("void ", "")
+    n = n if len(n) < 70 else n[:67] + "..."
+    print("%-14s %-70s vgpr %3d agpr %3d scratch %4d occupancy %d" % (r["tu"], n, r.get("vgpr", -1), r.get("agpr", -1), r.get("scratch", -1), r.get("occ", -1)))
+    if ("gemm8_kernel" in n or "gemm_kernel" in n) and r.get("vspill", 0) > 2:
+        bad.append((n, r.get("vspill")))
+if bad:
+    sys.exit("GEMM kernels spilling vector registers: %s" % bad)
+print("%d kernels, no GEMM kernel spills more than 2 VGPRs" % len(rows))
