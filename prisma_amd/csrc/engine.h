@@ -27,6 +27,8 @@ struct PackedW {
     int tapin = 0, taps = 1;
 };
 unsigned char pb_f32_to_e4m3(float x);     // OCP e4m3fn, round to nearest even, saturating (engine.hip)
+// slice-major K order of packed conv weights (gemm.h cTapInner): every row of `rowlen` halfs is a (taps x S) grid of 128-byte blocks; transposed in place
+void pb_rows_slice_major(f16 *rows, int64_t nrows, int64_t rowlen, int taps);
 
 struct Stage {
     const void *ptr;
@@ -97,6 +99,7 @@ class DepthEngine {
     pb_depth_cfg cfg_;
     // PB_PREC_SPLIT (tools/precision_budget.py): ViT linears and the metric head keep their weights as hi + lo (2 passes);
     // the DPT head keeps weights AND feature maps as hi + lo (3 passes; maps are [hi | lo] per pixel, hs_ = 2)
+    int head_tapin_ = 1;         // the head's 3x3 convolutions walk K slice-major (gemm.h cTapInner; PB_TAPIN=0 turns it off)
     int vit_sw_ = 0, head_sa_ = 0, head_sw_ = 0, hs_ = 1;
     // vit_mx_: the ViT linears' weight residual runs as an MX-fp8 segment (half the matrix-pipe time of an fp16 pass); their A
     // operands (LayerNorm out, attention out, GELU out) then carry an fp8 copy after the fp16 part of each row (row stride 1.5 K)

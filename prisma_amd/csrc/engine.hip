@@ -70,6 +70,17 @@ int DepthEngine::stats(pb_kernel_stat *out, int cap) {
 
 DepthEngine::DepthEngine(int dev, const pb_depth_cfg &cfg) : device(dev), cfg_(cfg) {}
 
+void pb_rows_slice_major(f16 *rows, int64_t nrows, int64_t rowlen, int taps) {
+    const int64_t S = rowlen / (64 * (int64_t)taps);
+    std::vector<f16> row((size_t)rowlen);
+    for (int64_t n = 0; n < nrows; ++n) {
+        f16 *r = rows + n * rowlen;
+        for (int t = 0; t < taps; ++t)
+            for (int64_t sidx = 0; sidx < S; ++sidx) std::copy_n(r + ((int64_t)t * S + sidx) * 64, 64, row.data() + (sidx * taps + t) * 64);
+        std::copy_n(row.data(), (size_t)rowlen, r);
+    }
+}
+
 unsigned char pb_f32_to_e4m3(float x) {
     const unsigned char s = x < 0.f ? 0x80 : 0x00;
     const float a = fabsf(x);
@@ -155,6 +166,10 @@ int DepthEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, co
     const int64_t Np = round_up(N, 256);
     const int segs = 1 + sa + sw, Cin = K / taps, Cp = Kpad / taps;
     PB_CHECK(K % taps == 0 && Kpad % taps == 0 && Cp >= Cin && (segs == 1 || Cp % 64 == 0), PB_ERR_ARG, "pack: K %d / Kpad %d / taps %d", K, Kpad, taps);
+    // 3x3 convolutions: slice-major K order (gemm.h cTapInner) - the taps of a 64-channel slice back to back, so the 256-channel maps'
+    // lines are re-used out of the XCD L2 instead of being fetched once per tap
+    const int tapin = head_tapin_ && taps > 1 && Cp % 64 == 0 ? 1 : 0;
+    out.tapin = tapin; out.taps = taps;
     if (head_mx_ && sa && sw) {        // mx3 layout: per tap [w_hi fp16 | w_lo e4m3 2^pw | w_hi e4m3 2^(pw - 12)]
         float mlo = 0.f, mhi = 0.f;
         for (int64_t i = 0; i < (int64_t)N * K; ++i) {
@@ -179,6 +194,7 @@ int DepthEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, co
                     d8[Cp + k] = pb_f32_to_e4m3(ldexpf((float)hi, pw - 12));
                 }
             }
+        if (tapin) pb_rows_slice_major(h.data(), Np, Kt, taps);
         void *p = nullptr;
         PB_HIP(hipMalloc(&p, h.size() * 2));
         owned_.push_back(p);
@@ -202,6 +218,7 @@ int DepthEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, co
                 if (sw) d[(1 + sa) * Cp + k] = (f16)(s[k] - (float)hi);
             }
         }
+    if (tapin) pb_rows_slice_major(h.data(), Np, Kt, taps);
     void *p = nullptr;
     PB_HIP(hipMalloc(&p, h.size() * 2));
     owned_.push_back(p);
@@ -224,6 +241,7 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         tmap_[w[i].name] = &w[i];
     }
     const int D = cfg_.embed_dim, Hd = 4 * D, F = cfg_.features;
+    if (const char *e = getenv("PB_TAPIN")) head_tapin_ = e[0] != '0';
     PB_CHECK(cfg_.precision == PB_PREC_F16 || cfg_.precision == PB_PREC_SPLIT, PB_ERR_ARG, "precision %d unknown", cfg_.precision);
     if (cfg_.precision == PB_PREC_SPLIT) {
         vit_sw_ = 1; head_sa_ = 1; head_sw_ = 1;
@@ -578,6 +596,7 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
             if (!a.cLd) a.cLd = 2 * a.cC;
             a.cC = 2 * w.Cseg;
             a.mx_period = 2 * w.Cseg / 64;
+            if (w.tapin) { a.mx_period = 0; a.nk16 = w.nk16 * w.taps; }       // every fp16 slice of all taps, then the fp8 slices
         }
     } else if (w.sa || w.sw) {          // split-fp16 segments along K (gemm.h): the callers pass cC / lda of ONE part
         if (amode == A_CONV) {
@@ -590,6 +609,7 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
             a.kwrap = w.sw ? (1 + w.sa) * w.Cseg / 64 : 0;
         }
     }
+    if (amode == A_CONV && w.tapin) { a.cTapInner = 1; a.cKH = w.taps / a.cKW; }
     if (w.nk16 && !w.mx3) { a.nk16 = w.nk16; a.mx_scale_a = 127 - kMxPa; a.mx_scale_b = 127 - w.mx_pw; }
     if (a.lo_off && head_mx_) { a.lo8 = 1; a.lo8_pa = kLo8Pa; }
     if (!a.N) a.N = w.N;

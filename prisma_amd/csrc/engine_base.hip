@@ -66,16 +66,7 @@ int EngineBase::pack(const float *src, int N, int K, int Kpad, PackedW &out, con
     // slice-major K order (gemm.h cTapInner): rows are (taps x S) grids of 128-byte blocks in every layout below - transpose them
     const int tapin = pack_tapin_ && taps > 1 && Kpad % (64 * taps) == 0 ? 1 : 0;
     auto to_slice_major = [&](std::vector<f16> &h, int64_t rowlen) {
-        if (!tapin) return;
-        const int64_t S = rowlen / (64 * (int64_t)taps);
-        std::vector<f16> row((size_t)rowlen);
-        for (int64_t n = 0; n < Np; ++n) {
-            f16 *r = h.data() + (size_t)n * rowlen;
-            for (int t = 0; t < taps; ++t)
-                for (int64_t sidx = 0; sidx < S; ++sidx)
-                    std::copy_n(r + ((int64_t)t * S + sidx) * 64, 64, row.data() + (sidx * taps + t) * 64);
-            std::copy_n(row.data(), (size_t)rowlen, r);
-        }
+        if (tapin) pb_rows_slice_major(h.data(), Np, rowlen, taps);
     };
     out.tapin = tapin; out.taps = taps;
     if (!sa && sw && mx_ && pack_mx2_ && Cp % 128 == 0) {        // mx2 layout: per tap [w_hi fp16 | w_lo e4m3 2^pw]

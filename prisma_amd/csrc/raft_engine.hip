@@ -411,6 +411,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         if ((r = conv(hx_, 128, Lhx, ND, h8_, w8_, 3, 3, 1, fh1_, fh_, 256, ACT_RELU, 0, nullptr, nullptr, 0, upd8_ ? 384 : 0))) return r;
         tic(F_CONV, 2.0 * rows * 2.0 * fh2_.Kreal, 0);
         r = launch_flow_head2(stream, fh_, fh2_.w, fh2_.bias, flow_, ND, h8_, w8_, fh2_.sw);
+        if (timer.enabled && !r) timer.recs[open_.back()].name = fh2_.sw ? "flow_head2_kernel<true>" : "flow_head2_kernel<false>";
         toc();
         if (r) return r;
     }

@@ -1,15 +1,37 @@
 """Per-launch algorithmic FLOPs / bytes of the bench's GEMM-shaped launches, from the layer shapes alone,
-so that bench.py's `roofline.flop_per_launch` and per-family totals can be re-derived by hand.
-FLOPs = 2 M N K of the layer (real channels: padding and split-fp16 passes not counted); bytes = A once + W once + output once.
+so that bench.py's `roofline.flop_per_launch` and per-family totals can be re-derived by hand.  A bench family is
+`<band>/<kernel symbol as rocprofv3 prints it>`; the symbol of a layer follows from launch_gemm's rule (csrc/gemm.hip): the 256 x 256
+ping-pong kernel when N % 256 == 0 and there are >= 256 tiles, the 256 x 64 tile for N <= 64, else the 128 x 128 tile; the last
+template parameter says whether the launch carries MX-fp8 residual tiles (split mode; always false in the f16 mode).
+FLOPs = 2 M N K of the layer (real channels: padding and the residual passes not counted); bytes = A once + W once + output once.
 python tools/flop_table.py [batch] [H W]"""
 import sys
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 H, W = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1080, 1920)
 rows = []
+DENSE, CONV = 0, 1
+STD, RESID, QKV, PIXSHUF, PATCH, HEAD, F32 = range(7)
 
 
-def add(band, fam, name, M, N, K, n=1, in_b=2, out_b=2):
+def symbol(amode, epi, M, N, mx):
+    """launch_gemm(TILE_AUTO) + the launchers' names (csrc/gemm.hip, gemm_kernels.h); BUFP (LDS-DMA through the buffer path) is true
+    unless an operand exceeds the 4 GB a buffer resource can address (the N = 32 head conv at batch 32)."""
+    m = "true" if mx else "false"
+    if epi == HEAD:
+        return f"gemm_kernel<256, 32, 4, 1, 1, 5, false, 2, {m}>"
+    if epi == PATCH:                                     # engine.hip launches the patch embed on the 128 x 128 tile
+        return f"gemm_kernel<128, 128, 2, 2, 0, 4, true, 2, {m}>"
+    if N % 256 == 0 and (M // 256) * (N // 256) >= 256:
+        return f"gemm8_kernel<{amode}, {epi}, 0, true, {m}>"
+    if epi == STD and N <= 64:
+        return f"gemm_kernel<256, 64, 4, 1, {amode}, {epi}, true, 2, {m}>"
+    return f"gemm_kernel<128, 128, 2, 2, {amode}, {epi}, true, 2, {m}>"
+
+
+def add(band, kind, name, M, N, K, n=1, in_b=2, out_b=2, mx=True, n_launch=None):
+    # n_launch: the N the launch is made with when it differs from the layer's (padded volume rows)
+    fam = kind if isinstance(kind, str) else symbol(kind[0], kind[1], M, n_launch or N, mx)
     rows.append((band, fam, name, n, M, N, K, 2.0 * M * N * K, in_b * M * K + 2.0 * N * K + out_b * M * N))
 
 
@@ -17,28 +39,28 @@ def add(band, fam, name, M, N, K, n=1, in_b=2, out_b=2):
 gh, gw, D, F = 37, 66, 1024, 256
 ntp, P = 2448, gh * gw
 Mv = B * ntp
-add("depth", "gemm_f16_resid*", "patch embed (EPI_PATCH, 128 tile)", B * P, D, 588)
-add("depth", "gemm_f16_qkv", "qkv", Mv, 3 * D, D, 24)
+add("depth", (DENSE, PATCH), "patch embed (+ pos embed)", B * P, D, 588, mx=False)
+add("depth", (DENSE, QKV), "qkv", Mv, 3 * D, D, 24)
 add("depth", "attention", "softmax(QK^T)V, 16 heads", B * 16 * 2443, 2443, 64 * 2, 24)        # 4 n h t^2 d
 rows[-1] = rows[-1][:8] + (4.0 * B * 16 * 2443 * 64 * 2,)                                       # q, k, v in + o out, fp16
-add("depth", "gemm_f16_resid", "proj (+ residual)", Mv, D, D, 24, out_b=8)
-add("depth", "gemm_f16", "fc1 + GELU", Mv, 4 * D, D, 24)
-add("depth", "gemm_f16_resid", "fc2 (+ residual)", Mv, D, 4 * D, 24, out_b=8)
+add("depth", (DENSE, RESID), "proj (+ residual)", Mv, D, D, 24, out_b=8)
+add("depth", (DENSE, STD), "fc1 + GELU", Mv, 4 * D, D, 24)
+add("depth", (DENSE, RESID), "fc2 (+ residual)", Mv, D, 4 * D, 24, out_b=8)
 oc = [256, 512, 1024, 1024]
 for i in range(4):
-    add("depth", "gemm_f16", f"projects.{i} 1x1", B * P, oc[i], D)
-add("depth", "gemm_f16", "resize_layers.0 convT 4x4", B * P, 16 * oc[0], oc[0])
-add("depth", "gemm_f16", "resize_layers.1 convT 2x2", B * P, 4 * oc[1], oc[1])
+    add("depth", (DENSE, STD), f"projects.{i} 1x1", B * P, oc[i], D)
+add("depth", (DENSE, PIXSHUF), "resize_layers.0 convT 4x4", B * P, 16 * oc[0], oc[0])
+add("depth", (DENSE, PIXSHUF), "resize_layers.1 convT 2x2", B * P, 4 * oc[1], oc[1])
 lh = [4 * gh, 2 * gh, gh, (gh - 1) // 2 + 1]
 lw = [4 * gw, 2 * gw, gw, (gw - 1) // 2 + 1]
-add("depth", "conv_igemm_f16", "resize_layers.3 3x3 s2", B * lh[3] * lw[3], oc[3], 9 * oc[3])
+add("depth", (CONV, STD), "resize_layers.3 3x3 s2", B * lh[3] * lw[3], oc[3], 9 * oc[3])
 for i in range(4):
-    add("depth", "conv_igemm_f16", f"layer{i + 1}_rn 3x3", B * lh[i] * lw[i], F, 9 * oc[i])
+    add("depth", (CONV, STD), f"layer{i + 1}_rn 3x3", B * lh[i] * lw[i], F, 9 * oc[i])
 for lv in range(3, -1, -1):
-    add("depth", "conv_igemm_f16", f"refinenet{lv + 1} RCU convs 3x3", B * lh[lv] * lw[lv], F, 9 * F, 4 if lv < 3 else 2)
-    add("depth", "gemm_f16", f"refinenet{lv + 1} out_conv 1x1 (before the upsample)", B * lh[lv] * lw[lv], F, F)
-add("depth", "conv_igemm_f16", "output_conv1 3x3", B * 4 * lh[0] * lw[0], F // 2, 9 * F)
-add("depth", "conv_igemm_f16*", "output_conv2 3x3 + ReLU + 1x1 + ReLU (EPI_HEAD, 256x32 tile)", B * 518 * 924, 32, 9 * F // 2)
+    add("depth", (CONV, STD), f"refinenet{lv + 1} RCU convs 3x3", B * lh[lv] * lw[lv], F, 9 * F, 4 if lv < 3 else 2)
+    add("depth", (DENSE, STD), f"refinenet{lv + 1} out_conv 1x1 (before the upsample)", B * lh[lv] * lw[lv], F, F)
+add("depth", (CONV, STD), "output_conv1 3x3", B * 4 * lh[0] * lw[0], F // 2, 9 * F)
+add("depth", (CONV, HEAD), "output_conv2 3x3 + ReLU + 1x1 + ReLU", B * 518 * 924, 32, 9 * F // 2)
 
 # ---- flow_raft at --scale 0.75: (H, W) -> (sh, sw) padded to /8
 sh, sw = round(H * 0.75), round(W * 0.75)
@@ -47,41 +69,42 @@ Fr, pairs = B, B - 1
 h2, w2, h4, w4, h8, w8 = Hp // 2, Wp // 2, Hp // 4, Wp // 4, Hp // 8, Wp // 8
 Pp = h8 * w8
 for enc in ("fnet", "cnet"):
-    add("flow", "conv_igemm_f16", f"{enc} stem 7x7 s2 (space-to-depth 3x3, N = 4 x 64)", Fr * h4 * w4, 256, 147)
-    add("flow", "conv_igemm_f16_tile256x64", f"{enc} layer1 3x3 64->64 @1/2", Fr * h2 * w2, 64, 9 * 64, 4)
-    add("flow", "conv_igemm_f16_tile128", f"{enc} layer2.0.conv1 3x3 s2 64->96", Fr * h4 * w4, 96, 9 * 64)
-    add("flow", "conv_igemm_f16_tile128", f"{enc} layer2 3x3 96->96 @1/4", Fr * h4 * w4, 96, 9 * 96, 3)
-    add("flow", "conv_igemm_f16_tile128", f"{enc} layer2 downsample 1x1 s2", Fr * h4 * w4, 96, 64)
-    add("flow", "conv_igemm_f16_tile128", f"{enc} layer3.0.conv1 3x3 s2 96->128", Fr * Pp, 128, 9 * 96)
-    add("flow", "conv_igemm_f16_tile128", f"{enc} layer3 3x3 128->128 @1/8", Fr * Pp, 128, 9 * 128, 3)
-    add("flow", "conv_igemm_f16_tile128", f"{enc} layer3 downsample 1x1 s2", Fr * Pp, 128, 96)
-    add("flow", "gemm_f16", f"{enc} conv2 1x1 128->256", Fr * Pp, 256, 128)
+    add("flow", (CONV, PIXSHUF), f"{enc} stem 7x7 s2 (space-to-depth 3x3, N = 4 x 64)", Fr * h4 * w4, 256, 147)
+    add("flow", (CONV, STD), f"{enc} layer1 3x3 64->64 @1/2", Fr * h2 * w2, 64, 9 * 64, 4)
+    add("flow", (CONV, STD), f"{enc} layer2.0.conv1 3x3 s2 64->96", Fr * h4 * w4, 96, 9 * 64)
+    add("flow", (CONV, STD), f"{enc} layer2 3x3 96->96 @1/4", Fr * h4 * w4, 96, 9 * 96, 3)
+    add("flow", (CONV, STD), f"{enc} layer2 downsample 1x1 s2", Fr * h4 * w4, 96, 64)
+    add("flow", (CONV, STD), f"{enc} layer3.0.conv1 3x3 s2 96->128", Fr * Pp, 128, 9 * 96)
+    add("flow", (CONV, STD), f"{enc} layer3 3x3 128->128 @1/8", Fr * Pp, 128, 9 * 128, 3)
+    add("flow", (CONV, STD), f"{enc} layer3 downsample 1x1 s2", Fr * Pp, 128, 96)
+    add("flow", (DENSE, STD), f"{enc} conv2 1x1 128->256", Fr * Pp, 256, 128)
 lv = [(h8, w8)]
 for _ in range(3):
     lv.append((lv[-1][0] // 2, lv[-1][1] // 2))
 for l, (a, b) in enumerate(lv):
-    add("flow", "gemm_f16", f"correlation volume level {l} (per pair)", Pp, a * b, 256, pairs)
+    add("flow", (DENSE, STD), f"correlation volume level {l} (per pair; rows padded to 8 x 8 target tiles)", Pp, a * b, 256, pairs, mx=False,
+        n_launch=((a + 7) // 8 * 8) * ((b + 7) // 8 * 8))
 Mu = pairs * Pp
 it = 12
-add("flow", "gemm_f16", "convc1 1x1 324->256", Mu, 256, 324, it)
-add("flow", "conv_igemm_f16_tile128", "convc2 3x3 256->192", Mu, 192, 9 * 256, it)
-add("flow", "gemm_f16", "convf1 7x7 2->128 (im2col GEMM)", Mu, 128, 98, it)
-add("flow", "conv_igemm_f16_tile256x64", "convf2 3x3 128->64", Mu, 64, 9 * 128, it)
-add("flow", "conv_igemm_f16_tile128", "motion conv 3x3 256->126", Mu, 126, 9 * 256, it)
-add("flow", "conv_igemm_f16", "GRU z|r 1x5 / 5x1 384->256", Mu, 256, 5 * 384, 2 * it)
-add("flow", "conv_igemm_f16_tile128", "GRU q 1x5 / 5x1 384->128", Mu, 128, 5 * 384, 2 * it)
-add("flow", "conv_igemm_f16", "flow head conv1 3x3 128->256", Mu, 256, 9 * 128, it)
-add("flow", "direct", "flow head conv2 3x3 256->2 (flow_head2_kernel)", Mu, 2, 9 * 256, it)
-add("flow", "conv_igemm_f16", "mask.0 3x3 128->256 (last iteration)", Mu, 256, 9 * 128)
-add("flow", "gemm_f16", "mask.2 1x1 256->576", Mu, 576, 256, out_b=4)
+add("flow", (CONV, STD), "convc1 1x1 324->256 (a 1 x 1 conv launch on the channel slice)", Mu, 256, 324, it, mx=False)
+add("flow", (CONV, STD), "convc2 3x3 256->192", Mu, 192, 9 * 256, it, mx=False)
+add("flow", (DENSE, STD), "convf1 7x7 2->128 (im2col GEMM)", Mu, 128, 98, it, mx=False)
+add("flow", (CONV, STD), "convf2 3x3 128->64", Mu, 64, 9 * 128, it, mx=False)
+add("flow", (CONV, STD), "motion conv 3x3 256->126", Mu, 126, 9 * 256, it, mx=False)
+add("flow", (CONV, STD), "GRU z|r 1x5 / 5x1 384->256", Mu, 256, 5 * 384, 2 * it, mx=False)
+add("flow", (CONV, STD), "GRU q 1x5 / 5x1 384->128", Mu, 128, 5 * 384, 2 * it, mx=False)
+add("flow", (CONV, STD), "flow head conv1 3x3 128->256", Mu, 256, 9 * 128, it, mx=False)
+add("flow", "flow_head2_kernel<true>", "flow head conv2 3x3 256->2 (direct kernel)", Mu, 2, 9 * 256, it)
+add("flow", (CONV, STD), "mask.0 3x3 128->256 (last iteration)", Mu, 256, 9 * 128, mx=False)
+add("flow", (DENSE, F32), "mask.2 1x1 256->576", Mu, 576, 256, out_b=4, mx=False)
 
 print(f"batch {B}, frame {W}x{H}; flow at 0.75: {sw}x{sh} -> network {Wp}x{Hp}, 1/8 grid {w8}x{h8}\n")
-print("| band | timer family | layer | launches / step | M | N | K | GFLOP / launch | algorithmic MB / launch |")
+print("| band | kernel symbol (split mode) | layer | launches / step | M | N | K | GFLOP / launch | algorithmic MB / launch |")
 print("|---|---|---|---|---|---|---|---|---|")
 tot = {}
 for band, fam, name, n, M, N, K, fl, by in rows:
     print(f"| {band} | {fam} | {name} | {n} | {M} | {N} | {K} | {fl / 1e9:.1f} | {by / 1e6:.0f} |")
-    k = (band, fam.rstrip("*"))
+    k = (band, fam)
     t = tot.setdefault(k, [0, 0.0, 0.0])
     t[0] += n; t[1] += n * fl; t[2] += n * by
 print("\n| band / family | launches / step | GFLOP / step | mean GFLOP / launch | mean algorithmic MB / launch |")
