@@ -256,7 +256,7 @@ def pmc_traffic(symbol):
     timed bench, so the figure is read from profiles/ (newest round first)."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     want = symbol.replace(" ", "")
-    for name in ("r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r02d_pmc_traffic.json", "r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(here, name)
         if not os.path.exists(path):
             continue
@@ -451,8 +451,8 @@ def main():
                        "precision": PREC_NAME[args.precision],
                        "parallelism": f"one clip per GPU on {world} GPU(s); per-frame scalars all-gathered (12 bytes per frame), nothing else crosses GPUs"},
             "precision_modes": {
-                "split-f16": "hi + lo fp16 operands where the error budget needs them (2-3 MFMA passes over K, one fp32 accumulator); max-norm and L2 error "
-                             "< 1e-3 against every reference vector (depth <= 4.0e-4, flow <= 6.1e-4 measured) - north_star's tolerance; the band scripts' mode",
+                "split-f16": "hi + lo operand pairs where the error budget needs them (the lo parts as fp16 or, on MX tiles, e4m3: 1.5-2 passes over K into one fp32 accumulator); max-norm and L2 error "
+                             "< 1e-3 against every reference vector (depth <= 4.4e-4, flow <= 5.8e-4 measured) - north_star's tolerance; the band scripts' mode",
                 "f16": "one fp16 MFMA pass per GEMM / conv, fp32 accumulate; against the fp32 reference depth 1.3e-3 max / 8e-4 L2, flow up to 2.2e-3 / 1.5e-3 "
                        "at 1280x720 - outside the tolerance, reported for comparison with round 1"},
             "roofline": {"bound": "mfma", "kernel": dom_sym, "family": dom_name,

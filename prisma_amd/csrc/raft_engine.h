@@ -10,6 +10,7 @@
 class RaftEngine : public EngineBase {
   public:
     explicit RaftEngine(int device) : EngineBase(device) {}
+    ~RaftEngine() override { for (auto &kv : snaps_) if (kv.second) hipFree(kv.second); }
     int load(const pb_tensor *w, int n);
     // frames: device uint8 [F, H, W, 3].  Outputs are device pointers (any may be null):
     //   flow_out [F-1, dirs, sh, sw, 2] fp32, rgb_out [F-1, dirs, sh, sw, 3] u8, maxdisp [F-1, dirs]
@@ -50,4 +51,8 @@ class RaftEngine : public EngineBase {
     int last_nd_ = 0;
     int upd8_ = 0;               // the update block's maps carry fp8 copies and its weights e4m3 residuals (MX segments; raft_engine.hip load)
     std::map<std::string, Stage> stages_;
+    // debug snapshots (pb_set_profiling bit 2): copies of buffers later iterations overwrite - the initial hidden state, the first
+    // lookup's output and the flow after the first iteration, the intermediates the reference goldens hold (tests/golden/raft_*.npz)
+    std::map<std::string, void *> snaps_;
+    int snapshot(const char *name, const void *src, size_t bytes, const Stage &as);
 };

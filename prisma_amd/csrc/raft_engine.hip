@@ -375,12 +375,15 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
             if (r) return r;
         }
 
+    if (debug && (r = snapshot("net0", h32_, (size_t)ND * P_ * 128 * 4, Stage{nullptr, 0, 0, P_, 1, 128, 128, (int64_t)P_ * 128}))) return r;
+
     // ---- GRU iterations (raft.py:124-144, update.py:122-136) ----
     for (int it = 0; it < iters; ++it) {
         tic(F_ELT, 0, 0);
         r = launch_corr_lookup(stream, pyr_, lh_, lw_, lwp_, pld_, flow_, P_, w8_, corr_, rows, Lhx, upd8_ ? 768 : 0, s8);
         toc();
         if (r) return r;
+        if (debug && it == 0 && (r = snapshot("corr0", corr_, (size_t)ND * P_ * Lhx * 2, Stage{nullptr, 1, ND, 324, h8_, w8_, Lhx, 0}))) return r;
         // BasicMotionEncoder.  With upd8_ every map is [a16 (C) | a8 (C bytes)] per pixel (pixel stride 1.5 C halfs): the conv epilogues
         // store the fp8 copy too (o8 = its byte offset from the output row: 2 Ctot - slice offset) and the MX segments read it
         if ((r = conv(corr_, 384, Lhx, ND, h8_, w8_, 1, 1, 1, convc1_, c1_, L256, ACT_RELU, 0, nullptr, nullptr, 0, 0, upd8_ ? 512 : 0))) return r;
@@ -414,6 +417,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         if (timer.enabled && !r) timer.recs[open_.back()].name = fh2_.sw ? "flow_head2_kernel<true>" : "flow_head2_kernel<false>";
         toc();
         if (r) return r;
+        if (debug && it == 0 && (r = snapshot("flow_it0", flow_, (size_t)ND * P_ * 2 * 4, Stage{nullptr, 0, 0, P_, 1, 2, 2, (int64_t)P_ * 2}))) return r;
     }
     stages_["flow_lo"] = Stage{flow_, 0, 0, P_, 1, 2, 2, (int64_t)P_ * 2};
 
@@ -445,6 +449,18 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     return r;
 }
 
+int RaftEngine::snapshot(const char *name, const void *src, size_t bytes, const Stage &as) {
+    void *&p = snaps_[name];
+    if (p) PB_HIP(hipFree(p));
+    p = nullptr;
+    PB_HIP(hipMalloc(&p, bytes));
+    PB_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToDevice, stream));
+    Stage st = as;
+    st.ptr = p;
+    stages_[name] = st;
+    return 0;
+}
+
 int64_t RaftEngine::get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]) {
     auto it = stages_.find(name);
     PB_CHECK(it != stages_.end(), PB_ERR_ARG, "unknown stage '%s'", name);
@@ -457,7 +473,7 @@ int64_t RaftEngine::get_stage(const char *name, float *out, int64_t cap, int64_t
         PB_HIP(hipMemcpy(out, s.ptr, total * 4, hipMemcpyDeviceToHost));
         return total;
     }
-    const int n = pF_;
+    const int n = s.n > 0 ? (int)s.n : pF_;
     const int64_t total = (int64_t)n * s.c * s.h * s.w;
     shape[0] = n; shape[1] = s.c; shape[2] = s.h; shape[3] = s.w;
     PB_CHECK(total <= cap, PB_ERR_ARG, "stage buffer too small");

@@ -49,8 +49,23 @@ def test_pair_against_reference_vectors(net, golden_dir):
     z = np.load(os.path.join(golden_dir, "raft_125x157.npz"))
     h, w = [int(v) for v in z["hw"]]
     fr = synth.frame_pair_sequence(2, h, w, seed=int(z["frame_seed"]))
+    net.set_profiling(timing=False, debug_stages=True)
     flow, rgb, mx = net.infer_sequence(fr, scale=1.0, iters=int(z["iters"]), backward=True)
+    net.set_profiling(timing=False, debug_stages=False)
     assert flow.shape == (1, 2, h, w, 2)
+    # intermediates against the pinned oracle's (tests/golden/raft_125x157.npz holds channel-strided samples from the run in which
+    # make_golden.py asserted oracle == reference; flow_lo below is the reference's own tensor): feature map
+    # (extractor.py BasicEncoder), initial hidden state (raft.py:112-115), the first 9x9x4 lookup (corr.py:29-50), the flow after one
+    # update (update.py:122-136) and the 1/8-resolution flow after all of them
+    h8, w8 = z["flow_lo"].shape[2:]
+    gfm = net.stage("fmap")                                   # [frames, 256, h8, w8]; golden fmap1 = [fwd: frame 0, bwd: frame 1][:, ::4]
+    net0 = net.stage("net0").reshape(2, h8, w8, 128).transpose(0, 3, 1, 2)
+    corr0 = net.stage("corr0")                                # [2, 324, h8, w8]
+    it0 = net.stage("flow_it0").reshape(2, h8, w8, 2).transpose(0, 3, 1, 2)
+    for name, got, ref in (("fmap1", gfm[:, ::4], z["fmap1"]), ("net0", net0[:, ::4], z["net0"]), ("corr0", corr0[:, ::3], z["corr0"]),
+                           ("flow_it0", it0, z["flow_it0"])):
+        print("\n  %-9s/golden relmax %.3e relL2 %.3e" % (name, relmax(got, ref), rell2(got, ref)), end="")
+        assert relmax(got, ref) < TOL_RANGE and rell2(got, ref) < TOL_L2, name
     # stages vs the oracle (same weights, same frames)
     import torch
     import torch.nn.functional as F
@@ -64,6 +79,7 @@ def test_pair_against_reference_vectors(net, golden_dir):
     print("\n  fmap      relmax %.3e relL2 %.3e" % (relmax(fmap, st["fmap1"]), rell2(fmap, st["fmap1"])))
     flo = net.stage("flow_lo").reshape(2, lo.shape[2], lo.shape[3], 2).transpose(0, 3, 1, 2)
     print("  flow_lo   relmax %.3e relL2 %.3e" % (relmax(flo, lo), rell2(flo, lo)))
+    assert relmax(fmap, st["fmap1"]) < TOL_RANGE and relmax(flo, lo) < TOL_RANGE and relmax(flo, z["flow_lo"]) < TOL_RANGE
     for name, got, ref in (("fwd", flow[0, 0], z["fwd"]), ("bwd", flow[0, 1], z["bwd"])):
         print("  %s/golden relmax %.3e relL2 %.3e  max|flow| %.2f" % (name, relmax(got, ref), rell2(got, ref), np.abs(ref).max()))
         assert relmax(got, ref) < TOL_RANGE and rell2(got, ref) < TOL_L2
