@@ -486,6 +486,9 @@ def main():
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items()
                               if v["flops"] > 0 and v["ms"] > 0},
             "kernel_launches_per_step": {k: v["launches"] / args.steps for k, v in sorted(fam.items())},
+            # algorithmic bytes (A + W + output once) per second of launch time: the figure to hold against HBM's ~8 TB/s for the launches
+            # that move more than they compute (the K = 256 correlation-volume GEMMs sit in flow/gemm_kernel<128, 128, 2, 2, 0, 0, ...>)
+            "kernel_algorithmic_tbps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e12, 3) for k, v in fam.items() if v["bytes"] > 0 and v["ms"] > 0},
         }
         out["this_precision"] = dict(mode_summary(main_res, args.steps), precision=PREC_NAME[args.precision])
         if other:

@@ -11,6 +11,7 @@ Reference entry points exercised
   vision_transformer.vit_large(depth=4)  .../facebookresearch_dinov2_main/vision_transformer.py:367-378
   d_anything.dpt.DPTHead                 bands/d_anything/dpt.py:22-136
   common.encode.heat_to_rgb/process_flow bands/common/encode.py:13-33,113-126
+  gmflow.gmflow.GMFlow                   bands/gmflow/gmflow.py:12-170 (case `gmflow`)
 """
 import os
 import sys
@@ -259,6 +260,42 @@ def raft_case(hgt=125, wid=157, seed=21, iters=12):
                         flow_it0=st["flow_it0"])
 
 
+def gmflow_case(hgt=125, wid=157, seed=51, bidir=True, tag=None):
+    """Reference GMFlow (bands/gmflow/gmflow.py) + InputPadder(padding_factor=16) on a seeded frame pair, called the way
+    bands/flow_gmflow.py:66-118 calls it (attn_splits_list [2], corr_radius_list [-1], prop_radius_list [-1], pred_bidir_flow when
+    backward flow / masks are wanted; scale = 1: cv2 is absent here)."""
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    from gmflow.gmflow import GMFlow
+    from common.flow import InputPadder
+    from oracle import gmflow_oracle as G
+    w = synth.gmflow_weights(seed=2468)
+    m = GMFlow(feature_channels=128, num_scales=1, upsample_factor=8, num_head=1, attention_type="swin", ffn_dim_expansion=4,
+               num_transformer_layers=6)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
+    fr = synth.frame_pair_sequence(2, hgt, wid, seed=seed)
+    a = torch.from_numpy(fr[0]).permute(2, 0, 1).float()[None]
+    c = torch.from_numpy(fr[1]).permute(2, 0, 1).float()[None]
+    padder = InputPadder(a.shape, padding_factor=16)
+    p1, p2 = padder.pad(a, c)
+    assert list(padder._pad) == G.pad_amounts(hgt, wid)
+    # the reference builds its shifted-window mask on device 'cuda' by default argument only; FeatureTransformer passes feature0.device
+    with torch.no_grad():
+        out = m(p1, p2, attn_splits_list=[2], corr_radius_list=[-1], prop_radius_list=[-1], pred_bidir_flow=bidir)["flow_preds"][-1]
+        fwd = padder.unpad(out[0]).permute(1, 2, 0).numpy()
+        bwd = padder.unpad(out[1]).permute(1, 2, 0).numpy() if bidir else None
+    up_o, st = G.gmflow_forward(w, p1.numpy(), p2.numpy(), bidir=bidir, return_stages=True)
+    f_o, b_o = G.infer_pair(w, fr[0], fr[1], scale=1.0, backward=bidir)
+    e = max(relerr(up_o, out.numpy()), relerr(f_o, fwd), relerr(b_o, bwd) if bidir else 0.0)
+    print(f"[gmflow {hgt}x{wid} pad {padder._pad} bidir {bidir}] oracle vs reference rel err {e:.2e}; |flow| max {np.abs(fwd).max():.2f} px, "
+          f"mean fwd {fwd.reshape(-1, 2).mean(0)}, match-stage |flow| max {np.abs(st['flow_match']).max():.2f}")
+    assert e < 2e-4, e
+    keep = dict(frame_seed=np.array(seed), hw=np.array([hgt, wid]), fwd=fwd, feat0=st["feat0"][:, ::4].copy(),
+                block0=st["block0"][:, :, ::4].copy(), tfeat0=st["tfeat0"][:, ::4].copy(), flow_match=st["flow_match"], flow_prop=st["flow_prop"])
+    if bidir:
+        keep["bwd"] = bwd
+    np.savez_compressed(os.path.join(GOLD, f"gmflow_{tag or (str(hgt) + 'x' + str(wid))}.npz"), **keep)
+
+
 def raft_full_case(seed=41, iters=12):
     """BASELINE configs[2] / [4] at full size: the REAL reference RAFT + InputPadder on (a) 8 consecutive-frame pairs of a 9-frame
     1280x720 sequence, forward direction, 12 iterations (configs[2]: batch of 8 pairs, no --scale), committed as 1/8-strided
@@ -426,6 +463,9 @@ if __name__ == "__main__":
         small_case("vitl_d4", 90, 120, 12)
     if "full" in which:
         full_case()
+    if "gmflow" in which:
+        gmflow_case()
+        gmflow_case(216, 300, 52, False)   # pads to 224x304: a 28 x 38 grid, 14 x 19 windows, forward only
     if "raft_full" in which:
         raft_full_case()
     if "raft" in which:

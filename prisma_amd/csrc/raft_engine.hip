@@ -205,6 +205,9 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
             // level l of the volume: fp16, one row per source pixel, targets in 8 x 8 tiles (raft_kernels.hip corr_tile_kernel)
             lwp_[l] = (int)round_up(lw_[l], 8);
             pld_[l] = (int)round_up(lh_[l], 8) * lwp_[l];
+            // a row stride that is a multiple of 256 lets launch_gemm pick the 256 x 256 ping-pong kernel for the level (measured at
+            // 18360 x 19136 x 256: 0.410 -> 0.339 ms, tools/volume_gemm_probe.py); taken when it costs under 2 % of the level's bytes
+            if (round_up(pld_[l], 256) * 50 <= (int64_t)pld_[l] * 51) pld_[l] = (int)round_up(pld_[l], 256);
             pyr_[l] = (f16 *)carve((size_t)ND * P_ * pld_[l] * 2 + slack);
             fpool_[l] = l == 0 ? nullptr : (f16 *)carve((size_t)round_up((int64_t)F * lh_[l] * lw_[l], 256) * 256 * 2 + slack);
             ftile_[l] = (f16 *)carve((size_t)(F * (int64_t)pld_[l] + 256) * 256 * 2 + slack);
@@ -362,7 +365,8 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
                 a.W = ftile_[l] + (int64_t)(i + 1 - d) * pld_[l] * 256;
                 a.K = 256; a.N = pld_[l];
                 a.out = pyr_[l] + (int64_t)n * P_ * pld_[l]; a.ldo = pld_[l]; a.zero = zero_;
-                tic(F_GEMM, 2.0 * P_ * (double)lh_[l] * lw_[l] * 256, 0);
+                // K = 256 against P x pld fp16 outputs: this launch is bound by writing the volume, not by the matrix pipe (bytes: A + W + out)
+                tic(F_GEMM, 2.0 * P_ * (double)lh_[l] * lw_[l] * 256, 2.0 * ((double)P_ * 256 + (double)pld_[l] * 256 + (double)P_ * pld_[l]));
                 r = launch_gemm(stream, A_DENSE, EPI_STD, TILE_AUTO, a);
                 if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
                 toc();

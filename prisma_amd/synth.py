@@ -499,3 +499,56 @@ def zoe_weights(seed: int = 2468) -> Dict[str, np.ndarray]:
                 gain = 0.5
             w[name] = g.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(shape[1]))
     return w
+
+
+# ---------------------------------------------------------------------------
+# GMFlow (bands/flow_gmflow.py defaults: feature_channels 128, 1 scale, 1 head, swin attention with 2 x 2 splits, 6 blocks, ffn x 4)
+# ---------------------------------------------------------------------------
+def gmflow_param_shapes(channels: int = 128, layers: int = 6, ffn: int = 4, upsample: int = 8):
+    """(name, shape) of every tensor of the reference's GMFlow state_dict at the band's defaults (bands/gmflow/gmflow.py:12-47,
+    backbone.py:5-117, transformer.py:104-139, 284-298).  InstanceNorm2d layers are affine-free: no entries."""
+    C = channels
+    out = [("backbone.conv1.weight", (64, 3, 7, 7))]
+    cin = 64
+    for li, dim in enumerate((64, 96, 128), start=1):
+        for bi in range(2):
+            p = f"backbone.layer{li}.{bi}."
+            out += [(p + "conv1.weight", (dim, cin if bi == 0 else dim, 3, 3)), (p + "conv2.weight", (dim, dim, 3, 3))]
+            if bi == 0 and li > 1:
+                out += [(p + "downsample.0.weight", (dim, cin, 1, 1)), (p + "downsample.0.bias", (dim,))]
+        cin = dim
+    out += [("backbone.conv2.weight", (C, 128, 1, 1)), ("backbone.conv2.bias", (C,))]
+    for i in range(layers):
+        for part, has_ffn in (("self_attn", False), ("cross_attn_ffn", True)):
+            p = f"transformer.layers.{i}.{part}."
+            out += [(p + n + ".weight", (C, C)) for n in ("q_proj", "k_proj", "v_proj", "merge")]
+            out += [(p + "norm1.weight", (C,)), (p + "norm1.bias", (C,))]
+            if has_ffn:
+                out += [(p + "mlp.0.weight", (2 * C * ffn, 2 * C)), (p + "mlp.2.weight", (C, 2 * C * ffn)),
+                        (p + "norm2.weight", (C,)), (p + "norm2.bias", (C,))]
+    out += [("feature_flow_attn.q_proj.weight", (C, C)), ("feature_flow_attn.q_proj.bias", (C,)),
+            ("feature_flow_attn.k_proj.weight", (C, C)), ("feature_flow_attn.k_proj.bias", (C,)),
+            ("upsampler.0.weight", (256, 2 + C, 3, 3)), ("upsampler.0.bias", (256,)),
+            ("upsampler.2.weight", (upsample * upsample * 9, 256, 1, 1)), ("upsampler.2.bias", (upsample * upsample * 9,))]
+    return out
+
+
+def gmflow_weights(seed: int = 2468) -> Dict[str, np.ndarray]:
+    """Seeded float32 tensors under the reference's state_dict names.  Scales keep the network in the regime of a trained one: unit-scale
+    features out of the backbone, LayerNorm'd messages at ~0.3 of the stream they are added to, so the matching softmax is sharply peaked on
+    the true correspondence of the translated synthetic texture without being a hard argmax."""
+    w: Dict[str, np.ndarray] = {}
+    for name, shape in gmflow_param_shapes():
+        g = _rng(seed, name)
+        if ".norm" in name:
+            w[name] = ((0.3 + 0.03 * g.standard_normal(shape, dtype=np.float32)) if name.endswith("weight")
+                       else 0.03 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        elif name.endswith("bias"):
+            w[name] = (0.05 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            gain = 1.4 if name.startswith("backbone.") and "conv2.weight" != name.split("backbone.")[-1] or name.startswith("upsampler.0") else 1.0
+            if name.startswith("upsampler.2"):
+                gain = 2.0                                # convex-combination logits with some contrast
+            w[name] = (g.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(fan_in)))
+    return w

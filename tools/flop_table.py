@@ -78,12 +78,19 @@ for enc in ("fnet", "cnet"):
     add("flow", (CONV, STD), f"{enc} layer3 3x3 128->128 @1/8", Fr * Pp, 128, 9 * 128, 3)
     add("flow", (CONV, STD), f"{enc} layer3 downsample 1x1 s2", Fr * Pp, 128, 96)
     add("flow", (DENSE, STD), f"{enc} conv2 1x1 128->256", Fr * Pp, 256, 128)
+def vol_stride(a, b):
+    # raft_engine.hip prepare(): targets in 8 x 8 tiles; rounded up to a multiple of 256 when that costs under 2 % (ping-pong kernel)
+    p = ((a + 7) // 8 * 8) * ((b + 7) // 8 * 8)
+    q = (p + 255) // 256 * 256
+    return q if q * 50 <= p * 51 else p
+
+
 lv = [(h8, w8)]
 for _ in range(3):
     lv.append((lv[-1][0] // 2, lv[-1][1] // 2))
 for l, (a, b) in enumerate(lv):
     add("flow", (DENSE, STD), f"correlation volume level {l} (per pair; rows padded to 8 x 8 target tiles)", Pp, a * b, 256, pairs, mx=False,
-        n_launch=((a + 7) // 8 * 8) * ((b + 7) // 8 * 8))
+        n_launch=vol_stride(a, b))
 Mu = pairs * Pp
 it = 12
 add("flow", (CONV, STD), "convc1 1x1 324->256 (a 1 x 1 conv launch on the channel slice)", Mu, 256, 324, it, mx=False)
