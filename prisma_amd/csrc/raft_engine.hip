@@ -367,8 +367,14 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
                 a.out = pyr_[l] + (int64_t)n * P_ * pld_[l]; a.ldo = pld_[l]; a.zero = zero_;
                 // K = 256 against P x pld fp16 outputs: this launch is bound by writing the volume, not by the matrix pipe (bytes: A + W + out)
                 tic(F_GEMM, 2.0 * P_ * (double)lh_[l] * lw_[l] * 256, 2.0 * ((double)P_ * 256 + (double)pld_[l] * 256 + (double)P_ * pld_[l]));
-                r = launch_gemm(stream, A_DENSE, EPI_STD, TILE_AUTO, a);
-                if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
+                static const bool generic = getenv("PB_VOLUME") && getenv("PB_VOLUME")[0] == '0';     // A/B: the generic GEMM kernels
+                if (generic) {
+                    r = launch_gemm(stream, A_DENSE, EPI_STD, TILE_AUTO, a);
+                    if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
+                } else {        // volume.hip: A-stationary, persistent along the targets; same accumulation order, same bits
+                    r = launch_corr_volume(stream, a.A, a.M, a.W, a.N, a.N, a.out, a.ldo);
+                    if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = "corr_volume_kernel";
+                }
                 toc();
                 if (r) return r;
             }

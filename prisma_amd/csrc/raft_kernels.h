@@ -16,6 +16,9 @@ int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2
                       float o8_scale = 16.f);
 int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C);
 int launch_corr_tile(hipStream_t s, const f16 *x, f16 *y, int F, int h, int w, int wp, int npad);
+// volume.hip: out[M, N] fp16 = A[M, 256] . W[N, 256]^T (one pair, one pyramid level); W has w_rows >= N addressable rows; the
+// A-stationary persistent kernel for this K = 256, output-bound shape
+int launch_corr_volume(hipStream_t s, const f16 *A, int M, const f16 *W, int N, int w_rows, f16 *out, int64_t ldo);
 int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], const int w[4], const int wp[4], const int ld[4],
                        const float *flow, int P, int w8, f16 *out, int64_t rows, int ldo = 384, int o8_off = 0, float o8_scale = 16.f);
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W, int split = 0);

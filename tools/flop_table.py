@@ -89,8 +89,7 @@ lv = [(h8, w8)]
 for _ in range(3):
     lv.append((lv[-1][0] // 2, lv[-1][1] // 2))
 for l, (a, b) in enumerate(lv):
-    add("flow", (DENSE, STD), f"correlation volume level {l} (per pair; rows padded to 8 x 8 target tiles)", Pp, a * b, 256, pairs, mx=False,
-        n_launch=vol_stride(a, b))
+    add("flow", "corr_volume_kernel", f"correlation volume level {l} (per pair; volume.hip, row stride {vol_stride(a, b)})", Pp, a * b, 256, pairs)
 Mu = pairs * Pp
 it = 12
 add("flow", (CONV, STD), "convc1 1x1 324->256 (a 1 x 1 conv launch on the channel slice)", Mu, 256, 324, it, mx=False)
