@@ -11,7 +11,9 @@
 //   * the stores are the direct interleaved ones of gemm_kernels.h (a lane owns two adjacent columns, 32 lanes write 128 B of a row).
 // Accumulation order over K is that of the generic kernels, so the volume is bit-identical to theirs.
 // Measured (1080p x 0.75, 31 pairs, 4 levels): 15.4 ms per step on the generic kernels -> 13.1 ms (2.3 TB/s of volume written).  What is
-// left is the store drain below, once per tile; a 3-slot ring at three workgroups per CU measured 13.6 ms.
+// left is the store drain below, once per tile.  Tried and measured slower: a 3-slot ring at three workgroups per CU (13.6 ms); a fifth,
+// load-only producer wave so that the compute waves never wait on their stores (28 ms: one wave cannot issue the 16 DMAs per stage
+// fast enough).
 // Waits: the DMAs of a stage are counted (vmcnt) while only loads are in flight; after a tile's stores the next wait drains
 // everything (loads and stores return out of order with respect to each other, a count would not be safe).
 #include "common.h"
