@@ -10,12 +10,13 @@
 //     (2x the LDS fragment traffic per MFMA of a 2 x 2 wave layout - affordable: the matrix pipe is needed a quarter of the time);
 //   * the stores are the direct interleaved ones of gemm_kernels.h (a lane owns two adjacent columns, 32 lanes write 128 B of a row).
 // Accumulation order over K is that of the generic kernels, so the volume is bit-identical to theirs.
-// Measured (1080p x 0.75, 31 pairs, 4 levels): 15.4 ms per step on the generic kernels -> 13.1 ms (2.3 TB/s of volume written).  What is
-// left is the store drain below, once per tile.  Tried and measured slower: a 3-slot ring at three workgroups per CU (13.6 ms); a fifth,
-// load-only producer wave so that the compute waves never wait on their stores (28 ms: one wave cannot issue the 16 DMAs per stage
-// fast enough).
-// Waits: the DMAs of a stage are counted (vmcnt) while only loads are in flight; after a tile's stores the next wait drains
-// everything (loads and stores return out of order with respect to each other, a count would not be safe).
+// Waits: loads and stores share vmcnt and return out of order with respect to each other, so a wait that must see a DMA land can only be
+// "everything but the newest stage".  A tile's stores are therefore issued one tile late, right after such a wait, and the next one is a
+// whole tile away.
+// Measured (1080p x 0.75, 31 pairs, 4 levels): 15.4 ms per step on the generic kernels -> 13.1 ms with stores issued at once -> 12.4 ms
+// deferred (2.4 TB/s of volume written).  Per tile the matrix pipe and the LDS fragment reads need ~1000 cycles each; the steps (two per
+// tile, 512 MFMA cycles) are short against their barrier + wait.  Tried and measured slower: a 3-slot ring at three workgroups per CU
+// (13.6 ms); a fifth, load-only producer wave so that the compute waves never wait on their stores (28 ms).
 #include "common.h"
 #include "raft_kernels.h"
 #include "../../include/prisma_bands.h"
@@ -88,45 +89,58 @@ __global__ __launch_bounds__(VNT, 2) void corr_volume_kernel(const f16 *__restri
     stage(0);
     stage(1);
     if (G > 2) stage(2);
-    bool drain = false;                                         // stores in flight: the next wait must be vmcnt(0)
-    for (int g = 0; g < G; ++g) {
-        const int ahead = G - 1 - g;                            // stages issued after stage g (at most 2 are in flight behind it)
-        if (drain || ahead == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        drain = false;
-        __syncthreads();                                        // stage g landed for every wave; slot (g + 3) & 3 = (g - 1) & 3 is free
-        if (g + 3 < G) stage(g + 3);
-        const char *sb = smem + (g & (VSTAGES - 1)) * VSTAGE_BYTES;
-        // af is indexed with compile-time k-steps inside each half (a runtime index would put it in scratch)
+    // af is indexed with compile-time k-steps inside each half (a runtime index would put it in scratch)
 #define PB_VOL_HALF(H)                                                                                                  \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                              \
-            const int c = kk * (VBN * 128) + ((2 * ks + lh) ^ fsw) * 16;                                                \
-            const f16x8 b0 = *(const f16x8 *)(sb + b_off[0] + c), b1 = *(const f16x8 *)(sb + b_off[1] + c);             \
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[H * 8 + kk * 4 + ks], b0, acc[0], 0, 0, 0);              \
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[H * 8 + kk * 4 + ks], b1, acc[1], 0, 0, 0);              \
-        }
-        if ((g & 1) == 0) {
-            PB_VOL_HALF(0)
-        } else {
-            PB_VOL_HALF(1)
-            // tile done: a lane owns columns 2 li, 2 li + 1 of the tile (acc[0], acc[1]) for 16 rows - 32 lanes write 128 B of a row
-            const int n = (nt0 + (g >> 1)) * VBN + 2 * li;
-            const bool nok = n < N;
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                  \
+        const int c = kk * (VBN * 128) + ((2 * ks + lh) ^ fsw) * 16;                                                    \
+        const f16x8 b0 = *(const f16x8 *)(sb + b_off[0] + c), b1 = *(const f16x8 *)(sb + b_off[1] + c);                 \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[H * 8 + kk * 4 + ks], b0, acc[0], 0, 0, 0);                  \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[H * 8 + kk * 4 + ks], b1, acc[1], 0, 0, 0);                  \
+    }
+    // A lane owns columns 2 li, 2 li + 1 of a tile (acc[0], acc[1]) for 16 rows: 32 lanes write 128 B of a row.  A tile's stores are issued
+    // one tile LATE (from `pk`), right after the wait of the next tile's first step: the wait that has to count them - loads and stores
+    // share vmcnt and return out of order with respect to each other, so a wait that must see a DMA land can only be "everything but the
+    // newest stage" - is then a whole tile (two steps) away, and they drain under that tile's MFMAs.
+    f16x2 pk[16];
+    int pk_n = -1;                                              // first column of the tile held in pk, -1: none
+    auto flush = [&]() {
+        if (pk_n >= 0 && pk_n < N) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (nok && m < M) {
-                    const f16x2 v = {(f16)acc[0][r], (f16)acc[1][r]};
-                    *(f16x2 *)(out + (int64_t)m * ldo + n) = v;
-                }
-                acc[0][r] = 0.f; acc[1][r] = 0.f;
+                if (m < M) *(f16x2 *)(out + (int64_t)m * ldo + pk_n) = pk[r];
             }
-            drain = true;
         }
-#undef PB_VOL_HALF
+    };
+    for (int j = 0; j < ntl; ++j) {
+        const int g = 2 * j;
+        // ---- step g: stages g and g + 1 must have landed; only stage g + 2 (4 DMAs) may stay in flight - and none of the stores ----
+        if (g + 2 < G) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                        // ... for every wave; slot (g + 3) & 3 = (g - 1) & 3 is free
+        if (g + 3 < G) stage(g + 3);
+        flush();                                                // the previous tile's results
+        {
+            const char *sb = smem + (g & (VSTAGES - 1)) * VSTAGE_BYTES;
+            PB_VOL_HALF(0)
+        }
+        // ---- step g + 1: landed already (waited for above); the barrier frees slot g & 3 for stage g + 4 ----
+        __syncthreads();
+        if (g + 4 < G) stage(g + 4);
+        {
+            const char *sb = smem + ((g + 1) & (VSTAGES - 1)) * VSTAGE_BYTES;
+            PB_VOL_HALF(1)
+        }
+        pk_n = (nt0 + j) * VBN + 2 * li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pk[r] = f16x2{(f16)acc[0][r], (f16)acc[1][r]};
+            acc[0][r] = 0.f; acc[1][r] = 0.f;
+        }
     }
+#undef PB_VOL_HALF
+    flush();
 }
 
 }  // namespace
