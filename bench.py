@@ -256,7 +256,7 @@ def pmc_traffic(symbol):
     timed bench, so the figure is read from profiles/ (newest round first)."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     want = symbol.replace(" ", "")
-    for name in ("r02e_pmc_traffic.json", "r02d_pmc_traffic.json", "r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r02f_pmc_traffic.json", "r02e_pmc_traffic.json", "r02d_pmc_traffic.json", "r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(here, name)
         if not os.path.exists(path):
             continue
