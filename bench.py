@@ -289,7 +289,7 @@ def main():
                          "1.3-2.2e-3 max-norm error).  The other mode is timed too (child process) and reported under `other_precision`")
     ap.add_argument("--one-precision", action="store_true", help="skip the second precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256, 4 simple 256")
+    ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256x256, 9 256x64")
     ap.add_argument("--conv-tile", type=int, default=0)
     ap.add_argument("--all-legs", action="store_true", help="also run the per-band legs below with their usual sizes (flow 720p, mask, pipeline, PCIe)")
     ap.add_argument("--latency", action="store_true", help="also time one 1280x720 frame at batch 1 (BASELINE configs[1])")

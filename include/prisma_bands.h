@@ -222,7 +222,7 @@ typedef struct {
     const char *name;     /* kernel family, e.g. "gemm_f16", "attention", "conv3x3"      */
     double ms;            /* summed event time of that family in the last call            */
     double flops;         /* algorithmic FLOPs those launches performed (2 M N K of the layers) */
-    double exec_flops;    /* MFMA FLOPs actually issued: x2 / x3 for split-fp16 layers (PB_PREC_SPLIT) */
+    double exec_flops;    /* MFMA work actually issued, in fp16-pass equivalents: x1.5 ... x3 for the split layers (PB_PREC_SPLIT; an e4m3 pass counts 0.5) */
     double bytes;         /* algorithmic HBM bytes (compulsory traffic) of those launches */
     int32_t launches;
 } pb_kernel_stat;
@@ -230,8 +230,8 @@ typedef struct {
  * masks, bit 2 = accumulate the timings over successive infer calls (pb_get_kernel_stats then reports the sums since
  * this call) instead of restarting at every infer call. */
 int pb_set_profiling(pb_ctx *ctx, int enabled);
-/* Tuning / A-B switches: "gemm_tile", "conv_tile" = 0 auto, 1 128x128, 2 256x256 ping-pong,
- * 4 256x256 single-barrier. */
+/* Tuning / A-B switches: "gemm_tile", "conv_tile" = 0 auto, 1 128x128, 2 256x256 ping-pong, 3 256x32, 9 256x64
+ * (prisma_amd/csrc/gemm.h; the other round-1 variants were measured slower and removed). */
 int pb_set_option(pb_ctx *ctx, const char *key, int value);
 int pb_get_kernel_stats(pb_ctx *ctx, pb_kernel_stat *out, int cap);
 
