@@ -7,8 +7,8 @@ FLOPs = 2 M N K of the layer (real channels: padding and the residual passes not
 python tools/flop_table.py [batch] [H W]"""
 import sys
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-H, W = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1080, 1920)
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 32
+H, W = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 and sys.argv[2].isdigit() else (1080, 1920)
 rows = []
 DENSE, CONV = 0, 1
 STD, RESID, QKV, PIXSHUF, PATCH, HEAD, F32 = range(7)
@@ -32,12 +32,24 @@ def symbol(amode, epi, M, N, mx):
 def add(band, kind, name, M, N, K, n=1, in_b=2, out_b=2, mx=True, n_launch=None):
     # n_launch: the N the launch is made with when it differs from the layer's (padded volume rows)
     fam = kind if isinstance(kind, str) else symbol(kind[0], kind[1], M, n_launch or N, mx)
-    rows.append((band, fam, name, n, M, N, K, 2.0 * M * N * K, in_b * M * K + 2.0 * N * K + out_b * M * N))
+    # algorithmic bytes as the engines count them (engine_base.hip conv / dense): the input MAP once - not its im2col expansion -, the
+    # weights once, the output once
+    taps, stride = 1, 1
+    if not isinstance(kind, str) and kind[0] == CONV and "space-to-depth" not in name:
+        taps = 9 if "3x3" in name else 5 if "1x5" in name else 1
+        stride = 2 if " s2" in name else 1
+    a_bytes = in_b * M * stride * stride * (K / taps)
+    if band == "depth":
+        n *= ND                                          # a 32-frame call runs as ND chunks of BD frames (DepthEngine::batch_cap, split mode)
+    rows.append((band, fam, name, n, M, N, K, 2.0 * M * N * K, a_bytes + 2.0 * N * K + out_b * M * N))
 
 
 # ---- depth_anything ViT-L @ 518 x 924 (any 16:9 frame): 37 x 66 patches, 2443 tokens padded to 2448 rows per frame
 gh, gw, D, F = 37, 66, 1024, 256
 ntp, P = 2448, gh * gw
+BD = 16 if B > 16 else B                                 # frames per launch: split-mode maps are capped at 2^31 elements (engine.hip batch_cap)
+ND = (B + BD - 1) // BD
+B_ALL, B = B, BD                                         # the depth rows below are per launch
 Mv = B * ntp
 add("depth", (DENSE, PATCH), "patch embed (+ pos embed)", B * P, D, 588, mx=False)
 add("depth", (DENSE, QKV), "qkv", Mv, 3 * D, D, 24)
@@ -62,6 +74,7 @@ for lv in range(3, -1, -1):
 add("depth", (CONV, STD), "output_conv1 3x3", B * 4 * lh[0] * lw[0], F // 2, 9 * F)
 add("depth", (CONV, HEAD), "output_conv2 3x3 + ReLU + 1x1 + ReLU", B * 518 * 924, 32, 9 * F // 2)
 
+B = B_ALL
 # ---- flow_raft at --scale 0.75: (H, W) -> (sh, sw) padded to /8
 sh, sw = round(H * 0.75), round(W * 0.75)
 Hp, Wp = (sh + 7) // 8 * 8, (sw + 7) // 8 * 8
@@ -104,19 +117,31 @@ add("flow", "flow_head2_kernel<true>", "flow head conv2 3x3 256->2 (direct kerne
 add("flow", (CONV, STD), "mask.0 3x3 128->256 (last iteration)", Mu, 256, 9 * 128, mx=False)
 add("flow", (DENSE, F32), "mask.2 1x1 256->576", Mu, 576, 256, out_b=4, mx=False)
 
-print(f"batch {B}, frame {W}x{H}; flow at 0.75: {sw}x{sh} -> network {Wp}x{Hp}, 1/8 grid {w8}x{h8}\n")
-print("| band | kernel symbol (split mode) | layer | launches / step | M | N | K | GFLOP / launch | algorithmic MB / launch |")
-print("|---|---|---|---|---|---|---|---|---|")
-tot = {}
-for band, fam, name, n, M, N, K, fl, by in rows:
-    print(f"| {band} | {fam} | {name} | {n} | {M} | {N} | {K} | {fl / 1e9:.1f} | {by / 1e6:.0f} |")
-    k = (band, fam)
-    t = tot.setdefault(k, [0, 0.0, 0.0])
-    t[0] += n; t[1] += n * fl; t[2] += n * by
-print("\n| band / family | launches / step | GFLOP / step | mean GFLOP / launch | mean algorithmic MB / launch |")
-print("|---|---|---|---|---|")
-for (band, fam), (n, fl, by) in sorted(tot.items()):
-    print(f"| {band}/{fam} | {n} | {fl / 1e9:.0f} | {fl / n / 1e9:.1f} | {by / n / 1e6:.0f} |")
-d = sum(v[1] for k, v in tot.items() if k[0] == "depth")
-f = sum(v[1] for k, v in tot.items() if k[0] == "flow")
-print(f"\ndepth: {d / 1e9 / B:.1f} GFLOP / frame (SURVEY 8d: 2583.1);  flow: {f / 1e9 / pairs:.1f} GFLOP / pair-direction at {Wp}x{Hp}")
+
+def totals():
+    """{(band, family): [launches per step, FLOPs per step, algorithmic bytes per step]}"""
+    tot = {}
+    for band, fam, name, n, M, N, K, fl, by in rows:
+        t = tot.setdefault((band, fam), [0, 0.0, 0.0])
+        t[0] += n; t[1] += n * fl; t[2] += n * by
+    return tot
+
+
+def main():
+    print(f"batch {B}, frame {W}x{H}; flow at 0.75: {sw}x{sh} -> network {Wp}x{Hp}, 1/8 grid {w8}x{h8}\n")
+    print("| band | kernel symbol (split mode) | layer | launches / step | M | N | K | GFLOP / launch | algorithmic MB / launch |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for band, fam, name, n, M, N, K, fl, by in rows:
+        print(f"| {band} | {fam} | {name} | {n} | {M} | {N} | {K} | {fl / 1e9:.1f} | {by / 1e6:.0f} |")
+    tot = totals()
+    print("\n| band / family | launches / step | GFLOP / step | mean GFLOP / launch | mean algorithmic MB / launch |")
+    print("|---|---|---|---|---|")
+    for (band, fam), (n, fl, by) in sorted(tot.items()):
+        print(f"| {band}/{fam} | {n} | {fl / 1e9:.0f} | {fl / n / 1e9:.1f} | {by / n / 1e6:.0f} |")
+    d = sum(v[1] for k, v in tot.items() if k[0] == "depth")
+    f = sum(v[1] for k, v in tot.items() if k[0] == "flow")
+    print(f"\ndepth: {d / 1e9 / B:.1f} GFLOP / frame (SURVEY 8d: 2583.1);  flow: {f / 1e9 / pairs:.1f} GFLOP / pair-direction at {Wp}x{Hp}")
+
+
+if __name__ == "__main__":
+    main()
