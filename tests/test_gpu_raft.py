@@ -221,3 +221,23 @@ def test_sequence_masks_match_flows():
     for i in range(2):
         mf, mb = ro.compute_fwdbwd_mask(flow[i, 0], flow[i, 1])
         assert np.array_equal(mask[i, 0], mf) and np.array_equal(mask[i, 1], mb)
+
+
+def test_volume_kernel_is_bit_identical_to_the_generic_gemm(tmp_path):
+    """volume.hip (A-stationary, persistent along the targets) accumulates over K in the order of the generic GEMM kernels: the whole
+    flow must not change by a bit when the correlation volume goes through those instead (PB_VOLUME=0, read once per process).
+    131x181 pads to a 17 x 23 grid: 391 source rows (not a multiple of 128) and level strides of 576 / 128 / 64 / 64 columns."""
+    import subprocess
+    import sys
+    fr = synth.frame_pair_sequence(3, 131, 181, seed=33)
+    n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0, precision=1)
+    flow, rgb, mx = n.infer_sequence(fr, scale=1.0, iters=6, backward=True)
+    n.close()
+    out = str(tmp_path / "generic.npy")
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from prisma_amd import engine, synth; "
+            "fr = synth.frame_pair_sequence(3, 131, 181, seed=33); n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0, precision=1); "
+            "f, _, _ = n.infer_sequence(fr, scale=1.0, iters=6, backward=True); np.save(%r, f)" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out))
+    env = dict(os.environ, PB_VOLUME="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert np.array_equal(np.load(out), flow)
