@@ -1,5 +1,5 @@
 """CPU: the per-launch FLOP table of DESIGN.md section 5 (tools/flop_table.py, derived from layer shapes alone) against what the engines
-counted on the GPU (profiles/r02g_all_legs_bench_line.json: launches per step and TFLOP/s x ms per kernel symbol).  This is the
+counted on the GPU (the newest profiles/r*_all_legs_bench_line.json: launches per step and TFLOP/s x ms per kernel symbol).  This is the
 re-derivation the roofline line's `flop_per_launch` can be audited with."""
 import importlib.util
 import json
@@ -10,6 +10,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _newest(suffix):
+    """the newest committed profile set (names sort by round and letter: r02g > r02b > r01k)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??[a-z]_" + suffix)))
+    assert files, suffix
+    return files[-1]
+
+
 def _table():
     spec = importlib.util.spec_from_file_location("flop_table", os.path.join(ROOT, "tools", "flop_table.py"))
     m = importlib.util.module_from_spec(spec)
@@ -18,7 +26,7 @@ def _table():
 
 
 def test_launch_counts_and_flops_match_the_profiled_bench_line():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02g_all_legs_bench_line.json")))
+    line = json.load(open(_newest("all_legs_bench_line.json")))
     launches, tflops, ms = line["kernel_launches_per_step"], line["kernel_tflops"], line["kernel_ms_per_step"]
     steps = line["steps"]
     table = _table()
@@ -41,7 +49,7 @@ def test_launch_counts_and_flops_match_the_profiled_bench_line():
 
 
 def test_roofline_flop_per_launch_is_the_table_entry():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02g_default_bench_line.json")))
+    d = json.load(open(_newest("default_bench_line.json")))
     r = d["roofline"]
     band, sym = r["family"].split("/", 1)
     n, flops, by = _table()[(band, sym)]
