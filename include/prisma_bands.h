@@ -251,6 +251,9 @@ int pb_op_layernorm(pb_ctx *ctx, const float *x, const float *g, const float *b,
 int pb_op_attention(pb_ctx *ctx, const float *q, const float *k, const float *v, float *o,
                     int B, int heads, int N);
 /* NCHW float32 conv2d via NHWC fp16 implicit GEMM: x [B,Ci,H,W], w [Co,Ci,kh,kw]. */
+/* single-head attention over 128-wide heads, q / k / v / o [B, L, 128]; region [B, L] or NULL: a key whose region id differs from the
+ * query's gets -100 on its logit (bands/gmflow/transformer.py:8-15, 18-44, 47-101) - a building block of the flow_gmflow band */
+int pb_op_attention128(pb_ctx *ctx, const float *q, const float *k, const float *v, const int8_t *region, float *o, int B, int L);
 int pb_op_conv2d(pb_ctx *ctx, const float *x, const float *w, const float *bias, float *y,
                  int B, int Ci, int H, int W, int Co, int ksize, int stride, int pad, int relu_in, int relu_out);
 /* bilinear resize NCHW float32, align_corners 0/1 (torch F.interpolate semantics). */

@@ -689,6 +689,31 @@ int pb_op_attention(pb_ctx *c, const float *q, const float *k, const float *v, f
     return 0;
 }
 
+int pb_op_attention128(pb_ctx *c, const float *q, const float *k, const float *v, const int8_t *region, float *o, int B, int L) {
+    PB_CHECK(c && q && k && v && o && B > 0 && L > 0, PB_ERR_ARG, "op_attention128: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const int ldv = (int)round_up(L, 32);
+    const size_t n = (size_t)B * L * 128;
+    std::vector<f16> hq(n), hk(n), hv((size_t)B * 128 * ldv, (f16)0.f);
+    for (size_t i = 0; i < n; ++i) { hq[i] = (f16)q[i]; hk[i] = (f16)k[i]; }
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < L; ++t)
+            for (int d = 0; d < 128; ++d) hv[((size_t)b * 128 + d) * ldv + t] = (f16)v[((size_t)b * L + t) * 128 + d];
+    DevMem dq, dk, dv, dr, dout;
+    PB_TRY(dq.alloc(n * 2)); PB_TRY(dk.alloc(n * 2)); PB_TRY(dv.alloc(hv.size() * 2)); PB_TRY(dout.alloc(n * 4));
+    PB_HIP(hipMemcpy(dq.p, hq.data(), n * 2, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dk.p, hk.data(), n * 2, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dv.p, hv.data(), hv.size() * 2, hipMemcpyHostToDevice));
+    if (region) {
+        PB_TRY(dr.alloc((size_t)B * L));
+        PB_HIP(hipMemcpy(dr.p, region, (size_t)B * L, hipMemcpyHostToDevice));
+    }
+    PB_TRY(launch_attention128(c->stream, dq.as<f16>(), dk.as<f16>(), dv.as<f16>(), region ? dr.as<int8_t>() : nullptr, dout.as<float>(), B, L, ldv));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(o, dout.p, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int pb_op_conv2d(pb_ctx *c, const float *x, const float *w, const float *bias, float *y, int B, int Ci, int H, int W,
                  int Co, int ks, int stride, int pad, int relu_in, int relu_out) {
     PB_CHECK(c && x && w && y && Co % 8 == 0 && (ks == 1 || ks == 3), PB_ERR_ARG, "op_conv2d: bad arguments");

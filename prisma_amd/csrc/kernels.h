@@ -39,5 +39,8 @@ int launch_init_minmax(hipStream_t s, unsigned *mm, int B);
 int launch_nchw_f32_to_nhwc_f16(hipStream_t s, const float *x, f16 *y, int B, int C, int H, int W, int ldc, int relu);
 int launch_nhwc_f16_to_nchw_f32(hipStream_t s, const f16 *x, float *y, int B, int C, int H, int W, int ldc);
 int launch_f32_to_f16(hipStream_t s, const float *x, f16 *y, int64_t rows, int cols, int ld_out);
+// attention128.hip: single-head attention over 128-wide heads (GMFlow's transformer / matching / propagation); Q, K [B, L, 128] fp16,
+// Vt [B, 128, ldv] fp16, region [B, L] int8 or null (shifted-window mask), O [B, L, 128] fp32
+int launch_attention128(hipStream_t s, const f16 *Q, const f16 *K, const f16 *Vt, const int8_t *region, float *O, int B, int L, int ldv);
 int launch_f16_to_f32(hipStream_t s, const f16 *x, float *y, int64_t rows, int cols, int ld_in);
 int launch_fill_random_f16(hipStream_t s, f16 *x, int64_t n, unsigned seed, float scale);

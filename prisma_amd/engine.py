@@ -139,6 +139,16 @@ class Ops(_Ctx):
         check(self.lib.pb_op_layernorm(self.ctx, _ptr(x), _ptr(g), _ptr(b), _ptr(out), x.shape[0], x.shape[1]))
         return out
 
+    def attention128(self, q, k, v, region=None) -> np.ndarray:
+        """softmax(q k^T / sqrt(128) + mask) v for q, k, v [B, L, 128] (one head); region [B, L] int8: keys of another region get -100"""
+        q, k, v = _f32(q), _f32(k), _f32(v)
+        B, L, D = q.shape
+        assert D == 128 and k.shape == q.shape and v.shape == q.shape
+        out = np.empty_like(q)
+        rg = None if region is None else np.ascontiguousarray(region, np.int8)
+        check(self.lib.pb_op_attention128(self.ctx, _ptr(q), _ptr(k), _ptr(v), _ptr(rg), _ptr(out), B, L))
+        return out
+
     def attention(self, q, k, v) -> np.ndarray:
         q, k, v = _f32(q), _f32(k), _f32(v)
         B, Hh, N, d = q.shape

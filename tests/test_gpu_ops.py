@@ -155,3 +155,26 @@ def test_encode_depth_bit_exact(ops, golden_dir):
     # degenerate frame: max == min -> NaN -> 0 like the reference
     rgb, mn, mx = ops.encode_depth(np.full((1, 8, 8), 2.5, np.float32))
     assert not rgb.any() and mn[0] == mx[0] == 2.5
+
+
+@pytest.mark.parametrize("B,L,masked", [(2, 80, False), (3, 391, True), (1, 4590, True)])
+def test_attention128_single_head(ops, B, L, masked):
+    """attention128.hip against float64 torch: softmax(q k^T / sqrt(128) + mask) v, one head of 128 (bands/gmflow/transformer.py:8-15,
+    47-101); L = 80 is one 8 x 10 window of the small golden, 391 an odd length with a key tail, 4590 the 51 x 90 window of 1080p x 0.75.
+    The mask is the shifted-window one (:18-44): -100 on the logit of a key from another region."""
+    import torch
+    g = np.random.default_rng(L)
+    q = (g.standard_normal((B, L, 128)) * 1.5).astype(np.float32)
+    k = (g.standard_normal((B, L, 128)) * 1.5).astype(np.float32)
+    v = g.standard_normal((B, L, 128)).astype(np.float32)
+    region = (g.integers(0, 3, (B, L)).astype(np.int8) if masked else None)
+    got = ops.attention128(q, k, v, region)
+    tq, tk, tv = (torch.from_numpy(t.astype(np.float16).astype(np.float64)) for t in (q, k, v))
+    s = tq @ tk.transpose(1, 2) / 128 ** 0.5
+    if masked:
+        r = torch.from_numpy(region.astype(np.int64))
+        s = s + torch.where(r[:, :, None] != r[:, None, :], -100.0, 0.0)
+    ref = (torch.softmax(s, -1) @ tv).numpy()
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    print("\n  attention128 B %d L %d masked %s: max err / range %.2e" % (B, L, masked, err))
+    assert err < 1e-3                                      # P is rounded to fp16 before P V: ~2e-4
