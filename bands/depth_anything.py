@@ -17,7 +17,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_depth  # noqa: E402
+from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_rgb  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
 from common.pipe import AsyncSink, prefetch  # noqa: E402
 from prisma_amd import engine, shard, synth  # noqa: E402
@@ -29,10 +29,12 @@ model = None
 data = None
 args = None
 ranks = None          # shard.Ranks(): one process per GPU under torchrun, world 1 otherwise
+_still = None         # engine.Ops ctx of the still-image encodes (write_depth_png)
 
 
 def heat_to_rgb(heat):
-    """bands/common/encode.py:13-33 (used only for still images; the video path encodes on the GPU)."""
+    """bands/common/encode.py:13-33 on the host: the ramp common.io.write_depth takes as an argument (tests compare the GPU encodes
+    with it; both the video path and the still-image path encode on the GPU)."""
     hue = (1.0 - np.asarray(heat, np.float64)) * 0.65
     rgb = np.stack([hue * 6.0, hue * 6.0 + 4.0, hue * 6.0 + 2.0], axis=-1)
     return np.clip(np.abs(np.mod(rgb, 6.0) - 3.0) - 1.0, 0.0, 1.0)
@@ -100,9 +102,20 @@ def infer(img, normalize=False):
     return model.infer(img, normalize=normalize)
 
 
+def write_depth_png(path, depth):
+    """write_depth(path, depth, normalize=True, flip, heatmap=True, encode_range=True) (reference :176-180, :221-225;
+    bands/common/io.py:138-172) with the encode on the GPU (pb_depth_encode_still): bytes equal common.io.write_depth's."""
+    global _still
+    if _still is None:      # its own ctx and stream: the --subpath dumps run on the sink thread while the band's ctx computes the next chunk
+        _still = engine.Ops(device=ranks.device if ranks else 0)
+    rgb, _, _ = _still.encode_still(depth, flip=_flip(), encode_range=True)
+    write_rgb(path, rgb)
+
+
 def process_image(a):
     if getattr(a, "ply", False):       # reference :168-174 write_pcl (camera intrinsics + plyfile): geometry export, SURVEY section 2 out of scope
-        raise NotImplementedError("--ply (point cloud export of a still image) is not built: SURVEY.md section 2.1 geom")
+        print(f"[{BAND}] --ply (point cloud export, reference :168-174) is not built (SURVEY.md section 2.1 geom); writing the depth image only",
+              file=sys.stderr)
     img = open_rgb(a.input)
     out_folder = os.path.dirname(a.output)
     pred = infer(img)
@@ -111,7 +124,7 @@ def process_image(a):
                                          "max": {"value": float(pred.max()), "type": "float"}}
     if a.npy:
         np.save(os.path.join(out_folder, BAND + ".npy"), pred)
-    write_depth(a.output, pred, heat_to_rgb, normalize=True, heatmap=True, encode_range=True, flip=_flip())
+    write_depth_png(a.output, pred)
 
 
 def process_video(a):
@@ -148,8 +161,7 @@ def process_video(a):
             if a.npy and a.subpath:
                 np.save(os.path.join(a.subpath, "{:05d}.npy".format(s + j)), depth[j])
             if a.subpath:
-                write_depth(os.path.join(a.subpath, "{:05d}.png".format(s + j)), depth[j], heat_to_rgb,
-                            normalize=True, flip=_flip(), heatmap=True, encode_range=True)
+                write_depth_png(os.path.join(a.subpath, "{:05d}.png".format(s + j)), depth[j])
 
     # the decode of chunk i+1 and the encode / writes of chunk i-1 overlap the engine's work on chunk i
     sink = AsyncSink(depth=2)

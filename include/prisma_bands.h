@@ -142,6 +142,16 @@ int pb_comm_unique_id(pb_comm_id *id_out);
 int pb_comm_init(pb_ctx *ctx, const pb_comm_id *id, int rank, int world);
 int pb_gather_scalars(pb_ctx *ctx, const float *local, int n_local, float *global);
 
+/* Still-image / `--subpath` post-process: write_depth(heatmap=True, encode_range) of bands/common/io.py:138-172 as called from
+ * bands/depth_anything.py:176-180,221-225, with encode.py:73-95 (float_to_edge, saturation) and :141-146 (float_to_rgb) -
+ * normalise by the map's own min / max, flip, heat ramp, Sobel-edge magnitude of the 8-bit map in the saturation, min / max packed
+ * as 24-bit fixed point of [0, 1000] into pixels (0, 0) and (0, 1), uint8 truncation.  Bytes equal the reference's
+ * (tests/golden/write_depth.npz; cv2.Sobel's ksize-1 taps restated).  Works on any ctx.
+ *   depth   : H x W float32 [host]        rgb_out : H x W x 3 uint8 RGB (what the PNG holds) [host]
+ *   min_out / max_out: the map's min / max, or NULL */
+int pb_depth_encode_still(pb_ctx *ctx, const float *depth, int H, int W, int flip, int encode_range, uint8_t *rgb_out,
+                          float *min_out, float *max_out);
+
 /* Network input size for an H x W frame: keep-aspect lower-bound resize to 518, each side a
  * multiple of 14 (bands/d_anything/util/transform.py:100-166). */
 int pb_depth_net_size(int H, int W, int *net_h, int *net_w);

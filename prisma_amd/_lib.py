@@ -66,6 +66,7 @@ SYMBOLS = {
     "pb_comm_unique_id": (C.c_int, [_P]),
     "pb_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "pb_gather_scalars": (C.c_int, [_P, _P, C.c_int, _P]),
+    "pb_depth_encode_still": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _F, _F]),
     "pb_depth_net_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_depth_get_stage": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "pb_mask_infer_batch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, _P]),

@@ -806,4 +806,24 @@ int pb_op_encode_depth(pb_ctx *c, const float *depth, int n, int H, int W, int f
     return 0;
 }
 
+int pb_depth_encode_still(pb_ctx *c, const float *depth, int H, int W, int flip, int encode_range, uint8_t *rgb_out, float *min_out,
+                          float *max_out) {
+    PB_CHECK(c && depth && rgb_out && H > 0 && W > 0, PB_ERR_ARG, "depth_encode_still: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const size_t px = (size_t)H * W;
+    DevMem dd, dr, dq, dm;
+    PB_TRY(dd.alloc(px * 4)); PB_TRY(dr.alloc(px * 3)); PB_TRY(dq.alloc(px)); PB_TRY(dm.alloc(64));
+    PB_HIP(hipMemcpy(dd.p, depth, px * 4, hipMemcpyHostToDevice));
+    unsigned *mm = dm.as<unsigned>();
+    PB_TRY(launch_still_encode(c->stream, dd.as<float>(), H, W, mm, mm + 2, dq.as<uint8_t>(), flip, encode_range, dr.as<uint8_t>(),
+                               (float *)(mm + 4)));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(rgb_out, dr.p, px * 3, hipMemcpyDeviceToHost));
+    float mnmx[2];
+    PB_HIP(hipMemcpy(mnmx, mm + 4, 8, hipMemcpyDeviceToHost));
+    if (min_out) *min_out = mnmx[0];
+    if (max_out) *max_out = mnmx[1];
+    return 0;
+}
+
 }  // extern "C"

@@ -317,6 +317,88 @@ __global__ __launch_bounds__(256) void heat_encode_kernel(const float *__restric
     }
 }
 
+// ---- still-image / --subpath encode: write_depth(heatmap=True) ---------------------------------------------------
+// bands/common/io.py:138-172 + encode.py:73-95 (float_to_edge, saturation), :141-146 (float_to_rgb): normalise (float32), flip,
+// q = uint8(d * 255) (truncation), Sobel ksize 1 = central differences of q with a reflect-101 border, edge = mag * (255 / max mag) / 255
+// in float64, heat ramp in float64, rgb = rgb * (1 - edge) + edge, min / max packed as 24-bit fixed point of [0, 1000] into pixels
+// (0, 0) and (0, 1), uint8 truncation.  Three passes after the min / max reduction: quantise, max |gradient|^2 (integers: exact, and
+// sqrt is monotone, so the max commutes with it), encode.  Every floating operation is separately rounded (common.h ex_*).
+__device__ __forceinline__ float still_norm(float v, float dmin, float range, int flip) {
+    float d = ex_fdiv(ex_fsub(v, dmin), range);
+    if (flip) d = ex_fsub(1.0f, d);
+    return d;
+}
+
+__global__ __launch_bounds__(256) void still_quant_kernel(const float *__restrict__ depth, int64_t per, const unsigned *__restrict__ mm,
+                                                          int flip, uint8_t *__restrict__ q) {
+    const float dmin = ord2f(mm[0]), range = ex_fsub(ord2f(mm[1]), dmin);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = ex_fmul(still_norm(depth[i], dmin, range, flip), 255.0f);
+        q[i] = (v == v) ? (uint8_t)(int)v : (uint8_t)0;
+    }
+}
+
+__device__ __forceinline__ int still_grad2(const uint8_t *__restrict__ q, int H, int W, int y, int x) {
+    // cv2.Sobel(img, CV_64F, 1, 0, ksize=1) / (0, 1): [-1, 0, 1], BORDER_REFLECT_101 (index -1 -> 1, n -> n - 2; a 1-pixel axis has no gradient)
+    const int xm = x > 0 ? x - 1 : (W > 1 ? 1 : 0), xp = x + 1 < W ? x + 1 : (W > 1 ? W - 2 : 0);
+    const int ym = y > 0 ? y - 1 : (H > 1 ? 1 : 0), yp = y + 1 < H ? y + 1 : (H > 1 ? H - 2 : 0);
+    const int gx = (int)q[(int64_t)y * W + xp] - (int)q[(int64_t)y * W + xm];
+    const int gy = (int)q[(int64_t)yp * W + x] - (int)q[(int64_t)ym * W + x];
+    return gx * gx + gy * gy;
+}
+
+__global__ __launch_bounds__(256) void still_gradmax_kernel(const uint8_t *__restrict__ q, int H, int W, unsigned *g2max) {
+    int best = 0;
+    const int64_t per = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = still_grad2(q, H, W, (int)(i / W), (int)(i % W));
+        best = g > best ? g : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(best, o); best = t > best ? t : best; }
+    if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(g2max, (unsigned)best);
+}
+
+// float_to_rgb(value, 0, 1000) * 255 -> uint8 with numpy >= 2 promotion (a float32 scalar stays float32 against Python scalars)
+__device__ __forceinline__ void still_range_px(float value, uint8_t *dst) {
+    float t = ex_fdiv(ex_fsub(value, 0.0f), ex_fsub(1000.0f, 0.0f));
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float L = ex_fmul(t, 16777215.0f);
+    const float c[3] = {ex_fdiv(floorf(fmodf(L, 256.0f)), 255.0f), ex_fdiv(fmodf(floorf(ex_fdiv(L, 256.0f)), 256.0f), 255.0f),
+                        ex_fdiv(fmodf(floorf(ex_fdiv(L, 65536.0f)), 256.0f), 255.0f)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dst[k] = (uint8_t)(int)ex_dmul((double)c[k], 255.0);
+}
+
+__global__ __launch_bounds__(256) void still_encode_kernel(const float *__restrict__ depth, const uint8_t *__restrict__ q, int H, int W,
+                                                           const unsigned *__restrict__ mm, const unsigned *__restrict__ g2max, int flip,
+                                                           int encode_range, uint8_t *__restrict__ rgb, float *mnmx) {
+    const float dmin = ord2f(mm[0]), dmax = ord2f(mm[1]), range = ex_fsub(dmax, dmin);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && mnmx) { mnmx[0] = dmin; mnmx[1] = dmax; }
+    const double magmax = sqrt((double)*g2max);
+    const double gain = ex_ddiv(255.0, magmax);                      // 255 / 0 = inf: a flat image encodes NaN -> 0 like the reference
+    const int64_t per = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t *dst = rgb + i * 3;
+        if (encode_range && i < 2) { still_range_px(i == 0 ? dmin : dmax, dst); continue; }
+        const float d = still_norm(depth[i], dmin, range, flip);
+        const double mag = sqrt((double)still_grad2(q, H, W, (int)(i / W), (int)(i % W)));
+        const double edge = ex_ddiv(ex_dmul(mag, gain), 255.0);
+        const double sat = ex_dsub(1.0, edge), inv = ex_dsub(1.0, sat);
+        const double h6 = ex_dmul(ex_dmul(ex_dsub(1.0, (double)d), 0.65), 6.0);
+        const double off[3] = {0.0, 4.0, 2.0};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = fmod(ex_dadd(h6, off[c]), 6.0);
+            if (v < 0.0) v = ex_dadd(v, 6.0);
+            v = ex_dsub(fabs(ex_dsub(v, 3.0)), 1.0);
+            v = fmin(fmax(v, 0.0), 1.0);
+            v = ex_dmul(ex_dadd(ex_dmul(v, sat), inv), 255.0);
+            dst[c] = (v == v) ? (uint8_t)(int)v : (uint8_t)0;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // layout converters (tests / stage dumps)
 // ------------------------------------------------------------------------------------------------
@@ -430,6 +512,21 @@ int launch_heat_encode(hipStream_t s, const float *depth, int B, int H, int W, c
     unsigned gx = nblk((int64_t)H * W);
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(heat_encode_kernel, dim3(gx, B), dim3(256), 0, s, depth, (int64_t)H * W, mm, flip, rgb, mn, mx);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_still_encode(hipStream_t s, const float *depth, int H, int W, unsigned *mm, unsigned *g2max, uint8_t *q, int flip, int encode_range,
+                        uint8_t *rgb, float *mnmx) {
+    const int64_t per = (int64_t)H * W;
+    unsigned gx = nblk(per);
+    if (gx > 1024) gx = 1024;
+    PB_HIP(hipMemsetAsync(g2max, 0, 4, s));
+    hipLaunchKernelGGL(init_minmax_kernel, dim3(1), dim3(64), 0, s, mm, 1);
+    hipLaunchKernelGGL(minmax_kernel, dim3(gx > 512 ? 512 : gx, 1), dim3(256), 0, s, depth, per, mm);
+    hipLaunchKernelGGL(still_quant_kernel, dim3(gx), dim3(256), 0, s, depth, per, mm, flip, q);
+    hipLaunchKernelGGL(still_gradmax_kernel, dim3(gx), dim3(256), 0, s, q, H, W, g2max);
+    hipLaunchKernelGGL(still_encode_kernel, dim3(gx), dim3(256), 0, s, depth, q, H, W, mm, g2max, flip, encode_range, rgb, mnmx);
     PB_HIP(hipGetLastError());
     return 0;
 }

@@ -34,6 +34,10 @@ int launch_minmax_only(hipStream_t s, const float *x, int B, int64_t per, unsign
 int launch_heat_encode(hipStream_t s, const float *depth, int B, int H, int W, const unsigned *mm, int flip,
                        uint8_t *rgb, float *mn, float *mx);
 int launch_init_minmax(hipStream_t s, unsigned *mm, int B);
+// write_depth(heatmap=True) of one float depth map (bands/common/io.py:138-172): heat ramp, Sobel-edge saturation, min / max packed in
+// pixels (0, 0), (0, 1).  Scratch: mm [2] ordered-uint min / max, g2max [1], q [H * W] bytes; mnmx [2] floats out (optional).
+int launch_still_encode(hipStream_t s, const float *depth, int H, int W, unsigned *mm, unsigned *g2max, uint8_t *q, int flip, int encode_range,
+                        uint8_t *rgb, float *mnmx);
 
 // layout converters used by the op-level tests and the stage dumps
 int launch_nchw_f32_to_nhwc_f16(hipStream_t s, const float *x, f16 *y, int B, int C, int H, int W, int ldc, int relu);

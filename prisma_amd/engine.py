@@ -89,6 +89,15 @@ class _Ctx:
     def sync(self):
         check(self.lib.pb_sync(self.ctx))
 
+    def encode_still(self, depth: np.ndarray, flip: bool = True, encode_range: bool = True):
+        """write_depth(heatmap=True) of one float32 depth map on the GPU (bands/common/io.py:138-172): -> (rgb u8 [H,W,3], min, max)."""
+        depth = _f32(depth)
+        H, W = depth.shape
+        rgb = np.empty((H, W, 3), np.uint8)
+        lo, hi = C.c_float(), C.c_float()
+        check(self.lib.pb_depth_encode_still(self.ctx, _ptr(depth), H, W, int(flip), int(encode_range), _ptr(rgb), C.byref(lo), C.byref(hi)))
+        return rgb, lo.value, hi.value
+
     def set_option(self, key: str, value: int):
         check(self.lib.pb_set_option(self.ctx, key.encode(), int(value)))
 

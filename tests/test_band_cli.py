@@ -66,6 +66,15 @@ def test_cli_video_and_image(tmp_path):
     band.main(["-i", str(tmp_path / "img.png"), "--encoder", "vits"])
     png = np.asarray(Image.open(tmp_path / "depth_anything.png"))
     assert png.shape == (90, 160, 3)
+    # the PNG the band wrote on the GPU box = the reference's write_depth arithmetic (common/io.py:138-172
+    # restated in bands/common/io.py, byte-pinned to the real one in tests/test_oracle_golden.py) applied to the engine's own float
+    # depth through the BAND's heat ramp, byte for byte; its range pixels decode back to the depth's min / max (view.py:186-210)
+    from common import io as IO
+    d0 = band.infer(frames[0])
+    IO.write_depth(str(tmp_path / "host.png"), d0.copy(), band.heat_to_rgb, normalize=True, flip=True, heatmap=True, encode_range=True)
+    assert np.array_equal(png, np.asarray(Image.open(tmp_path / "host.png")))
+    dec = lambda px: (float(px[0]) + float(px[1]) * 256 + float(px[2]) * 65536) / (256 ** 3 - 1) * 1000.0
+    assert abs(dec(png[0, 0]) - d0.min()) < 1e-4 and abs(dec(png[0, 1]) - d0.max()) < 1e-4
     band.model.close()
     band.model = None
 

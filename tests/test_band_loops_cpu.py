@@ -48,8 +48,13 @@ def test_depth_loop(tmp_path, monkeypatch, n, batch):
             depth = (idx[:, None, None] + np.broadcast_to(ramp, fr.shape[:3])).astype(np.float32) if want_depth else None
             return depth, fr.copy(), idx, idx + 1.0
 
+    class FakeStill:                # the --subpath PNG encode runs on the GPU (pb_depth_encode_still); here only the file plumbing is under test
+        def encode_still(self, depth, flip=True, encode_range=True):
+            return np.zeros(depth.shape + (3,), np.uint8), float(depth.min()), float(depth.max())
+
     monkeypatch.setattr(band, "BATCH", batch)
     monkeypatch.setattr(band, "model", Fake())
+    monkeypatch.setattr(band, "_still", FakeStill())
     monkeypatch.setattr(band, "ranks", _Ranks())
     monkeypatch.setattr(band, "data", json.load(open(folder / "metadata.json")))
     band.data["bands"][band.BAND] = {"url": "depth_anything.npy"}

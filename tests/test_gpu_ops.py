@@ -178,3 +178,36 @@ def test_attention128_single_head(ops, B, L, masked):
     err = np.abs(got - ref).max() / np.abs(ref).max()
     print("\n  attention128 B %d L %d masked %s: max err / range %.2e" % (B, L, masked, err))
     assert err < 1e-3                                      # P is rounded to fp16 before P V: ~2e-4
+
+
+def test_encode_still_bytes_match_the_reference(ops, golden_dir):
+    """SURVEY 8 a-1.10 / f-3 on the GPU: pb_depth_encode_still against what the REAL reference write_depth (bands/common/io.py:138-172,
+    encode.py:73-95,141-146) handed to cv2.imwrite for the same depth map (tests/golden/write_depth.npz, made by oracle/make_golden.py
+    write_depth): every byte - heat ramp, Sobel-edge saturation, min / max packed in pixels (0,0), (0,1), uint8 truncation - relative
+    (flipped) and metric (not flipped); and against the band's own host restatement on odd shapes (1-pixel borders, ragged sizes)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "bands"))
+    from common import io as IO
+    import depth_anything as band
+    from PIL import Image
+    z = np.load(os.path.join(golden_dir, "write_depth.npz"))
+    depth = np.ascontiguousarray(z["depth"], np.float32)
+    for name, flip in (("rel_rgb", True), ("met_rgb", False)):
+        rgb, lo, hi = ops.encode_still(depth, flip=flip)
+        assert rgb.shape == z[name].shape
+        assert np.array_equal(rgb, z[name]), (name, int((rgb != z[name]).sum()))
+        assert lo == float(depth.min()) and hi == float(depth.max())
+    dec = lambda px: (float(px[0]) + float(px[1]) * 256 + float(px[2]) * 65536) / (256 ** 3 - 1) * 1000.0   # viewer contract, view.py:186-210
+    assert abs(dec(rgb[0, 0]) - depth.min()) < 1e-4 and abs(dec(rgb[0, 1]) - depth.max()) < 1e-4
+    g = np.random.default_rng(9)
+    for (H, W) in ((1, 7), (5, 1), (33, 47), (90, 160), (1080, 1920)):
+        d = (g.standard_normal((H, W)).cumsum(1).cumsum(0) * 0.37 + 5.0).astype(np.float32)
+        for flip in (True, False):
+            rgb, _, _ = ops.encode_still(d, flip=flip)
+            import tempfile
+            with tempfile.TemporaryDirectory() as t:
+                p = os.path.join(t, "a.png")
+                IO.write_depth(p, d.copy(), band.heat_to_rgb, normalize=True, flip=flip, heatmap=True, encode_range=True)
+                want = np.asarray(Image.open(p))
+            assert np.array_equal(rgb, want), (H, W, flip, int((rgb != want).sum()))

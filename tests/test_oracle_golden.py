@@ -83,7 +83,8 @@ def test_write_depth_png_bytes_match_the_reference(golden_dir, tmp_path):
     from common import io as IO
     z = np.load(os.path.join(golden_dir, "write_depth.npz"))
     depth = z["depth"]
-    heat = lambda h: O.heat_to_rgb(h)
+    import depth_anything as band
+    heat = band.heat_to_rgb              # the band script's own ramp (bands/depth_anything.py), not the oracle's
     for name, flip in (("rel_rgb", True), ("met_rgb", False)):
         p = str(tmp_path / (name + ".png"))
         IO.write_depth(p, depth.copy(), heat, normalize=True, flip=flip, heatmap=True, encode_range=True)
