@@ -201,7 +201,7 @@ def test_encode_still_bytes_match_the_reference(ops, golden_dir):
     dec = lambda px: (float(px[0]) + float(px[1]) * 256 + float(px[2]) * 65536) / (256 ** 3 - 1) * 1000.0   # viewer contract, view.py:186-210
     assert abs(dec(rgb[0, 0]) - depth.min()) < 1e-4 and abs(dec(rgb[0, 1]) - depth.max()) < 1e-4
     g = np.random.default_rng(9)
-    for (H, W) in ((1, 7), (5, 1), (33, 47), (90, 160), (1080, 1920)):
+    for (H, W) in ((1, 7), (5, 2), (33, 47), (90, 160), (1080, 1920)):
         d = (g.standard_normal((H, W)).cumsum(1).cumsum(0) * 0.37 + 5.0).astype(np.float32)
         for flip in (True, False):
             rgb, _, _ = ops.encode_still(d, flip=flip)
