@@ -173,11 +173,12 @@ def process_video(a):
         hi += [float(v) for v in mx]
     sink.close()
     if rk.world > 1:
-        if rk.main:
-            relay.drain(n, BATCH, lambda s, c: [out.write(f) for f in c["rgb"]])
+        # scalars first (every rank gets here when its own compute is done), then rank 0 muxes the other ranks' chunks while they
+        # wait on a file signal in relay.close() - no collective is pending during the mux
         mm = rk.gather(np.asarray([lo, hi], np.float32).T.reshape(-1, 2), n, ctx=model)
         if rk.main:
             lo, hi = [float(v) for v in mm[:, 0]], [float(v) for v in mm[:, 1]]
+            relay.drain(n, BATCH, lambda s, c: [out.write(f) for f in c["rgb"]])
     relay.close()
     if not rk.main:
         return

@@ -51,8 +51,16 @@ def load_weights(path):
 
 def init_model(args=None, device=0):
     global model
-    if args is not None and (getattr(args, "small", False) or getattr(args, "alternate_corr", False)):
-        raise NotImplementedError("--small / --alternate_corr select other RAFT variants; only the basic model is built")
+    if args is not None and getattr(args, "small", False):
+        # reference raft.py:30-36,52-53 (hidden 96, corr radius 3, SmallEncoder / SmallUpdateBlock, its own checkpoint raft-small.pth):
+        # another network, not another code path of this one - its weights cannot be loaded into the basic model
+        raise SystemExit(f"[{BAND}] --small (RAFT-small: a different network and checkpoint) is not built; drop the flag to run the basic model")
+    if args is not None and getattr(args, "alternate_corr", False):
+        # reference raft.py:103-106: AlternateCorrBlock computes the same correlations on the fly (memory saving, needs the alt_cuda_corr
+        # extension); results are those of CorrBlock, and the volume is no memory problem in 288 GB - run the normal path
+        print(f"[{BAND}] --alternate_corr: same result as the default correlation block (reference raft.py:103-106); flag ignored", file=sys.stderr)
+    if args is not None and getattr(args, "mixed_precision", False):
+        print(f"[{BAND}] --mixed_precision: the engine's precision is set by PRISMA_PRECISION (split-fp16 by default); flag ignored", file=sys.stderr)
     _SYNTH[0] = bool(getattr(args, "synthetic", False))
     model = engine.FlowRaft(load_weights(getattr(args, "model", MODEL) if args else MODEL), device=device)
     return model
@@ -154,9 +162,9 @@ def process_video(args):
     sink.close()
     mx_all = np.asarray(mxs, np.float32)
     if rk.world > 1:
+        mx_all = rk.gather(mx_all, n - 1, ctx=model)         # before the drain: no collective pending while rank 0 muxes
         if rk.main:
             relay.drain(n - 1, CHUNK, write_chunk)
-        mx_all = rk.gather(mx_all, n - 1, ctx=model)
     relay.close()
     if not rk.main:
         return

@@ -78,24 +78,37 @@ class Relay:
 
     north_star allows a collective only for the per-frame scalars, so the frames do not travel through torch.distributed at
     all: the ranks are the GPUs of one node, and a rank > 0 drops each finished chunk ({name: array}, typically 16-32 encoded
-    frames) as one file into a spool directory next to the output (write to a temporary name, then rename: the consumer
-    never sees a partial file).  Rank 0 writes its own chunks straight to the video as they finish and then walks the other
-    ranks' chunk plans in frame order, waiting for each file, muxing it and deleting it.  Memory is bounded by one chunk per
-    rank; the spool holds, at most, the other ranks' encoded shards until rank 0 gets to them.  PRISMA_SPOOL overrides the
-    directory (e.g. a tmpfs)."""
+    frames) as one file into a spool directory (write to a temporary name, then rename: the consumer never sees a partial
+    file).  Rank 0 writes its own chunks straight to the video as they finish and then walks the other ranks' chunk plans in
+    frame order, waiting for each file, muxing it and deleting it.  Memory is bounded by one chunk per rank.
 
-    def __init__(self, ranks: "Ranks", out_path: str, timeout_s: float = 900.0):
+    The spool is PER RUN: `<base>/prisma_spool.<basename(out)>.<token>` where the token is drawn by rank 0 and broadcast, so two
+    jobs (or two bands of one job) never share a namespace and nobody deletes anybody else's files.  `base` is PRISMA_SPOOL if
+    set, else /dev/shm when it exists (8 ranks x ~200 frames/s x 6.2 MB of 1080p frames is ~10 GB/s: memory, not the output
+    filesystem), else the output's folder.  It holds, at most, the other ranks' encoded shards until rank 0 gets to them; with
+    PRISMA_SPOOL_MAX_CHUNKS = K > 0 a producer waits while K of its chunks are unconsumed (bounded spool, but the producers then
+    finish one after the other at rank 0's mux speed: the default 0 keeps every GPU computing).
+
+    End of a run: the scalar all-gather happens BEFORE the drain - every rank reaches it as soon as its own compute
+    is done - and the ranks > 0 then wait for rank 0's `done` FILE (wait_done), not inside a collective, so no communicator
+    watchdog runs while rank 0 muxes (world - 1) / world of the video."""
+
+    def __init__(self, ranks: "Ranks", out_path: str, timeout_s: float = 0.0):
         import os
-        self.rk, self.timeout = ranks, timeout_s
-        self.dir = os.environ.get("PRISMA_SPOOL") or (out_path + ".spool")
+        self.rk = ranks
+        self.timeout = timeout_s or float(os.environ.get("PRISMA_RELAY_TIMEOUT_S", "21600"))
+        self.max_chunks = int(os.environ.get("PRISMA_SPOOL_MAX_CHUNKS", "0"))
+        self.dir = ""
+        self._mine: List[str] = []
         if ranks.world > 1:
+            import uuid
             import torch.distributed as dist
+            base = os.environ.get("PRISMA_SPOOL") or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK)
+                                                      else os.path.dirname(os.path.abspath(out_path)))
+            box = [os.path.join(base, "prisma_spool.%s.%s" % (os.path.basename(out_path), uuid.uuid4().hex[:12])) if ranks.main else None]
+            dist.broadcast_object_list(box, src=0)
+            self.dir = box[0]
             os.makedirs(self.dir, exist_ok=True)
-            if ranks.main:                   # leftovers of an aborted run must not be mistaken for this run's chunks
-                for f in os.listdir(self.dir):
-                    if f.startswith("chunk_"):
-                        os.remove(os.path.join(self.dir, f))
-            dist.barrier()
 
     def _path(self, start: int) -> str:
         import os
@@ -104,10 +117,19 @@ class Relay:
     def put(self, start: int, arrays: dict):
         """rank > 0: publish the chunk whose first unit (frame / pair index) is `start`."""
         import os
+        import time
+        if self.max_chunks > 0:
+            t0 = time.time()
+            while sum(os.path.exists(p) for p in self._mine) >= self.max_chunks:
+                if time.time() - t0 > self.timeout:
+                    raise TimeoutError(f"rank 0 did not consume rank {self.rk.rank}'s chunks within {self.timeout:.0f} s")
+                time.sleep(0.005)
+            self._mine = [p for p in self._mine if os.path.exists(p)]
         tmp = self._path(start) + ".tmp.%d" % self.rk.rank
         with open(tmp, "wb") as f:
             np.savez(f, **{k: np.ascontiguousarray(v) for k, v in arrays.items()})
         os.replace(tmp, self._path(start))
+        self._mine.append(self._path(start))
 
     def drain(self, n_units: int, chunk: int, write):
         """rank 0: for every other rank, in rank (= frame) order, for every chunk start of its shard: wait for the file, call
@@ -127,9 +149,28 @@ class Relay:
                 os.remove(p)
 
     def close(self):
+        """rank 0: publish `done`; ranks > 0: wait for it (a file poll, no collective in flight), then the last one out removes the
+        directory."""
         import os
-        if self.rk.world > 1 and self.rk.main:
+        import time
+        if self.rk.world <= 1:
+            return
+        done = os.path.join(self.dir, "done")
+        if self.rk.main:
+            with open(done + ".tmp", "w") as f:
+                f.write("ok\n")
+            os.replace(done + ".tmp", done)
+        else:
+            t0 = time.time()
+            while not os.path.exists(done):
+                if time.time() - t0 > self.timeout:
+                    raise TimeoutError(f"rank 0 did not finish muxing within {self.timeout:.0f} s")
+                time.sleep(0.02)
+        import torch.distributed as dist
+        dist.barrier()                       # short: every rank is past its file wait
+        if self.rk.main:
             try:
+                os.remove(done)
                 os.rmdir(self.dir)
             except OSError:
                 pass
@@ -152,7 +193,11 @@ class Ranks:
             if not dist.is_initialized():
                 if self.backend == "nccl":
                     torch.cuda.set_device(self.device)
-                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+                # the only collectives are the scalar gather and short barriers, but they sit behind minutes of per-rank work of
+                # different lengths (rank 0 also muxes): give the communicator watchdog hours, not torch's 10 minutes
+                import datetime
+                hours = float(os.environ.get("PRISMA_DIST_TIMEOUT_H", "12"))
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, timeout=datetime.timedelta(hours=hours))
 
     @property
     def device(self) -> int:

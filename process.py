@@ -44,6 +44,7 @@ EXTRA_ARGS = {"rgba": "", "mask_mmdet": "--sdf ", "depth_midas": " ", "depth_mar
               "depth_patchfusion": "", "depth_anything": "--metric outdoor ", "flow_raft": "", "flow_gmflow": ""}
 
 COMMANDS = []        # every command run() issued, in order (tests read it)
+RESULTS = []         # (band, return code) of every BUILT band run() launched; unbuilt bands are "skipped", not failures
 
 
 def build_command(band, input_folder, output_file="", subpath=False, extra_args=""):
@@ -66,7 +67,9 @@ def run(band, input_folder, output_file="", subpath=False, extra_args=""):
     cmd = build_command(band, input_folder, output_file, subpath, extra_args)
     COMMANDS.append(cmd)
     print(" ".join(shlex.quote(c) for c in cmd), "\n")
-    return subprocess.run(cmd, cwd=ROOT).returncode
+    rc = subprocess.run(cmd, cwd=ROOT).returncode
+    RESULTS.append((band, rc))
+    return rc
 
 
 def main(argv=None):
@@ -88,6 +91,7 @@ def main(argv=None):
     if args.record3d or args.rgbd:
         raise SystemExit("process.py: --record3d / --rgbd (side-by-side RGB-D captures) are not built in this repo")
     del COMMANDS[:]
+    del RESULTS[:]
 
     # 1. input parameters, 2. folder + metadata (reference :101-117)
     input_path = args.input
@@ -163,6 +167,13 @@ def main(argv=None):
         set_default_band(folder_name, "flow_mask", fdef + "_mask")
         set_default_band(folder_name, "flow_mask_bwd", fdef + "_mask_bwd")
         run("camera_colmap", folder_name, subpath=True)
+    # a band that failed (missing checkpoint, bad input ...) leaves a PRISMA folder without its entries: say so and fail the run
+    # (the reference's os.system() ignores band failures; a drop-in that now refuses to run without weights must not exit 0 on them)
+    failed = [(b, rc) for b, rc in RESULTS if rc != 0]
+    if failed:
+        print("\nprocess.py: %d band(s) FAILED: %s - %s is incomplete" % (len(failed), ", ".join("%s (exit %d)" % f for f in failed), folder_name),
+              file=sys.stderr)
+        raise SystemExit(1)
     return folder_name
 
 

@@ -1,8 +1,9 @@
-"""CPU: the distributed glue of bench.py (barrier, max over ranks, scalar all-gather) with two ranks over gloo."""
+"""CPU: the distributed glue of bench.py (barrier, max over ranks, scalar all-gather) with two and eight ranks over gloo."""
 import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -25,19 +26,21 @@ def _worker(rank, world, port, q):
     R.close()
 
 
-def test_ranks_gloo_world2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_gloo(world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=180) for _ in range(2)]
+    got = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     for rank, slowest, gathered in got:
-        assert slowest == 2.0
-        assert torch.equal(gathered[0], torch.full((3, 4), 1.0)) and torch.equal(gathered[1], torch.full((3, 4), 2.0))
+        assert slowest == float(world)
+        for r in range(world):
+            assert torch.equal(gathered[r], torch.full((3, 4), float(r + 1)))

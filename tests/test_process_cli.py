@@ -74,6 +74,23 @@ def test_unbuilt_band_is_reported_not_run(tmp_path, monkeypatch, capsys):
     assert [os.path.basename(c[1]) for c in process.COMMANDS] == ["rgba.py", "mask_mmdet.py"]
 
 
+def test_failed_band_fails_the_run(tmp_path, monkeypatch, capsys):
+    """a band that exits non-zero (missing checkpoint ...) must not leave `process.py` exiting 0 with a partial folder."""
+    real = subprocess.run
+
+    def fake(cmd, **kw):
+        name = os.path.basename(cmd[1])
+        if name == "rgba.py":
+            return real(cmd, **kw)
+        return subprocess.CompletedProcess(cmd, 3 if name == "depth_anything.py" else 0)
+    monkeypatch.setattr(process.subprocess, "run", fake)
+    with pytest.raises(SystemExit) as e:
+        process.main(["-i", str(_png(tmp_path)), "-d", "depth_anything"])
+    assert e.value.code == 1
+    assert "depth_anything (exit 3)" in capsys.readouterr().err
+    assert ("mask_mmdet", 0) in process.RESULTS and ("depth_anything", 3) in process.RESULTS
+
+
 def test_missing_checkpoint_is_an_error_without_opt_in(monkeypatch):
     sys.path.insert(0, os.path.join(ROOT, "bands"))
     import flow_raft
