@@ -104,6 +104,13 @@ typedef struct {
 
 const char *pb_last_error(void);
 int pb_version(void);
+/* ABI guard: bumped whenever a public struct's layout or an entry point's signature changes.  A binding compares
+ * pb_abi_version() with the PB_ABI_VERSION it was written against and pb_struct_size(which) with its own sizeof before the first
+ * call (prisma_amd/_lib.py load(); integration/depth_anything_stub.py) - a stale binding fails at load, not by reading shifted
+ * fields.  which: 0 pb_tensor, 1 pb_depth_cfg, 2 pb_flow_cfg, 3 pb_mask_cfg, 4 pb_kernel_stat, 5 pb_comm_id; -1 for others. */
+#define PB_ABI_VERSION 3
+int pb_abi_version(void);
+int pb_struct_size(int which);
 /* Number of visible HIP devices (0 on a CPU-only box; never fails). */
 int pb_device_count(void);
 

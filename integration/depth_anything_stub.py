@@ -14,6 +14,9 @@ class pb_depth_cfg(C.Structure):                   # include/prisma_bands.h pb_d
                 ("pos_grid", C.c_int32), ("max_batch", C.c_int32), ("metric", C.c_int32),
                 ("precision", C.c_int32)]
 
+# a stale binding fails here, not by reading shifted struct fields (include/prisma_bands.h PB_ABI_VERSION, pb_struct_size)
+assert _lib.pb_abi_version() == 3 and _lib.pb_struct_size(0) == C.sizeof(pb_tensor) and _lib.pb_struct_size(1) == C.sizeof(pb_depth_cfg)
+
 _CFG = {"vits": (384, 12, 6, 64, (48, 96, 192, 384)),
         "vitb": (768, 12, 12, 128, (96, 192, 384, 768)),
         "vitl": (1024, 24, 16, 256, (256, 512, 1024, 1024))}

@@ -28,6 +28,7 @@ class pb_flow_cfg(C.Structure):
 
 
 PREC_F16, PREC_SPLIT = 0, 1
+ABI_VERSION = 3          # include/prisma_bands.h PB_ABI_VERSION this binding was written against
 
 
 def default_precision() -> int:
@@ -57,6 +58,8 @@ _U8 = C.POINTER(C.c_uint8)
 SYMBOLS = {
     "pb_last_error": (C.c_char_p, []),
     "pb_version": (C.c_int, []),
+    "pb_abi_version": (C.c_int, []),
+    "pb_struct_size": (C.c_int, [C.c_int]),
     "pb_device_count": (C.c_int, []),
     "pb_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.POINTER(pb_tensor), C.c_int, _P, C.c_size_t]),
     "pb_destroy": (None, [_P]),
@@ -124,6 +127,12 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    if lib.pb_abi_version() != ABI_VERSION:
+        raise PrismaBandsError(f"{LIB_PATH}: ABI version {lib.pb_abi_version()}, this binding expects {ABI_VERSION} - rebuild the library "
+                               "(make -C prisma_amd/csrc) or update prisma_amd/_lib.py")
+    for which, st in enumerate((pb_tensor, pb_depth_cfg, pb_flow_cfg, pb_mask_cfg, pb_kernel_stat)):
+        if lib.pb_struct_size(which) != C.sizeof(st):
+            raise PrismaBandsError(f"{LIB_PATH}: sizeof({st.__name__}) is {lib.pb_struct_size(which)} in the library, {C.sizeof(st)} in the binding")
     _lib = lib
     return lib
 

@@ -110,6 +110,18 @@ extern "C" {
 
 const char *pb_last_error(void) { return g_err; }
 int pb_version(void) { return 100; }
+int pb_abi_version(void) { return PB_ABI_VERSION; }
+int pb_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(pb_tensor);
+        case 1: return (int)sizeof(pb_depth_cfg);
+        case 2: return (int)sizeof(pb_flow_cfg);
+        case 3: return (int)sizeof(pb_mask_cfg);
+        case 4: return (int)sizeof(pb_kernel_stat);
+        case 5: return (int)sizeof(pb_comm_id);
+        default: return -1;
+    }
+}
 
 int pb_device_count(void) {
     int n = 0;
