@@ -161,6 +161,59 @@ def full_case():
         minmax=np.array([dmin, dmax]), rgb_s8=rgb[::8, ::8].copy())
 
 
+def heavy_case():
+    """Round 3: the same reference models on HEAVY-TAILED weights (prisma_amd/synth.py *_heavy: outlier LayerNorm / BatchNorm channels
+    x 30-50 with partly compensated consumers), so that activations reach tens to hundreds where the engine's split-precision copies
+    live.  ViT-L from a 720p frame (strided samples, like depth_vitl_720p) and RAFT on a 184 x 256 pair, 12 iterations."""
+    from d_anything.dpt import DPT_DINOv2
+    cfg = synth.DEPTH_CFGS["vitl"]
+    w = synth.depth_anything_weights_heavy(cfg, seed=1234)
+    m = DPT_DINOv2(encoder="vitl", features=cfg.features, out_channels=list(cfg.out_channels))
+    load_into(m, w)
+    m = m.eval()
+    st = hook_stages(m)
+    frame = synth.frames(1, 720, 1280, seed=3)[0]
+    x = O.preprocess(frame)[None]
+    with torch.no_grad():
+        d_net = m(torch.from_numpy(x))
+        d_ref = torch.nn.functional.interpolate(d_net[None], (720, 1280), mode="bilinear", align_corners=False)[0, 0].numpy()
+    d_or = O.infer(w, frame, cfg.depth, cfg.heads)
+    e = relerr(d_or, d_ref)
+    amax = {k: float(np.abs(v).max()) for k, v in st.items()}
+    print(f"[vitl heavy 720p] oracle vs reference rel err {e:.2e}; depth {d_ref.min():.4f}..{d_ref.max():.4f} mean {d_ref.mean():.4f}; "
+          f"max |activation|: block0 {amax.get('block0', 0):.1f}, block23 {amax.get('block23', 0):.1f}, layer1_rn {amax.get('layer1_rn', 0):.1f}, "
+          f"path1 {amax.get('path1', 0):.1f}, output_conv1 {amax.get('output_conv1', 0):.1f}")
+    assert e < 5e-5 and np.isfinite(d_ref).all() and d_ref.max() > d_ref.min() >= 0 and (d_ref > 0).mean() > 0.8, e
+    np.savez_compressed(os.path.join(GOLD, "depth_vitl_heavy_720p.npz"), frame_seed=np.array(3), depth_s8=d_ref[::8, ::8].copy(),
+                        net_s8=d_net[0].numpy()[::8, ::8].copy(),
+                        depth_sum=np.array([d_ref.astype(np.float64).sum(), np.abs(d_ref.astype(np.float64)).sum()]))
+    import argparse
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    from raft.raft import RAFT
+    from common.flow import InputPadder
+    from oracle import raft_oracle as R
+    rw = synth.raft_weights_heavy(seed=4321)
+    rm = RAFT(argparse.Namespace()).eval()
+    rm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rw.items()}, strict=True)
+    hgt, wid, iters = 184, 256, 12
+    fr = synth.frame_pair_sequence(2, hgt, wid, seed=23)
+    a = torch.from_numpy(fr[0]).permute(2, 0, 1).float()[None]
+    c = torch.from_numpy(fr[1]).permute(2, 0, 1).float()[None]
+    i1, i2 = torch.cat([a, c], 0), torch.cat([c, a], 0)
+    padder = InputPadder(i1.shape)
+    p1, p2 = padder.pad(i1, i2)
+    with torch.no_grad():
+        lo, up = rm(p1, p2, iters=iters, test_mode=True)
+        fwd = padder.unpad(up[0]).permute(1, 2, 0).numpy()
+        bwd = padder.unpad(up[1]).permute(1, 2, 0).numpy()
+    f_o, b_o = R.infer_pair(rw, fr[0], fr[1], scale=1.0, iters=iters)
+    e = max(relerr(f_o, fwd), relerr(b_o, bwd))
+    print(f"[raft heavy {hgt}x{wid}] oracle vs reference rel err {e:.2e}; |flow| max {np.abs(fwd).max():.2f} px")
+    assert e < 2e-4 and np.isfinite(fwd).all(), e
+    np.savez_compressed(os.path.join(GOLD, "raft_heavy_184x256.npz"), frame_seed=np.array(23), hw=np.array([hgt, wid]), iters=np.array(iters),
+                        fwd=fwd, bwd=bwd)
+
+
 def encode_case():
     sys.modules.setdefault("cv2", types.ModuleType("cv2"))   # common/encode.py:10 imports cv2 for Sobel only
     from common import encode as E
@@ -463,6 +516,8 @@ if __name__ == "__main__":
         small_case("vitl_d4", 90, 120, 12)
     if "full" in which:
         full_case()
+    if "heavy" in which:
+        heavy_case()
     if "gmflow" in which:
         gmflow_case()
         gmflow_case(216, 300, 52, False)   # pads to 224x304: a 28 x 38 grid, 14 x 19 windows, forward only

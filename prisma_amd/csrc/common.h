@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 
@@ -39,6 +40,11 @@ void pb_set_error(const char *fmt, ...);
     } while (0)
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+// integer tuning knob from the environment (read where an engine is constructed; the default is the shipped value)
+static inline int pb_env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
 
 // ---- device helpers --------------------------------------------------------------------------
 #if defined(__HIPCC__)

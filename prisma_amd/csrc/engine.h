@@ -104,8 +104,10 @@ class DepthEngine {
     // vit_mx_: the ViT linears' weight residual runs as an MX-fp8 segment (half the matrix-pipe time of an fp16 pass); their A
     // operands (LayerNorm out, attention out, GELU out) then carry an fp8 copy after the fp16 part of each row (row stride 1.5 K)
     int vit_mx_ = 0, head_mx_ = 0;              // head_mx_: the DPT head's maps / weights carry e4m3 residual parts (PackedW::mx3)
-    static constexpr int kLo8Pa = 3;            // ... stored as hi 2^3 and lo 2^15 (|x| up to 56 before the copy saturates)
-    static constexpr int kMxPa = 4;             // fp8 activation copies are stored scaled by 2^4 (|a| up to 28 before saturation)
+    // storage scales of the e4m3 copies (engine_base.h kLo8Pa has the reasoning): head maps hi8 = e4m3(x 2^kLo8Pa), lo8 = e4m3(lo 2^(kLo8Pa + 12));
+    // ViT token rows a8 = e4m3(a 2^kMxPa).  2^0 since round 3: the copies saturate at |x| = 448 (were 2^3 / 2^4: 56 / 28)
+    const int kLo8Pa = pb_env_int("PB_LO8_POW", 0);
+    const int kMxPa = pb_env_int("PB_A8_POW", 0);
     int batch_cap(int H, int W) const;          // frames per chunk the 32-bit tensor offsets allow for this frame size
     std::map<std::string, const pb_tensor *> tmap_;
     std::vector<void *> owned_;                 // permanent device allocations (weights)

@@ -21,10 +21,14 @@ class EngineBase {
     int split_w_ = 0;            // PB_PREC_SPLIT: weights packed as hi + lo fp16, two passes over K (set before load)
     int mx_ = 0;                 // ... and where activations are split too (sa) the residual parts are e4m3: maps [hi | hi8 | lo8],
                                  // weights [w_hi | w_lo8 | w_hi8] per tap, fp8 tiles through the MX-scaled MFMA (PackedW::mx3)
-    static constexpr int kLo8Pa = 3;
+    // power-of-two storage scales of the e4m3 copies.  hi8 = e4m3(x 2^kLo8Pa), lo8 = e4m3((x - fp16(x)) 2^(kLo8Pa + 12)); e4m3 saturates at
+    // 448, so the copy of |x| > 448 / 2^kLo8Pa clamps and that element's correction term degrades to the single-pass error.  Round 3:
+    // 2^0 (saturation at 448; was 2^3 = 56) - a correction term needs a few significant bits of a NORMAL e4m3 (|x| >= 2^-6) and what
+    // lies below contributes |x| 2^-12 |w| at most (tools/precision_budget.py --scales; tests/test_gpu_outliers.py)
+    const int kLo8Pa = pb_env_int("PB_LO8_POW", 0);
     int pack_mx2_ = 0;           // while set, pack() lays weights out as [w_hi fp16 | w_lo e4m3] per tap (PackedW::mx2): the layer's input
                                  // map carries an fp8 copy after its fp16 part ([a16 (Ctot) | a8 (Ctot bytes)], scaled by 2^kMx2Pa)
-    static constexpr int kMx2Pa = 4;
+    const int kMx2Pa = pb_env_int("PB_A8_POW", 0);      // [a16 | a8] maps: a8 = e4m3(a 2^kMx2Pa); 2^0 since round 3 (was 2^4: |a| > 28 clamped)
     int pack_tapin_ = 0;         // while set, pack() stores convolution weights (taps > 1) in slice-major K order (gemm.h cTapInner)
     const f16 *zero_page() const { return zero_; }
 

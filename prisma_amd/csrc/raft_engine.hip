@@ -184,7 +184,7 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
     lh_[0] = h8_; lw_[0] = w8_;
     for (int l = 1; l < 4; ++l) { lh_[l] = lh_[l - 1] / 2; lw_[l] = lw_[l - 1] / 2; }
     const int64_t ND = (int64_t)(F - 1) * dirs;
-    const int h2 = Hp_ / 2, w2 = Wp_ / 2;
+    const int h2 = Hp_ / 2, w2 = Wp_ / 2, h4 = Hp_ / 4, w4 = Wp_ / 4;
     const size_t slack = 1 << 20;
     for (int pass = 0; pass < 2; ++pass) {
         planning_ = pass == 0;

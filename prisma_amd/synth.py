@@ -552,3 +552,65 @@ def gmflow_weights(seed: int = 2468) -> Dict[str, np.ndarray]:
                 gain = 2.0                                # convex-combination logits with some contrast
             w[name] = (g.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(fan_in)))
     return w
+
+
+# ----------------------------------------------------------------------------
+# Heavy-tailed variants (round 3): trained checkpoints have outlier channels - a few LayerNorm gains tens of times the rest, a few
+# convolution channels far above unit scale - which the unit-scale synthetic weights never exercise.  These variants re-scale the SAME
+# seeded tensors: a producer's channel c is multiplied by `up` and every consumer's weights on that input channel divided by `down`
+# (< up, so the channel also carries `up / down` times its share of the consumer's output).  The functions stay well conditioned (the
+# reference model is still the arbiter: oracle/make_golden.py heavy) while the activations the split-precision copies have to hold
+# reach tens to hundreds - what the fixed power-of-two e4m3 scales of the engine must survive (tests/test_gpu_outliers.py).
+# ----------------------------------------------------------------------------
+def _heavy_channels(seed: int, name: str, n: int, k: int) -> np.ndarray:
+    return np.sort(_rng(seed, name + "#heavy").choice(n, size=k, replace=False))
+
+
+def depth_anything_weights_heavy(cfg: DepthCfg | str = "vitl", seed: int = 1234, up: float = 50.0, down: float = 12.5,
+                                 conv_up: float = 30.0, conv_down: float = 7.5) -> Dict[str, np.ndarray]:
+    """depth_anything_weights with 4 outlier channels per LayerNorm (gamma and beta x `up`, the consuming qkv / fc1 / projects columns /
+    `down`) and 3 outlier channels per DPT `layerN_rn` output (x `conv_up`; the refinenet's consumers of that channel / `conv_down`)."""
+    if isinstance(cfg, str):
+        cfg = DEPTH_CFGS[cfg]
+    w = {k: v.copy() for k, v in depth_anything_weights(cfg, seed).items()}
+    D = cfg.embed_dim
+    for i in range(cfg.depth):
+        p = f"pretrained.blocks.{i}."
+        for norm, consumer in (("norm1", "attn.qkv.weight"), ("norm2", "mlp.fc1.weight")):
+            ch = _heavy_channels(seed, p + norm, D, 4)
+            w[p + norm + ".weight"][ch] *= np.float32(up)
+            w[p + norm + ".bias"][ch] *= np.float32(up)
+            w[p + consumer][:, ch] /= np.float32(down)
+    ch = _heavy_channels(seed, "pretrained.norm", D, 4)          # the final norm feeds the four DPT taps
+    w["pretrained.norm.weight"][ch] *= np.float32(up)
+    w["pretrained.norm.bias"][ch] *= np.float32(up)
+    for i in range(4):
+        w[f"depth_head.projects.{i}.weight"][:, ch] /= np.float32(down)
+    F = cfg.features
+    for i in range(4):
+        ch = _heavy_channels(seed, f"depth_head.scratch.layer{i + 1}_rn", F, 3)
+        w[f"depth_head.scratch.layer{i + 1}_rn.weight"][ch] *= np.float32(conv_up)
+        r = f"depth_head.scratch.refinenet{i + 1}."
+        for cons in ("resConfUnit1.conv1.weight", "resConfUnit2.conv1.weight", "out_conv.weight"):
+            w[r + cons][:, ch] /= np.float32(conv_down)
+    return w
+
+
+def raft_weights_heavy(seed: int = 4321, up: float = 30.0, down: float = 7.5) -> Dict[str, np.ndarray]:
+    """raft_weights with 3 outlier channels in every cnet residual block's first norm (eval BatchNorm: weight and bias x `up`, so the
+    ReLU'd map that conv2 reads carries them; conv2's weights on those inputs / `down`) and in fnet's / cnet's last 1x1 conv input
+    (layer3.1's second norm cannot be re-scaled under InstanceNorm, so there the 1x1 `conv2` rows are scaled instead: output channels
+    x 4 on the correlation features / context)."""
+    w = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in raft_weights(seed).items()}
+    dims = (64, 96, 128)
+    for li in range(3):
+        for bi in range(2):
+            p = f"cnet.layer{li + 1}.{bi}."
+            ch = _heavy_channels(seed, p + "norm1", dims[li], 3)
+            w[p + "norm1.weight"][ch] *= np.float32(up)
+            w[p + "norm1.bias"][ch] *= np.float32(up)
+            w[p + "conv2.weight"][:, ch] /= np.float32(down)
+    for enc in ("fnet", "cnet"):
+        ch = _heavy_channels(seed, enc + ".conv2", 128, 3)
+        w[enc + ".conv2.weight"][:, ch] *= np.float32(4.0)
+    return w
