@@ -271,6 +271,11 @@ int pb_op_attention(pb_ctx *ctx, const float *q, const float *k, const float *v,
 /* single-head attention over 128-wide heads, q / k / v / o [B, L, 128]; region [B, L] or NULL: a key whose region id differs from the
  * query's gets -100 on its logit (bands/gmflow/transformer.py:8-15, 18-44, 47-101) - a building block of the flow_gmflow band */
 int pb_op_attention128(pb_ctx *ctx, const float *q, const float *k, const float *v, const int8_t *region, float *o, int B, int L);
+/* the same attention in the flow_gmflow band's split precision (q, k, v and the probabilities as hi + lo fp16 pairs: three MFMA passes
+ * for the scores and for P V); v / o [B, L, vcols] with vcols 128 or 32 (coordinates / flow padded to 32 columns); region [nreg, L],
+ * batch element b uses row b % nreg; keys and values of batch element b are those of b ^ kxor (cross attention between a pair's frames) */
+int pb_op_attention128_split(pb_ctx *ctx, const float *q, const float *k, const float *v, const int8_t *region, int nreg, float *o,
+                             int B, int L, int vcols, int kxor);
 int pb_op_conv2d(pb_ctx *ctx, const float *x, const float *w, const float *bias, float *y,
                  int B, int Ci, int H, int W, int Co, int ksize, int stride, int pad, int relu_in, int relu_out);
 /* bilinear resize NCHW float32, align_corners 0/1 (torch F.interpolate semantics). */

@@ -100,6 +100,7 @@ SYMBOLS = {
     "pb_op_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),
     "pb_op_attention": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "pb_op_attention128": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int]),
+    "pb_op_attention128_split": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pb_op_conv2d": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int] * 10),
     "pb_op_bilinear": (C.c_int, [_P, _P, _P] + [C.c_int] * 7),
     "pb_op_preprocess": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int]),

@@ -9,6 +9,7 @@
 
 #include "engine.h"
 #include "mask_engine.h"
+#include "gmflow_engine.h"
 #include "raft_engine.h"
 
 static thread_local char g_err[1024] = "";
@@ -156,21 +157,22 @@ int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *we
         }
         c->stream = c->depth->stream;
         c->zero = (f16 *)c->depth->zero_page();
-    } else if (!strcmp(band, "flow_raft")) {
+    } else if (!strcmp(band, "flow_raft") || !strcmp(band, "flow_gmflow")) {
+        const bool gm = band[5] == 'g';
         if (!weights || n_weights <= 0 || (cfg && cfg_bytes != sizeof(pb_flow_cfg))) {
             delete c;
-            PB_CHECK(false, PB_ERR_ARG, "flow_raft: needs weights (and cfg = NULL or a pb_flow_cfg of %zu bytes, got %zu)", sizeof(pb_flow_cfg), cfg_bytes);
+            PB_CHECK(false, PB_ERR_ARG, "%s: needs weights (and cfg = NULL or a pb_flow_cfg of %zu bytes, got %zu)", band, sizeof(pb_flow_cfg), cfg_bytes);
         }
         const int prec = cfg ? ((const pb_flow_cfg *)cfg)->precision : PB_PREC_F16;
         if (prec != PB_PREC_F16 && prec != PB_PREC_SPLIT) {
             delete c;
-            PB_CHECK(false, PB_ERR_ARG, "flow_raft: precision %d unknown", prec);
+            PB_CHECK(false, PB_ERR_ARG, "%s: precision %d unknown", band, prec);
         }
-        c->raft = new RaftEngine(device_id);
+        c->raft = gm ? new GmflowEngine(device_id) : new RaftEngine(device_id);      // GmflowEngine overrides load / infer / get_stage
         c->raft->split_w_ = prec == PB_PREC_SPLIT;
         {
             const char *mx = getenv("PB_MX");
-            c->raft->mx_ = c->raft->split_w_ && !(mx && mx[0] == '0');
+            c->raft->mx_ = !gm && c->raft->split_w_ && !(mx && mx[0] == '0');
         }
         int r = c->raft->load(weights, n_weights);
         if (r) {
@@ -210,7 +212,7 @@ int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *we
         c->own_stream = true;
     } else {
         delete c;
-        PB_CHECK(false, PB_ERR_ARG, "unknown band '%s' (depth_anything | flow_raft | mask_mmdet | ops)", band);
+        PB_CHECK(false, PB_ERR_ARG, "unknown band '%s' (depth_anything | flow_raft | flow_gmflow | mask_mmdet | ops)", band);
     }
     *out = c;
     return 0;
@@ -723,6 +725,41 @@ int pb_op_attention128(pb_ctx *c, const float *q, const float *k, const float *v
     PB_TRY(launch_attention128(c->stream, dq.as<f16>(), dk.as<f16>(), dv.as<f16>(), region ? dr.as<int8_t>() : nullptr, dout.as<float>(), B, L, ldv));
     PB_HIP(hipStreamSynchronize(c->stream));
     PB_HIP(hipMemcpy(o, dout.p, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pb_op_attention128_split(pb_ctx *c, const float *q, const float *k, const float *v, const int8_t *region, int nreg, float *o, int B, int L,
+                             int vcols, int kxor) {
+    PB_CHECK(c && q && k && v && o && B > 0 && L > 0 && (vcols == 128 || vcols == 32), PB_ERR_ARG, "op_attention128_split: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const int ldv = (int)round_up(L, 32);
+    const size_t n = (size_t)B * L * 128;
+    std::vector<f16> hq(2 * n), hk(2 * n), hv((size_t)B * 2 * vcols * ldv, (f16)0.f);
+    auto split = [](float x, f16 &hi, f16 &lo) { hi = (f16)x; lo = (f16)(x - (float)hi); };
+    for (size_t r = 0; r < (size_t)B * L; ++r)
+        for (int d = 0; d < 128; ++d) {
+            split(q[r * 128 + d], hq[r * 256 + d], hq[r * 256 + 128 + d]);
+            split(k[r * 128 + d], hk[r * 256 + d], hk[r * 256 + 128 + d]);
+        }
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < L; ++t)
+            for (int d = 0; d < vcols; ++d)
+                split(v[((size_t)b * L + t) * vcols + d], hv[(((size_t)b * 2 + 0) * vcols + d) * ldv + t], hv[(((size_t)b * 2 + 1) * vcols + d) * ldv + t]);
+    DevMem dq, dk, dv, dr, dout;
+    PB_TRY(dq.alloc(2 * n * 2)); PB_TRY(dk.alloc(2 * n * 2)); PB_TRY(dv.alloc(hv.size() * 2)); PB_TRY(dout.alloc((size_t)B * L * vcols * 4));
+    PB_HIP(hipMemcpy(dq.p, hq.data(), 2 * n * 2, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dk.p, hk.data(), 2 * n * 2, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(dv.p, hv.data(), hv.size() * 2, hipMemcpyHostToDevice));
+    if (region) {
+        PB_TRY(dr.alloc((size_t)nreg * L));
+        PB_HIP(hipMemcpy(dr.p, region, (size_t)nreg * L, hipMemcpyHostToDevice));
+    }
+    Attn128Args a;
+    a.Q = dq.as<f16>(); a.K = dk.as<f16>(); a.Vt = dv.as<f16>(); a.region = region ? dr.as<int8_t>() : nullptr; a.nreg = nreg;
+    a.O = dout.as<float>(); a.B = B; a.L = L; a.ldv = ldv; a.split = 1; a.vcols = vcols; a.kxor = kxor;
+    PB_TRY(launch_attention128x(c->stream, a));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(o, dout.p, (size_t)B * L * vcols * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -46,5 +46,19 @@ int launch_f32_to_f16(hipStream_t s, const float *x, f16 *y, int64_t rows, int c
 // attention128.hip: single-head attention over 128-wide heads (GMFlow's transformer / matching / propagation); Q, K [B, L, 128] fp16,
 // Vt [B, 128, ldv] fp16, region [B, L] int8 or null (shifted-window mask), O [B, L, 128] fp32
 int launch_attention128(hipStream_t s, const f16 *Q, const f16 *K, const f16 *Vt, const int8_t *region, float *O, int B, int L, int ldv);
+// general form.  split = 1: Q, K rows are [hi (128) | lo (128)], Vt holds hi rows then lo rows, P is split in registers (three MFMA
+// passes for S and for O).  vcols = 128, or 32 for a V padded to 32 columns (coordinates / flow); O is [B, L, vcols] fp32.
+// Batch element b reads its queries at Q + b q_bstride and its keys / values at index b ^ kxor (K + (b ^ kxor) k_bstride, Vt + (b ^ kxor)
+// v_bstride); strides in halfs, 0 = contiguous [B, L, ...] / [B, (2,) vcols, ldv]; v_shared: one Vt for every b; region [nreg, L]: b uses row b % nreg.
+struct Attn128Args {
+    const f16 *Q = nullptr, *K = nullptr, *Vt = nullptr;
+    const int8_t *region = nullptr;
+    int nreg = 0;
+    float *O = nullptr;
+    int B = 0, L = 0, ldv = 0, split = 0, vcols = 128, v_shared = 0, kxor = 0;
+    int ldq = 0;             // row stride of Q and K in halfs (0: 256 with split, else 128); a non-split call may read the hi part of split rows
+    int64_t q_bstride = 0, k_bstride = 0, v_bstride = 0;
+};
+int launch_attention128x(hipStream_t s, const Attn128Args &a);
 int launch_f16_to_f32(hipStream_t s, const f16 *x, float *y, int64_t rows, int cols, int ld_in);
 int launch_fill_random_f16(hipStream_t s, f16 *x, int64_t n, unsigned seed, float scale);

@@ -11,19 +11,24 @@ class RaftEngine : public EngineBase {
   public:
     explicit RaftEngine(int device) : EngineBase(device) {}
     ~RaftEngine() override { for (auto &kv : snaps_) if (kv.second) hipFree(kv.second); }
-    int load(const pb_tensor *w, int n);
+    virtual int load(const pb_tensor *w, int n);
     // frames: device uint8 [F, H, W, 3].  Outputs are device pointers (any may be null):
     //   flow_out [F-1, dirs, sh, sw, 2] fp32, rgb_out [F-1, dirs, sh, sw, 3] u8, maxdisp [F-1, dirs]
-    int infer(const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward, float *flow_out,
-              uint8_t *rgb_out, float *maxdisp, uint8_t *mask_out = nullptr, float alpha1 = 0.05f,
-              float alpha2 = 0.5f);
-    int64_t get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]);
+    virtual int infer(const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward, float *flow_out,
+                      uint8_t *rgb_out, float *maxdisp, uint8_t *mask_out = nullptr, float alpha1 = 0.05f,
+                      float alpha2 = 0.5f);
+    virtual int64_t get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]);
     static void out_size(int H, int W, float scale, int *sh, int *sw);
 
-  private:
+  protected:            // shared with GmflowEngine (gmflow_engine.h): GMFlow's CNNEncoder is this encoder without conv biases
     struct Enc {                    // BasicEncoder weights (BN folded for cnet)
         PackedW stem, l[3][2][2], ds[3], out;
     };
+    int pack_encoder(const std::string &en, bool bnf, bool conv_bias, Enc &E);
+    int run_encoder(const Enc &E, bool inorm, int F, const f16 **x_out);
+    void geometry(int H, int W, float scale, int factor);
+    void carve_encoder(int F);
+    int upload_resize_tables(int H, int W, float scale);
     int prepare(int F, int H, int W, float scale, int dirs);
     Enc fnet_, cnet_;
     PackedW convc1_, convc2_, convf1_, convf2_, convm_, zr_[2], q_[2], fh1_, fh2_, mk0_, mk2_;

@@ -48,59 +48,67 @@ void RaftEngine::out_size(int H, int W, float scale, int *sh, int *sw) {
     *sw = (int)nearbyint((double)W * scale);
 }
 
+// BasicEncoder weights (extractor.py:118-192) up to the last residual block: stem, layer1-3, downsample paths.  bnf: eval BatchNorm folded
+// into the convolutions (cnet); conv_bias: the 3x3 / 7x7 convolutions carry biases (RAFT yes, GMFlow's CNNEncoder no - its 1x1 downsample
+// convolutions do, backbone.py:22-25)
+int RaftEngine::pack_encoder(const std::string &en, bool bnf, bool conv_bias, Enc &E) {
+    int r;
+    const int dims[3] = {64, 96, 128};
+    std::vector<float> sc, sf;
+    {   // stem 7x7 / stride 2 (extractor.py:124,171): on the 4 x 4 space-to-depth image (64 channels = (dy, dx, c), raft_prep) it is a
+        // 3x3 / stride 1 convolution whose 4 x 64 output channels are the 2 x 2 output pixels of a block - an implicit GEMM on the
+        // ping-pong kernel with the pixel-shuffle epilogue instead of an im2col round trip (2.8 GB per 32 frames at 1080p x 0.75).
+        // W2[(sy, sx, o)][(ty, tx)][(dy, dx, c)] = w[o][c][ky][kx],  ky = 4 (ty - 1) + dy - 2 sy + 3 (same in x), zero outside 0..6
+        auto iw = tmap_.find(en + ".conv1.weight"), ib = tmap_.find(en + ".conv1.bias");
+        PB_CHECK(iw != tmap_.end() && (ib != tmap_.end() || !conv_bias), PB_ERR_ARG, "missing %s.conv1", en.c_str());
+        if (bnf && (r = fold_bn(en + ".norm1", 64, sc, sf))) return r;
+        const float *wt = (const float *)iw->second->data, *bs = conv_bias ? (const float *)ib->second->data : nullptr;
+        std::vector<float> g((size_t)256 * 576, 0.f), bb(256);
+        for (int sy = 0; sy < 2; ++sy)
+            for (int sx = 0; sx < 2; ++sx)
+                for (int o = 0; o < 64; ++o) {
+                    const float s = bnf ? sc[o] : 1.f;
+                    const int n = (sy * 2 + sx) * 64 + o;
+                    bb[n] = (bs ? bs[o] : 0.f) * s + (bnf ? sf[o] : 0.f);
+                    for (int ty = 0; ty < 3; ++ty)
+                        for (int tx = 0; tx < 3; ++tx)
+                            for (int dy = 0; dy < 4; ++dy)
+                                for (int dx = 0; dx < 4; ++dx) {
+                                    const int ky = 4 * (ty - 1) + dy - 2 * sy + 3, kx = 4 * (tx - 1) + dx - 2 * sx + 3;
+                                    if (ky < 0 || ky > 6 || kx < 0 || kx > 6) continue;
+                                    for (int c = 0; c < 3; ++c)
+                                        g[(size_t)n * 576 + (ty * 3 + tx) * 64 + (dy * 4 + dx) * 4 + c] = wt[((size_t)o * 3 + c) * 49 + ky * 7 + kx] * s;
+                                }
+                }
+        if ((r = pack(g.data(), 256, 576, 576, E.stem, bb.data(), 9, 1))) return r;
+        E.stem.Kreal = 147;
+    }
+    for (int li = 0; li < 3; ++li)
+        for (int bi = 0; bi < 2; ++bi) {
+            const std::string p = en + ".layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+            for (int c = 0; c < 2; ++c) {
+                if (bnf && (r = fold_bn(p + ".norm" + std::to_string(c + 1), dims[li], sc, sf))) return r;
+                if ((r = pack_conv(p + ".conv" + std::to_string(c + 1), conv_bias, bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr,
+                                   E.l[li][bi][c], 1)))
+                    return r;
+            }
+            if (bi == 0 && li > 0) {
+                if (bnf && (r = fold_bn(p + ".norm3", dims[li], sc, sf))) return r;
+                if ((r = pack_conv(p + ".downsample.0", true, bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr, E.ds[li], 1))) return r;
+            }
+        }
+    return 0;
+}
+
 int RaftEngine::load(const pb_tensor *w, int n) {
     int r0 = begin_load(w, n);
     if (r0) return r0;
     int r;
-    const int dims[3] = {64, 96, 128};
     pack_tapin_ = getenv("PB_TAPIN") && getenv("PB_TAPIN")[0] == '2';
     for (int e = 0; e < 2; ++e) {
         const std::string en = e == 0 ? "fnet" : "cnet";
         Enc &E = e == 0 ? fnet_ : cnet_;
-        const bool bnf = e == 1;
-        std::vector<float> sc, sf;
-        {   // stem 7x7 / stride 2 (extractor.py:124,171): on the 4 x 4 space-to-depth image (64 channels = (dy, dx, c), raft_prep) it is a
-            // 3x3 / stride 1 convolution whose 4 x 64 output channels are the 2 x 2 output pixels of a block - an implicit GEMM on the
-            // ping-pong kernel with the pixel-shuffle epilogue instead of an im2col round trip (2.8 GB per 32 frames at 1080p x 0.75).
-            // W2[(sy, sx, o)][(ty, tx)][(dy, dx, c)] = w[o][c][ky][kx],  ky = 4 (ty - 1) + dy - 2 sy + 3 (same in x), zero outside 0..6
-            auto iw = tmap_.find(en + ".conv1.weight"), ib = tmap_.find(en + ".conv1.bias");
-            PB_CHECK(iw != tmap_.end() && ib != tmap_.end(), PB_ERR_ARG, "missing %s.conv1", en.c_str());
-            if (bnf && (r = fold_bn(en + ".norm1", 64, sc, sf))) return r;
-            const float *wt = (const float *)iw->second->data, *bs = (const float *)ib->second->data;
-            std::vector<float> g((size_t)256 * 576, 0.f), bb(256);
-            for (int sy = 0; sy < 2; ++sy)
-                for (int sx = 0; sx < 2; ++sx)
-                    for (int o = 0; o < 64; ++o) {
-                        const float s = bnf ? sc[o] : 1.f;
-                        const int n = (sy * 2 + sx) * 64 + o;
-                        bb[n] = bs[o] * s + (bnf ? sf[o] : 0.f);
-                        for (int ty = 0; ty < 3; ++ty)
-                            for (int tx = 0; tx < 3; ++tx)
-                                for (int dy = 0; dy < 4; ++dy)
-                                    for (int dx = 0; dx < 4; ++dx) {
-                                        const int ky = 4 * (ty - 1) + dy - 2 * sy + 3, kx = 4 * (tx - 1) + dx - 2 * sx + 3;
-                                        if (ky < 0 || ky > 6 || kx < 0 || kx > 6) continue;
-                                        for (int c = 0; c < 3; ++c)
-                                            g[(size_t)n * 576 + (ty * 3 + tx) * 64 + (dy * 4 + dx) * 4 + c] = wt[((size_t)o * 3 + c) * 49 + ky * 7 + kx] * s;
-                                    }
-                    }
-            if ((r = pack(g.data(), 256, 576, 576, E.stem, bb.data(), 9, 1))) return r;
-            E.stem.Kreal = 147;
-        }
-        for (int li = 0; li < 3; ++li)
-            for (int bi = 0; bi < 2; ++bi) {
-                const std::string p = en + ".layer" + std::to_string(li + 1) + "." + std::to_string(bi);
-                for (int c = 0; c < 2; ++c) {
-                    if (bnf && (r = fold_bn(p + ".norm" + std::to_string(c + 1), dims[li], sc, sf))) return r;
-                    if ((r = pack_conv(p + ".conv" + std::to_string(c + 1), true, bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr,
-                                       E.l[li][bi][c], 1)))
-                        return r;
-                }
-                if (bi == 0 && li > 0) {
-                    if (bnf && (r = fold_bn(p + ".norm3", dims[li], sc, sf))) return r;
-                    if ((r = pack_conv(p + ".downsample.0", true, bnf ? sc.data() : nullptr, bnf ? sf.data() : nullptr, E.ds[li], 1))) return r;
-                }
-            }
+        if ((r = pack_encoder(en, e == 1, true, E))) return r;
         if ((r = pack_conv(en + ".conv2", true, nullptr, nullptr, E.out, 1))) return r;
     }
     const std::string u = "update_block.";
@@ -174,31 +182,17 @@ int RaftEngine::load(const pb_tensor *w, int n) {
 int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
     if (F <= pF_ && H == pH_ && W == pW_ && scale == pS_ && dirs <= pD_) return 0;
     PB_HIP(hipStreamSynchronize(stream));
-    out_size(H, W, scale, &sh_, &sw_);
-    const int ph = (((sh_ / 8) + 1) * 8 - sh_) % 8, pw = (((sw_ / 8) + 1) * 8 - sw_) % 8;   // InputPadder 'sintel' (flow.py:43-55)
-    padl_ = pw / 2; padt_ = ph / 2;
-    Hp_ = sh_ + ph; Wp_ = sw_ + pw;
-    h8_ = Hp_ / 8; w8_ = Wp_ / 8; P_ = h8_ * w8_;
+    geometry(H, W, scale, 8);
     PB_CHECK(h8_ >= 16 && w8_ >= 16, PB_ERR_ARG, "flow_raft: %dx%d is too small (the 4-level pyramid needs >= 128 px)", sh_, sw_);
     P8_ = (P_ + 7) / 8 * 8;       // row stride of the level-0 volume (the GEMM epilogue writes 8-column groups)
     lh_[0] = h8_; lw_[0] = w8_;
     for (int l = 1; l < 4; ++l) { lh_[l] = lh_[l - 1] / 2; lw_[l] = lw_[l - 1] / 2; }
     const int64_t ND = (int64_t)(F - 1) * dirs;
-    const int h2 = Hp_ / 2, w2 = Wp_ / 2, h4 = Hp_ / 4, w4 = Wp_ / 4;
     const size_t slack = 1 << 20;
     for (int pass = 0; pass < 2; ++pass) {
         planning_ = pass == 0;
         arena_off_ = 0;
-        xi_ = (int *)carve((size_t)sw_ * 16); xc_ = (int *)carve((size_t)sw_ * 16);
-        yi_ = (int *)carve((size_t)sh_ * 16); yc_ = (int *)carve((size_t)sh_ * 16);
-        // split-fp16 mode: the encoders' maps (image included) are [hi | lo] per pixel (es = 2)
-        const size_t es = split_w_ ? 2 : 1;
-        img_ = (f16 *)carve((size_t)F * Hp_ * Wp_ * 8 * es);
-        for (auto &b : r1_) b = (f16 *)carve((size_t)round_up((int64_t)F * h2 * w2, 256) * 64 * 2 * es);
-        for (auto &b : r2_) b = (f16 *)carve((size_t)round_up((int64_t)F * h4 * w4, 256) * 128 * 2 * es);
-        for (auto &b : r3_) b = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 128 * 2 * es);
-        for (auto &b : st_) b = (float *)carve((size_t)F * 256 * 2 * 4);
-        stp_ = (float *)carve((size_t)in_stats_chunks(h2 * w2) * F * 256 * 2 * 4);     // per-chunk partial sums of the largest map
+        carve_encoder(F);
         fmap_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2 + slack);
         ctx_ = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 256 * 2);
         for (int l = 0; l < 4; ++l) {
@@ -229,6 +223,37 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
             if (rc) return rc;
         }
     }
+    int rt = upload_resize_tables(H, W, scale);
+    if (rt) return rt;
+    pF_ = F; pH_ = H; pW_ = W; pS_ = scale; pD_ = dirs;
+    return 0;
+}
+
+// scaled size, InputPadder('sintel', padding_factor = factor) amounts (bands/common/flow.py:43-55) and the 1/8 grid
+void RaftEngine::geometry(int H, int W, float scale, int factor) {
+    out_size(H, W, scale, &sh_, &sw_);
+    const int ph = (((sh_ / factor) + 1) * factor - sh_) % factor, pw = (((sw_ / factor) + 1) * factor - sw_) % factor;
+    padl_ = pw / 2; padt_ = ph / 2;
+    Hp_ = sh_ + ph; Wp_ = sw_ + pw;
+    h8_ = Hp_ / 8; w8_ = Wp_ / 8; P_ = h8_ * w8_;
+}
+
+// arena buffers of frame prep and run_encoder (call between the planning / carving passes of a prepare)
+void RaftEngine::carve_encoder(int F) {
+    const int h2 = Hp_ / 2, w2 = Wp_ / 2, h4 = Hp_ / 4, w4 = Wp_ / 4;
+    xi_ = (int *)carve((size_t)sw_ * 16); xc_ = (int *)carve((size_t)sw_ * 16);
+    yi_ = (int *)carve((size_t)sh_ * 16); yc_ = (int *)carve((size_t)sh_ * 16);
+    // split-fp16 mode: the encoders' maps (image included) are [hi | lo] per pixel (es = 2)
+    const size_t es = split_w_ ? 2 : 1;
+    img_ = (f16 *)carve((size_t)F * Hp_ * Wp_ * 8 * es);
+    for (auto &b : r1_) b = (f16 *)carve((size_t)round_up((int64_t)F * h2 * w2, 256) * 64 * 2 * es);
+    for (auto &b : r2_) b = (f16 *)carve((size_t)round_up((int64_t)F * h4 * w4, 256) * 128 * 2 * es);
+    for (auto &b : r3_) b = (f16 *)carve((size_t)round_up((int64_t)F * P_, 256) * 128 * 2 * es);
+    for (auto &b : st_) b = (float *)carve((size_t)F * 256 * 2 * 4);
+    stp_ = (float *)carve((size_t)in_stats_chunks(h2 * w2) * F * 256 * 2 * 4);     // per-chunk partial sums of the largest map
+}
+
+int RaftEngine::upload_resize_tables(int H, int W, float scale) {
     if (scale != 1.f) {
         std::vector<int> xi, xc, yi, yc;
         cubic_taps_u8(W, sw_, scale, xi, xc);
@@ -239,7 +264,88 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         PB_HIP(hipMemcpyAsync(yc_, yc.data(), yc.size() * 4, hipMemcpyHostToDevice, stream));
     }
     PB_HIP(hipStreamSynchronize(stream));
-    pF_ = F; pH_ = H; pW_ = W; pS_ = scale; pD_ = dirs;
+    return 0;
+}
+
+// BasicEncoder.forward (extractor.py:171-192) without its last 1x1 convolution, on the F prepared frames in img_: stem, three stages of two
+// residual blocks.  inorm: InstanceNorm with run-time statistics (fnet; GMFlow's backbone) - otherwise the folded BatchNorm path (cnet).
+// *x_out = the last block's output map [F, h8, w8, 128] (split-fp16 layout in PB_PREC_SPLIT).
+int RaftEngine::run_encoder(const Enc &E, bool inorm, int F, const f16 **x_out) {
+    int r = 0;
+    const int h2 = Hp_ / 2, w2 = Wp_ / 2;
+    const int es = split_w_ ? 2 : 1;                         // encoder maps are [hi | lo] in split-fp16 mode
+    auto lo = [&](int c) { return split_w_ ? c : 0; };
+    const int l8 = split_w_ && mx_ ? kLo8Pa : -1;            // the residual parts of the encoder maps are e4m3 ([hi | hi8 | lo8])
+    auto norm_relu = [&](const f16 *t, float *st, f16 *y, int HW, int C, const f16 *b, const float *sb) -> int {
+        tic(F_ELT, 0, 0);
+        int rr = launch_in_apply(stream, t, st, b, sb, y, F, HW, C, es * C, lo(C), l8);
+        toc();
+        return rr;
+    };
+    auto stats = [&](const f16 *t, float *st, int HW, int C) -> int {
+        tic(F_ELT, 0, 0);
+        int rr = launch_in_stats(stream, t, F, HW, C, es * C, stp_, st, lo(C), l8);
+        toc();
+        return rr;
+    };
+    // stem (BasicEncoder.forward, extractor.py:171-192)
+    {
+        GemmArgs a;
+        a.A = img_; a.N = 256;
+        a.cH = Hp_ / 4; a.cW = Wp_ / 4; a.cC = 64; a.cLd = es * 64; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1;
+        set_weights(a, E.stem, true);
+        a.cOH = a.cH; a.cOW = a.cW; a.M = F * a.cH * a.cW;
+        a.out = r1_[5]; a.ldo = es * 64; a.lo_off = lo(64); a.act = inorm ? ACT_NONE : ACT_RELU;
+        if (l8 >= 0) { a.lo8 = 1; a.lo8_pa = l8; }
+        a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
+        tic(F_CONV, 2.0 * F * h2 * w2 * 64.0 * 147, 0, E.stem.mx3 ? 2.0 : 1.0 + E.stem.sa + E.stem.sw);
+        r = launch_gemm(stream, A_CONV, EPI_PIXSHUF, TILE_AUTO, a);
+        if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
+        toc();
+        if (r) return r;
+    }
+    const f16 *x = r1_[5];
+    if (inorm) {
+        if ((r = stats(r1_[5], st_[0], h2 * w2, 64))) return r;
+        if ((r = norm_relu(r1_[5], st_[0], r1_[6], h2 * w2, 64, nullptr, nullptr))) return r;
+        x = r1_[6];
+    }
+    int H_ = h2, W_ = w2, C_ = 64;
+    for (int li = 0; li < 3; ++li) {
+        const int stride = li == 0 ? 1 : 2;
+        const int Cn = li == 0 ? 64 : 128;               // 96 is carried as 128 (zero padded channels)
+        f16 **R = li == 0 ? r1_ : (li == 1 ? r2_ : r3_);
+        for (int bi = 0; bi < 2; ++bi) {                  // ResidualBlock.forward (extractor.py:46-56)
+            const int s = bi == 0 ? stride : 1;
+            const int OH = (H_ - 1) / s + 1, OW = (W_ - 1) / s + 1;
+            const int Cin = bi == 0 ? C_ : Cn;
+            f16 *t1 = R[0], *t2 = R[1], *t3 = R[2], *outb = R[3 + bi];
+            if (inorm) {
+                if ((r = conv(x, Cin, es * Cin, F, H_, W_, 3, 3, s, E.l[li][bi][0], t1, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
+                if ((r = stats(t1, st_[0], OH * OW, Cn))) return r;
+                if ((r = norm_relu(t1, st_[0], t1, OH * OW, Cn, nullptr, nullptr))) return r;
+                if ((r = conv(t1, Cn, es * Cn, F, OH, OW, 3, 3, 1, E.l[li][bi][1], t2, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
+                if ((r = stats(t2, st_[1], OH * OW, Cn))) return r;
+                if (s != 1) {
+                    if ((r = conv(x, Cin, es * Cin, F, H_, W_, 1, 1, s, E.ds[li], t3, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
+                    if ((r = stats(t3, st_[2], OH * OW, Cn))) return r;
+                    if ((r = norm_relu(t2, st_[1], outb, OH * OW, Cn, t3, st_[2]))) return r;
+                } else {
+                    if ((r = norm_relu(t2, st_[1], outb, OH * OW, Cn, x, nullptr))) return r;
+                }
+            } else {
+                if ((r = conv(x, Cin, es * Cin, F, H_, W_, 3, 3, s, E.l[li][bi][0], t1, es * Cn, ACT_RELU, 0, nullptr, nullptr, lo(Cn)))) return r;
+                const f16 *xs = x;
+                if (s != 1) {
+                    if ((r = conv(x, Cin, es * Cin, F, H_, W_, 1, 1, s, E.ds[li], t3, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
+                    xs = t3;
+                }
+                if ((r = conv(t1, Cn, es * Cn, F, OH, OW, 3, 3, 1, E.l[li][bi][1], outb, es * Cn, ACT_RELU, 1, xs, nullptr, lo(Cn)))) return r;
+            }
+            x = outb; H_ = OH; W_ = OW; C_ = Cn;
+        }
+    }
+    *x_out = x;
     return 0;
 }
 
@@ -253,7 +359,6 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     if (r) return r;
     timer.reset();
     stages_.clear();
-    const int h2 = Hp_ / 2, w2 = Wp_ / 2;
     const int ND = (F - 1) * dirs;
     last_nd_ = ND;
     const int64_t rows = (int64_t)ND * P_;
@@ -272,76 +377,8 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     // ---- the two encoders ----
     for (int e = 0; e < 2; ++e) {
         const Enc &E = e == 0 ? fnet_ : cnet_;
-        const bool inorm = e == 0;
-        auto norm_relu = [&](const f16 *t, float *st, f16 *y, int HW, int C, const f16 *b, const float *sb) -> int {
-            tic(F_ELT, 0, 0);
-            int rr = launch_in_apply(stream, t, st, b, sb, y, F, HW, C, es * C, lo(C), l8);
-            toc();
-            return rr;
-        };
-        auto stats = [&](const f16 *t, float *st, int HW, int C) -> int {
-            tic(F_ELT, 0, 0);
-            int rr = launch_in_stats(stream, t, F, HW, C, es * C, stp_, st, lo(C), l8);
-            toc();
-            return rr;
-        };
-        // stem (BasicEncoder.forward, extractor.py:171-192)
-        {
-            GemmArgs a;
-            a.A = img_; a.N = 256;
-            a.cH = Hp_ / 4; a.cW = Wp_ / 4; a.cC = 64; a.cLd = es * 64; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1;
-            set_weights(a, E.stem, true);
-            a.cOH = a.cH; a.cOW = a.cW; a.M = F * a.cH * a.cW;
-            a.out = r1_[5]; a.ldo = es * 64; a.lo_off = lo(64); a.act = inorm ? ACT_NONE : ACT_RELU;
-            if (l8 >= 0) { a.lo8 = 1; a.lo8_pa = l8; }
-            a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
-            tic(F_CONV, 2.0 * F * h2 * w2 * 64.0 * 147, 0, E.stem.mx3 ? 2.0 : 1.0 + E.stem.sa + E.stem.sw);
-            r = launch_gemm(stream, A_CONV, EPI_PIXSHUF, TILE_AUTO, a);
-            if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
-            toc();
-            if (r) return r;
-        }
-        const f16 *x = r1_[5];
-        if (inorm) {
-            if ((r = stats(r1_[5], st_[0], h2 * w2, 64))) return r;
-            if ((r = norm_relu(r1_[5], st_[0], r1_[6], h2 * w2, 64, nullptr, nullptr))) return r;
-            x = r1_[6];
-        }
-        int H_ = h2, W_ = w2, C_ = 64;
-        for (int li = 0; li < 3; ++li) {
-            const int stride = li == 0 ? 1 : 2;
-            const int Cn = li == 0 ? 64 : 128;               // 96 is carried as 128 (zero padded channels)
-            f16 **R = li == 0 ? r1_ : (li == 1 ? r2_ : r3_);
-            for (int bi = 0; bi < 2; ++bi) {                  // ResidualBlock.forward (extractor.py:46-56)
-                const int s = bi == 0 ? stride : 1;
-                const int OH = (H_ - 1) / s + 1, OW = (W_ - 1) / s + 1;
-                const int Cin = bi == 0 ? C_ : Cn;
-                f16 *t1 = R[0], *t2 = R[1], *t3 = R[2], *outb = R[3 + bi];
-                if (inorm) {
-                    if ((r = conv(x, Cin, es * Cin, F, H_, W_, 3, 3, s, E.l[li][bi][0], t1, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
-                    if ((r = stats(t1, st_[0], OH * OW, Cn))) return r;
-                    if ((r = norm_relu(t1, st_[0], t1, OH * OW, Cn, nullptr, nullptr))) return r;
-                    if ((r = conv(t1, Cn, es * Cn, F, OH, OW, 3, 3, 1, E.l[li][bi][1], t2, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
-                    if ((r = stats(t2, st_[1], OH * OW, Cn))) return r;
-                    if (s != 1) {
-                        if ((r = conv(x, Cin, es * Cin, F, H_, W_, 1, 1, s, E.ds[li], t3, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
-                        if ((r = stats(t3, st_[2], OH * OW, Cn))) return r;
-                        if ((r = norm_relu(t2, st_[1], outb, OH * OW, Cn, t3, st_[2]))) return r;
-                    } else {
-                        if ((r = norm_relu(t2, st_[1], outb, OH * OW, Cn, x, nullptr))) return r;
-                    }
-                } else {
-                    if ((r = conv(x, Cin, es * Cin, F, H_, W_, 3, 3, s, E.l[li][bi][0], t1, es * Cn, ACT_RELU, 0, nullptr, nullptr, lo(Cn)))) return r;
-                    const f16 *xs = x;
-                    if (s != 1) {
-                        if ((r = conv(x, Cin, es * Cin, F, H_, W_, 1, 1, s, E.ds[li], t3, es * Cn, ACT_NONE, 0, nullptr, nullptr, lo(Cn)))) return r;
-                        xs = t3;
-                    }
-                    if ((r = conv(t1, Cn, es * Cn, F, OH, OW, 3, 3, 1, E.l[li][bi][1], outb, es * Cn, ACT_RELU, 1, xs, nullptr, lo(Cn)))) return r;
-                }
-                x = outb; H_ = OH; W_ = OW; C_ = Cn;
-            }
-        }
+        const f16 *x = nullptr;
+        if ((r = run_encoder(E, e == 0, F, &x))) return r;
         if ((r = dense(x, es * 128, (int64_t)F * P_, E.out, e == 0 ? fmap_ : ctx_, 256, ACT_NONE))) return r;
     }
     stages_["fmap"] = Stage{fmap_, 1, 0, 256, h8_, w8_, 256, 0};

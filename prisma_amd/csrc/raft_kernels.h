@@ -4,7 +4,7 @@
 
 int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, int sh, int sw, int Hp, int Wp, int pad_l,
                      int pad_t, int resize, const int *xi, const int *xc, const int *yi, const int *yc, f16 *out,
-                     uint8_t *scaled_out, int s2d = 0, int lo_off = 0, int lo8_pa = -1);
+                     uint8_t *scaled_out, int s2d = 0, int lo_off = 0, int lo8_pa = -1, int norm_mode = 0);     // norm_mode 1: ImageNet mean / std (GMFlow)
 // ld: row stride of `out` in halfs (0 = Kp); o8: also store the row as e4m3 (unscaled) after its Kp halfs (gemm.h nk16)
 int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp, int ld = 0, int o8 = 0);
 int in_stats_chunks(int HW);

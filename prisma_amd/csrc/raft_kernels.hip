@@ -14,12 +14,19 @@ inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t
 // frame prep: uint8 RGB frame -> [optional 8-bit fixed-point bicubic resize] -> replicate pad to /8 ->
 // 2*(x/255)-1 -> fp16 [F][Hp][Wp][4] (channel 3 = 0).  One thread per padded pixel.
 // ------------------------------------------------------------------------------------------------
+// mode 0: RAFT 2 (x / 255) - 1 (raft.py:91-92); mode 1: GMFlow (x / 255 - mean) / std with the ImageNet statistics (gmflow/utils.py:53-58)
+__device__ __forceinline__ float prep_norm(int v, int c, int mode) {
+    if (mode == 0) return 2.f * ((float)v / 255.f) - 1.f;
+    const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f), sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+    return ((float)v / 255.f - mean) / sd;
+}
+
 __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restrict__ frames, int F, int H, int W, int sh,
                                                         int sw, int Hp, int Wp, int pad_l, int pad_t, int resize,
                                                         const int *__restrict__ xi, const int *__restrict__ xc,
                                                         const int *__restrict__ yi, const int *__restrict__ yc,
                                                         f16 *__restrict__ out, uint8_t *__restrict__ scaled_out, int s2d, int lo_off,
-                                                        int lo8_pa) {
+                                                        int lo8_pa, int norm_mode) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)F * Hp * Wp) return;
     const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), f = (int)(i / ((int64_t)Wp * Hp));
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
     f16x4 o, l;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float t = 2.f * ((float)v[c] / 255.f) - 1.f;
+        const float t = prep_norm(v[c], c, norm_mode);
         o[c] = (f16)t;
         l[c] = (f16)(t - (float)o[c]);
     }
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
             const float shi = __builtin_ldexpf(1.f, lo8_pa), slo = __builtin_ldexpf(1.f, lo8_pa + 12);
             float t[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) t[c] = 2.f * ((float)v[c] / 255.f) - 1.f;
+            for (int c = 0; c < 3; ++c) t[c] = prep_norm(v[c], c, norm_mode);
             char *pb = (char *)(out + px - ((y & 3) * 4 + (x & 3)) * 4);
             const int col = ((y & 3) * 4 + (x & 3)) * 4;
             *(int *)(pb + 2 * lo_off + col) = pb_fp8x4((float)o[0] * shi, (float)o[1] * shi, (float)o[2] * shi, 0.f);
@@ -642,9 +649,9 @@ __global__ void fill_u32_kernel(unsigned *p, unsigned v, int n) {
 
 int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, int sh, int sw, int Hp, int Wp, int pad_l,
                      int pad_t, int resize, const int *xi, const int *xc, const int *yi, const int *yc, f16 *out,
-                     uint8_t *scaled_out, int s2d, int lo_off, int lo8_pa) {
+                     uint8_t *scaled_out, int s2d, int lo_off, int lo8_pa, int norm_mode) {
     hipLaunchKernelGGL(raft_prep_kernel, dim3(nblk((int64_t)F * Hp * Wp)), dim3(256), 0, s, frames, F, H, W, sh, sw, Hp, Wp,
-                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d, lo_off, lo8_pa);
+                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d, lo_off, lo8_pa, norm_mode);
     LAUNCH_CHECK();
 }
 int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp, int ld, int o8) {

@@ -158,6 +158,18 @@ class Ops(_Ctx):
         check(self.lib.pb_op_attention128(self.ctx, _ptr(q), _ptr(k), _ptr(v), _ptr(rg), _ptr(out), B, L))
         return out
 
+    def attention128_split(self, q, k, v, region=None, kxor: int = 0) -> np.ndarray:
+        """the same in the flow_gmflow band's split precision; v [B, L, 128 or 32]; region [nreg, L] int8; keys / values of b are those of b ^ kxor"""
+        q, k, v = _f32(q), _f32(k), _f32(v)
+        B, L, D = q.shape
+        vc = v.shape[2]
+        assert D == 128 and k.shape == q.shape and v.shape[:2] == (B, L) and vc in (32, 128)
+        out = np.empty((B, L, vc), np.float32)
+        rg = None if region is None else np.ascontiguousarray(region, np.int8)
+        check(self.lib.pb_op_attention128_split(self.ctx, _ptr(q), _ptr(k), _ptr(v), _ptr(rg), 0 if rg is None else rg.shape[0], _ptr(out),
+                                                B, L, vc, kxor))
+        return out
+
     def attention(self, q, k, v) -> np.ndarray:
         q, k, v = _f32(q), _f32(k), _f32(v)
         B, Hh, N, d = q.shape
@@ -286,6 +298,8 @@ class FlowRaft(_Ctx):
     weights: reference checkpoint naming without the `module.` prefix (fnet.*, cnet.*, update_block.*).
     """
 
+    BAND = b"flow_raft"
+
     def __init__(self, weights: Dict[str, np.ndarray], device: int = 0, precision: Optional[int] = None):
         super().__init__()
         self.precision = _lib.default_precision() if precision is None else int(precision)
@@ -299,7 +313,7 @@ class FlowRaft(_Ctx):
             for j, s in enumerate(w.shape):
                 arr[i].shape[j] = s
             arr[i].data = w.ctypes.data
-        check(self.lib.pb_create(C.byref(self.ctx), device, b"flow_raft", arr, len(keep), C.byref(fc), C.sizeof(fc)))
+        check(self.lib.pb_create(C.byref(self.ctx), device, self.BAND, arr, len(keep), C.byref(fc), C.sizeof(fc)))
 
     def infer_sequence(self, frames: np.ndarray, scale: float = 0.75, iters: int = 12, backward: bool = False,
                        want_flow: bool = True, want_rgb: bool = True):
@@ -356,6 +370,15 @@ class FlowRaft(_Ctx):
         while len(dims) > 1 and dims[-1] == 1:
             dims.pop()
         return out[:n].reshape(dims).copy()
+
+
+class FlowGMFlow(FlowRaft):
+    """GMFlow optical-flow band on one GPU (bands/flow_gmflow.py:42-118 init_model / infer; the model at the band's default flags).
+
+    weights: reference checkpoint naming (backbone.*, transformer.layers.N.*, feature_flow_attn.*, upsampler.*).  Same calls as FlowRaft
+    (`iters` is ignored: GMFlow is not iterative; frames are padded to multiples of 16).  stage(): "feat", "block0", "tfeat" as
+    [frames, tokens, 128], "flow_match", "flow_prop" as [pairs * dirs, tokens, 2]."""
+    BAND = b"flow_gmflow"
 
 
 def _mask_cfg(cfg: MaskCfg, max_batch: int, precision: int = 0) -> "_lib.pb_mask_cfg":

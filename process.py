@@ -27,12 +27,12 @@ from bands.common.meta import (add_band, create_metadata, is_video, load_metadat
                                write_metadata)
 
 # Default BANDS & MODELS (reference :17-30; defaults narrowed to what is built here)
-BUILT = ("rgba", "depth_anything", "flow_raft", "mask_mmdet")
+BUILT = ("rgba", "depth_anything", "flow_raft", "flow_gmflow", "mask_mmdet")
 DEPTH_VIDEO_DEFAULT = "depth_anything"
 DEPTH_IMAGE_DEFAULT = "depth_anything"          # reference: depth_patchfusion (not built)
 DEPTH_BANDS = ["depth_midas", "depth_marigold", "depth_zoedepth", "depth_patchfusion", "depth_anything"]
 DEPTH_OPTIONS = DEPTH_BANDS + ["all"]
-FLOW_DEFAULT = "flow_raft"                      # reference: flow_gmflow (not built)
+FLOW_DEFAULT = "flow_gmflow"                    # reference :23
 FLOW_BANDS = ["flow_gmflow", "flow_raft"]
 FLOW_OPTIONS = FLOW_BANDS + ["all"]
 MASK_DEFAULT = "mask_mmdet"

@@ -103,6 +103,41 @@ def test_flow_cli_video(tmp_path):
     band.model = None
 
 
+@pytest.mark.gpu
+def test_flow_gmflow_cli_video(tmp_path):
+    """bands/flow_gmflow.py (prisma's default flow band): same folder contract as flow_raft under its own names, the reference's
+    architecture flags accepted at their defaults and rejected otherwise."""
+    import flow_gmflow as band
+    from prisma_amd import synth
+    folder = tmp_path / "clip"
+    folder.mkdir()
+    frames = synth.frame_pair_sequence(4, 176, 256, seed=6)
+    np.save(folder / "rgba.npy", frames)
+    (folder / "metadata.json").write_text(json.dumps({"bands": {"rgba": {"url": "rgba.npy"}}}))
+    os.environ["PRISMA_OVERWRITE"] = "1"
+    band.model = None
+    band.main(["-i", str(folder), "--scale", "1.0", "-b", "--mask", "--num_transformer_layers", "6", "--attn_splits_list", "2"])
+    out = np.load(folder / "flow_gmflow.npy")
+    assert out.shape == (4, 176, 256, 3) and out.dtype == np.uint8 and not out[-1].any() and out[0].any()
+    assert np.load(folder / "flow_gmflow_bwd.npy").shape == out.shape
+    assert np.load(folder / "flow_gmflow_mask.npy").shape == out.shape
+    dist = [float(x) for x in open(folder / "flow_gmflow.csv")]
+    assert len(dist) == 4 and dist[-1] == 0.0 and all(d > 0 for d in dist[:-1])
+    md = json.load(open(folder / "metadata.json"))
+    assert md["bands"]["flow_gmflow"]["values"]["dist"] == {"type": "float", "url": "flow_gmflow.csv"}
+    assert md["bands"]["flow_gmflow_bwd"]["url"] == "flow_gmflow_bwd.npy" and md["bands"]["flow_gmflow_mask"]["url"] == "flow_gmflow_mask.npy"
+    # module API of the reference (:66-118): infer(args, prev, curr) on CHW float frames
+    import types
+    a = types.SimpleNamespace(backwards=True, output_mask="", subpath_mask="")
+    fwd, bwd, fm, bm = band.infer(a, frames[0].transpose(2, 0, 1).astype(np.float32), frames[1].transpose(2, 0, 1).astype(np.float32))
+    assert fwd.shape == (176, 256, 2) and bwd.shape == (176, 256, 2) and fm is None and bm is None
+    assert abs(float(np.sqrt((fwd ** 2).sum(-1)).max()) - dist[0]) < 1e-4
+    with pytest.raises(SystemExit, match="only the band's default GMFlow"):
+        band.main(["-i", str(folder), "--num_scales", "2"])
+    band.model.close()
+    band.model = None
+
+
 def test_flow_file_writers(tmp_path):
     """.flo layout (bands/common/io.py:175-197) and the 16-bit flow+mask PNG (encode.py:105-110 through cv2.imwrite)."""
     from common.io import encode_flow, write_flo, write_flow_png

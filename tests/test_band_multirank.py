@@ -40,6 +40,7 @@ def _clip(tmp_path, name, frames):
     ("flow_raft.py", ["--iterations", "3", "--scale", "1.0", "-b", "--mask"],
      ["flow_raft.npy", "flow_raft_bwd.npy", "flow_raft_mask.npy", "flow_raft_mask_bwd.npy", "flow_raft.csv"]),
     ("mask_mmdet.py", ["--arch", "tiny"], ["mask.npy"]),
+    ("flow_gmflow.py", ["--scale", "1.0", "-b"], ["flow_gmflow.npy", "flow_gmflow_bwd.npy", "flow_gmflow.csv"]),
 ])
 def test_two_ranks_equal_one(tmp_path, script, extra, outputs):
     from prisma_amd import synth

@@ -60,10 +60,12 @@ def test_extra_levels_and_video_band_order(tmp_path, monkeypatch):
     md = json.load(open(os.path.join(folder, "metadata.json")))
     assert (md["width"], md["height"], md["frames"]) == (64, 48, 3) and md["duration"] == 3 / md["fps"]
     names = [os.path.basename(c[1]) for c in process.COMMANDS]
-    assert names == ["rgba.py", "mask_mmdet.py", "depth_anything.py", "flow_raft.py"]          # camera_colmap is not built: skipped
+    assert names == ["rgba.py", "mask_mmdet.py", "depth_anything.py", "flow_gmflow.py"]        # reference default flow band (:23); camera_colmap is not built: skipped
     depth, flow = process.COMMANDS[2], process.COMMANDS[3]
     assert depth[2:] == ["-i", folder, "--ply", "--metric", "outdoor", "--subpath", "depth_anything"]    # -e >= 1 adds --ply (:196-197, 208-210)
-    assert flow[2:] == ["-i", folder, "--backwards", "--mask", "--subpath", "flow_raft"]                  # -e >= 2 adds --flo -> subpath (:199-200, 268)
+    assert flow[2:] == ["-i", folder, "--backwards", "--mask", "--subpath", "flow_gmflow"]                # -e >= 2 adds --flo -> subpath (:199-200, 268)
+    process.main(["-i", str(clip), "-f", "flow_raft"])
+    assert [os.path.basename(c[1]) for c in process.COMMANDS][-1] == "flow_raft.py" and process.COMMANDS[-1][2:] == ["-i", folder]
     assert os.path.exists(os.path.join(folder, "images", "000002.png"))                                  # rgba --subpath images
 
 
