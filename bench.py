@@ -149,6 +149,49 @@ def flow_leg(args, R):
     return out
 
 
+def gmflow_leg(args, R):
+    """flow_gmflow (prisma's default flow band, SURVEY 8 f-4) on the headline flow shape: the forward pairs of a 1080p clip at the band's
+    default --scale 0.75 (816 x 1440 after padding to /16: 18360 tokens per frame, 51 x 90 attention windows), args.gmflow_pairs per step."""
+    local_rank, world, rank = R.device, R.world, R.rank
+    from prisma_amd import engine, synth
+    H, W, pairs = 1080, 1920, args.gmflow_pairs
+    net = engine.FlowGMFlow(synth.gmflow_weights(seed=2468), device=local_rank, precision=args.precision)
+    frames = synth.frame_pair_sequence(pairs + 1, H, W, seed=150 + rank)
+    d_frames = torch.from_numpy(frames).cuda()
+    sh, sw = engine.flow_out_size(H, W, 0.75)
+    d_rgb = torch.empty((pairs, sh, sw, 3), dtype=torch.uint8, device="cuda")
+    d_mx = torch.empty((pairs,), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        net.infer_sequence_dev(d_frames.data_ptr(), pairs + 1, H, W, 0.75, 1, False, 0, d_rgb.data_ptr(), d_mx.data_ptr())
+        net.sync()
+
+    step()
+    R.barrier()
+    steps = max(1, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    R.barrier()
+    dt = R.max_over_ranks(time.perf_counter() - t0)
+    net.set_profiling(timing=True)
+    fam = {}
+    step()
+    for s in net.kernel_stats():
+        f = fam.setdefault(s["name"], dict(ms=0.0, flops=0.0, exec=0.0))
+        f["ms"] += s["ms"]; f["flops"] += s["flops"]; f["exec"] += s["exec_flops"]
+    mx = d_mx.cpu().numpy()
+    assert np.isfinite(mx).all() and (mx > 0).all()
+    net.close()
+    return {"metric": "frame-pairs/sec (flow_gmflow, 1080p x 0.75, forward)", "value": round(world * pairs * steps / dt, 3), "unit": "pairs/s",
+            "ms_per_step": round(dt / steps * 1e3, 3), "pairs_per_step_per_gpu": pairs, "precision": PREC_NAME[args.precision],
+            "gflop_per_pair": round(sum(v["flops"] for v in fam.values()) / pairs / 1e9, 1),
+            "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in sorted(fam.items())},
+            "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items() if v["flops"] > 0 and v["ms"] > 0},
+            "kernel_executed_tflops": {k: round(v["exec"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items() if v["exec"] > 0 and v["ms"] > 0}}
+
+
 def mask_leg(args, R):
     local_rank, world, rank = R.device, R.world, R.rank
     """Third line: the mask band (SOLOv2 R-101 FPN) on 1920x1080 frames, args.mask_frames per GPU per step, resident in
@@ -296,11 +339,13 @@ def main():
     ap.add_argument("--host-chunks", type=int, default=0, help="batches pushed through the host-pointer API for the PCIe-inclusive rate")
     ap.add_argument("--pipeline-frames", type=int, default=0, help="frames per step of the three-band pipeline leg")
     ap.add_argument("--mask-frames", type=int, default=0, help="frames per step of the mask_mmdet leg")
+    ap.add_argument("--gmflow-pairs", type=int, default=0, help="frame pairs per GPU per step of the flow_gmflow leg (1080p x 0.75)")
     ap.add_argument("--flow-pairs", type=int, default=0, help="frame pairs per GPU per step of the 720p flow_raft leg (BASELINE configs[2])")
     args = ap.parse_args()
     if args.all_legs:
         args.latency = True
         args.host_chunks, args.pipeline_frames, args.mask_frames, args.flow_pairs = 4, 32, 32, 8
+        args.gmflow_pairs = args.gmflow_pairs or 15
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the bands engine has no CPU path")
@@ -417,6 +462,7 @@ def main():
             other = {"error": (r.stderr or "")[-400:]}
     flow = flow_leg(args, R) if args.flow_pairs > 0 else None
     mask = mask_leg(args, R) if args.mask_frames > 0 else None
+    gmf = gmflow_leg(args, R) if args.gmflow_pairs > 0 else None
     pipe = pipeline_leg(args, R) if args.pipeline_frames > 1 else None
 
     if rank == 0:
@@ -504,6 +550,8 @@ def main():
             out["flow_raft_720p"] = flow
         if mask:
             out["mask_mmdet"] = mask
+        if gmf:
+            out["flow_gmflow"] = gmf
         if pipe:
             out["pipeline"] = pipe
         print(json.dumps(out))
