@@ -91,6 +91,11 @@ struct GemmArgs {
 // Launches the kernel on `stream`.  tile: TILE_AUTO picks from the shape.
 int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs &a);
 
+// halo_conv.hip: halo-tiled direct 3x3 convolution 64 -> 64 on mx3 operands (RAFT / GMFlow encoder stage 1).  `a` as EngineBase::conv builds it
+// (after set_weights); conv3x3_c64_supported tells whether the shape / layout / epilogue fit (PB_HALO=0 turns the kernel off for A/B runs).
+bool conv3x3_c64_supported(const GemmArgs &a);
+int launch_conv3x3_c64(hipStream_t stream, const GemmArgs &a);
+
 // Name of the kernel the last launch_gemm call of this thread launched, spelled like the symbol rocprofv3 reports
 // ("gemm8_kernel<1, 0, 0, true, false>"): the engines' per-launch timers are keyed by it, so a bench family IS one symbol.
 const char *pb_gemm_last_kernel();

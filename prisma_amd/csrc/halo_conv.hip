@@ -1,0 +1,239 @@
+// Halo-tiled direct 3x3 convolution, 64 -> 64 channels, stride 1, over split maps with e4m3 residual parts (gemm.h lo8) - the
+// half-resolution stage of RAFT's encoders (bands/raft/extractor.py:118-192 layer1: four 3x3 convolutions per encoder on maps of
+// (H / 2) x (W / 2) x 64; the same layers of GMFlow's CNNEncoder, bands/gmflow/backbone.py:66-72).
+//
+// Why not the implicit GEMM (gemm_kernels.h): with N = 64 a 256-pixel tile does 2.1 MFLOP per K tile against 40 KB of LDS-DMA, and every
+// input pixel is staged nine times (once per tap).  Measured (profiles/r02g): 2.46 ms per launch on 9.4 M pixels = 282 TF/s, 2.4x the
+// algorithmic HBM bytes - the kernel is bound by the L2 -> LDS stream, not by the matrix pipe or by HBM.  Here a workgroup stages an
+// 8 x 32 output tile's 10 x 34 input pixels ONCE (1.33x the tile's own pixels instead of 9x) and walks the nine taps out of the LDS:
+//   * LDS: input tile 340 pixels x 256 B ([hi fp16 (64) | hi e4m3 (64) | lo e4m3 (64)] per pixel, the 16-byte chunk index XOR-swizzled
+//     with (pixel & 15): the fragment reads of 32 consecutive pixels are bank-conflict free) + two 16 KB weight slabs (one tap each:
+//     64 output channels x [w_hi fp16 | w_lo e4m3 | w_hi e4m3]), double buffered - 117 KB, one workgroup per CU;
+//   * everything arrives by LDS-DMA through buffer resources (`buffer_load ... lds`, out-of-range offsets return zeros: the zero padding
+//     of the image border and of ragged tiles costs nothing); the swizzle is applied on the SOURCE address, per lane and loop invariant;
+//   * 4 waves x (2 row segments of 32 pixels) x 64 channels: per tap 16 fp16 MFMAs (a_hi w_hi) and 8 MX-scaled fp8 MFMAs
+//     (a_hi8 w_lo8 + a_lo8 w_hi8) into the same fp32 accumulators - the arithmetic of the implicit-GEMM path (gemm.h nk16 / mx_period);
+//   * persistent over tiles: the next tile's input and first weight slab are requested before the epilogue of the current one, so the
+//     HBM latency of a tile hides under the previous tile's stores;
+//   * epilogue as EPI_STD's: bias, ReLU before / after, one skip tensor (read as hi + lo8), outputs as [hi | hi8 | lo8].  Weight rows are
+//     fed interleaved (LDS row tn * 32 + j <- output channel 2 j + tn) so a lane owns two adjacent channels and half a wave stores one
+//     contiguous 128-byte line per pixel (gemm_kernels.h "interleaved output columns").
+#include "gemm.h"
+
+#include <stdlib.h>
+
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TH = 8, TW = 32, IW = TW + 2, IH = TH + 2, NPIX = IW * IH;      // 340 input pixels per tile
+constexpr int PXB = 256;                                                       // bytes per pixel / per (channel row, tap) of the weights
+constexpr int IN_BYTES = NPIX * PXB, W_BYTES = 64 * PXB, SMEM = IN_BYTES + 2 * W_BYTES;
+constexpr int IN_DMAS = NPIX / 4;                                              // 85 DMA instructions of 1 KB (4 pixels) per tile
+static_assert(NPIX % 4 == 0, "a DMA instruction carries 4 pixels");
+
+__device__ __forceinline__ i32x8 cat2(f16x8 a, f16x8 b) {
+    union { f16x8 h[2]; i32x8 v; } u;
+    u.h[0] = a; u.h[1] = b;
+    return u.v;
+}
+
+__global__ __launch_bounds__(256) void conv3x3_c64_mx_kernel(const GemmArgs p, int tilesX, int tilesPerImg, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_in = smem, *s_w = smem + IN_BYTES;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int H = p.cH, W = p.cW;
+    const int64_t img_bytes = (int64_t)H * W * PXB;
+
+    // ---- loop-invariant DMA geometry ----
+    // input: instruction j of this wave carries pixels q = 4 (wave + 4 j) + (lane >> 4) = q0 + 16 j; q & 15 (the swizzle key) does not change
+    const int q0 = 4 * wave + (lane >> 4);
+    const int in_chunk = (lane & 15) ^ (q0 & 15);                       // logical 16-byte chunk this lane fetches
+    int in_row0 = q0 / IW, in_col0 = q0 - in_row0 * IW;
+    // weights: instruction j carries LDS rows r = q0 + 16 j (same lane pattern); LDS row r holds output channel 2 (r & 31) + (r >> 5)
+    unsigned w_voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = q0 + 16 * j, n = 2 * (r & 31) + (r >> 5);
+        w_voff[j] = (unsigned)(n * p.K * 2 + (((lane & 15) ^ (r & 15)) * 16));
+    }
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.W, (unsigned)(64 * p.K * 2));
+    auto stage_weights = [&](int tap, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_buf(rsW, (int)w_voff[j], tap * PXB, s_w + buf * W_BYTES + (wave + 4 * j) * 1024);
+    };
+    auto stage_input = [&](int tile) {
+        const int b = tile / tilesPerImg, t = tile - b * tilesPerImg;
+        const int ty = t / tilesX, tx = t - ty * tilesX;
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc((const char *)p.A + (int64_t)b * img_bytes, (unsigned)img_bytes);
+        int row = in_row0, col = in_col0;
+        for (int j = 0; 4 * j + wave < IN_DMAS; ++j) {
+            const int iy = y0 + row, ix = x0 + col;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const unsigned off = ok ? (unsigned)((iy * W + ix) * PXB + in_chunk * 16) : 0xFFFFFF00u;      // out of range: the load returns zeros
+            glds16_buf(rs, (int)off, 0, s_in + (wave + 4 * j) * 1024);
+            col += 16;
+            if (col >= IW) { col -= IW; ++row; }
+        }
+    };
+
+    // ---- fragment addressing ----
+    // A: output row segment s = 2 wave + tm (tile row), pixel li; tap (ky, kx) reads input pixel q = (s + ky) * 34 + li + kx
+    // B: LDS row tn * 32 + li
+    int b_off[2], b_key[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) { const int r = tn * 32 + li; b_off[tn] = r * PXB; b_key[tn] = r & 15; }
+    const int sa = p.mx_scale_a * 0x01010101, sb = p.mx_scale_b * 0x01010101;
+
+    // per-lane epilogue constants: channels n = 2 li, 2 li + 1
+    const int n = 2 * li;
+    const float b0 = p.bias ? p.bias[n] : 0.f, b1 = p.bias ? p.bias[n + 1] : 0.f;
+    const float shi = __builtin_ldexpf(1.f, p.lo8_pa), slo = __builtin_ldexpf(1.f, p.lo8_pa + 12), inv_lo = __builtin_ldexpf(1.f, -(p.lo8_pa + 12));
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) { stage_input(tile); stage_weights(0, 0); }
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the input tile and of tap 0's weights (and its old stores)
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            if (tap + 1 < 9) stage_weights(tap + 1, (tap + 1) & 1);
+            const char *sw = s_w + (tap & 1) * W_BYTES;
+            f16x8 af[2][8], bf[2][8];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int q = (2 * wave + tm + ky) * IW + li + kx;
+                const char *base = s_in + q * PXB;
+                const int key = q & 15;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) af[tm][c] = *(const f16x8 *)(base + (((2 * c + lh) ^ key) * 16));
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) bf[tn][c] = *(const f16x8 *)(sw + b_off[tn] + (((2 * c + lh) ^ b_key[tn]) * 16));
+            // chunks 2 c + lh, c = 0..3: the four fp16 k-steps (a_hi w_hi); c = 4..7: the 128 e4m3 bytes [hi8 | lo8] x [w_lo8 | w_hi8] as two
+            // MX-scaled MFMAs of 64 bytes each (fragments c, c + 1 form the 32-byte operand; any byte order shared by A and B is valid)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm][c], bf[tn][c], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int c = 4; c < 8; c += 2)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat2(af[tm][c], af[tm][c + 1]), cat2(bf[tn][c], bf[tn][c + 1]),
+                                                                                     acc[tm][tn], 0, 0, 0, sa, 0, sb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tap's weights (this wave's pieces)
+            __syncthreads();                                      // ... everyone's; and everyone is done with this tap's slab
+        }
+        // the input tile and both weight slabs are dead: request the next tile before storing this one
+        const int next = tile + gridDim.x;
+        if (next < ntiles) { stage_input(next); stage_weights(0, 0); }
+
+        // ---- epilogue (EPI_STD semantics, gemm_kernels.h direct_epilogue_f16_impl LOM = 2) ----
+        const int b = tile / tilesPerImg, t = tile - b * tilesPerImg;
+        const int ty = t / tilesX, tx = t - ty * tilesX;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int y = ty * TH + 2 * wave + tm;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float v0[8], v1[8];
+                int64_t off[8];
+                bool ok[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = hf * 8 + q;
+                    const int x = tx * TW + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    ok[q] = y < H && x < W;
+                    const int xc = x < W ? x : W - 1, yc = y < H ? y : H - 1;
+                    off[q] = (((int64_t)b * H + yc) * W + xc) * p.ldo;
+                    v0[q] = acc[tm][0][r] + b0; v1[q] = acc[tm][1][r] + b1;
+                }
+                if (p.pre_relu) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+                }
+                if (p.add1) {
+                    f16x2 a[8];
+                    unsigned short l8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        a[q] = *(const f16x2 *)(p.add1 + off[q] + n);
+                        l8[q] = *(const unsigned short *)((const char *)(p.add1 + off[q]) + 3 * p.lo_off + n);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f32x2 l = __builtin_amdgcn_cvt_pk_f32_fp8((int)l8[q], false);
+                        v0[q] += (float)a[q][0] + l[0] * inv_lo; v1[q] += (float)a[q][1] + l[1] * inv_lo;
+                    }
+                }
+                if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (!ok[q]) continue;
+                    const f16 h0 = (f16)v0[q], h1 = (f16)v1[q];
+                    f16x2 o; o[0] = h0; o[1] = h1;
+                    *(f16x2 *)(p.out + off[q] + n) = o;
+                    char *pb = (char *)(p.out + off[q]);
+                    *(unsigned short *)(pb + 2 * p.lo_off + n) = pb_fp8x2((float)h0 * shi, (float)h1 * shi);
+                    *(unsigned short *)(pb + 3 * p.lo_off + n) = pb_fp8x2((v0[q] - (float)h0) * slo, (v1[q] - (float)h1) * slo);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Whether launch_conv3x3_c64 can run this convolution (after EngineBase::set_weights): 3x3 / stride 1 / pad 1, 64 -> 64 channels on mx3
+// operands (maps [hi | hi8 | lo8] with 128-half pixels, tap-major weights [w_hi | w_lo8 | w_hi8]), plain EPI_STD epilogue
+bool conv3x3_c64_supported(const GemmArgs &a) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("PB_HALO"); on = e ? atoi(e) : 1; }
+    return on && a.cKW == 3 && a.cStride == 1 && a.cPad == 1 && (a.cPadX < 0 || a.cPadX == 1) && a.N == 64 && a.cLd == 128 && a.ldo == 128 && a.lo_off == 64 && a.lo8 &&
+           a.nk16 == 1 && a.mx_period == 2 && a.cC == 128 && a.K == 9 * 128 && !a.cTapInner && !a.kwrap && !a.out2 && !a.add2 && !a.gru_h && !a.o8_off &&
+           (a.act == ACT_NONE || a.act == ACT_RELU) && a.cOH == a.cH && a.cOW == a.cW && (int64_t)a.cH * a.cW * PXB < (1LL << 32) - (1 << 20);
+}
+
+int launch_conv3x3_c64(hipStream_t stream, const GemmArgs &a) {
+    PB_CHECK(conv3x3_c64_supported(a), -1, "conv3x3_c64: unsupported shape / layout");
+    static bool attr_set = false;
+    if (!attr_set) {
+        PB_HIP(hipFuncSetAttribute((const void *)conv3x3_c64_mx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tilesX = (a.cW + TW - 1) / TW, tilesY = (a.cH + TH - 1) / TH, nimg = a.M / (a.cH * a.cW);
+    const int ntiles = tilesX * tilesY * nimg;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        PB_HIP(hipGetDevice(&dev));
+        PB_HIP(hipGetDeviceProperties(&prop, dev));
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    pb_gemm_set_last_kernel("conv3x3_c64_mx_kernel");
+    hipLaunchKernelGGL(conv3x3_c64_mx_kernel, dim3(grid), dim3(256), SMEM, stream, a, tilesX, tilesX * tilesY, ntiles);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
