@@ -28,7 +28,7 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int TH = 8, TW = 32, IW = TW + 2, IH = TH + 2, NPIX = IW * IH;      // 340 input pixels per tile
 constexpr int PXB = 256;                                                       // bytes per pixel / per (channel row, tap) of the weights
-constexpr int IN_BYTES = NPIX * PXB, W_BYTES = 64 * PXB, SMEM = IN_BYTES + 2 * W_BYTES;
+constexpr int IN_BYTES = NPIX * PXB, W_BYTES = 64 * PXB, SMEM = IN_BYTES + 3 * W_BYTES;
 constexpr int IN_DMAS = NPIX / 4;                                              // 85 DMA instructions of 1 KB (4 pixels) per tile
 static_assert(NPIX % 4 == 0, "a DMA instruction carries 4 pixels");
 
@@ -38,6 +38,11 @@ __device__ __forceinline__ i32x8 cat2(f16x8 a, f16x8 b) {
     return u.v;
 }
 
+// PIPE = 0: one weight slab ahead, a tap's fragments read right before its MFMAs (the first version: 2.11 ms per launch against the implicit
+// GEMM's 2.48).  PIPE = 1: two slabs ahead on a three-slab ring, and tap t + 1's fragments are read from the LDS under tap t's MFMAs (with
+// one wave per SIMD nothing else hides the ~500 cycles the 128 KB of fragment reads per tap take); the next tile's input is requested
+// before the LAST tap's MFMAs.
+template <int PIPE>
 __global__ __launch_bounds__(256) void conv3x3_c64_mx_kernel(const GemmArgs p, int tilesX, int tilesPerImg, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_in = smem, *s_w = smem + IN_BYTES;
@@ -91,8 +96,48 @@ __global__ __launch_bounds__(256) void conv3x3_c64_mx_kernel(const GemmArgs p, i
     const float b0 = p.bias ? p.bias[n] : 0.f, b1 = p.bias ? p.bias[n + 1] : 0.f;
     const float shi = __builtin_ldexpf(1.f, p.lo8_pa), slo = __builtin_ldexpf(1.f, p.lo8_pa + 12), inv_lo = __builtin_ldexpf(1.f, -(p.lo8_pa + 12));
 
+    // fragments of one tap: A = input pixels of this wave's two row segments shifted by (ky, kx), B = the tap's weight slab
+    auto load_frags = [&](int tap, const char *sw, f16x8 (&af)[2][8], f16x8 (&bf)[2][8]) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int q = (2 * wave + tm + ky) * IW + li + kx;
+            const char *base = s_in + q * PXB;
+            const int key = q & 15;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) af[tm][c] = *(const f16x8 *)(base + (((2 * c + lh) ^ key) * 16));
+        }
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) bf[tn][c] = *(const f16x8 *)(sw + b_off[tn] + (((2 * c + lh) ^ b_key[tn]) * 16));
+    };
+    // chunks 2 c + lh, c = 0..3: the four fp16 k-steps (a_hi w_hi); c = 4..7: the 128 e4m3 bytes [hi8 | lo8] x [w_lo8 | w_hi8] as two
+    // MX-scaled MFMAs of 64 bytes each (fragments c, c + 1 form the 32-byte operand; any byte order shared by A and B is valid)
+    auto mfmas = [&](f32x16 (&acc)[2][2], const f16x8 (&af)[2][8], const f16x8 (&bf)[2][8]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm][c], bf[tn][c], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int c = 4; c < 8; c += 2)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat2(af[tm][c], af[tm][c + 1]), cat2(bf[tn][c], bf[tn][c + 1]),
+                                                                                 acc[tm][tn], 0, 0, 0, sa, 0, sb);
+    };
+
     int tile = blockIdx.x;
-    if (tile < ntiles) { stage_input(tile); stage_weights(0, 0); }
+    if (tile < ntiles) {
+        stage_input(tile);
+        stage_weights(0, 0);
+        if (PIPE) stage_weights(1, 1);
+    }
     for (; tile < ntiles; tile += gridDim.x) {
         f32x16 acc[2][2];
 #pragma unroll
@@ -101,49 +146,39 @@ __global__ __launch_bounds__(256) void conv3x3_c64_mx_kernel(const GemmArgs p, i
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the input tile and of tap 0's weights (and its old stores)
-        __syncthreads();
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            if (tap + 1 < 9) stage_weights(tap + 1, (tap + 1) & 1);
-            const char *sw = s_w + (tap & 1) * W_BYTES;
-            f16x8 af[2][8], bf[2][8];
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                const int q = (2 * wave + tm + ky) * IW + li + kx;
-                const char *base = s_in + q * PXB;
-                const int key = q & 15;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) af[tm][c] = *(const f16x8 *)(base + (((2 * c + lh) ^ key) * 16));
-            }
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) bf[tn][c] = *(const f16x8 *)(sw + b_off[tn] + (((2 * c + lh) ^ b_key[tn]) * 16));
-            // chunks 2 c + lh, c = 0..3: the four fp16 k-steps (a_hi w_hi); c = 4..7: the 128 e4m3 bytes [hi8 | lo8] x [w_lo8 | w_hi8] as two
-            // MX-scaled MFMAs of 64 bytes each (fragments c, c + 1 form the 32-byte operand; any byte order shared by A and B is valid)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm][c], bf[tn][c], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int c = 4; c < 8; c += 2)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat2(af[tm][c], af[tm][c + 1]), cat2(bf[tn][c], bf[tn][c + 1]),
-                                                                                     acc[tm][tn], 0, 0, 0, sa, 0, sb);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tap's weights (this wave's pieces)
-            __syncthreads();                                      // ... everyone's; and everyone is done with this tap's slab
-        }
-        // the input tile and both weight slabs are dead: request the next tile before storing this one
         const int next = tile + gridDim.x;
-        if (next < ntiles) { stage_input(next); stage_weights(0, 0); }
+        if constexpr (PIPE == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the input tile and of tap 0's weights (and its old stores)
+            __syncthreads();
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) stage_weights(tap + 1, (tap + 1) & 1);
+                f16x8 af[2][8], bf[2][8];
+                load_frags(tap, s_w + (tap & 1) * W_BYTES, af, bf);
+                mfmas(acc, af, bf);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tap's weights (this wave's pieces)
+                __syncthreads();                                      // ... everyone's; and everyone is done with this tap's slab
+            }
+            // the input tile and both weight slabs are dead: request the next tile before storing this one
+            if (next < ntiles) { stage_input(next); stage_weights(0, 0); }
+        } else {
+            f16x8 af[2][2][8], bf[2][2][8];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // slab of tap t: t % 3.  On entry the DMAs in flight are those of tap + 1's slab (tap 0: also the input tile and slab 0)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                 // slab tap + 1 complete; every wave has read tap's fragments, so slab (tap + 2) % 3 (= tap - 1's) is free
+                if (tap == 0) load_frags(0, s_w, af[0], bf[0]);
+                if (tap + 2 < 9) stage_weights(tap + 2, (tap + 2) % 3);
+                if (tap == 8 && next < ntiles) {         // the input tile was last read for tap 8's fragments (under tap 7): request the next tile now
+                    stage_input(next);
+                    stage_weights(0, 0);
+                    stage_weights(1, 1);
+                }
+                if (tap + 1 < 9) load_frags(tap + 1, s_w + ((tap + 1) % 3) * W_BYTES, af[(tap + 1) & 1], bf[(tap + 1) & 1]);
+                mfmas(acc, af[tap & 1], bf[tap & 1]);
+            }
+        }
 
         // ---- epilogue (EPI_STD semantics, gemm_kernels.h direct_epilogue_f16_impl LOM = 2) ----
         const int b = tile / tilesPerImg, t = tile - b * tilesPerImg;
@@ -218,7 +253,8 @@ int launch_conv3x3_c64(hipStream_t stream, const GemmArgs &a) {
     PB_CHECK(conv3x3_c64_supported(a), -1, "conv3x3_c64: unsupported shape / layout");
     static bool attr_set = false;
     if (!attr_set) {
-        PB_HIP(hipFuncSetAttribute((const void *)conv3x3_c64_mx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        PB_HIP(hipFuncSetAttribute((const void *)conv3x3_c64_mx_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        PB_HIP(hipFuncSetAttribute((const void *)conv3x3_c64_mx_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
     const int tilesX = (a.cW + TW - 1) / TW, tilesY = (a.cH + TH - 1) / TH, nimg = a.M / (a.cH * a.cW);
@@ -232,8 +268,11 @@ int launch_conv3x3_c64(hipStream_t stream, const GemmArgs &a) {
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int grid = ntiles < ncu ? ntiles : ncu;
-    pb_gemm_set_last_kernel("conv3x3_c64_mx_kernel");
-    hipLaunchKernelGGL(conv3x3_c64_mx_kernel, dim3(grid), dim3(256), SMEM, stream, a, tilesX, tilesX * tilesY, ntiles);
+    static int pipe = -1;
+    if (pipe < 0) { const char *e = getenv("PB_HALO"); pipe = e && atoi(e) == 1 ? 0 : 1; }      // PB_HALO=1: the unpipelined first version (A/B)
+    pb_gemm_set_last_kernel(pipe ? "conv3x3_c64_mx_kernel<1>" : "conv3x3_c64_mx_kernel<0>");
+    if (pipe) hipLaunchKernelGGL(conv3x3_c64_mx_kernel<1>, dim3(grid), dim3(256), SMEM, stream, a, tilesX, tilesX * tilesY, ntiles);
+    else hipLaunchKernelGGL(conv3x3_c64_mx_kernel<0>, dim3(grid), dim3(256), SMEM, stream, a, tilesX, tilesX * tilesY, ntiles);
     PB_HIP(hipGetLastError());
     return 0;
 }
