@@ -76,7 +76,8 @@ class DepthEngine {
     int prepare(int B, int H, int W);
     int run_chunk(const uint8_t *frames, int n, float *depth_out, uint8_t *rgb_out, float *mn, float *mx, int flip);
     int vit(int n);
-    int head(int n);
+    int head(int f0, int n);
+    int tail(int n, float *depth_out, uint8_t *rgb_out, float *mn, float *mx, int flip);
     // ZoeDepth metric head (engine_zoe.hip)
     int load_metric();
     int plan_metric(int B, int H, int W);
@@ -125,6 +126,7 @@ class DepthEngine {
 
     // plan
     int pB_ = 0, pH_ = 0, pW_ = 0, last_n_ = 0;
+    int hB_ = 1;                                // frames per DPT-head chunk (<= batch_cap: 32-bit offsets of the high-resolution split maps)
     int nh_ = 0, nw_ = 0, gh_ = 0, gw_ = 0, ntok_ = 0, ntp_ = 0, P_ = 0;
     int lh_[4] = {0, 0, 0, 0}, lw_[4] = {0, 0, 0, 0};      // DPT level sizes (level 0 = finest)
     char *arena_ = nullptr;

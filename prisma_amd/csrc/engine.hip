@@ -510,8 +510,14 @@ int DepthEngine::prepare(int B, int H, int W) {
     lh_[0] = 4 * gh_; lw_[0] = 4 * gw_; lh_[1] = 2 * gh_; lw_[1] = 2 * gw_; lh_[2] = gh_; lw_[2] = gw_;
     lh_[3] = (gh_ - 1) / 2 + 1; lw_[3] = (gw_ - 1) / 2 + 1;
     const int D = cfg_.embed_dim, F = cfg_.features, Fp = cp64(F), F2p = cp64(F / 2);
-    // GEMM row indices and per-tensor element offsets are 32-bit in the kernels (infer() chunks by batch_cap)
-    PB_CHECK((int64_t)B * nh_ * nw_ * F2p * hs_ < (1LL << 31) && (int64_t)B * 4 * lh_[0] * lw_[0] * Fp * hs_ < (1LL << 31), PB_ERR_ARG,
+    // GEMM row indices and per-tensor element offsets are 32-bit in the kernels.  The ViT's largest tensor (the fc1 output, 4 D x 1.5 halfs
+    // per token) allows ~140 frames per launch; the DPT head's high-resolution split maps only batch_cap() of them (16 at 518 x 924): a call
+    // runs the ViT on all B frames at once - its N = 1024 GEMMs have 2.4 rounds of tiles at 16 frames (3 rounds paid) but 4.8 at 32 -
+    // and the head in chunks of HB frames (run_chunk)
+    const int HB = std::min(B, batch_cap(H, W));
+    hB_ = HB;
+    PB_CHECK((int64_t)HB * nh_ * nw_ * F2p * hs_ < (1LL << 31) && (int64_t)HB * 4 * lh_[0] * lw_[0] * Fp * hs_ < (1LL << 31) &&
+                 (int64_t)B * ntp_ * 4 * D * 3 / 2 < (1LL << 31), PB_ERR_ARG,
              "batch %d too large for %dx%d frames (32-bit tensor offsets); lower max_batch", B, H, W);
     const int64_t rows = round_up((int64_t)B * ntp_, 256);
     const size_t slack = 32768;
@@ -532,23 +538,23 @@ int DepthEngine::prepare(int B, int H, int W) {
         // split-fp16 head (hs_ = 2): every head map holds [hi | lo] per pixel / token
         for (int i = 0; i < 4; ++i) feat_[i] = (f16 *)carve((size_t)round_up((int64_t)B * P_, 256) * D * 2 * hs_);
         for (int i = 0; i < 4; ++i) {
-            const size_t pix = (size_t)round_up((int64_t)B * lh_[i] * lw_[i], 256) * hs_;
+            const size_t pix = (size_t)round_up((int64_t)HB * lh_[i] * lw_[i], 256) * hs_;
             const int ocp = cp64(cfg_.out_channels[i]);
-            pj_[i] = (f16 *)carve((size_t)round_up((int64_t)B * P_, 256) * ocp * 2 * hs_);
+            pj_[i] = (f16 *)carve((size_t)round_up((int64_t)HB * P_, 256) * ocp * 2 * hs_);
             lay_[i] = i == 2 ? pj_[2] : (f16 *)carve(pix * ocp * 2);
             rnraw_[i] = (f16 *)carve(pix * Fp * 2); rnrelu_[i] = (f16 *)carve(pix * Fp * 2);
             tmp_[i] = (f16 *)carve(pix * Fp * 2);
             sraw_[i] = (f16 *)carve(pix * Fp * 2); srelu_[i] = (f16 *)carve(pix * Fp * 2);
             yb_[i] = (f16 *)carve(pix * Fp * 2); ocb_[i] = (f16 *)carve(pix * Fp * 2);
             const int th = i == 0 ? 2 * lh_[0] : lh_[i - 1], tw = i == 0 ? 2 * lw_[0] : lw_[i - 1];
-            path_[i] = (f16 *)carve((size_t)round_up((int64_t)B * th * tw, 256) * Fp * 2 * hs_);
+            path_[i] = (f16 *)carve((size_t)round_up((int64_t)HB * th * tw, 256) * Fp * 2 * hs_);
         }
-        o1_ = (f16 *)carve((size_t)round_up((int64_t)B * 4 * lh_[0] * lw_[0], 256) * F2p * 2 * hs_);
-        up_ = (f16 *)carve((size_t)round_up((int64_t)B * nh_ * nw_, 256) * F2p * 2 * hs_);
-        netd_ = (float *)carve((size_t)B * nh_ * nw_ * 4);
-        full_ = (float *)carve((size_t)B * H * W * 4);
-        mm_ = (unsigned *)carve((size_t)B * 8);
-        if (cfg_.metric && (r = plan_metric(B, H, W))) return r;
+        o1_ = (f16 *)carve((size_t)round_up((int64_t)HB * 4 * lh_[0] * lw_[0], 256) * F2p * 2 * hs_);
+        up_ = (f16 *)carve((size_t)round_up((int64_t)HB * nh_ * nw_, 256) * F2p * 2 * hs_);
+        netd_ = (float *)carve((size_t)HB * nh_ * nw_ * 4);
+        full_ = (float *)carve((size_t)HB * H * W * 4);
+        mm_ = (unsigned *)carve((size_t)HB * 8);
+        if (cfg_.metric && (r = plan_metric(HB, H, W))) return r;
         if (pass == 0) {
             if (arena_off_ > arena_bytes_) {
                 if (arena_) PB_HIP(hipFree(arena_));
@@ -714,7 +720,8 @@ int DepthEngine::vit(int n) {
     return 0;
 }
 
-int DepthEngine::head(int n) {
+// frames [f0, f0 + n) of the ViT batch (the four normalised taps feat_[i] hold all of it)
+int DepthEngine::head(int f0, int n) {
     const int D = cfg_.embed_dim, F = cfg_.features, Fp = cp64(F), F2 = F / 2, F2p = cp64(F2);
     const int *oc = cfg_.out_channels;
     int r;
@@ -732,7 +739,7 @@ int DepthEngine::head(int n) {
     // reassemble: 1x1 projection of each tap, then x4 / x2 transposed convs, identity, 3x3 stride 2
     for (int i = 0; i < 4; ++i) {
         GemmArgs a;
-        a.A = feat_[i]; a.lda = hs * D; a.M = n * P_; a.out = pj_[i]; a.ldo = hs * cp64(oc[i]); a.lo_off = lo(cp64(oc[i]));
+        a.A = feat_[i] + (int64_t)f0 * P_ * hs * D; a.lda = hs * D; a.M = n * P_; a.out = pj_[i]; a.ldo = hs * cp64(oc[i]); a.lo_off = lo(cp64(oc[i]));
         if ((r = gemm(A_DENSE, EPI_STD, a, proj_[i]))) return r;
     }
     for (int i = 0; i < 2; ++i) {
@@ -808,7 +815,23 @@ int DepthEngine::run_chunk(const uint8_t *frames, int n, float *depth_out, uint8
     toc();
     if (r) return r;
     if ((r = vit(n))) return r;
-    if ((r = head(n))) return r;
+    // the DPT head and the tail in balanced chunks of at most hB_ frames (32-bit offsets of the high-resolution split maps)
+    const int nch = (n + hB_ - 1) / hB_, step = (n + nch - 1) / nch;
+    const int64_t px = (int64_t)pH_ * pW_;
+    for (int f0 = 0; f0 < n; f0 += step) {
+        const int c = std::min(step, n - f0);
+        last_n_ = c;                                     // the head's stages hold the last head chunk
+        if ((r = head(f0, c))) return r;
+        if ((r = tail(c, depth_out ? depth_out + f0 * px : nullptr, rgb_out ? rgb_out + f0 * px * 3 : nullptr, mn ? mn + f0 : nullptr,
+                      mx ? mx + f0 : nullptr, flip)))
+            return r;
+    }
+    return 0;
+}
+
+// net depth of the n frames the head just produced -> band resize, per-frame min / max, heat encode (reference :132-133, :215-221)
+int DepthEngine::tail(int n, float *depth_out, uint8_t *rgb_out, float *mn, float *mx, int flip) {
+    int r;
     // dpt.py:163-164 (bilinear to the same size with align_corners=True, ReLU) is the identity on netd_.
     float *full = depth_out ? depth_out : full_;
     if (cfg_.metric) {      // ZoeDepth head -> Pillow resize to the frame -> per-frame min / max -> heat encode
@@ -839,7 +862,7 @@ int DepthEngine::infer(const uint8_t *frames, int n, int H, int W, float *depth_
                        float *mx, int flip) {
     PB_CHECK(frames && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "infer: bad arguments");
     PB_HIP(hipSetDevice(device));
-    const int cap = std::min(std::max(1, cfg_.max_batch), batch_cap(H, W));
+    const int cap = std::max(1, cfg_.max_batch);         // frames per ViT launch; the head runs in chunks of batch_cap(H, W) inside (run_chunk)
     int r = prepare(std::min(n, cap), H, W);
     if (r) return r;
     timer.reset();
