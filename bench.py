@@ -354,8 +354,18 @@ def main():
 
     from prisma_amd import engine, synth
     cfg = synth.DEPTH_CFGS[args.encoder]
-    weights = synth.depth_anything_weights(cfg, seed=1234)
-    rweights = synth.raft_weights(seed=4321)
+    if world > 1:
+        # one rank generates the seeded weights (~10 s of one core for ViT-L), the others map them from the node's tmpfs (synth.cached_weights):
+        # an 8-rank launch does not spend its start-up with eight processes competing for the host cores over identical tensors
+        if rank == 0:
+            synth.cached_weights("depth", cfg, 1234)
+            synth.cached_weights("raft", 4321)
+        R.barrier()
+        weights = synth.cached_weights("depth", cfg, 1234)
+        rweights = synth.cached_weights("raft", 4321)
+    else:
+        weights = synth.depth_anything_weights(cfg, seed=1234)
+        rweights = synth.raft_weights(seed=4321)
     B, H, W = args.batch, args.height, args.width
 
     # one synthetic clip per rank (a seeded noise texture shifted by a known step per frame, so the flow is not degenerate),

@@ -614,3 +614,41 @@ def raft_weights_heavy(seed: int = 4321, up: float = 30.0, down: float = 7.5) ->
         ch = _heavy_channels(seed, enc + ".conv2", 128, 3)
         w[enc + ".conv2.weight"][:, ch] *= np.float32(4.0)
     return w
+
+
+# ----------------------------------------------------------------------------
+# Weight cache for multi-rank launches: the ranks of one node all need the same seeded tensors, and generating ViT-L's 335 M parameters
+# takes ~10 s of one core.  bench.py lets rank 0 generate and store them (uncompressed .npy files in a tmpfs directory keyed by generator,
+# arguments and this file's hash), waits on a barrier and has the other ranks memory-map the files.
+# ----------------------------------------------------------------------------
+def _cache_dir(kind: str, key: str) -> str:
+    import hashlib
+    import os
+    src = hashlib.sha1(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:12]
+    base = os.environ.get("PRISMA_SYNTH_CACHE") or ("/dev/shm/prisma_synth_cache" if os.path.isdir("/dev/shm") else os.path.join(os.path.expanduser("~"), ".cache", "prisma_synth"))
+    return os.path.join(base, f"{kind}-{key}-{src}")
+
+
+def cached_weights(kind: str, *args) -> Dict[str, np.ndarray]:
+    """{"depth": depth_anything_weights, "raft": raft_weights, "gmflow": gmflow_weights, "solov2": solov2_weights}[kind](*args), through
+    the cache.  A complete cache entry has a `done` marker written last; an incomplete one is regenerated privately (no locks needed)."""
+    import os
+    gen = {"depth": depth_anything_weights, "raft": raft_weights, "gmflow": gmflow_weights, "solov2": solov2_weights}[kind]
+    key = "_".join(str(getattr(a, "name", a)) for a in args) or "default"
+    d = _cache_dir(kind, key)
+    if os.path.exists(os.path.join(d, "done")):
+        names = [l.rstrip("\n") for l in open(os.path.join(d, "names.txt"))]
+        return {n: np.load(os.path.join(d, "%04d.npy" % i), mmap_mode="r") for i, n in enumerate(names)}
+    w = gen(*args)
+    try:
+        tmp = d + ".tmp.%d" % os.getpid()
+        os.makedirs(tmp, exist_ok=True)
+        for i, (n, v) in enumerate(w.items()):
+            np.save(os.path.join(tmp, "%04d.npy" % i), np.asarray(v))
+        with open(os.path.join(tmp, "names.txt"), "w") as f:
+            f.writelines(n + "\n" for n in w)
+        open(os.path.join(tmp, "done"), "w").close()
+        os.replace(tmp, d)                  # atomic publish; if another process won the race the rename fails and its entry is used next time
+    except OSError:
+        pass
+    return w

@@ -139,3 +139,17 @@ def test_two_concurrent_relays_do_not_share_a_spool(tmp_path, monkeypatch):
         assert muxed == [i % 251 for i in range(40)] and not left and mx == list(map(float, range(40)))
         spools.append(spool)
     assert spools[0] != spools[1] and all(s.startswith(str(tmp_path)) for s in spools)
+
+
+def test_cached_weights_equal_generated_ones(tmp_path, monkeypatch):
+    """bench.py's multi-rank start-up: rank 0 generates the seeded weights once, the others memory-map them (synth.cached_weights)."""
+    from prisma_amd import synth
+    monkeypatch.setenv("PRISMA_SYNTH_CACHE", str(tmp_path))
+    first = synth.cached_weights("raft", 4321)               # generated + stored
+    again = synth.cached_weights("raft", 4321)               # memory-mapped
+    ref = synth.raft_weights(4321)
+    assert list(first) == list(again) == list(ref)
+    assert all(np.array_equal(np.asarray(again[k]), ref[k]) and np.asarray(again[k]).dtype == ref[k].dtype for k in ref)
+    assert isinstance(again["fnet.conv1.weight"], np.memmap)
+    small = synth.cached_weights("depth", synth.DEPTH_CFGS["vits"], 7)
+    assert np.array_equal(np.asarray(synth.cached_weights("depth", synth.DEPTH_CFGS["vits"], 7)["pretrained.cls_token"]), small["pretrained.cls_token"])
