@@ -32,6 +32,10 @@ class RaftEngine : public EngineBase {
     int prepare(int F, int H, int W, float scale, int dirs);
     Enc fnet_, cnet_;
     PackedW convc1_, convc2_, convf1_, convf2_, convm_, zr_[2], q_[2], fh1_, fh2_, mk0_, mk2_;
+    // context hoist (raft_engine.hip load()): zr_ / q_ then cover [h | motion] only, zr_in_ / q_in_ the context features' 128 channels
+    PackedW zr_in_[2], q_in_[2];
+    int hoist_ = 0;
+    float *gz_[2] = {}, *gq_[2] = {};
 
     // plan
     int pF_ = 0, pH_ = 0, pW_ = 0, pD_ = 0;

@@ -139,6 +139,15 @@ int RaftEngine::load(const pb_tensor *w, int n) {
                 for (int tp = 0; tp < 49; ++tp) g[(size_t)o * 98 + tp * 2 + c] = wt[((size_t)o * 2 + c) * 49 + tp];
         if ((r = pack(g.data(), 128, 98, 128, convf1_, (const float *)ib->second->data))) return r;
     }
+    // Context hoist (default; PB_GRU_HOIST=0 or PB_MX_UPD=1 turn it off): the GRU's input is cat(h, inp, motion) and `inp` - the context
+    // features - does not change over the iterations (raft.py:112-115, update.py:131).  A convolution is linear in its input channels, so
+    // the inp share of every gate's pre-activation is computed ONCE per frame pair (fp32, bias-free) and the per-iteration convolutions run
+    // on [h | motion] alone (K = 5 x 256 instead of 5 x 384), their accumulators starting from that share (gemm.h acc0).  The buffers hold
+    // [h | motion | inp] so that the two varying parts are adjacent.
+    {
+        const char *e = getenv("PB_GRU_HOIST");
+        hoist_ = !upd8_ && !(e && e[0] == '0');
+    }
     for (int half = 0; half < 2; ++half) {
         // z and r gates share their input: one GEMM with N = 256 ([z | r]); q separately
         const std::string sfx = std::to_string(half + 1);
@@ -148,19 +157,43 @@ int RaftEngine::load(const pb_tensor *w, int n) {
         };
         const pb_tensor *wz = get(u + "gru.convz" + sfx + ".weight"), *wr = get(u + "gru.convr" + sfx + ".weight");
         const pb_tensor *bz = get(u + "gru.convz" + sfx + ".bias"), *br = get(u + "gru.convr" + sfx + ".bias");
-        PB_CHECK(wz && wr && bz && br, PB_ERR_ARG, "missing gru z/r weights");
-        const int K = 5 * 384;
-        std::vector<float> g((size_t)256 * K, 0.f), bb(256);
-        for (int part = 0; part < 2; ++part) {
-            const float *wt = (const float *)(part == 0 ? wz : wr)->data, *bs = (const float *)(part == 0 ? bz : br)->data;
-            for (int o = 0; o < 128; ++o) {
-                for (int c = 0; c < 384; ++c)
-                    for (int tp = 0; tp < 5; ++tp) g[(size_t)(part * 128 + o) * K + tp * 384 + c] = wt[((size_t)o * 384 + c) * 5 + tp];
-                bb[part * 128 + o] = bs[o];
-            }
+        const pb_tensor *wq = get(u + "gru.convq" + sfx + ".weight"), *bq = get(u + "gru.convq" + sfx + ".bias");
+        PB_CHECK(wz && wr && bz && br && wq && bq, PB_ERR_ARG, "missing gru weights");
+        // rows [o][tap][c] over the channel range [c0, c0 + nc) of the reference's 384 input channels (h 0..127, inp 128..255, motion 256..383),
+        // written at column offset `dst` of a [taps x width] row
+        auto fill = [&](std::vector<float> &g, int row0, int width, int dst, const pb_tensor *w, int c0, int nc) {
+            const float *wt = (const float *)w->data;
+            for (int o = 0; o < 128; ++o)
+                for (int c = 0; c < nc; ++c)
+                    for (int tp = 0; tp < 5; ++tp) g[(size_t)(row0 + o) * 5 * width + tp * width + dst + c] = wt[((size_t)o * 384 + c0 + c) * 5 + tp];
+        };
+        std::vector<float> bb(256);
+        for (int o = 0; o < 128; ++o) { bb[o] = ((const float *)bz->data)[o]; bb[128 + o] = ((const float *)br->data)[o]; }
+        if (!hoist_) {
+            const int K = 5 * 384;
+            std::vector<float> g((size_t)256 * K, 0.f);
+            fill(g, 0, 384, 0, wz, 0, 384);
+            fill(g, 128, 384, 0, wr, 0, 384);
+            if ((r = pack(g.data(), 256, K, K, zr_[half], bb.data(), 5))) return r;
+            if ((r = pack_conv(u + "gru.convq" + sfx, true, nullptr, nullptr, q_[half]))) return r;
+            continue;
         }
-        if ((r = pack(g.data(), 256, K, K, zr_[half], bb.data(), 5))) return r;
-        if ((r = pack_conv(u + "gru.convq" + sfx, true, nullptr, nullptr, q_[half]))) return r;
+        {   // [h | motion] parts (with the biases) and the inp parts (bias-free: their result is the accumulators' starting value)
+            std::vector<float> g((size_t)256 * 5 * 256, 0.f), gi((size_t)256 * 5 * 128, 0.f);
+            fill(g, 0, 256, 0, wz, 0, 128);   fill(g, 0, 256, 128, wz, 256, 128);
+            fill(g, 128, 256, 0, wr, 0, 128); fill(g, 128, 256, 128, wr, 256, 128);
+            fill(gi, 0, 128, 0, wz, 128, 128);
+            fill(gi, 128, 128, 0, wr, 128, 128);
+            if ((r = pack(g.data(), 256, 5 * 256, 5 * 256, zr_[half], bb.data(), 5))) return r;
+            if ((r = pack(gi.data(), 256, 5 * 128, 5 * 128, zr_in_[half], nullptr, 5))) return r;
+        }
+        {
+            std::vector<float> g((size_t)128 * 5 * 256, 0.f), gi((size_t)128 * 5 * 128, 0.f);
+            fill(g, 0, 256, 0, wq, 0, 128); fill(g, 0, 256, 128, wq, 256, 128);
+            fill(gi, 0, 128, 0, wq, 128, 128);
+            if ((r = pack(g.data(), 128, 5 * 256, 5 * 256, q_[half], (const float *)bq->data, 5))) return r;
+            if ((r = pack(gi.data(), 128, 5 * 128, 5 * 128, q_in_[half], nullptr, 5))) return r;
+        }
     }
     if ((r = pack_conv(u + "flow_head.conv1", true, nullptr, nullptr, fh1_))) return r;
     pack_mx2_ = 0;                                          // flow_head2 is a direct kernel, mask.2 an fp32-output GEMM: fp16 residuals
@@ -215,6 +248,10 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         corflo_ = (f16 *)carve((size_t)rows * 256 * u8); fa_ = (f16 *)carve((size_t)rows * 128 * u8);
         f1_ = (f16 *)carve((size_t)rows * 128 * u8); zrb_ = (f16 *)carve((size_t)rows * 256 * 2);
         fh_ = (f16 *)carve((size_t)rows * 256 * 2);
+        for (int half = 0; half < 2; ++half) {            // the context features' share of the GRU pre-activations (hoist_), fp32
+            gz_[half] = hoist_ ? (float *)carve((size_t)rows * 256 * 4) : nullptr;
+            gq_[half] = hoist_ ? (float *)carve((size_t)rows * 128 * 4) : nullptr;
+        }
         m0_ = (f16 *)carve((size_t)rows * 256 * 2);
         up_ = (float *)carve((size_t)ND * sh_ * sw_ * 2 * 4);
         maxd_ = (unsigned *)carve((size_t)ND * 4);
@@ -417,12 +454,33 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
             }
             tic(F_ELT, 0, 0);
             r = launch_init_state(stream, ctx_ + (int64_t)(i + d) * P_ * 256, h32_ + (int64_t)n * P_ * 128,
-                                  hx_ + (int64_t)n * P_ * Lhx, hx2_ + (int64_t)n * P_ * Lhx, flow_ + (int64_t)n * P_ * 2, P_, Lhx, upd8_ ? 768 : 0, s8);
+                                  hx_ + (int64_t)n * P_ * Lhx, hx2_ + (int64_t)n * P_ * Lhx, flow_ + (int64_t)n * P_ * 2, P_, Lhx, upd8_ ? 768 : 0, s8, hoist_ ? 256 : 128);
             toc();
             if (r) return r;
         }
 
     if (debug && (r = snapshot("net0", h32_, (size_t)ND * P_ * 128 * 4, Stage{nullptr, 0, 0, P_, 1, 128, 128, (int64_t)P_ * 128}))) return r;
+
+    // ---- the context features' share of the SepConvGRU gates, once per call (hoist_, see load()) ----
+    const int mot = hoist_ ? 128 : 256;                     // channel offset of the motion features inside hx_ / hx2_
+    if (hoist_) {
+        for (int half = 0; half < 2; ++half)
+            for (int g = 0; g < 2; ++g) {
+                const PackedW &w = g == 0 ? zr_in_[half] : q_in_[half];
+                GemmArgs a;
+                a.A = hx_ + 256; a.N = w.N;
+                a.cH = h8_; a.cW = w8_; a.cC = 128; a.cLd = Lhx; a.cKW = half == 0 ? 5 : 1; a.cStride = 1;
+                a.cPad = half == 0 ? 0 : 2; a.cPadX = half == 0 ? 2 : 0;
+                a.cOH = h8_; a.cOW = w8_; a.M = ND * P_;
+                set_weights(a, w, true);
+                a.out32 = g == 0 ? gz_[half] : gq_[half]; a.ldo = w.N; a.scale = 1.f;
+                tic(F_CONV128, 2.0 * a.M * (double)w.N * w.Kreal, 2.0 * ((double)a.M * 128 + (double)w.N * w.Kreal) + 4.0 * a.M * w.N, 1.0 + w.sw);
+                r = launch_gemm(stream, A_CONV, EPI_F32, TILE_AUTO, a);
+                if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
+                toc();
+                if (r) return r;
+            }
+    }
 
     // ---- GRU iterations (raft.py:124-144, update.py:122-136) ----
     for (int it = 0; it < iters; ++it) {
@@ -443,19 +501,20 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         if ((r = conv(f1_, 128, L128, ND, h8_, w8_, 3, 3, 1, convf2_, corflo_ + 192, L256, ACT_RELU, 0, nullptr, nullptr, 0, 0, upd8_ ? 512 - 192 : 0))) return r;
         // HX = [h | inp | motion] feeds the z / r convs, HX2 = [r * h | inp | motion] the q conv: the motion features are
         // written to both by the producing conv (its ReLU'd second output), r * h and the state update by the GRU epilogues
-        ConvFuse dup; dup.out2 = hx2_ + 256;
-        if ((r = conv(corflo_, 256, L256, ND, h8_, w8_, 3, 3, 1, convm_, hx_ + 256, Lhx, ACT_RELU, 0, nullptr, &dup, 0, 0, upd8_ ? 768 - 256 : 0))) return r;
+        ConvFuse dup; dup.out2 = hx2_ + mot;
+        if ((r = conv(corflo_, 256, L256, ND, h8_, w8_, 3, 3, 1, convm_, hx_ + mot, Lhx, ACT_RELU, 0, nullptr, &dup, 0, 0, upd8_ ? 768 - 256 : 0))) return r;
         tic(F_ELT, 0, 0);
-        r = launch_put_flow(stream, flow_, hx_, hx2_, rows, Lhx, upd8_ ? 768 : 0, s8);
+        r = launch_put_flow(stream, flow_, hx_, hx2_, rows, Lhx, upd8_ ? 768 : 0, s8, mot + 126);
         toc();
         if (r) return r;
         // SepConvGRU: (1 x 5) then (5 x 1)
         for (int half = 0; half < 2; ++half) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1;
-            ConvFuse fz; fz.gru_h = h32_; fz.gru_rh = hx2_; fz.gru_ld = Lhx;
-            if ((r = conv(hx_, 384, Lhx, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_GRU_ZR, 0, nullptr, &fz, 0, 0, upd8_ ? 768 : 0))) return r;
-            ConvFuse fq; fq.gru_h = h32_; fq.gru_z = zrb_;
-            if ((r = conv(hx2_, 384, Lhx, ND, h8_, w8_, kh, kw, 1, q_[half], hx_, Lhx, ACT_GRU_Q, 0, nullptr, &fq, 0, 0, upd8_ ? 768 : 0))) return r;
+            const int gc = hoist_ ? 256 : 384;               // channels the per-iteration convolutions read: [h | motion] (+ inp without the hoist)
+            ConvFuse fz; fz.gru_h = h32_; fz.gru_rh = hx2_; fz.gru_ld = Lhx; fz.acc0 = gz_[half]; fz.ld0 = 256;
+            if ((r = conv(hx_, gc, Lhx, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_GRU_ZR, 0, nullptr, &fz, 0, 0, upd8_ ? 768 : 0))) return r;
+            ConvFuse fq; fq.gru_h = h32_; fq.gru_z = zrb_; fq.acc0 = gq_[half]; fq.ld0 = 128;
+            if ((r = conv(hx2_, gc, Lhx, ND, h8_, w8_, kh, kw, 1, q_[half], hx_, Lhx, ACT_GRU_Q, 0, nullptr, &fq, 0, 0, upd8_ ? 768 : 0))) return r;
         }
         // FlowHead -> delta_flow (fp32), coords1 += delta (the h slice's fp8 copy sits 384 halfs after it)
         if ((r = conv(hx_, 128, Lhx, ND, h8_, w8_, 3, 3, 1, fh1_, fh_, 256, ACT_RELU, 0, nullptr, nullptr, 0, upd8_ ? 384 : 0))) return r;

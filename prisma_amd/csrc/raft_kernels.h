@@ -13,7 +13,7 @@ int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, 
                     int C, int ldc, int lo_off = 0, int lo8_pa = -1);
 // ld: pixel stride of hx / hx2 (384, or 576 with the fp8 copy at byte o8_off = 768, scaled by o8_scale)
 int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows, int ld = 384, int o8_off = 0,
-                      float o8_scale = 16.f);
+                      float o8_scale = 16.f, int inp_off = 128);      // inp_off: channel offset of the context features inside hx / hx2
 int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C);
 int launch_corr_tile(hipStream_t s, const f16 *x, f16 *y, int F, int h, int w, int wp, int npad);
 // volume.hip: out[M, N] fp16 = A[M, 256] . W[N, 256]^T (one pair, one pyramid level); W has w_rows >= N addressable rows; the
@@ -22,7 +22,8 @@ int launch_corr_volume(hipStream_t s, const f16 *A, int M, const f16 *W, int N, 
 int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], const int w[4], const int wp[4], const int ld[4],
                        const float *flow, int P, int w8, f16 *out, int64_t rows, int ldo = 384, int o8_off = 0, float o8_scale = 16.f);
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W, int split = 0);
-int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows, int ld = 384, int o8_off = 0, float o8_scale = 16.f);
+int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows, int ld = 384, int o8_off = 0, float o8_scale = 16.f,
+                    int flow_off = 382);       // flow_off: channel offset of the two flow channels inside hx / hx2
 int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, int h8, int w8, int pad_l, int pad_t, int sh,
                     int sw, float *out, unsigned *maxd);
 int launch_flow_encode(hipStream_t s, const float *flow, int N, int sh, int sw, const unsigned *maxd, uint8_t *rgb,

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const f16 *__restrict__ a
 // inp = relu(c[128:]) in HX[:, 128:256]; flow = 0.
 __global__ __launch_bounds__(256) void init_state_kernel(const f16 *__restrict__ c, float *__restrict__ h32,
                                                           f16 *__restrict__ hx, f16 *__restrict__ hx2, float *__restrict__ flow, int64_t rows,
-                                                          int ld, int o8_off, float o8_scale) {
+                                                          int ld, int o8_off, float o8_scale, int inp_off) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * 32) return;
     const int c8 = (int)(i % 32);
@@ -284,14 +284,15 @@ __global__ __launch_bounds__(256) void init_state_kernel(const f16 *__restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (f16)fmaxf((float)v[j], 0.f);
     }
-    *(f16x8 *)(hx + r * ld + c8 * 8) = o;
-    if (c8 >= 16) *(f16x8 *)(hx2 + r * ld + c8 * 8) = o;      // the context half of the q conv's input [r * h | inp | motion]
+    const int dc = c8 < 16 ? c8 * 8 : inp_off + (c8 - 16) * 8;      // h at 0, the context features at inp_off (128, or 256 with the hoisted layout [h | motion | inp])
+    *(f16x8 *)(hx + r * ld + dc) = o;
+    if (c8 >= 16) *(f16x8 *)(hx2 + r * ld + dc) = o;          // the context part of the q conv's input
     if (o8_off) {
         int2 o8;
         o8.x = pb_fp8x4((float)o[0] * o8_scale, (float)o[1] * o8_scale, (float)o[2] * o8_scale, (float)o[3] * o8_scale);
         o8.y = pb_fp8x4((float)o[4] * o8_scale, (float)o[5] * o8_scale, (float)o[6] * o8_scale, (float)o[7] * o8_scale);
-        *(int2 *)((char *)(hx + r * ld) + o8_off + c8 * 8) = o8;
-        if (c8 >= 16) *(int2 *)((char *)(hx2 + r * ld) + o8_off + c8 * 8) = o8;
+        *(int2 *)((char *)(hx + r * ld) + o8_off + dc) = o8;
+        if (c8 >= 16) *(int2 *)((char *)(hx2 + r * ld) + o8_off + dc) = o8;
     }
     if (c8 == 0) { flow[r * 2] = 0.f; flow[r * 2 + 1] = 0.f; }
 }
@@ -429,17 +430,17 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const floa
 
 // flow (fp32 [rows][2]) -> HX[:, 382:384] (the last two input channels of the GRU, update.py:97)
 __global__ void put_flow_kernel(const float *__restrict__ flow, f16 *__restrict__ hx, f16 *__restrict__ hx2, int64_t rows, int ld, int o8_off,
-                                float o8_scale) {
+                                float o8_scale, int flow_off) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     f16x2 o;
     o[0] = (f16)flow[r * 2]; o[1] = (f16)flow[r * 2 + 1];
-    *(f16x2 *)(hx + r * ld + 382) = o;
-    *(f16x2 *)(hx2 + r * ld + 382) = o;
+    *(f16x2 *)(hx + r * ld + flow_off) = o;
+    *(f16x2 *)(hx2 + r * ld + flow_off) = o;
     if (o8_off) {
         const unsigned short o8 = pb_fp8x2((float)o[0] * o8_scale, (float)o[1] * o8_scale);
-        *(unsigned short *)((char *)(hx + r * ld) + o8_off + 382) = o8;
-        *(unsigned short *)((char *)(hx2 + r * ld) + o8_off + 382) = o8;
+        *(unsigned short *)((char *)(hx + r * ld) + o8_off + flow_off) = o8;
+        *(unsigned short *)((char *)(hx2 + r * ld) + o8_off + flow_off) = o8;
     }
 }
 
@@ -672,8 +673,8 @@ int launch_in_apply(hipStream_t s, const f16 *a, const float *sa, const f16 *b, 
     hipLaunchKernelGGL(in_apply_kernel, dim3(nblk((int64_t)B * HW * (C / 8))), dim3(256), 0, s, a, sa, b, sb, out, B, HW, C / 8, ldc, lo_off, lo8_pa);
     LAUNCH_CHECK();
 }
-int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows, int ld, int o8_off, float o8_scale) {
-    hipLaunchKernelGGL(init_state_kernel, dim3(nblk(rows * 32)), dim3(256), 0, s, c, h32, hx, hx2, flow, rows, ld, o8_off, o8_scale);
+int launch_init_state(hipStream_t s, const f16 *c, float *h32, f16 *hx, f16 *hx2, float *flow, int64_t rows, int ld, int o8_off, float o8_scale, int inp_off) {
+    hipLaunchKernelGGL(init_state_kernel, dim3(nblk(rows * 32)), dim3(256), 0, s, c, h32, hx, hx2, flow, rows, ld, o8_off, o8_scale, inp_off);
     LAUNCH_CHECK();
 }
 int launch_avgpool2_nhwc(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C) {
@@ -692,8 +693,8 @@ int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], co
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)((rows + 6) / 7)), dim3(256), 0, s, py, flow, P, w8, out, rows, ldo, o8_off, o8_scale);
     LAUNCH_CHECK();
 }
-int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows, int ld, int o8_off, float o8_scale) {
-    hipLaunchKernelGGL(put_flow_kernel, dim3(nblk(rows)), dim3(256), 0, s, flow, hx, hx2, rows, ld, o8_off, o8_scale);
+int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows, int ld, int o8_off, float o8_scale, int flow_off) {
+    hipLaunchKernelGGL(put_flow_kernel, dim3(nblk(rows)), dim3(256), 0, s, flow, hx, hx2, rows, ld, o8_off, o8_scale, flow_off);
     LAUNCH_CHECK();
 }
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W, int split) {
