@@ -848,7 +848,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if constexpr (EPI == EPI_RESID) resid_io<TM, TN, false>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
-    if constexpr (EPI == EPI_STD && AMODE == A_CONV && TN == 2) {
+    if constexpr (EPI == EPI_STD && AMODE == A_CONV && TN == 2 && !MX) {      // (fp16-only builds: the MX build of this tile loses a workgroup per CU to the extra code)
         if (p.acc0) acc_init_f32<TM>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
     }
 
@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f16x8 fa[2][4], fb0[4], fb1[4];
     if constexpr (EPI == EPI_RESID) resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-    if constexpr (EPI == EPI_STD && AMODE == A_CONV) {
+    if constexpr (EPI == EPI_STD && AMODE == A_CONV && !MX) {
         if (p.acc0) acc_init_f32<4>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
     }
 

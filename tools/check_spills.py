@@ -1,5 +1,5 @@
 """Reads the -Rpass-analysis=kernel-resource-usage remarks the Makefile keeps per translation unit (prisma_amd/csrc/build/*.log), prints
-one line per kernel and fails when a GEMM kernel spills vector registers: a spill in the K loop of the 256 x 256 kernel costs 2-3x
+one line per kernel and fails when a GEMM kernel spills vector registers or loses its second wave per SIMD: a spill in the K loop of the 256 x 256 kernel costs 2-3x
 (round 2: a two-sided `if` in the conv tap cursor spilled 128 VGPRs in gemm8_kernel<1, 0, 0, *, true> and tripled the DPT head's time).
 python tools/check_spills.py [build_dir]"""
 import glob, os, re, subprocess, sys
@@ -26,7 +26,12 @@ for r, n in zip(rows, names):
     n = n if len(n) < 70 else n[:67] + "..."
     print("%-14s %-70s vgpr %3d agpr %3d scratch %4d occupancy %d" % (r["tu"], n, r.get("vgpr", -1), r.get("agpr", -1), r.get("scratch", -1), r.get("occ", -1)))
     if ("gemm8_kernel" in n or "gemm_kernel" in n) and r.get("vspill", 0) > 2:
-        bad.append((n, r.get("vspill")))
+        bad.append((n, "%d VGPRs spilled" % r.get("vspill")))
+    # the 128 x 128 / 256 x 64 / 256 x 32 tiles are built to run TWO workgroups per CU (4 waves each, <= 256 registers per lane), the ping-pong
+    # kernel two waves per SIMD: an edit that pushes VGPRs + AGPRs past 256 silently halves their latency hiding (round 3: a few lines in the
+    # prologue of gemm_kernel<128, 128, ..., MX> cost its second workgroup and 50 % of its speed) - fail the build instead
+    if ("gemm8_kernel<" in n or "gemm_kernel<" in n) and r.get("occ", 2) < 2:
+        bad.append((n, "occupancy %d (vgpr %d + agpr %d)" % (r.get("occ", -1), r.get("vgpr", -1), r.get("agpr", -1))))
 if bad:
-    sys.exit("GEMM kernels spilling vector registers: %s" % bad)
-print("%d kernels, no GEMM kernel spills more than 2 VGPRs" % len(rows))
+    sys.exit("GEMM kernels with register problems: %s" % bad)
+print("%d kernels, no GEMM kernel spills more than 2 VGPRs or drops below two waves per SIMD" % len(rows))
