@@ -61,7 +61,7 @@ class EngineBase {
     void toc();
     // fusion hooks of one conv() call: a second (ReLU'd) copy of the output, and the SepConvGRU epilogues (gemm.h ACT_GRU_*)
     struct ConvFuse { f16 *out2 = nullptr; float *gru_h = nullptr; const f16 *gru_z = nullptr; f16 *gru_rh = nullptr; int gru_ld = 384;
-                      const float *acc0 = nullptr; int ld0 = 0; };      // acc0: fp32 partial sum the accumulators start from (gemm.h)
+                      const f16 *add2 = nullptr; };       // add2: a second skip tensor (same row stride as the output), added next to add1
     // lo_off != 0: out (and add1) are split-fp16 maps, the rounding residual of every output goes to +lo_off (gemm.h)
     int conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh, int kw, int stride, const PackedW &w, f16 *out, int ldo,
              int act, int pre_relu = 0, const f16 *add1 = nullptr, const ConvFuse *fuse = nullptr, int lo_off = 0, int a8_rel = 0,

@@ -261,7 +261,7 @@ int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh
     a.M = n * a.cOH * a.cOW;
     a.out = out; a.ldo = ldo; a.act = act; a.pre_relu = pre_relu; a.add1 = add1; a.lo_off = lo_off;
     if (lo_off && mx_) { a.lo8 = 1; a.lo8_pa = kLo8Pa; }
-    if (fuse) { a.out2 = fuse->out2; a.gru_h = fuse->gru_h; a.gru_z = fuse->gru_z; a.gru_rh = fuse->gru_rh; a.gru_ld = fuse->gru_ld; a.acc0 = fuse->acc0; a.ld0 = fuse->ld0; }
+    if (fuse) { a.out2 = fuse->out2; a.gru_h = fuse->gru_h; a.gru_z = fuse->gru_z; a.gru_rh = fuse->gru_rh; a.gru_ld = fuse->gru_ld; a.add2 = fuse->add2; }
     if (w.mx2 && a8_rel && a8_rel != cC) { a.kwrap = cC; a.kshift = a8_rel - cC; }      // the fp8 copy of a channel slice is not adjacent
     if (o8_off) { a.o8_off = o8_off; a.o8_scale = (float)(1 << kMx2Pa); }
     PB_CHECK(!w.sw || w.Cseg == cC, PB_ERR_STATE, "split conv: %d channels, weights packed for %d", cC, w.Cseg);

@@ -66,11 +66,6 @@ struct GemmArgs {
     const f16 *gru_z = nullptr;
     f16 *gru_rh = nullptr;
     int pre_relu = 0;                     // EPI_STD: v = relu(acc + bias) before the skip adds
-    // EPI_STD convolutions: the accumulators START from acc0[m * ld0 + n] (fp32) instead of zero - a partial sum computed elsewhere, e.g.
-    // the contribution of input channels that do not change between the iterations of a recurrence (raft_engine.hip: the context
-    // features' share of the SepConvGRU convolutions is computed once per frame pair, not once per iteration)
-    const float *acc0 = nullptr;
-    int64_t ld0 = 0;
     float *out32 = nullptr;               // EPI_F32: out32[m*ldo + n] = (acc + bias) * scale
     float scale = 1.f;
     float *resid = nullptr;               // fp32 residual stream [rows, ldr]

@@ -55,7 +55,6 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
     // MX builds write / read split maps with e4m3 residual parts, fp16-only builds with fp16 residual parts
     PB_CHECK(!a.lo_off || (a.lo8 != 0) == mx, -1, "gemm: split-map format (lo8 = %d) does not match the weights' (nk16 = %d)", a.lo8, a.nk16);
     PB_CHECK(!a.o8_off || mx, -1, "gemm: an fp8 output copy needs an MX build");
-    PB_CHECK(!a.acc0 || (!mx && amode == A_CONV && epi == EPI_STD && tile != TILE_256x64 && a.N > 64), -1, "gemm: acc0 is built for fp16-only EPI_STD convolutions on the 128 / 256 tiles");
     if (amode == A_DENSE && epi == EPI_STD) return mx ? pb_gemm_dense_std_mx(stream, tile, a) : pb_gemm_dense_std_f16(stream, tile, a);
     if (amode == A_DENSE && epi == EPI_RESID) return mx ? pb_gemm_dense_resid_mx(stream, tile, a) : pb_gemm_dense_resid_f16(stream, tile, a);
     if (amode == A_DENSE && epi == EPI_QKV) return mx ? pb_gemm_dense_qkv_mx(stream, tile, a) : pb_gemm_dense_qkv_f16(stream, tile, a);

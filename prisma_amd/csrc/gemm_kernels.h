@@ -317,24 +317,6 @@ __device__ __forceinline__ void resid_io(const GemmArgs &p, f32x16 (&acc)[TM][TN
     }
 }
 
-// EPI_STD with GemmArgs::acc0: accumulators start from an fp32 partial sum.  Interleaved layout (TN == 2): lane li holds columns 2 li and
-// 2 li + 1 of a row in acc[.][0] / acc[.][1], i.e. one 8-byte load per row and 256 contiguous bytes per half wave.
-template <int TM>
-__device__ __forceinline__ void acc_init_f32(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
-    const int li = lane & 31, lh = lane >> 5;
-    const int n = wave_n0 + 2 * li;
-    const int nc = n + 1 < p.N ? n : 0;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = wave_m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int mc = m < p.M ? m : p.M - 1;
-            const f32x2 v = *(const f32x2 *)(p.acc0 + (int64_t)mc * p.ld0 + nc);
-            acc[tm][0][r] = v[0]; acc[tm][1][r] = v[1];
-        }
-}
-
 // ---- interleaved output columns (fp16 epilogues, TN == 2) -----------------------------------------
 // A global store instruction is cheapest when each half wave writes ONE contiguous 128-byte line (measured:
 // ~11 cycles per instruction and CU for 2 x 128 B against ~140 for the 8 x 128 B pattern of the LDS-transposed
@@ -848,9 +830,6 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if constexpr (EPI == EPI_RESID) resid_io<TM, TN, false>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
-    if constexpr (EPI == EPI_STD && AMODE == A_CONV && TN == 2 && !MX) {      // (fp16-only builds: the MX build of this tile loses a workgroup per CU to the extra code)
-        if (p.acc0) acc_init_f32<TM>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
-    }
 
     // K loop: one barrier per K tile; inside a tile the fragments of k-step ks+1 are read from LDS while the
     // MFMAs of k-step ks run (register double buffer), and the next tile's DMAs are issued behind the first reads.
@@ -1142,9 +1121,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f16x8 fa[2][4], fb0[4], fb1[4];
     if constexpr (EPI == EPI_RESID) resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-    if constexpr (EPI == EPI_STD && AMODE == A_CONV && !MX) {
-        if (p.acc0) acc_init_f32<4>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-    }
 
     // prologue: A_0(0) B_0(0) B_1(0) A_1(0) A_0(1) B_0(1)   (issuing these BEFORE the residual loads measured 5 % slower on proj)
     stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);

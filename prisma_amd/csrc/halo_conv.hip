@@ -245,7 +245,7 @@ bool conv3x3_c64_supported(const GemmArgs &a) {
     static int on = -1;
     if (on < 0) { const char *e = getenv("PB_HALO"); on = e ? atoi(e) : 1; }
     return on && a.cKW == 3 && a.cStride == 1 && a.cPad == 1 && (a.cPadX < 0 || a.cPadX == 1) && a.N == 64 && a.cLd == 128 && a.ldo == 128 && a.lo_off == 64 && a.lo8 &&
-           a.nk16 == 1 && a.mx_period == 2 && a.cC == 128 && a.K == 9 * 128 && !a.cTapInner && !a.kwrap && !a.out2 && !a.add2 && !a.gru_h && !a.o8_off && !a.acc0 &&
+           a.nk16 == 1 && a.mx_period == 2 && a.cC == 128 && a.K == 9 * 128 && !a.cTapInner && !a.kwrap && !a.out2 && !a.add2 && !a.gru_h && !a.o8_off &&
            (a.act == ACT_NONE || a.act == ACT_RELU) && a.cOH == a.cH && a.cOW == a.cW && (int64_t)a.cH * a.cW * PXB < (1LL << 32) - (1 << 20);
 }
 

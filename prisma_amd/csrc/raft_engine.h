@@ -35,7 +35,7 @@ class RaftEngine : public EngineBase {
     // context hoist (raft_engine.hip load()): zr_ / q_ then cover [h | motion] only, zr_in_ / q_in_ the context features' 128 channels
     PackedW zr_in_[2], q_in_[2];
     int hoist_ = 0;
-    float *gz_[2] = {}, *gq_[2] = {};
+    f16 *gz_[2] = {}, *gq_[2] = {};             // hoisted shares: [hi plane | lo plane], rows x 256 (z | r) and rows x Lhx (q)
 
     // plan
     int pF_ = 0, pH_ = 0, pW_ = 0, pD_ = 0;

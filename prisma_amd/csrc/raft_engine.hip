@@ -141,9 +141,11 @@ int RaftEngine::load(const pb_tensor *w, int n) {
     }
     // Context hoist (default; PB_GRU_HOIST=0 or PB_MX_UPD=1 turn it off): the GRU's input is cat(h, inp, motion) and `inp` - the context
     // features - does not change over the iterations (raft.py:112-115, update.py:131).  A convolution is linear in its input channels, so
-    // the inp share of every gate's pre-activation is computed ONCE per frame pair (fp32, bias-free) and the per-iteration convolutions run
-    // on [h | motion] alone (K = 5 x 256 instead of 5 x 384), their accumulators starting from that share (gemm.h acc0).  The buffers hold
-    // [h | motion | inp] so that the two varying parts are adjacent.
+    // the inp share of every gate's pre-activation is computed ONCE per call (bias-free, stored as an fp16 hi plane + an fp16 lo plane: ~22
+    // bits) and the per-iteration convolutions run on [h | motion] alone (K = 5 x 256 instead of 5 x 384), adding the two planes as the
+    // epilogue's skip tensors (add1, add2) before the gate's activation.  The buffers hold [h | motion | inp] so that the two varying
+    // parts are adjacent.  (First version: fp32 share as the accumulators' starting value - its 256 KB per tile were a prologue burst that
+    // ate half of what the smaller K saved; as an fp32 read in the GRU epilogues it cost every EPI_STD kernel its register allocation.)
     {
         const char *e = getenv("PB_GRU_HOIST");
         hoist_ = !upd8_ && !(e && e[0] == '0');
@@ -242,15 +244,16 @@ int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
         const int64_t rows = round_up(ND * P_, 256);
         h32_ = (float *)carve((size_t)rows * 128 * 4); flow_ = (float *)carve((size_t)rows * 2 * 4);
         mask_ = (float *)carve((size_t)rows * 576 * 4);
+        const int Lq = upd8_ ? 576 : 384;
         const size_t u8 = upd8_ ? 3 : 2;                   // bytes per channel of an update-block map: fp16 (+ its fp8 copy after the pixel's fp16 part)
         hx_ = (f16 *)carve((size_t)rows * 384 * u8); hx2_ = (f16 *)carve((size_t)rows * 384 * u8);
         corr_ = (f16 *)carve((size_t)rows * 384 * u8); c1_ = (f16 *)carve((size_t)rows * 256 * u8);
         corflo_ = (f16 *)carve((size_t)rows * 256 * u8); fa_ = (f16 *)carve((size_t)rows * 128 * u8);
         f1_ = (f16 *)carve((size_t)rows * 128 * u8); zrb_ = (f16 *)carve((size_t)rows * 256 * 2);
         fh_ = (f16 *)carve((size_t)rows * 256 * 2);
-        for (int half = 0; half < 2; ++half) {            // the context features' share of the GRU pre-activations (hoist_), fp32
-            gz_[half] = hoist_ ? (float *)carve((size_t)rows * 256 * 4) : nullptr;
-            gq_[half] = hoist_ ? (float *)carve((size_t)rows * 128 * 4) : nullptr;
+        for (int half = 0; half < 2; ++half) {            // the context features' share of the GRU pre-activations (hoist_): hi plane, lo plane
+            gz_[half] = hoist_ ? (f16 *)carve((size_t)rows * 256 * 2 * 2) : nullptr;           // row stride 256 = zrb_'s
+            gq_[half] = hoist_ ? (f16 *)carve((size_t)rows * Lq * 2 * 2) : nullptr;            // row stride = hx_'s (the q convolution writes h there)
         }
         m0_ = (f16 *)carve((size_t)rows * 256 * 2);
         up_ = (float *)carve((size_t)ND * sh_ * sw_ * 2 * 4);
@@ -464,22 +467,17 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     // ---- the context features' share of the SepConvGRU gates, once per call (hoist_, see load()) ----
     const int mot = hoist_ ? 128 : 256;                     // channel offset of the motion features inside hx_ / hx2_
     if (hoist_) {
-        for (int half = 0; half < 2; ++half)
-            for (int g = 0; g < 2; ++g) {
-                const PackedW &w = g == 0 ? zr_in_[half] : q_in_[half];
-                GemmArgs a;
-                a.A = hx_ + 256; a.N = w.N;
-                a.cH = h8_; a.cW = w8_; a.cC = 128; a.cLd = Lhx; a.cKW = half == 0 ? 5 : 1; a.cStride = 1;
-                a.cPad = half == 0 ? 0 : 2; a.cPadX = half == 0 ? 2 : 0;
-                a.cOH = h8_; a.cOW = w8_; a.M = ND * P_;
-                set_weights(a, w, true);
-                a.out32 = g == 0 ? gz_[half] : gq_[half]; a.ldo = w.N; a.scale = 1.f;
-                tic(F_CONV128, 2.0 * a.M * (double)w.N * w.Kreal, 2.0 * ((double)a.M * 128 + (double)w.N * w.Kreal) + 4.0 * a.M * w.N, 1.0 + w.sw);
-                r = launch_gemm(stream, A_CONV, EPI_F32, TILE_AUTO, a);
-                if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
-                toc();
-                if (r) return r;
-            }
+        PB_CHECK(rows * Lhx < (1LL << 31), PB_ERR_ARG, "flow_raft: %lld update-block rows exceed the 32-bit plane offset of the hoisted GRU share", (long long)rows);
+        const int mx_saved = mx_;
+        mx_ = 0;                                             // fp16 residual plane (these weights are packed without MX tiles)
+        for (int half = 0; half < 2; ++half) {
+            const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1;
+            // [hi plane | lo plane]: lo_off = one whole plane, so both planes have the row stride of the tensor they are added to
+            if ((r = conv(hx_ + 256, 128, Lhx, ND, h8_, w8_, kh, kw, 1, zr_in_[half], gz_[half], 256, ACT_NONE, 0, nullptr, nullptr, (int)(rows * 256)))) break;
+            if ((r = conv(hx_ + 256, 128, Lhx, ND, h8_, w8_, kh, kw, 1, q_in_[half], gq_[half], Lhx, ACT_NONE, 0, nullptr, nullptr, (int)(rows * Lhx)))) break;
+        }
+        mx_ = mx_saved;
+        if (r) return r;
     }
 
     // ---- GRU iterations (raft.py:124-144, update.py:122-136) ----
@@ -511,10 +509,10 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         for (int half = 0; half < 2; ++half) {
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1;
             const int gc = hoist_ ? 256 : 384;               // channels the per-iteration convolutions read: [h | motion] (+ inp without the hoist)
-            ConvFuse fz; fz.gru_h = h32_; fz.gru_rh = hx2_; fz.gru_ld = Lhx; fz.acc0 = gz_[half]; fz.ld0 = 256;
-            if ((r = conv(hx_, gc, Lhx, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_GRU_ZR, 0, nullptr, &fz, 0, 0, upd8_ ? 768 : 0))) return r;
-            ConvFuse fq; fq.gru_h = h32_; fq.gru_z = zrb_; fq.acc0 = gq_[half]; fq.ld0 = 128;
-            if ((r = conv(hx2_, gc, Lhx, ND, h8_, w8_, kh, kw, 1, q_[half], hx_, Lhx, ACT_GRU_Q, 0, nullptr, &fq, 0, 0, upd8_ ? 768 : 0))) return r;
+            ConvFuse fz; fz.gru_h = h32_; fz.gru_rh = hx2_; fz.gru_ld = Lhx; fz.add2 = hoist_ ? gz_[half] + rows * 256 : nullptr;
+            if ((r = conv(hx_, gc, Lhx, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_GRU_ZR, 0, hoist_ ? gz_[half] : nullptr, &fz, 0, 0, upd8_ ? 768 : 0))) return r;
+            ConvFuse fq; fq.gru_h = h32_; fq.gru_z = zrb_; fq.add2 = hoist_ ? gq_[half] + rows * Lhx : nullptr;
+            if ((r = conv(hx2_, gc, Lhx, ND, h8_, w8_, kh, kw, 1, q_[half], hx_, Lhx, ACT_GRU_Q, 0, hoist_ ? gq_[half] : nullptr, &fq, 0, 0, upd8_ ? 768 : 0))) return r;
         }
         // FlowHead -> delta_flow (fp32), coords1 += delta (the h slice's fp8 copy sits 384 halfs after it)
         if ((r = conv(hx_, 128, Lhx, ND, h8_, w8_, 3, 3, 1, fh1_, fh_, 256, ACT_RELU, 0, nullptr, nullptr, 0, upd8_ ? 384 : 0))) return r;
