@@ -22,11 +22,14 @@ namespace {
 
 constexpr int AQ = 128, AKT = 32, AD = 128;                     // queries per workgroup, keys per tile, head dim
 
-template <bool SPLIT, int NVB>
+// SPLIT: Q, K as hi + lo (three MFMA passes for S); SPV: V and P as hi + lo (three passes for P V).  The flow_gmflow band runs its window
+// attention with SPLIT only - rounding P and V to fp16 there moves the flow by 2.6e-4 of its range (tools/precision_budget_gmflow.py),
+// q / k by 5.8e-4 - and the global matching / propagation, whose V are coordinates and flows, with both.
+template <bool SPLIT, bool SPV, int NVB>
 struct AttnGeom {
     static constexpr int KROW = (SPLIT ? 2 : 1) * AD * 2 + 16;  // LDS row strides in bytes (272 / 528, 80)
     static constexpr int VROW = AKT * 2 + 16;
-    static constexpr int VR = (SPLIT ? 2 : 1) * NVB * 32;       // Vt rows per tile: [hi rows | lo rows]
+    static constexpr int VR = (SPV ? 2 : 1) * NVB * 32;         // Vt rows per tile: [hi rows | lo rows]
     static constexpr int K_BYTES = AKT * KROW, V_BYTES = VR * VROW, BUF = K_BYTES + V_BYTES;
 };
 
@@ -35,18 +38,18 @@ struct AttnGeom {
 // Vt:   [.., VR, ldv] fp16 (v_bstride = 0 shares one V between all batch elements): rows [0, NVB * 32) hi, then lo.
 // region: [nreg, L] int8 or null; batch element b uses row b % nreg.
 // O:    [B, L, NVB * 32] fp32.
-template <bool SPLIT, int NVB>
+template <bool SPLIT, bool SPV, int NVB>
 __global__ __launch_bounds__(256) void attn128_kernel(const f16 *__restrict__ Q, const f16 *__restrict__ K, const f16 *__restrict__ Vt,
                                                       const int8_t *__restrict__ region, float *__restrict__ O, int L, int ldq, int ldv,
                                                       int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int kxor, int nreg) {
-    using G = AttnGeom<SPLIT, NVB>;
+    using G = AttnGeom<SPLIT, SPV, NVB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int b = blockIdx.y, q0 = blockIdx.x * AQ + wave * 32;
     const f16 *Qb = Q + (int64_t)b * q_bstride, *Kb = K + (int64_t)(b ^ kxor) * k_bstride, *Vb = Vt + (int64_t)(b ^ kxor) * v_bstride;
     const int8_t *rg = region ? region + (int64_t)(b % nreg) * L : nullptr;
     const int kperm = (li & 19) | ((li & 4) << 1) | ((li & 8) >> 1);
-    constexpr int NP = SPLIT ? 2 : 1;
+    constexpr int NP = SPLIT ? 2 : 1, NPV = SPV ? 2 : 1;
 
     // Q fragments (B operand of S^T): query q0 + li, k-steps 0..7 of the hi (and lo) part
     f16x8 qf[NP][8];
@@ -116,13 +119,13 @@ __global__ __launch_bounds__(256) void attn128_kernel(const f16 *__restrict__ Q,
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mn = fmaxf(m, tmax), corr = __builtin_amdgcn_exp2f(m - mn);
         float psum = 0.f;
-        f16x8 pf[NP][2];
+        f16x8 pf[NPV][2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(st[r] - mn);
             const f16 ph = (f16)p;
             pf[0][r >> 3][r & 7] = ph;
-            if constexpr (SPLIT) {
+            if constexpr (SPV) {
                 const f16 pl = (f16)(p - (float)ph);
                 pf[1][r >> 3][r & 7] = pl;
                 psum += (float)ph + (float)pl;                  // the sum of what P V uses
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void attn128_kernel(const f16 *__restrict__ Q,
             for (int s = 0; s < 2; ++s) {
                 const f16x8 vh = *(const f16x8 *)(sv + (bb * 32 + li) * G::VROW + (s * 16 + lh * 8) * 2);
                 o[bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pf[0][s], o[bb], 0, 0, 0);
-                if constexpr (SPLIT) {
+                if constexpr (SPV) {
                     const f16x8 vl = *(const f16x8 *)(sv + ((NVB + bb) * 32 + li) * G::VROW + (s * 16 + lh * 8) * 2);
                     o[bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pf[1][s], o[bb], 0, 0, 0);
                     o[bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pf[0][s], o[bb], 0, 0, 0);
@@ -162,11 +165,11 @@ __global__ __launch_bounds__(256) void attn128_kernel(const f16 *__restrict__ Q,
     }
 }
 
-template <bool SPLIT, int NVB>
+template <bool SPLIT, bool SPV, int NVB>
 int launch_t(hipStream_t s, const f16 *Q, const f16 *K, const f16 *Vt, const int8_t *region, float *O, int B, int L, int ldq, int ldv,
              int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int kxor, int nreg) {
-    using G = AttnGeom<SPLIT, NVB>;
-    auto kern = attn128_kernel<SPLIT, NVB>;
+    using G = AttnGeom<SPLIT, SPV, NVB>;
+    auto kern = attn128_kernel<SPLIT, SPV, NVB>;
     static bool attr_set = false;
     if (!attr_set) {
         PB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G::BUF));
@@ -184,7 +187,7 @@ int launch_t(hipStream_t s, const f16 *Q, const f16 *K, const f16 *Vt, const int
 // O [B, L, 128] fp32.
 int launch_attention128(hipStream_t s, const f16 *Q, const f16 *K, const f16 *Vt, const int8_t *region, float *O, int B, int L, int ldv) {
     PB_CHECK(Q && K && Vt && O && B > 0 && L > 0 && ldv % 32 == 0 && ldv >= (L + 31) / 32 * 32, PB_ERR_ARG, "attention128: bad arguments");
-    return launch_t<false, 4>(s, Q, K, Vt, region, O, B, L, AD, ldv, (int64_t)L * AD, (int64_t)L * AD, (int64_t)AD * ldv, 0, B);
+    return launch_t<false, false, 4>(s, Q, K, Vt, region, O, B, L, AD, ldv, (int64_t)L * AD, (int64_t)L * AD, (int64_t)AD * ldv, 0, B);
 }
 
 // The general form (kernels.h Attn128Args).
@@ -194,10 +197,11 @@ int launch_attention128x(hipStream_t s, const Attn128Args &a) {
              PB_ERR_ARG, "attention128x: bad arguments");
     const int ldq = a.ldq ? a.ldq : (a.split ? 2 * AD : AD), nr = a.region ? a.nreg : 1;
     const int64_t qb = a.q_bstride ? a.q_bstride : (int64_t)a.L * ldq, kb = a.k_bstride ? a.k_bstride : (int64_t)a.L * ldq;
-    const int64_t vb = a.v_shared ? 0 : (a.v_bstride ? a.v_bstride : (int64_t)(a.split ? 2 : 1) * a.vcols * a.ldv);
-    if (a.split)
-        return a.vcols == 128 ? launch_t<true, 4>(s, a.Q, a.K, a.Vt, a.region, a.O, a.B, a.L, ldq, a.ldv, qb, kb, vb, a.kxor, nr)
-                              : launch_t<true, 1>(s, a.Q, a.K, a.Vt, a.region, a.O, a.B, a.L, ldq, a.ldv, qb, kb, vb, a.kxor, nr);
-    return a.vcols == 128 ? launch_t<false, 4>(s, a.Q, a.K, a.Vt, a.region, a.O, a.B, a.L, ldq, a.ldv, qb, kb, vb, a.kxor, nr)
-                          : launch_t<false, 1>(s, a.Q, a.K, a.Vt, a.region, a.O, a.B, a.L, ldq, a.ldv, qb, kb, vb, a.kxor, nr);
+    const int spv = a.split && !a.pv_single;
+    const int64_t vb = a.v_shared ? 0 : (a.v_bstride ? a.v_bstride : (int64_t)(spv ? 2 : 1) * a.vcols * a.ldv);
+#define PB_ATT(S, P, N) launch_t<S, P, N>(s, a.Q, a.K, a.Vt, a.region, a.O, a.B, a.L, ldq, a.ldv, qb, kb, vb, a.kxor, nr)
+    if (a.split && spv) return a.vcols == 128 ? PB_ATT(true, true, 4) : PB_ATT(true, true, 1);
+    if (a.split) return a.vcols == 128 ? PB_ATT(true, false, 4) : PB_ATT(true, false, 1);
+    return a.vcols == 128 ? PB_ATT(false, false, 4) : PB_ATT(false, false, 1);
+#undef PB_ATT
 }

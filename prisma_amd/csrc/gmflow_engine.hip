@@ -195,7 +195,8 @@ int GmflowEngine::gemm16(const f16 *A, int lda, int64_t M, const PackedW &w, f16
 
 int GmflowEngine::attention(const Attn128Args &a, double keys_per_query) {
     // S and P V: 2 x 2 x (128 + vcols) flops per (query, key); three MFMA passes each in split mode
-    tic(F_ATTN, 2.0 * a.B * (double)a.L * keys_per_query * (128.0 + a.vcols), 0, a.split ? 3.0 : 1.0);
+    const double qk = 2.0 * a.B * (double)a.L * keys_per_query * 128.0, pv = 2.0 * a.B * (double)a.L * keys_per_query * a.vcols;
+    tic(F_ATTN, qk + pv, 0, ((a.split ? 3.0 : 1.0) * qk + (a.split && !a.pv_single ? 3.0 : 1.0) * pv) / (qk + pv));
     int r = launch_attention128x(cur_, a);
     toc();
     return r;
@@ -251,6 +252,7 @@ int GmflowEngine::infer(const uint8_t *frames, int F, int H, int W, float scale,
         Attn128Args a;
         a.Q = Qw_; a.K = Kw_; a.Vt = Vtw_; a.region = shifted ? region_ : nullptr; a.nreg = 4; a.O = Ow_;
         a.B = Bw; a.L = g_.Lw; a.ldv = g_.ldv; a.split = split; a.vcols = 128; a.ldq = 256; a.v_bstride = (int64_t)2 * 128 * g_.ldv;
+        a.pv_single = 1;                  // window attention: P and V as single fp16 (2.6e-4 of the budget), q / k split (attention128.hip)
         if ((r = attention(a, g_.Lw))) return r;
         tic(F_ELT, 0, 0);
         r = launch_gm_split_rows(stream, Ow_, 128, 128, Os_, R);

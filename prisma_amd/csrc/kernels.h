@@ -56,6 +56,7 @@ struct Attn128Args {
     int nreg = 0;
     float *O = nullptr;
     int B = 0, L = 0, ldv = 0, split = 0, vcols = 128, v_shared = 0, kxor = 0;
+    int pv_single = 0;       // with split: P and V stay single fp16 (one MFMA pass for P V; Vt's hi rows only are read)
     int ldq = 0;             // row stride of Q and K in halfs (0: 256 with split, else 128); a non-split call may read the hi part of split rows
     int64_t q_bstride = 0, k_bstride = 0, v_bstride = 0;
 };
