@@ -297,15 +297,13 @@ def pmc_traffic(symbol):
     """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC summary of THIS command (tools/pmc_summary.py; separate
     FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md).  PMC passes cannot run inside the
     timed bench, so the figure is read from profiles/ (newest round first)."""
+    import glob
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     want = symbol.replace(" ", "")
-    for name in ("r02g_pmc_traffic.json", "r02f_pmc_traffic.json", "r02d_pmc_traffic.json", "r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json"):
-        path = os.path.join(here, name)
-        if not os.path.exists(path):
-            continue
+    for path in sorted(glob.glob(os.path.join(here, "r??[a-z]_pmc_traffic.json")), reverse=True):      # newest round / letter first
         for kname, v in json.load(open(path))["kernels"].items():
             if want in kname.replace(" ", ""):
-                return round(v["fetch_bytes"] + v["write_bytes"]), "profiles/" + name
+                return round(v["fetch_bytes"] + v["write_bytes"]), "profiles/" + os.path.basename(path)
     return None, None
 
 

@@ -1,7 +1,8 @@
 """Per-launch algorithmic FLOPs / bytes of the bench's GEMM-shaped launches, from the layer shapes alone,
 so that bench.py's `roofline.flop_per_launch` and per-family totals can be re-derived by hand.  A bench family is
 `<band>/<kernel symbol as rocprofv3 prints it>`; the symbol of a layer follows from launch_gemm's rule (csrc/gemm.hip): the 256 x 256
-ping-pong kernel when N % 256 == 0 and there are >= 256 tiles, the 256 x 64 tile for N <= 64, else the 128 x 128 tile; the last
+ping-pong kernel when N % 256 == 0 and there are >= 256 tiles, the 256 x 64 tile for N <= 64 (round 3: the halo-tiled direct kernel for the
+3x3 64 -> 64 layers on mx3 maps), else the 128 x 128 tile; the last
 template parameter says whether the launch carries MX-fp8 residual tiles (split mode; always false in the f16 mode).
 FLOPs = 2 M N K of the layer (real channels: padding and the residual passes not counted); bytes = A once + W once + output once.
 python tools/flop_table.py [batch] [H W]"""
@@ -14,7 +15,7 @@ DENSE, CONV = 0, 1
 STD, RESID, QKV, PIXSHUF, PATCH, HEAD, F32 = range(7)
 
 
-def symbol(amode, epi, M, N, mx):
+def symbol(amode, epi, M, N, mx, halo=False):
     """launch_gemm(TILE_AUTO) + the launchers' names (csrc/gemm.hip, gemm_kernels.h); BUFP (LDS-DMA through the buffer path) is true
     unless an operand exceeds the 4 GB a buffer resource can address (the N = 32 head conv at batch 32)."""
     m = "true" if mx else "false"
@@ -25,13 +26,16 @@ def symbol(amode, epi, M, N, mx):
     if N % 256 == 0 and (M // 256) * (N // 256) >= 256:
         return f"gemm8_kernel<{amode}, {epi}, 0, true, {m}>"
     if epi == STD and N <= 64:
+        if halo:                                         # 3x3, 64 -> 64, stride 1 on mx3 maps: the halo-tiled direct kernel (halo_conv.hip)
+            return "conv3x3_c64_mx_kernel<1>"
         return f"gemm_kernel<256, 64, 4, 1, {amode}, {epi}, true, 2, {m}>"
     return f"gemm_kernel<128, 128, 2, 2, {amode}, {epi}, true, 2, {m}>"
 
 
-def add(band, kind, name, M, N, K, n=1, in_b=2, out_b=2, mx=True, n_launch=None):
+def add(band, kind, name, M, N, K, n=1, in_b=2, out_b=2, mx=True, n_launch=None, per_call=False):
     # n_launch: the N the launch is made with when it differs from the layer's (padded volume rows)
-    fam = kind if isinstance(kind, str) else symbol(kind[0], kind[1], M, n_launch or N, mx)
+    halo = not isinstance(kind, str) and kind == (CONV, STD) and mx and N == 64 and K == 9 * 64 and " s2" not in name
+    fam = kind if isinstance(kind, str) else symbol(kind[0], kind[1], M, n_launch or N, mx, halo)
     # algorithmic bytes as the engines count them (engine_base.hip conv / dense): the input MAP once - not its im2col expansion -, the
     # weights once, the output once
     taps, stride = 1, 1
@@ -39,8 +43,8 @@ def add(band, kind, name, M, N, K, n=1, in_b=2, out_b=2, mx=True, n_launch=None)
         taps = 9 if "3x3" in name else 5 if "1x5" in name else 1
         stride = 2 if " s2" in name else 1
     a_bytes = in_b * M * stride * stride * (K / taps)
-    if band == "depth":
-        n *= ND                                          # a 32-frame call runs as ND chunks of BD frames (DepthEngine::batch_cap, split mode)
+    if band == "depth" and not per_call:
+        n *= ND                                          # the DPT head of a 32-frame call runs as ND chunks of BD frames (DepthEngine::batch_cap, split mode)
     rows.append((band, fam, name, n, M, N, K, 2.0 * M * N * K, a_bytes + 2.0 * N * K + out_b * M * N))
 
 
@@ -50,14 +54,16 @@ ntp, P = 2448, gh * gw
 BD = 16 if B > 16 else B                                 # frames per launch: split-mode maps are capped at 2^31 elements (engine.hip batch_cap)
 ND = (B + BD - 1) // BD
 B_ALL, B = B, BD                                         # the depth rows below are per launch
-Mv = B * ntp
-add("depth", (DENSE, PATCH), "patch embed (+ pos embed)", B * P, D, 588, mx=False)
-add("depth", (DENSE, QKV), "qkv", Mv, 3 * D, D, 24)
-add("depth", "attention", "softmax(QK^T)V, 16 heads", B * 16 * 2443, 2443, 64 * 2, 24)        # 4 n h t^2 d
-rows[-1] = rows[-1][:8] + (4.0 * B * 16 * 2443 * 64 * 2,)                                       # q, k, v in + o out, fp16
-add("depth", (DENSE, RESID), "proj (+ residual)", Mv, D, D, 24, out_b=8)
-add("depth", (DENSE, STD), "fc1 + GELU", Mv, 4 * D, D, 24)
-add("depth", (DENSE, RESID), "fc2 (+ residual)", Mv, D, 4 * D, 24, out_b=8)
+# round 3: the ViT runs on the whole call (B_ALL frames) at once - 4.8 rounds of 256 x 256 tiles on its N = 1024 GEMMs instead of 2 x 2.4 -,
+# only the DPT head below is chunked (engine.hip run_chunk)
+Mv = B_ALL * ntp
+add("depth", (DENSE, PATCH), "patch embed (+ pos embed)", B_ALL * P, D, 588, mx=False, per_call=True)
+add("depth", (DENSE, QKV), "qkv", Mv, 3 * D, D, 24, per_call=True)
+add("depth", "attention", "softmax(QK^T)V, 16 heads", B_ALL * 16 * 2443, 2443, 64 * 2, 24, per_call=True)        # 4 n h t^2 d
+rows[-1] = rows[-1][:8] + (4.0 * B_ALL * 16 * 2443 * 64 * 2,)                                   # q, k, v in + o out, fp16
+add("depth", (DENSE, RESID), "proj (+ residual)", Mv, D, D, 24, out_b=8, per_call=True)
+add("depth", (DENSE, STD), "fc1 + GELU", Mv, 4 * D, D, 24, per_call=True)
+add("depth", (DENSE, RESID), "fc2 (+ residual)", Mv, D, 4 * D, 24, out_b=8, per_call=True)
 oc = [256, 512, 1024, 1024]
 for i in range(4):
     add("depth", (DENSE, STD), f"projects.{i} 1x1", B * P, oc[i], D)
@@ -110,8 +116,12 @@ add("flow", (CONV, STD), "convc2 3x3 256->192", Mu, 192, 9 * 256, it, mx=False)
 add("flow", (DENSE, STD), "convf1 7x7 2->128 (im2col GEMM)", Mu, 128, 98, it, mx=False)
 add("flow", (CONV, STD), "convf2 3x3 128->64", Mu, 64, 9 * 128, it, mx=False)
 add("flow", (CONV, STD), "motion conv 3x3 256->126", Mu, 126, 9 * 256, it, mx=False)
-add("flow", (CONV, STD), "GRU z|r 1x5 / 5x1 384->256", Mu, 256, 5 * 384, 2 * it, mx=False)
-add("flow", (CONV, STD), "GRU q 1x5 / 5x1 384->128", Mu, 128, 5 * 384, 2 * it, mx=False)
+# round 3, context hoist (raft_engine.hip load()): the context features' 128 of the GRU's 384 input channels do not change over the
+# iterations - their share of every gate is computed once per call, the per-iteration convolutions read [h | motion] (256 channels)
+add("flow", (CONV, STD), "GRU z|r context share 1x5 / 5x1 128->256 (once per call)", Mu, 256, 5 * 128, 2, mx=False)
+add("flow", (CONV, STD), "GRU q context share 1x5 / 5x1 128->128 (once per call)", Mu, 128, 5 * 128, 2, mx=False)
+add("flow", (CONV, STD), "GRU z|r 1x5 / 5x1 [h | motion] 256->256", Mu, 256, 5 * 256, 2 * it, mx=False)
+add("flow", (CONV, STD), "GRU q 1x5 / 5x1 [r h | motion] 256->128", Mu, 128, 5 * 256, 2 * it, mx=False)
 add("flow", (CONV, STD), "flow head conv1 3x3 128->256", Mu, 256, 9 * 128, it, mx=False)
 add("flow", "flow_head2_kernel<true>", "flow head conv2 3x3 256->2 (direct kernel)", Mu, 2, 9 * 256, it)
 add("flow", (CONV, STD), "mask.0 3x3 128->256 (last iteration)", Mu, 256, 9 * 128, mx=False)
