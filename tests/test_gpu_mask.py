@@ -98,7 +98,7 @@ def test_end_to_end_mask_image_close_to_oracle(tiny):
     out = net.infer_batch(frames, 0.5, KEEP)[0]
     ref = SO.infer(w, cfg, frames[0], synth.COCO_CLASSES, synth.BAND_CLASSES, 0.5)
     mism = (out != ref).mean()
-    print("  end-to-end mask image pixel mismatch vs fp32 oracle: %.3e" % mism)
+    print("  end-to-end mask image pixel mismatch vs fp32 oracle: %.3e (%d of %d pixels)" % (mism, int((out[..., 0] != ref[..., 0]).sum()), out[..., 0].size))
     assert mism < 0.03          # discrete decisions on fp16-perturbed scores: instance boundaries and near-threshold cells
 
 
