@@ -237,6 +237,156 @@ __global__ __launch_bounds__(256) void conv3x3_c64_mx_kernel(const GemmArgs p, i
     }
 }
 
+// ---- second geometry: 8 x 16 output tiles, two workgroups per CU --------------------------------------------------------------
+// The 8 x 32 kernel above holds 117-136 KB of LDS: one workgroup per CU, so nothing runs while a tile's 87 KB arrive or its 64 KB leave -
+// and the layer is HBM-bound (5.9 GB per launch), i.e. those phases ARE the kernel.  Here a workgroup takes 8 x 16 outputs (10 x 18 input
+// pixels: 45 KB, halo 1.41x; two weight slabs), 77 KB in all, and TWO workgroups share a CU: one's loads and stores run under the other's
+// MFMAs.  A wave owns 32 pixels = two rows of 16 (MFMA row li -> row li >> 4, column li & 15); the swizzle key is the pixel's COLUMN in
+// the input tile (mod 16), so the two rows a fragment read touches use the same keys at different columns and stay conflict free.
+constexpr int TH2 = 8, TW2 = 16, IW2 = TW2 + 2, IH2 = TH2 + 2, NPIX2 = IW2 * IH2;       // 180 input pixels
+constexpr int IN2_BYTES = NPIX2 * PXB, SMEM2 = IN2_BYTES + 2 * W_BYTES, IN2_DMAS = NPIX2 / 4;
+static_assert(NPIX2 % 4 == 0, "a DMA instruction carries 4 pixels");
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_mx2_kernel(const GemmArgs p, int tilesX, int tilesPerImg, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_in = smem, *s_w = smem + IN2_BYTES;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int H = p.cH, W = p.cW;
+    const int64_t img_bytes = (int64_t)H * W * PXB;
+
+    const int q0 = 4 * wave + (lane >> 4);                          // instruction j of this wave carries pixel q0 + 16 j
+    const int in_row0 = q0 / IW2, in_col0 = q0 - in_row0 * IW2;
+    unsigned w_voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = q0 + 16 * j, n = 2 * (r & 31) + (r >> 5);
+        w_voff[j] = (unsigned)(n * p.K * 2 + (((lane & 15) ^ (r & 15)) * 16));
+    }
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.W, (unsigned)(64 * p.K * 2));
+    auto stage_weights = [&](int tap, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_buf(rsW, (int)w_voff[j], tap * PXB, s_w + buf * W_BYTES + (wave + 4 * j) * 1024);
+    };
+    auto stage_input = [&](int tile) {
+        const int b = tile / tilesPerImg, t = tile - b * tilesPerImg;
+        const int ty = t / tilesX, tx = t - ty * tilesX;
+        const int y0 = ty * TH2 - 1, x0 = tx * TW2 - 1;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc((const char *)p.A + (int64_t)b * img_bytes, (unsigned)img_bytes);
+        int row = in_row0, col = in_col0;
+        for (int j = 0; 4 * j + wave < IN2_DMAS; ++j) {
+            const int iy = y0 + row, ix = x0 + col;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int chunk = (lane & 15) ^ (col & 15);              // swizzle key = the pixel's column in the tile
+            const unsigned off = ok ? (unsigned)((iy * W + ix) * PXB + chunk * 16) : 0xFFFFFF00u;
+            glds16_buf(rs, (int)off, 0, s_in + (wave + 4 * j) * 1024);
+            col += 16;
+            if (col >= IW2) { col -= IW2; ++row; }
+        }
+    };
+
+    int b_off[2], b_key[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) { const int r = tn * 32 + li; b_off[tn] = r * PXB; b_key[tn] = r & 15; }
+    const int sa = p.mx_scale_a * 0x01010101, sb = p.mx_scale_b * 0x01010101;
+    const int arow = 2 * wave + (li >> 4), acol = li & 15;          // this lane's A row: tile row, tile column
+    const int n = 2 * li;
+    const float b0 = p.bias ? p.bias[n] : 0.f, b1 = p.bias ? p.bias[n + 1] : 0.f;
+    const float shi = __builtin_ldexpf(1.f, p.lo8_pa), slo = __builtin_ldexpf(1.f, p.lo8_pa + 12), inv_lo = __builtin_ldexpf(1.f, -(p.lo8_pa + 12));
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) { stage_input(tile); stage_weights(0, 0); }
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            if (tap + 1 < 9) stage_weights(tap + 1, (tap + 1) & 1);
+            const char *sw = s_w + (tap & 1) * W_BYTES;
+            f16x8 af[8], bf[2][8];
+            {
+                const int q = (arow + ky) * IW2 + acol + kx, key = (acol + kx) & 15;
+                const char *base = s_in + q * PXB;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) af[c] = *(const f16x8 *)(base + (((2 * c + lh) ^ key) * 16));
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) bf[tn][c] = *(const f16x8 *)(sw + b_off[tn] + (((2 * c + lh) ^ b_key[tn]) * 16));
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[c], bf[tn][c], acc[tn], 0, 0, 0);
+#pragma unroll
+            for (int c = 4; c < 8; c += 2)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat2(af[c], af[c + 1]), cat2(bf[tn][c], bf[tn][c + 1]), acc[tn], 0, 0, 0, sa, 0, sb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        const int next = tile + gridDim.x;
+        if (next < ntiles) { stage_input(next); stage_weights(0, 0); }
+
+        const int b = tile / tilesPerImg, t = tile - b * tilesPerImg;
+        const int ty = t / tilesX, tx = t - ty * tilesX;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            float v0[8], v1[8];
+            int64_t off[8];
+            bool ok[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = hf * 8 + q;
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;       // accumulator row = pixel of this wave's 2 x 16 block
+                const int y = ty * TH2 + 2 * wave + (i >> 4), x = tx * TW2 + (i & 15);
+                ok[q] = y < H && x < W;
+                const int xc = x < W ? x : W - 1, yc = y < H ? y : H - 1;
+                off[q] = (((int64_t)b * H + yc) * W + xc) * p.ldo;
+                v0[q] = acc[0][r] + b0; v1[q] = acc[1][r] + b1;
+            }
+            if (p.pre_relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            }
+            if (p.add1) {
+                f16x2 a[8];
+                unsigned short l8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    a[q] = *(const f16x2 *)(p.add1 + off[q] + n);
+                    l8[q] = *(const unsigned short *)((const char *)(p.add1 + off[q]) + 3 * p.lo_off + n);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x2 l = __builtin_amdgcn_cvt_pk_f32_fp8((int)l8[q], false);
+                    v0[q] += (float)a[q][0] + l[0] * inv_lo; v1[q] += (float)a[q][1] + l[1] * inv_lo;
+                }
+            }
+            if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (!ok[q]) continue;
+                const f16 h0 = (f16)v0[q], h1 = (f16)v1[q];
+                f16x2 o; o[0] = h0; o[1] = h1;
+                *(f16x2 *)(p.out + off[q] + n) = o;
+                char *pb = (char *)(p.out + off[q]);
+                *(unsigned short *)(pb + 2 * p.lo_off + n) = pb_fp8x2((float)h0 * shi, (float)h1 * shi);
+                *(unsigned short *)(pb + 3 * p.lo_off + n) = pb_fp8x2((v0[q] - (float)h0) * slo, (v1[q] - (float)h1) * slo);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Whether launch_conv3x3_c64 can run this convolution (after EngineBase::set_weights): 3x3 / stride 1 / pad 1, 64 -> 64 channels on mx3
@@ -257,7 +407,10 @@ int launch_conv3x3_c64(hipStream_t stream, const GemmArgs &a) {
         PB_HIP(hipFuncSetAttribute((const void *)conv3x3_c64_mx_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    const int tilesX = (a.cW + TW - 1) / TW, tilesY = (a.cH + TH - 1) / TH, nimg = a.M / (a.cH * a.cW);
+    static int mode = -1;
+    if (mode < 0) { const char *e = getenv("PB_HALO"); mode = e ? atoi(e) : 3; }      // 1: 8 x 32 unpipelined, 2: 8 x 32 pipelined, 3 (default): 8 x 16, two workgroups per CU
+    const bool small = mode >= 3;
+    const int tilesX = small ? (a.cW + TW2 - 1) / TW2 : (a.cW + TW - 1) / TW, tilesY = (a.cH + TH - 1) / TH, nimg = a.M / (a.cH * a.cW);
     const int ntiles = tilesX * tilesY * nimg;
     static int ncu = 0;
     if (!ncu) {
@@ -267,9 +420,20 @@ int launch_conv3x3_c64(hipStream_t stream, const GemmArgs &a) {
         PB_HIP(hipGetDeviceProperties(&prop, dev));
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    if (small) {
+        static bool attr2 = false;
+        if (!attr2) {
+            PB_HIP(hipFuncSetAttribute((const void *)conv3x3_c64_mx2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2));
+            attr2 = true;
+        }
+        const int grid2 = ntiles < 2 * ncu ? ntiles : 2 * ncu;
+        pb_gemm_set_last_kernel("conv3x3_c64_mx2_kernel");
+        hipLaunchKernelGGL(conv3x3_c64_mx2_kernel, dim3(grid2), dim3(256), SMEM2, stream, a, tilesX, tilesX * tilesY, ntiles);
+        PB_HIP(hipGetLastError());
+        return 0;
+    }
     const int grid = ntiles < ncu ? ntiles : ncu;
-    static int pipe = -1;
-    if (pipe < 0) { const char *e = getenv("PB_HALO"); pipe = e && atoi(e) == 1 ? 0 : 1; }      // PB_HALO=1: the unpipelined first version (A/B)
+    const int pipe = mode != 1;
     pb_gemm_set_last_kernel(pipe ? "conv3x3_c64_mx_kernel<1>" : "conv3x3_c64_mx_kernel<0>");
     if (pipe) hipLaunchKernelGGL(conv3x3_c64_mx_kernel<1>, dim3(grid), dim3(256), SMEM, stream, a, tilesX, tilesX * tilesY, ntiles);
     else hipLaunchKernelGGL(conv3x3_c64_mx_kernel<0>, dim3(grid), dim3(256), SMEM, stream, a, tilesX, tilesX * tilesY, ntiles);
