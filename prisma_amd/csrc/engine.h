@@ -104,6 +104,7 @@ class DepthEngine {
     int vit_sw_ = 0, head_sa_ = 0, head_sw_ = 0, hs_ = 1;
     // vit_mx_: the ViT linears' weight residual runs as an MX-fp8 segment (half the matrix-pipe time of an fp16 pass); their A
     // operands (LayerNorm out, attention out, GELU out) then carry an fp8 copy after the fp16 part of each row (row stride 1.5 K)
+    int vit_res_ = 15;           // which ViT linears keep their weight residual: bit 0 qkv, 1 proj, 2 fc1, 3 fc2 (engine.hip load())
     int vit_mx_ = 0, head_mx_ = 0;              // head_mx_: the DPT head's maps / weights carry e4m3 residual parts (PackedW::mx3)
     // storage scales of the e4m3 copies (engine_base.h kLo8Pa has the reasoning): head maps hi8 = e4m3(x 2^kLo8Pa), lo8 = e4m3(lo 2^(kLo8Pa + 12));
     // ViT token rows a8 = e4m3(a 2^kMxPa).  2^0 since round 3: the copies saturate at |x| = 448 (were 2^3 / 2^4: 56 / 28)

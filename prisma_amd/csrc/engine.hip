@@ -252,6 +252,12 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         hs_ = head_sa_ ? 2 : 1;
         const char *mx = getenv("PB_MX");
         vit_mx_ = vit_sw_ && D % 128 == 0 && !(mx && mx[0] == '0');
+        // Which ViT linears keep their weight residual (bit 0 qkv, 1 proj, 2 fc1, 3 fc2).  tools/precision_budget_vit_layers.py (ViT-L 360x640,
+        // everything else as the split mode runs it; max / range, L2): all four 3.9e-4 / 2.2e-4; without fc1's 4.2e-4 / 2.6e-4, without
+        // qkv's 4.8e-4 / 2.9e-4, without fc2's 5.3e-4 / 3.3e-4, without proj's 5.9e-4 / 3.8e-4, none 7.9e-4 / 5.0e-4: the two layers that
+        // read LayerNorm outputs are the cheap ones to drop - 58 % of the ViT linears' FLOPs run one pass instead of 1.5, and the LayerNorm
+        // kernels stop writing e4m3 copies - for ~5.1e-4 / 3.2e-4 in quadrature.  Default 10 = proj + fc2; PB_VIT_RES=15 is round 2's mode.
+        vit_res_ = vit_mx_ ? pb_env_int("PB_VIT_RES", 10) & 15 : 15;
         head_mx_ = head_sa_ && head_sw_ && !(mx && (mx[0] == '0' || mx[1] == '0'));      // PB_MX=10: MX in the ViT only
     }
     PB_CHECK(D % 128 == 0 && D <= 1024 && D / cfg_.heads == 64, PB_ERR_ARG, "embed_dim %d / heads %d unsupported", D,
@@ -295,23 +301,34 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         UP(B.ls1, b + "ls1.gamma", D);     UP(B.ls2, b + "ls2.gamma", D);
         int r;
         { NEED(wt, b + "attn.qkv.weight", (int64_t)3 * D * D); NEED(bs, b + "attn.qkv.bias", 3 * D);
-          if ((r = vit_mx_ ? pack_mx(wt, 3 * D, D, B.qkv, bs) : pack(wt, 3 * D, D, D, B.qkv, bs, 1, 0, vit_sw_))) return r; }
+          if (vit_mx_ && !(vit_res_ & 1)) r = pack(wt, 3 * D, D, D, B.qkv, bs, 1, 0, 0);       // single fp16 pass (vit_res_)
+          else r = vit_mx_ ? pack_mx(wt, 3 * D, D, B.qkv, bs) : pack(wt, 3 * D, D, D, B.qkv, bs, 1, 0, vit_sw_);
+          if (r) return r; }
         // LayerScale (layer_scale.py:27-28) is folded into the weights: x + g*(W y + b) = x + (g.W) y + g.b, so the GEMM
         // can accumulate straight onto the residual stream
-        auto pack_scaled = [&](const float *wt, const float *bs, const float *g, int N, int K, PackedW &out) -> int {
+        auto pack_scaled = [&](const float *wt, const float *bs, const float *g, int N, int K, PackedW &out, bool keep_res) -> int {
             std::vector<float> ws((size_t)N * K), bb(N);
             for (int n = 0; n < N; ++n) {
                 for (int k = 0; k < K; ++k) ws[(size_t)n * K + k] = wt[(size_t)n * K + k] * g[n];
                 bb[n] = bs[n] * g[n];
             }
+            if (vit_mx_ && !keep_res) return pack(ws.data(), N, K, K, out, bb.data(), 1, 0, 0);
             return vit_mx_ ? pack_mx(ws.data(), N, K, out, bb.data()) : pack(ws.data(), N, K, K, out, bb.data(), 1, 0, vit_sw_);
         };
         { NEED(wt, b + "attn.proj.weight", (int64_t)D * D); NEED(bs, b + "attn.proj.bias", D); NEED(g1, b + "ls1.gamma", D);
-          if ((r = pack_scaled(wt, bs, g1, D, D, B.proj))) return r; }
+          if ((r = pack_scaled(wt, bs, g1, D, D, B.proj, (vit_res_ & 2) != 0))) return r; }
         { NEED(wt, b + "mlp.fc1.weight", (int64_t)Hd * D); NEED(bs, b + "mlp.fc1.bias", Hd);
-          if ((r = vit_mx_ ? pack_mx(wt, Hd, D, B.fc1, bs) : pack(wt, Hd, D, D, B.fc1, bs, 1, 0, vit_sw_))) return r; }
+          if (vit_mx_ && !(vit_res_ & 4)) {
+              r = pack(wt, Hd, D, D, B.fc1, bs, 1, 0, 0);
+              // no fp8 tiles of its own, but fc2 wants the e4m3 copy of fc1's output: that epilogue lives in the MX build of the kernel,
+              // which nk16 = K / 64 selects (every K tile is an fp16 tile; gemm.h nk16)
+              if (!r && (vit_res_ & 8)) B.fc1.nk16 = D / 64;
+          } else {
+              r = vit_mx_ ? pack_mx(wt, Hd, D, B.fc1, bs) : pack(wt, Hd, D, D, B.fc1, bs, 1, 0, vit_sw_);
+          }
+          if (r) return r; }
         { NEED(wt, b + "mlp.fc2.weight", (int64_t)D * Hd); NEED(bs, b + "mlp.fc2.bias", D); NEED(g2, b + "ls2.gamma", D);
-          if ((r = pack_scaled(wt, bs, g2, D, Hd, B.fc2))) return r; }
+          if ((r = pack_scaled(wt, bs, g2, D, Hd, B.fc2, (vit_res_ & 8) != 0))) return r; }
     }
     UP(normg_, P + "norm.weight", D);
     UP(normb_, P + "norm.bias", D);
@@ -623,7 +640,7 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
     a.zero = zero_;
     const double flops = 2.0 * a.M * (double)a.N * w.Kreal;
     const double bytes = 2.0 * ((double)a.M * w.Kreal + (double)a.N * w.Kreal + (double)a.M * a.N);
-    tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes, w.mx3 ? 2.0 : 1.0 + w.sa + w.sw + (w.nk16 ? 0.5 : 0.0));
+    tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes, w.mx3 ? 2.0 : 1.0 + w.sa + w.sw + (w.nk16 && w.K > w.Kreal ? 0.5 : 0.0));
     if (tile == TILE_AUTO) tile = amode == A_CONV ? conv_tile : gemm_tile;
     int r = launch_gemm(stream, amode, epi, tile, a);
     if (timer.enabled && !r) timer.recs.back().name = pb_gemm_last_kernel();
@@ -667,43 +684,47 @@ int DepthEngine::vit(int n) {
     }
     snapshot("tokens");
     const double ln_bytes = (double)n * ntok_ * D * 6.0;
-    // MX mode: rows of Y_ / AO_ / Hd_ are [fp16 (K) | fp8 (K bytes)], i.e. 1.5 K halfs apart; the fp8 copy is stored x 2^kMxPa
+    // MX mode: rows of Y_ / AO_ / Hd_ are [fp16 (K) | fp8 (K bytes)], i.e. 1.5 K halfs apart; the fp8 copy is stored x 2^kMxPa.  A buffer
+    // whose consumers run without a weight residual (vit_res_) is plain fp16: Y_ feeds qkv (after norm1) and fc1 (after norm2)
+    const bool y8 = vit_mx_ && (vit_res_ & 5) != 0, ao8 = vit_mx_ && (vit_res_ & 2), hd8 = vit_mx_ && (vit_res_ & 8);
+    PB_CHECK(!vit_mx_ || (vit_res_ & 5) == 0 || (vit_res_ & 5) == 5, PB_ERR_ARG, "PB_VIT_RES: qkv and fc1 share their input buffer - keep or drop both residuals");
     const int ldy = vit_mx_ ? D + D / 2 : D, o8 = vit_mx_ ? 2 * D : 0;
+    const int ldY = y8 ? ldy : D, o8Y = y8 ? o8 : 0, ldA = ao8 ? ldy : D, o8A = ao8 ? o8 : 0, ldH = hd8 ? 4 * ldy : 4 * D;
     const float o8s = (float)(1 << kMxPa);
     for (int i = 0; i < cfg_.depth; ++i) {
         const Block &b = blocks_[i];
         tic(F_LN, 0, ln_bytes);
-        r = launch_layernorm(stream, X_, b.ln1g, b.ln1b, Y_, n, ntp_, ntok_, D, 1e-6f, 0, ldy, 0, o8, o8s);
+        r = launch_layernorm(stream, X_, b.ln1g, b.ln1b, Y_, n, ntp_, ntok_, D, 1e-6f, 0, ldY, 0, o8Y, o8s);
         toc();
         if (r) return r;
         {
             GemmArgs a;
-            a.A = Y_; a.lda = ldy; a.M = M;
+            a.A = Y_; a.lda = ldY; a.M = M;
             a.q = Q_; a.k = K_; a.vt = Vt_; a.ntp = ntp_; a.heads = cfg_.heads; a.D = D; a.qscale = PB_QSCALE;
             if ((r = gemm(A_DENSE, EPI_QKV, a, b.qkv))) return r;
         }
         tic(F_ATTN, 4.0 * n * cfg_.heads * (double)ntok_ * ntok_ * 64.0, (double)n * ntok_ * D * 2.0 * 4.0);
-        r = launch_attention(stream, Q_, K_, Vt_, AO_, n, cfg_.heads, ntp_, ntok_, ldy, 0, o8, o8s);
+        r = launch_attention(stream, Q_, K_, Vt_, AO_, n, cfg_.heads, ntp_, ntok_, ldA, 0, o8A, o8s);
         toc();
         if (r) return r;
         {
             GemmArgs a;
-            a.A = AO_; a.lda = ldy; a.M = M; a.resid = X_; a.ldr = D; a.gamma = b.ls1;
+            a.A = AO_; a.lda = ldA; a.M = M; a.resid = X_; a.ldr = D; a.gamma = b.ls1;
             if ((r = gemm(A_DENSE, EPI_RESID, a, b.proj))) return r;
         }
         tic(F_LN, 0, ln_bytes);
-        r = launch_layernorm(stream, X_, b.ln2g, b.ln2b, Y_, n, ntp_, ntok_, D, 1e-6f, 0, ldy, 0, o8, o8s);
+        r = launch_layernorm(stream, X_, b.ln2g, b.ln2b, Y_, n, ntp_, ntok_, D, 1e-6f, 0, ldY, 0, o8Y, o8s);
         toc();
         if (r) return r;
         {
             GemmArgs a;
-            a.A = Y_; a.lda = ldy; a.M = M; a.out = Hd_; a.ldo = 4 * ldy; a.act = ACT_GELU;
-            if (vit_mx_) { a.o8_off = 4 * D * 2; a.o8_scale = o8s; }
+            a.A = Y_; a.lda = ldY; a.M = M; a.out = Hd_; a.ldo = ldH; a.act = ACT_GELU;
+            if (hd8) { a.o8_off = 4 * D * 2; a.o8_scale = o8s; }
             if ((r = gemm(A_DENSE, EPI_STD, a, b.fc1))) return r;
         }
         {
             GemmArgs a;
-            a.A = Hd_; a.lda = 4 * ldy; a.M = M; a.resid = X_; a.ldr = D; a.gamma = b.ls2;
+            a.A = Hd_; a.lda = ldH; a.M = M; a.resid = X_; a.ldr = D; a.gamma = b.ls2;
             if ((r = gemm(A_DENSE, EPI_RESID, a, b.fc2))) return r;
         }
         if (debug) snapshot("block" + std::to_string(i));

@@ -22,6 +22,8 @@
 
 #include <stdlib.h>
 
+#include <vector>
+
 namespace {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -293,6 +295,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_mx2_kernel(const GemmArgs 
     const float b0 = p.bias ? p.bias[n] : 0.f, b1 = p.bias ? p.bias[n + 1] : 0.f;
     const float shi = __builtin_ldexpf(1.f, p.lo8_pa), slo = __builtin_ldexpf(1.f, p.lo8_pa + 12), inv_lo = __builtin_ldexpf(1.f, -(p.lo8_pa + 12));
 
+    // optional cycle stamps (PB_HALO_DBG=1, launcher): per workgroup and tile 0..3: [loop top, input landed, taps done, epilogue issued]
+    long long *dbg = p.dbg ? p.dbg + (long long)blockIdx.x * 16 : nullptr;
+    int tcount = 0;
     int tile = blockIdx.x;
     if (tile < ntiles) { stage_input(tile); stage_weights(0, 0); }
     for (; tile < ntiles; tile += gridDim.x) {
@@ -301,8 +306,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_mx2_kernel(const GemmArgs 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        if (dbg && tid == 0 && tcount < 4) dbg[tcount * 4 + 0] = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (dbg && tid == 0 && tcount < 4) dbg[tcount * 4 + 1] = __builtin_readcyclecounter();
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -331,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_mx2_kernel(const GemmArgs 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        if (dbg && tid == 0 && tcount < 4) dbg[tcount * 4 + 2] = __builtin_readcyclecounter();
         const int next = tile + gridDim.x;
         if (next < ntiles) { stage_input(next); stage_weights(0, 0); }
 
@@ -373,17 +381,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_mx2_kernel(const GemmArgs 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
             }
+            // Stores: this half is ONE tile row - 16 consecutive pixels, i.e. 4 KB of contiguous [hi | hi8 | lo8] records.  Written from the
+            // accumulator layout they would be 24 narrow store instructions per lane (4-byte hi pairs, 2-byte e4m3 pairs): measured, the epilogue
+            // took 10.4k of a tile's 24.5k cycles.  The records are assembled in the LDS (this wave's 4 KB of the idle weight slab 1) and leave as
+            // four 16-byte stores per lane, 1 KB contiguous per instruction.
+            char *stg = s_w + W_BYTES + wave * 4096;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if (!ok[q]) continue;
+                const int r = hf * 8 + q;
+                const int px = ((r & 3) + 8 * (r >> 2) + 4 * lh) & 15;
                 const f16 h0 = (f16)v0[q], h1 = (f16)v1[q];
                 f16x2 o; o[0] = h0; o[1] = h1;
-                *(f16x2 *)(p.out + off[q] + n) = o;
-                char *pb = (char *)(p.out + off[q]);
-                *(unsigned short *)(pb + 2 * p.lo_off + n) = pb_fp8x2((float)h0 * shi, (float)h1 * shi);
-                *(unsigned short *)(pb + 3 * p.lo_off + n) = pb_fp8x2((v0[q] - (float)h0) * slo, (v1[q] - (float)h1) * slo);
+                char *rec = stg + px * PXB;
+                *(f16x2 *)(rec + 2 * n) = o;
+                *(unsigned short *)(rec + 128 + n) = pb_fp8x2((float)h0 * shi, (float)h1 * shi);
+                *(unsigned short *)(rec + 192 + n) = pb_fp8x2((v0[q] - (float)h0) * slo, (v1[q] - (float)h1) * slo);
+            }
+            {
+                const int y = ty * TH2 + 2 * wave + hf, x0 = tx * TW2;
+                char *row = (char *)(p.out + (((int64_t)b * H + (y < H ? y : H - 1)) * W + x0) * p.ldo);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const int c = lane + 64 * c4;                    // 16-byte chunk of the row: pixel c >> 4
+                    const f16x8 v = *(const f16x8 *)(stg + c * 16);
+                    if (y < H && x0 + (c >> 4) < W) *(f16x8 *)(row + c * 16) = v;
+                }
             }
         }
+        if (dbg && tid == 0 && tcount < 4) dbg[tcount * 4 + 3] = __builtin_readcyclecounter();
+        ++tcount;
     }
 }
 
@@ -428,6 +454,31 @@ int launch_conv3x3_c64(hipStream_t stream, const GemmArgs &a) {
         }
         const int grid2 = ntiles < 2 * ncu ? ntiles : 2 * ncu;
         pb_gemm_set_last_kernel("conv3x3_c64_mx2_kernel");
+        static int dbg_left = -1;
+        if (dbg_left < 0) { const char *e = getenv("PB_HALO_DBG"); dbg_left = e ? atoi(e) : 0; }
+        if (dbg_left > 0 && grid2 == 2 * ncu) {          // phase stamps of one launch (experiment switch; synchronises)
+            --dbg_left;
+            long long *d = nullptr;
+            PB_HIP(hipMalloc((void **)&d, (size_t)grid2 * 16 * 8));
+            PB_HIP(hipMemsetAsync(d, 0, (size_t)grid2 * 16 * 8, stream));
+            GemmArgs b = a;
+            b.dbg = d;
+            hipLaunchKernelGGL(conv3x3_c64_mx2_kernel, dim3(grid2), dim3(256), SMEM2, stream, b, tilesX, tilesX * tilesY, ntiles);
+            PB_HIP(hipStreamSynchronize(stream));
+            std::vector<long long> h((size_t)grid2 * 16);
+            PB_HIP(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+            PB_HIP(hipFree(d));
+            double w = 0, tp = 0, ep = 0, tot = 0;
+            int cnt = 0;
+            for (int g = 0; g < grid2; ++g)
+                for (int t = 1; t < 3; ++t) {            // tiles 1 and 2 of every workgroup (steady state)
+                    const long long *x = h.data() + (size_t)g * 16 + t * 4;
+                    if (!x[3] || !x[4]) continue;
+                    w += x[1] - x[0]; tp += x[2] - x[1]; ep += x[3] - x[2]; tot += x[4] - x[0]; ++cnt;
+                }
+            if (cnt) fprintf(stderr, "[halo dbg] per tile (cycles, mean of %d): wait for input %.0f, nine taps %.0f, request + epilogue %.0f, tile period %.0f\n", cnt, w / cnt, tp / cnt, ep / cnt, tot / cnt);
+            return 0;
+        }
         hipLaunchKernelGGL(conv3x3_c64_mx2_kernel, dim3(grid2), dim3(256), SMEM2, stream, a, tilesX, tilesX * tilesY, ntiles);
         PB_HIP(hipGetLastError());
         return 0;
