@@ -58,7 +58,7 @@ B_ALL, B = B, BD                                         # the depth rows below 
 # only the DPT head below is chunked (engine.hip run_chunk)
 Mv = B_ALL * ntp
 add("depth", (DENSE, PATCH), "patch embed (+ pos embed)", B_ALL * P, D, 588, mx=False, per_call=True)
-add("depth", (DENSE, QKV), "qkv", Mv, 3 * D, D, 24, per_call=True, mx=False)       # round 3: qkv and fc1 run without a weight residual (PB_VIT_RES)
+add("depth", (DENSE, QKV), "qkv", Mv, 3 * D, D, 24, per_call=True)
 add("depth", "attention", "softmax(QK^T)V, 16 heads", B_ALL * 16 * 2443, 2443, 64 * 2, 24, per_call=True)        # 4 n h t^2 d
 rows[-1] = rows[-1][:8] + (4.0 * B_ALL * 16 * 2443 * 64 * 2,)                                   # q, k, v in + o out, fp16
 add("depth", (DENSE, RESID), "proj (+ residual)", Mv, D, D, 24, out_b=8, per_call=True)
