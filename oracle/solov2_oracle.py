@@ -301,7 +301,8 @@ def get_results_single(cfg, kernel_preds, cls_scores, mask_feats, img_shape, ori
     mp = F.interpolate(mp, size=(H, W), mode="bilinear", align_corners=False).squeeze(0)
     out = (scores, labels, mp > cfg.mask_thr)
     if return_debug:
-        return out + ({"pre_nms_scores": cs, "sum_masks": sum_masks, "keep_inds": keep_inds, "n_candidates": int(score_mask.sum())},)
+        return out + ({"pre_nms_scores": cs, "sum_masks": sum_masks, "keep_inds": keep_inds, "n_candidates": int(score_mask.sum()),
+                       "soft": mp},)
     return out
 
 

@@ -46,7 +46,8 @@ class EngineBase {
     // eval-mode BatchNorm2d (eps 1e-5) as a per-channel (scale, shift)
     int fold_bn(const std::string &bn, int C, std::vector<float> &scale, std::vector<float> &shift);
     // conv weight [co, ci, kh, kw] (+ bias) -> rows [co][(ky * kw + kx) * round_up(ci, 64) + c], optional per-output affine
-    int pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out, int sa = 0);
+    // ci_pad: input channels the rows are padded to (default round_up(ci, 64))
+    int pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out, int sa = 0, int ci_pad = 0);
 
     // direct launch_gemm callers: K, and with split-fp16 weights the K wrap / channel bookkeeping of gemm.h (a.cC, a.cLd of
     // ONE part must be set before the call for convolutions)
@@ -69,7 +70,7 @@ class EngineBase {
     // a8_rel (mx2 weights): half-offset from `in` to the fp8 copy of its channels (0 = right after the cC channels); o8_off: byte
     // offset, from the output row, of the fp8 copy the epilogue also stores (0 = none)
     int dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1 = nullptr, int o8_off = 0,
-              int a_pa = -1);          // a_pa: power-of-two scale the A operand's fp8 copy was stored with (default kMx2Pa)
+              int a_pa = -1, int lo_off = 0);          // a_pa: power-of-two scale the A operand's fp8 copy was stored with (default kMx2Pa)
 
     std::map<std::string, const pb_tensor *> tmap_;
     std::vector<void *> owned_;                 // permanent device allocations (weights), freed by the destructor

@@ -174,7 +174,7 @@ int EngineBase::fold_bn(const std::string &bn, int C, std::vector<float> &scale,
     return 0;
 }
 
-int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out, int sa) {
+int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *scale, const float *shift, PackedW &out, int sa, int ci_pad) {
     const pb_tensor *t = find(name + ".weight");
     PB_CHECK(t && t->ndim == 4, PB_ERR_ARG, "missing conv '%s'", name.c_str());
     const float *b = nullptr;
@@ -185,7 +185,8 @@ int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *s
     }
     const int co = (int)t->shape[0], ci = (int)t->shape[1], kh = (int)t->shape[2], kw = (int)t->shape[3];
     const float *w = (const float *)t->data;
-    const int cip = cp64(ci), K = kh * kw * cip;
+    const int cip = ci_pad ? ci_pad : cp64(ci), K = kh * kw * cip;
+    PB_CHECK(cip >= ci && cip % 64 == 0, PB_ERR_ARG, "pack_conv '%s': %d input channels padded to %d", name.c_str(), ci, cip);
     std::vector<float> g((size_t)co * K, 0.f), bb(co);
     for (int o = 0; o < co; ++o) {
         const float s = scale ? scale[o] : 1.f;
@@ -279,11 +280,13 @@ int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh
     return r;
 }
 
-int EngineBase::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1, int o8_off, int a_pa) {
+int EngineBase::dense(const f16 *A, int lda, int64_t M, const PackedW &w, f16 *out, int ldo, int act, const f16 *add1, int o8_off, int a_pa,
+                      int lo_off) {
     GemmArgs a;
     a.A = A; a.lda = lda; a.N = w.N; a.M = (int)M;
     set_weights(a, w, false);
-    a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1;
+    a.out = out; a.ldo = ldo; a.act = act; a.add1 = add1; a.lo_off = lo_off;
+    if (lo_off && mx_) { a.lo8 = 1; a.lo8_pa = kLo8Pa; }
     if (o8_off) { a.o8_off = o8_off; a.o8_scale = (float)(1 << kMx2Pa); }
     if (w.mx2 && a_pa >= 0) a.mx_scale_a = 127 - a_pa;
     tic(F_GEMM, 2.0 * M * (double)a.N * w.Kreal, 2.0 * ((double)M * w.Kreal + (double)a.N * w.Kreal + (double)M * a.N), w.mx3 ? 2.0 : (w.mx2 ? 1.5 : 1.0 + w.sa + w.sw));

@@ -42,11 +42,15 @@ class MaskEngine : public EngineBase {
     int ensure_post(size_t cands, int frames);
 
     int conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, const PackedW &w, float *out, int ldo);
-    int conv_gn_relu(const f16 *in, int cC, int cLd, int n, int H, int W, int k, const ConvGN &c, f16 *tmp, f16 *out, int ldo);
+    // channel counts / strides below are those of ONE part; L() / lo() turn them into the row stride and residual offset of a split map
+    int conv_gn_relu(const f16 *in, int cC, int cLd, int n, int H, int W, int k, const ConvGN &c, f16 *tmp, f16 *out, int ldo, int dup = 0);
+    int L(int c) const { return c * (1 + sa_); }
+    int lo(int c) const { return sa_ ? c : 0; }
     int load_gn(const std::string &name, int C, GN &out);
-    int load_conv_gn(const std::string &name, ConvGN &out);
+    int load_conv_gn(const std::string &name, ConvGN &out, int ci_pad = 0);
 
     pb_mask_cfg cfg_;
+    int sa_ = 0;                 // PB_PREC_SPLIT: feature maps are [hi | lo] fp16 pairs (mask_engine.hip load)
 
     // weights
     PackedW stem_;

@@ -86,8 +86,8 @@ int MaskEngine::load_gn(const std::string &name, int C, GN &out) {
 }
 
 // mmcv ConvModule with a norm: conv without bias -> GroupNorm(32) -> ReLU; submodules `conv` and `gn`
-int MaskEngine::load_conv_gn(const std::string &name, ConvGN &out) {
-    int r = pack_conv(name + ".conv", false, nullptr, nullptr, out.w);
+int MaskEngine::load_conv_gn(const std::string &name, ConvGN &out, int ci_pad) {
+    int r = pack_conv(name + ".conv", false, nullptr, nullptr, out.w, sa_, ci_pad);
     if (r) return r;
     return load_gn(name + ".gn", (int)tmap_[name + ".conv.weight"]->shape[0], out.gn);
 }
@@ -99,6 +99,10 @@ int MaskEngine::load(const pb_tensor *w, int n) {
              PB_ERR_ARG, "mask_mmdet: unsupported configuration");
     PB_CHECK(cfg_.precision == PB_PREC_F16 || cfg_.precision == PB_PREC_SPLIT, PB_ERR_ARG, "mask_mmdet: precision %d unknown", cfg_.precision);
     split_w_ = cfg_.precision == PB_PREC_SPLIT;
+    // round 3: PB_PREC_SPLIT splits the activations too - every feature map is [hi (C) | lo (C)] fp16 pairs per pixel, the weights are packed
+    // per tap as [w_hi | w_hi | w_lo] (engine_base.h pack sa) and every GEMM / convolution runs a_hi w_hi + a_lo w_hi + a_hi w_lo into one fp32
+    // accumulator.  PB_MASK_SA=0 keeps single-fp16 activations (the round-2 schedule) for A/B.
+    sa_ = split_w_ && pb_env_int("PB_MASK_SA", 1) ? 1 : 0;
     int r0 = begin_load(w, n);
     if (r0) return r0;
     for (int l = 0; l < 5; ++l) {
@@ -131,7 +135,7 @@ int MaskEngine::load(const pb_tensor *w, int n) {
                                         g[(size_t)nn * 576 + (ty * 3 + tx) * 64 + (dy * 4 + dx) * 4 + c] = wt[((size_t)o * 3 + c) * 49 + ky * 7 + kx] * sc[o];
                                 }
                 }
-        if ((r = pack(g.data(), 256, 576, 576, stem_, bb.data(), 9))) return r;
+        if ((r = pack(g.data(), 256, 576, 576, stem_, bb.data(), 9, sa_))) return r;
         stem_.Kreal = 147;
     }
     int inpl = 64;
@@ -143,21 +147,21 @@ int MaskEngine::load(const pb_tensor *w, int n) {
             const std::string p = "backbone.layer" + std::to_string(li + 1) + "." + std::to_string(b);
             B.planes = planes; B.inpl = inpl;
             B.stride = (b == 0 && li > 0) ? 2 : 1;              // style 'pytorch': the 3x3 carries the stride
-            if ((r = fold_bn(p + ".bn1", planes, sc, sf)) || (r = pack_conv(p + ".conv1", false, sc.data(), sf.data(), B.c1))) return r;
-            if ((r = fold_bn(p + ".bn2", planes, sc, sf)) || (r = pack_conv(p + ".conv2", false, sc.data(), sf.data(), B.c2))) return r;
-            if ((r = fold_bn(p + ".bn3", planes * 4, sc, sf)) || (r = pack_conv(p + ".conv3", false, sc.data(), sf.data(), B.c3))) return r;
+            if ((r = fold_bn(p + ".bn1", planes, sc, sf)) || (r = pack_conv(p + ".conv1", false, sc.data(), sf.data(), B.c1, sa_))) return r;
+            if ((r = fold_bn(p + ".bn2", planes, sc, sf)) || (r = pack_conv(p + ".conv2", false, sc.data(), sf.data(), B.c2, sa_))) return r;
+            if ((r = fold_bn(p + ".bn3", planes * 4, sc, sf)) || (r = pack_conv(p + ".conv3", false, sc.data(), sf.data(), B.c3, sa_))) return r;
             B.has_ds = b == 0;
             if (B.has_ds) {
                 if ((r = fold_bn(p + ".downsample.1", planes * 4, sc, sf)) ||
-                    (r = pack_conv(p + ".downsample.0", false, sc.data(), sf.data(), B.ds)))
+                    (r = pack_conv(p + ".downsample.0", false, sc.data(), sf.data(), B.ds, sa_)))
                     return r;
             }
             inpl = planes * 4;
         }
     }
     for (int i = 0; i < 4; ++i) {
-        if ((r = pack_conv("neck.lateral_convs." + std::to_string(i) + ".conv", true, nullptr, nullptr, lat_[i]))) return r;
-        if ((r = pack_conv("neck.fpn_convs." + std::to_string(i) + ".conv", true, nullptr, nullptr, fpnc_[i]))) return r;
+        if ((r = pack_conv("neck.lateral_convs." + std::to_string(i) + ".conv", true, nullptr, nullptr, lat_[i], sa_))) return r;
+        if ((r = pack_conv("neck.fpn_convs." + std::to_string(i) + ".conv", true, nullptr, nullptr, fpnc_[i], sa_))) return r;
     }
     const std::string h = "mask_head.mask_feature_head.";
     for (int i = 0; i < 4; ++i)
@@ -168,11 +172,13 @@ int MaskEngine::load(const pb_tensor *w, int n) {
     cconv_.resize(cfg_.stacked_convs);
     for (int i = 0; i < cfg_.stacked_convs; ++i) {
         if ((r = load_conv_gn("mask_head.kernel_convs." + std::to_string(i), kconv_[i]))) return r;
-        if ((r = load_conv_gn("mask_head.cls_convs." + std::to_string(i), cconv_[i]))) return r;
+        // cate_feat = kernel_feat[:, :-2]: a channel slice of a split map has its residuals at +320, not +256, which the K wrap of the GEMM
+        // cannot express - the first cls conv is packed for all 320 channels with zero weights on the coordinates instead
+        if ((r = load_conv_gn("mask_head.cls_convs." + std::to_string(i), cconv_[i], i == 0 && sa_ ? 320 : 0))) return r;
     }
-    if ((r = pack_conv("mask_head.conv_cls", true, nullptr, nullptr, conv_cls_))) return r;
+    if ((r = pack_conv("mask_head.conv_cls", true, nullptr, nullptr, conv_cls_, sa_))) return r;
     conv_cls_.N = (int)round_up(conv_cls_.N, 8);             // the GEMM writes 8-column groups; the pad rows are zero
-    if ((r = pack_conv("mask_head.conv_kernel", true, nullptr, nullptr, conv_kernel_))) return r;
+    if ((r = pack_conv("mask_head.conv_kernel", true, nullptr, nullptr, conv_kernel_, sa_))) return r;
     PB_CHECK(conv_kernel_.N == cfg_.mask_out_channels && mfpred_.w.N == cfg_.mask_out_channels, PB_ERR_ARG,
              "mask_mmdet: kernel / mask feature widths do not match the configuration");
     tmap_.clear();
@@ -203,12 +209,13 @@ int MaskEngine::prepare(int n, int H, int W) {
     goff_[5] = pts_;
     const int fc = cfg_.feat_channels, mfc = cfg_.mask_feat_channels, Cp = conv_cls_.N;
     const size_t slack = 1 << 20;
-    auto rows = [&](int i) { return (size_t)round_up((int64_t)B * lh_[i] * lw_[i], 256); };
+    const int sp = 1 + sa_;                                 // fp16 parts per element of a feature map
+    auto rows = [&](int i) { return (size_t)round_up((int64_t)B * lh_[i] * lw_[i], 256) * sp; };
     for (int pass = 0; pass < 2; ++pass) {
         planning_ = pass == 0;
         arena_off_ = 0;
         xt_ = (int *)carve((size_t)nw_ * 16); yt_ = (int *)carve((size_t)nh_ * 16);
-        img_ = (f16 *)carve((size_t)B * Hp_ * Wp_ * 8 + slack);
+        img_ = (f16 *)carve((size_t)B * Hp_ * Wp_ * 8 * sp + slack);
         chw_ = debug ? (float *)carve((size_t)B * 3 * Hp_ * Wp_ * 4) : nullptr;
         stem_out_ = (f16 *)carve(rows(5) * 64 * 2);
         pool_ = (f16 *)carve(rows(0) * 64 * 2 + slack);
@@ -225,11 +232,11 @@ int MaskEngine::prepare(int n, int H, int W) {
         mt_[0] = (f16 *)carve(rows(0) * 256 * 2 + slack);
         mg_[0] = (f16 *)carve(rows(0) * mfc * 2 + slack); mg_[1] = (f16 *)carve(rows(0) * mfc * 2 + slack);
         macc_ = (f16 *)carve(rows(0) * mfc * 2 + slack);
-        mf_ = (f16 *)carve(rows(0) * 256 * 2 + slack);
+        mf_ = (f16 *)carve(rows(0) / sp * (sa_ ? 3 : 1) * 256 * 2 + slack);       // split: [hi | hi | lo] rows (B operand of the dynamic convolution)
         p5cc_ = (f16 *)carve(rows(3) * 320 * 2 + slack);
         for (int l = 0; l < 5; ++l) {                        // each level's two branches run on their own stream
             const int fl = l == 0 ? 1 : (l == 4 ? 3 : l);     // resolution after resize_feats
-            const size_t grows = (size_t)round_up((int64_t)B * cfg_.num_grids[l] * cfg_.num_grids[l], 256);
+            const size_t grows = (size_t)round_up((int64_t)B * cfg_.num_grids[l] * cfg_.num_grids[l], 256) * sp;
             fcc_[l] = (f16 *)carve(rows(fl) * 320 * 2 + slack);
             rs_[l] = (l == 0 || l == 4) ? (f16 *)carve(rows(fl) * 256 * 2 + slack) : nullptr;
             grid_[l] = (f16 *)carve(grows * 320 * 2 + slack);
@@ -258,7 +265,7 @@ int MaskEngine::prepare(int n, int H, int W) {
 int MaskEngine::conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, const PackedW &w, float *out, int ldo) {
     GemmArgs a;
     a.A = in; a.N = w.N;
-    a.cH = H; a.cW = W; a.cC = cC; a.cLd = cLd; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1; a.cOH = H; a.cOW = W;
+    a.cH = H; a.cW = W; a.cC = cC; a.cLd = L(cLd); a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1; a.cOH = H; a.cOW = W;
     a.M = n * H * W;
     a.out32 = out; a.ldo = ldo; a.scale = 1.f;
     set_weights(a, w, true);
@@ -271,11 +278,15 @@ int MaskEngine::conv_f32(const f16 *in, int cC, int cLd, int n, int H, int W, co
 }
 
 int MaskEngine::conv_gn_relu(const f16 *in, int cC, int cLd, int n, int H, int W, int k, const ConvGN &c, f16 *tmp, f16 *out,
-                             int ldo) {
-    int r = k == 1 ? dense(in, cLd, (int64_t)n * H * W, c.w, tmp, c.w.N, ACT_NONE) : conv(in, cC, cLd, n, H, W, k, k, 1, c.w, tmp, c.w.N, ACT_NONE);
+                             int ldo, int dup) {
+    const int N = c.w.N;
+    int r = k == 1 ? dense(in, L(cLd), (int64_t)n * H * W, c.w, tmp, L(N), ACT_NONE, nullptr, 0, -1, lo(N))
+                   : conv(in, cC, L(cLd), n, H, W, k, k, 1, c.w, tmp, L(N), ACT_NONE, 0, nullptr, nullptr, lo(N));
     if (r) return r;
-    tic(F_ELT, 0, (double)n * H * W * c.w.N * 6);
-    r = launch_gn_relu(cur_, tmp, out, n, H * W, c.gn.C, c.w.N, ldo, 32, c.gn.g, c.gn.b, gst_cur_, gaff_cur_);
+    tic(F_ELT, 0, (double)n * H * W * N * 6 * (1 + sa_));
+    // dup (split only): rows [hi | hi | lo] instead of [hi | lo]
+    r = launch_gn_relu(cur_, tmp, out, n, H * W, c.gn.C, L(N), dup && sa_ ? 3 * ldo : L(ldo), 32, c.gn.g, c.gn.b, gst_cur_, gaff_cur_, lo(N),
+                       dup && sa_ ? 2 * ldo : lo(ldo), dup && sa_ ? ldo : 0);
     toc();
     return r;
 }
@@ -286,10 +297,10 @@ int MaskEngine::backbone(int n) {
     {
         GemmArgs a;
         a.A = img_; a.N = 256;
-        a.cH = Hp_ / 4; a.cW = Wp_ / 4; a.cC = 64; a.cLd = 64; a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1;
+        a.cH = Hp_ / 4; a.cW = Wp_ / 4; a.cC = 64; a.cLd = L(64); a.cKW = 3; a.cStride = 1; a.cPad = 1; a.cPadX = 1;
         set_weights(a, stem_, true);
         a.cOH = a.cH; a.cOW = a.cW; a.M = n * a.cH * a.cW;
-        a.out = stem_out_; a.ldo = 64; a.act = ACT_RELU;
+        a.out = stem_out_; a.ldo = L(64); a.lo_off = lo(64); a.act = ACT_RELU;
         a.ps_h = a.cH; a.ps_w = a.cW; a.ps_s = 2; a.ps_co = 64;
         tic(F_CONV, 2.0 * n * H2 * W2 * 64.0 * 147, 0);
         r = launch_gemm(cur_, A_CONV, EPI_PIXSHUF, TILE_AUTO, a);
@@ -298,7 +309,7 @@ int MaskEngine::backbone(int n) {
         if (r) return r;
     }
     tic(F_ELT, 0, 0);
-    r = launch_maxpool3x3s2(stream, stem_out_, pool_, n, H2, W2, 64);
+    r = launch_maxpool3x3s2(stream, stem_out_, pool_, n, H2, W2, 64, sa_);
     toc();
     if (r) return r;
     const f16 *x = pool_;
@@ -307,22 +318,22 @@ int MaskEngine::backbone(int n) {
         for (size_t b = 0; b < blocks_[s].size(); ++b) {
             const Bneck &B = blocks_[s][b];
             const int ho = (hi - 1) / B.stride + 1, wo = (wi - 1) / B.stride + 1, p = B.planes;
-            if ((r = dense(x, B.inpl, (int64_t)n * hi * wi, B.c1, st1_[s], p, ACT_RELU))) return r;
-            if ((r = conv(st1_[s], p, p, n, hi, wi, 3, 3, B.stride, B.c2, st2_[s], p, ACT_RELU))) return r;
+            if ((r = dense(x, L(B.inpl), (int64_t)n * hi * wi, B.c1, st1_[s], L(p), ACT_RELU, nullptr, 0, -1, lo(p)))) return r;
+            if ((r = conv(st1_[s], p, L(p), n, hi, wi, 3, 3, B.stride, B.c2, st2_[s], L(p), ACT_RELU, 0, nullptr, nullptr, lo(p)))) return r;
             const f16 *idt = x;
             if (B.has_ds) {
-                if (B.stride == 1) r = dense(x, B.inpl, (int64_t)n * hi * wi, B.ds, sds_[s], 4 * p, ACT_NONE);
-                else r = conv(x, B.inpl, B.inpl, n, hi, wi, 1, 1, B.stride, B.ds, sds_[s], 4 * p, ACT_NONE);
+                if (B.stride == 1) r = dense(x, L(B.inpl), (int64_t)n * hi * wi, B.ds, sds_[s], L(4 * p), ACT_NONE, nullptr, 0, -1, lo(4 * p));
+                else r = conv(x, B.inpl, L(B.inpl), n, hi, wi, 1, 1, B.stride, B.ds, sds_[s], L(4 * p), ACT_NONE, 0, nullptr, nullptr, lo(4 * p));
                 if (r) return r;
                 idt = sds_[s];
             }
             f16 *out = sx_[s][b & 1];
-            if ((r = dense(st2_[s], p, (int64_t)n * ho * wo, B.c3, out, 4 * p, ACT_RELU, idt))) return r;
+            if ((r = dense(st2_[s], L(p), (int64_t)n * ho * wo, B.c3, out, L(4 * p), ACT_RELU, idt, 0, -1, lo(4 * p)))) return r;
             x = out; hi = ho; wi = wo;
         }
         PB_CHECK(hi == lh_[s] && wi == lw_[s], PB_ERR_STATE, "backbone: stage %d size %dx%d != %dx%d", s, hi, wi, lh_[s], lw_[s]);
         c_[s] = x;
-        stages_["c" + std::to_string(s + 2)] = Stage{x, 1, 0, 256 << s, lh_[s], lw_[s], 256 << s, 0};
+        stages_["c" + std::to_string(s + 2)] = Stage{x, 1, 0, 256 << s, lh_[s], lw_[s], L(256 << s), lo(256 << s)};
     }
     return 0;
 }
@@ -330,19 +341,19 @@ int MaskEngine::backbone(int n) {
 int MaskEngine::neck(int n) {
     int r;
     for (int i = 0; i < 4; ++i)
-        if ((r = dense(c_[i], 256 << i, (int64_t)n * lh_[i] * lw_[i], lat_[i], latb_[i], 256, ACT_NONE))) return r;
+        if ((r = dense(c_[i], L(256 << i), (int64_t)n * lh_[i] * lw_[i], lat_[i], latb_[i], L(256), ACT_NONE, nullptr, 0, -1, lo(256)))) return r;
     for (int i = 3; i > 0; --i) {
         tic(F_ELT, 0, 0);
-        r = launch_nearest_add(stream, latb_[i - 1], latb_[i], n, lh_[i - 1], lw_[i - 1], lh_[i], lw_[i], 256);
+        r = launch_nearest_add(stream, latb_[i - 1], latb_[i], n, lh_[i - 1], lw_[i - 1], lh_[i], lw_[i], 256, sa_);
         toc();
         if (r) return r;
     }
     for (int i = 0; i < 4; ++i)
-        if ((r = conv(latb_[i], 256, 256, n, lh_[i], lw_[i], 3, 3, 1, fpnc_[i], p_[i], 256, ACT_NONE))) return r;
+        if ((r = conv(latb_[i], 256, L(256), n, lh_[i], lw_[i], 3, 3, 1, fpnc_[i], p_[i], L(256), ACT_NONE, 0, nullptr, nullptr, lo(256)))) return r;
     tic(F_ELT, 0, 0);
-    r = launch_subsample2(stream, p_[3], p_[4], n, lh_[3], lw_[3], 256);
+    r = launch_subsample2(stream, p_[3], p_[4], n, lh_[3], lw_[3], L(256));         // whole rows: both parts of a split map
     toc();
-    for (int i = 0; i < 5; ++i) stages_["p" + std::to_string(i + 2)] = Stage{p_[i], 1, 0, 256, lh_[i], lw_[i], 256, 0};
+    for (int i = 0; i < 5; ++i) stages_["p" + std::to_string(i + 2)] = Stage{p_[i], 1, 0, 256, lh_[i], lw_[i], L(256), lo(256)};
     return r;
 }
 
@@ -356,7 +367,7 @@ int MaskEngine::head(int n) {
         int cC = 256, h = lh_[i], w = lw_[i];
         if (i == 3) {
             tic(F_ELT, 0, 0);
-            r = launch_coord_concat(stream, p_[3], p5cc_, n, h, w, 256, 256);
+            r = launch_coord_concat(stream, p_[3], p5cc_, n, h, w, 256, L(256), lo(256));
             toc();
             if (r) return r;
             x = p5cc_; cC = 320;
@@ -365,15 +376,15 @@ int MaskEngine::head(int n) {
             if ((r = conv_gn_relu(x, cC, cC, n, h, w, 3, mfc_[i][j], mt_[0], mg_[0], mfc))) return r;
             const bool last = j == i - 1;
             tic(F_ELT, 0, 0);
-            r = launch_bilinear(stream, mg_[0], last ? macc_ : mg_[1], n, h, w, 2 * h, 2 * w, mfc, mfc, mfc, last ? 1 : 0);
+            r = launch_bilinear(stream, mg_[0], last ? macc_ : mg_[1], n, h, w, 2 * h, 2 * w, mfc, L(mfc), L(mfc), last ? 1 : 0, lo(mfc), lo(mfc));
             toc();
             if (r) return r;
             x = mg_[1]; cC = mfc; h *= 2; w *= 2;
         }
         PB_CHECK(h == lh_[0] && w == lw_[0], PB_ERR_STATE, "mask feature level %d ends at %dx%d", i, h, w);
     }
-    if ((r = conv_gn_relu(macc_, mfc, mfc, n, lh_[0], lw_[0], 1, mfpred_, mt_[0], mf_, 256))) return r;
-    stages_["mask_feats"] = Stage{mf_, 1, 0, 256, lh_[0], lw_[0], 256, 0};
+    if ((r = conv_gn_relu(macc_, mfc, mfc, n, lh_[0], lw_[0], 1, mfpred_, mt_[0], mf_, 256, 1))) return r;
+    stages_["mask_feats"] = Stage{mf_, 1, 0, 256, lh_[0], lw_[0], sa_ ? 768 : 256, sa_ ? 512 : 0};
 
     return 0;
 }
@@ -389,14 +400,14 @@ int MaskEngine::head_level(int n, int lvl) {
     if (lvl == 0 || lvl == 4) {
         const int th = lvl == 0 ? lh_[1] : lh_[3], tw = lvl == 0 ? lw_[1] : lw_[3];
         tic(F_ELT, 0, 0);
-        r = launch_bilinear(cur_, src, rs, n, fh, fw, th, tw, 256, 256, 256, 0);
+        r = launch_bilinear(cur_, src, rs, n, fh, fw, th, tw, 256, L(256), L(256), 0, lo(256), lo(256));
         toc();
         if (r) return r;
         src = rs; fh = th; fw = tw;
     }
     tic(F_ELT, 0, 0);
-    r = launch_coord_concat(cur_, src, fcc, n, fh, fw, 256, 256);
-    if (!r) r = launch_bilinear(cur_, fcc, grid, n, fh, fw, g, g, 320, 320, 320, 0);
+    r = launch_coord_concat(cur_, src, fcc, n, fh, fw, 256, L(256), lo(256));
+    if (!r) r = launch_bilinear(cur_, fcc, grid, n, fh, fw, g, g, 320, L(320), L(320), 0, lo(320), lo(320));
     toc();
     if (r) return r;
     const f16 *x = grid;
@@ -408,7 +419,7 @@ int MaskEngine::head_level(int n, int lvl) {
     }
     float *kp = kp_ + (int64_t)n * goff_[lvl] * 256;
     if ((r = conv_f32(x, fc, fc, n, g, g, conv_kernel_, kp, 256))) return r;
-    x = grid; cC = 256; cLd = 320;                                   // cate_feat = kernel_feat[:, :-2]
+    x = grid; cC = sa_ ? 320 : 256; cLd = 320;                       // cate_feat = kernel_feat[:, :-2] (split maps: zero weights on the coordinates, load())
     for (int i = 0; i < cfg_.stacked_convs; ++i) {
         f16 *o = hk[1 + (i & 1)];
         if ((r = conv_gn_relu(x, cC, cLd, n, g, g, 3, cconv_[i], hk[0], o, fc))) return r;
@@ -434,7 +445,7 @@ int MaskEngine::ensure_post(size_t cands, int frames) {
         void **bufs[] = {(void **)&pk_, (void **)&plog_, (void **)&pstat_, (void **)&pidx_};
         for (auto b : bufs)
             if (*b) { PB_HIP(hipFree(*b)); *b = nullptr; }
-        PB_HIP(hipMalloc((void **)&pk_, (need + 256) * 256 * 2));
+        PB_HIP(hipMalloc((void **)&pk_, (need + 256) * 256 * 2 * (1 + sa_)));
         PB_HIP(hipMalloc((void **)&plog_, need * HW4 * 4));
         PB_HIP(hipMalloc((void **)&pstat_, need * 2 * 4));
         PB_HIP(hipMalloc((void **)&pidx_, need * 4));
@@ -510,7 +521,7 @@ int MaskEngine::post_chunk(int n, int first, float confidence, const std::vector
     if (total) {
         PB_HIP(hipMemcpyAsync(pidx_, rows.data(), total * 4, hipMemcpyHostToDevice, stream));
         tic(F_PP, 0, (double)total * 256 * 6);
-        r = launch_gather_rows_f16(stream, kp_, pidx_, pk_, (int)total, (int)total, 256);
+        r = launch_gather_rows_f16(stream, kp_, pidx_, pk_, (int)total, (int)total, 256, sa_);
         toc();
         if (r) return r;
     }
@@ -519,9 +530,11 @@ int MaskEngine::post_chunk(int n, int first, float confidence, const std::vector
         const int K = (int)f.cand.size();
         if (!K) { if ((r = finish_empty(b))) return r; continue; }
         GemmArgs a;         // dynamic convolution: logits[k][pixel] = <kernel_k, mask_feats[pixel]>
-        a.A = pk_ + f.off * 256; a.lda = 256; a.M = K; a.W = mf_ + (int64_t)b * HW4 * 256; a.K = 256; a.N = HW4;
+        // split: kernels [k_hi | k_lo] x features [f_hi | f_hi | f_lo] with the K wrap of gemm.h - k_hi f_hi + k_lo f_hi + k_hi f_lo
+        a.A = pk_ + f.off * L(256); a.lda = L(256); a.M = K; a.W = mf_ + (int64_t)b * HW4 * (sa_ ? 768 : 256); a.K = sa_ ? 768 : 256; a.N = HW4;
+        if (sa_) a.kwrap = 8;
         a.out32 = plog_ + f.off * HW4; a.ldo = HW4; a.scale = 1.f; a.zero = zero_;
-        tic(F_GEMM, 2.0 * K * (double)HW4 * 256, 0);
+        tic(F_GEMM, 2.0 * K * (double)HW4 * 256, 0, sa_ ? 3.0 : 1.0);
         r = launch_gemm(stream, A_DENSE, EPI_F32, TILE_AUTO, a);
         if (timer.enabled && !r && !open_.empty()) timer.recs[open_.back()].name = pb_gemm_last_kernel();
         toc();
@@ -633,7 +646,7 @@ int MaskEngine::run_chunk(const uint8_t *frames, int n, int first, float confide
     int r;
     last_n_ = n;
     tic(F_PP, 0, (double)n * ((double)pH_ * pW_ * 3 + (double)Hp_ * Wp_ * 8));
-    r = launch_mask_prep(stream, frames, n, pH_, pW_, nh_, nw_, Hp_, Wp_, xt_, yt_, img_, chw_);
+    r = launch_mask_prep(stream, frames, n, pH_, pW_, nh_, nw_, Hp_, Wp_, xt_, yt_, img_, chw_, sa_);
     toc();
     if (r) return r;
     if (chw_) stages_["input"] = Stage{chw_, 2, 0, 3, Hp_, Wp_, 0, 0};
@@ -708,6 +721,14 @@ int64_t MaskEngine::get_stage(const char *name, float *out, int64_t cap, int64_t
     if (r) return r;
     PB_HIP(hipStreamSynchronize(stream));
     PB_HIP(hipMemcpy(out, tmp, total * 4, hipMemcpyDeviceToHost));
+    if (s.bstride) {             // split map: add the residual parts (bstride = their half offset)
+        std::vector<float> lo_part((size_t)total);
+        r = launch_nhwc_f16_to_nchw_f32(stream, (const f16 *)s.ptr + s.bstride, tmp, n, (int)s.c, (int)s.h, (int)s.w, (int)s.ld);
+        if (r) return r;
+        PB_HIP(hipStreamSynchronize(stream));
+        PB_HIP(hipMemcpy(lo_part.data(), tmp, total * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < total; ++i) out[i] += lo_part[(size_t)i];
+    }
     PB_HIP(hipFree(tmp));
     return total;
 }

@@ -31,6 +31,26 @@ __device__ __forceinline__ void lerp_src(int dst, float scale, int in, int &i0, 
     l1 = src - (float)i0;
 }
 
+// Split maps (PB_PREC_SPLIT, mask_engine.hip): every pixel holds [hi (C) | lo (C)] fp16 pairs, value = hi + lo, lo = the fp16 rounding
+// residual of the fp32 value.  The kernels below take `lo` = the half offset from an element to its residual; 0 = a plain fp16 map.
+__device__ __forceinline__ void ld8(const f16 *p, int lo, float v[8]) {
+    const f16x8 h = *(const f16x8 *)p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+    if (lo) {
+        const f16x8 l = *(const f16x8 *)(p + lo);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
+    }
+}
+__device__ __forceinline__ void st8(f16 *p, int lo, const float v[8]) {
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[j] = (f16)v[j]; l[j] = (f16)(v[j] - (float)h[j]); }
+    *(f16x8 *)p = h;
+    if (lo) *(f16x8 *)(p + lo) = l;
+}
+
 // ------------------------------------------------------------------------------------------------
 // frame prep: uint8 RGB [n][H][W][3] -> OpenCV 8-bit INTER_LINEAR resize to (nh, nw) (11-bit fixed-point
 // coefficients, tables from the host) -> (v - mean) * (1 / std) in fp32 -> zero pad to (Hp, Wp) ->
@@ -40,12 +60,13 @@ __device__ __forceinline__ void lerp_src(int dst, float scale, int in, int &i0, 
 __global__ __launch_bounds__(256) void mask_prep_kernel(const uint8_t *__restrict__ frames, int n, int H, int W, int nh, int nw,
                                                         int Hp, int Wp, const int4 *__restrict__ xt,
                                                         const int4 *__restrict__ yt, f16 *__restrict__ out,
-                                                        float *__restrict__ chw) {
+                                                        float *__restrict__ chw, int lo) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * Hp * Wp) return;
     const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), f = (int)(i / ((int64_t)Wp * Hp));
-    f16x4 o;
+    f16x4 o, ol;
     o[0] = o[1] = o[2] = o[3] = (f16)0.f;
+    ol = o;
     float v[3] = {0.f, 0.f, 0.f};
     if (y < nh && x < nw) {
         const int4 tx = xt[x], ty = yt[y];
@@ -60,9 +81,12 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(const uint8_t *__restric
             q = q < 0 ? 0 : (q > 255 ? 255 : q);
             v[c] = ex_fmul(ex_fsub((float)q, mean[c]), istd[c]);
             o[c] = (f16)v[c];
+            ol[c] = (f16)(v[c] - (float)o[c]);
         }
     }
-    *(f16x4 *)(out + ((((int64_t)f * (Hp >> 2) + (y >> 2)) * (Wp >> 2) + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)) * 4) = o;
+    f16 *dst = out + (((int64_t)f * (Hp >> 2) + (y >> 2)) * (Wp >> 2) + (x >> 2)) * (64 + lo) + ((y & 3) * 4 + (x & 3)) * 4;
+    *(f16x4 *)dst = o;
+    if (lo) *(f16x4 *)(dst + lo) = ol;
     if (chw)
 #pragma unroll
         for (int c = 0; c < 3; ++c) chw[(((int64_t)f * 3 + c) * Hp + y) * Wp + x] = v[c];
@@ -72,12 +96,13 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(const uint8_t *__restric
 // max_pool2d(3, stride 2, padding 1), NHWC fp16, 8 channels per thread
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int n, int H, int W,
-                                                           int OH, int OW, int C8) {
+                                                           int OH, int OW, int C8, int lo) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * OH * OW * C8) return;
     const int c = (int)(i % C8);
     const int64_t pix = i / C8;
     const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    const int ld = C8 * 8 + lo;
     float m[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
@@ -89,32 +114,31 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f16 *__restrict
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = ox * 2 - 1 + kx;
             if ((unsigned)ix >= (unsigned)W) continue;
-            const f16x8 v = *(const f16x8 *)(x + (((int64_t)b * H + iy) * W + ix) * C8 * 8 + c * 8);
+            float v[8];
+            ld8(x + (((int64_t)b * H + iy) * W + ix) * ld + c * 8, lo, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)v[j]);
+            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], v[j]);
         }
     }
-    f16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (f16)m[j];
-    *(f16x8 *)(y + i * 8) = o;
+    st8(y + pix * ld + c * 8, lo, m);
 }
 
 // dst[n][h][w][C] += src[n][sh][sw][C] at the torch 'nearest' source pixel min(floor(d * sh / h), sh - 1)
 __global__ __launch_bounds__(256) void nearest_add_kernel(f16 *__restrict__ dst, const f16 *__restrict__ src, int n, int h, int w,
-                                                          int sh, int sw, int C8, float fy, float fx) {
+                                                          int sh, int sw, int C8, float fy, float fx, int lo) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * h * w * C8) return;
     const int c = (int)(i % C8);
     const int64_t pix = i / C8;
     const int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((int64_t)w * h));
     const int sy = min((int)floorf((float)y * fy), sh - 1), sx = min((int)floorf((float)x * fx), sw - 1);
-    const f16x8 a = *(const f16x8 *)(dst + i * 8);
-    const f16x8 s = *(const f16x8 *)(src + (((int64_t)b * sh + sy) * sw + sx) * C8 * 8 + c * 8);
-    f16x8 o;
+    const int ld = C8 * 8 + lo;
+    float a[8], s[8];
+    ld8(dst + pix * ld + c * 8, lo, a);
+    ld8(src + (((int64_t)b * sh + sy) * sw + sx) * ld + c * 8, lo, s);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (f16)((float)a[j] + (float)s[j]);
-    *(f16x8 *)(dst + i * 8) = o;
+    for (int j = 0; j < 8; ++j) a[j] += s[j];
+    st8(dst + pix * ld + c * 8, lo, a);
 }
 
 // max_pool2d(kernel 1, stride 2): out[y][x] = in[2y][2x]
@@ -136,31 +160,34 @@ __device__ __forceinline__ float linspace_pm1(int i, int steps) {
 }
 
 // [n][h][w][C] (ld ldi) -> [n][h][w][C + 64]: channels C, C+1 = (x, y) coordinates in [-1, 1], rest 0
+// split maps: the input's residuals at +lo_in, the output is [hi (C + 64) | lo (C + 64)]
 __global__ __launch_bounds__(256) void coord_concat_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int n, int h, int w,
-                                                           int C8, int ldi) {
+                                                           int C8, int ldi, int lo_in) {
     const int O8 = C8 + 8;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * h * w * O8) return;
     const int c = (int)(i % O8);
     const int64_t pix = i / O8;
-    f16x8 o;
+    float o[8];
     if (c < C8) {
-        o = *(const f16x8 *)(x + pix * ldi + c * 8);
+        ld8(x + pix * ldi + c * 8, lo_in, o);
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
         if (c == C8) {
             const int px = (int)(pix % w), py = (int)((pix / w) % h);
-            o[0] = (f16)linspace_pm1(px, w);
-            o[1] = (f16)linspace_pm1(py, h);
+            o[0] = linspace_pm1(px, w);
+            o[1] = linspace_pm1(py, h);
         }
     }
-    *(f16x8 *)(y + pix * (int64_t)(O8 * 8) + c * 8) = o;
+    const int lo_out = lo_in ? O8 * 8 : 0;
+    st8(y + pix * (int64_t)(O8 * 8 + lo_out) + c * 8, lo_out, o);
 }
 
 // NHWC fp16 bilinear resize, align_corners = False, separate pixel strides, optional accumulate into y
 __global__ __launch_bounds__(256) void bilinear_kernel(const f16 *__restrict__ x, f16 *__restrict__ y, int n, int H, int W, int OH,
-                                                       int OW, int C8, int ldi, int ldo, float sy, float sx, int accumulate) {
+                                                       int OW, int C8, int ldi, int ldo, float sy, float sx, int accumulate, int lo_in,
+                                                       int lo_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * OH * OW * C8) return;
     const int c = (int)(i % C8);
@@ -171,20 +198,20 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const f16 *__restrict__ x
     lerp_src(oy, sy, H, y0, y1, ly);
     lerp_src(ox, sx, W, x0, x1, lx);
     const f16 *base = x + (int64_t)b * H * W * ldi + c * 8;
-    const f16x8 v00 = *(const f16x8 *)(base + ((int64_t)y0 * W + x0) * ldi);
-    const f16x8 v01 = *(const f16x8 *)(base + ((int64_t)y0 * W + x1) * ldi);
-    const f16x8 v10 = *(const f16x8 *)(base + ((int64_t)y1 * W + x0) * ldi);
-    const f16x8 v11 = *(const f16x8 *)(base + ((int64_t)y1 * W + x1) * ldi);
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    ld8(base + ((int64_t)y0 * W + x0) * ldi, lo_in, v00);
+    ld8(base + ((int64_t)y0 * W + x1) * ldi, lo_in, v01);
+    ld8(base + ((int64_t)y1 * W + x0) * ldi, lo_in, v10);
+    ld8(base + ((int64_t)y1 * W + x1) * ldi, lo_in, v11);
     const float hy = 1.f - ly, hx = 1.f - lx;
     f16 *dst = y + pix * ldo + c * 8;
-    f16x8 o;
-    if (accumulate) o = *(const f16x8 *)dst;
+    if (accumulate) ld8(dst, lo_out, o);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float v = hy * (hx * (float)v00[j] + lx * (float)v01[j]) + ly * (hx * (float)v10[j] + lx * (float)v11[j]);
-        o[j] = (f16)(accumulate ? (float)o[j] + v : v);
+        const float v = hy * (hx * v00[j] + lx * v01[j]) + ly * (hx * v10[j] + lx * v11[j]);
+        o[j] = accumulate ? o[j] + v : v;
     }
-    *(f16x8 *)dst = o;
+    st8(dst, lo_out, o);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -194,7 +221,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const f16 *__restrict__ x
 // share the launch or on block scheduling.  x: [n][HW][ldc] fp16; part: [n][nchunk][C][2].
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_stats_kernel(const f16 *__restrict__ x, int HW, int C8, int ldc, float *__restrict__ part,
-                                                       int chunk) {
+                                                       int chunk, int lo) {
     __shared__ float red[256 * 16];
     const int b = blockIdx.y;
     const int c8 = threadIdx.x % C8, pl = threadIdx.x / C8, npl = blockDim.x / C8;
@@ -204,9 +231,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16 *__restrict__ x
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
     if (pl < npl) {
         for (int p = p0 + pl; p < p1; p += npl) {
-            const f16x8 v = *(const f16x8 *)(x + ((int64_t)b * HW + p) * ldc + c8 * 8);
+            float v[8];
+            ld8(x + ((int64_t)b * HW + p) * ldc + c8 * 8, lo, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+            for (int j = 0; j < 8; ++j) { const float f = v[j]; s[j] += f; q[j] += f * f; }
         }
     }
 #pragma unroll
@@ -254,18 +282,21 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
 }
 
 __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const f16 *__restrict__ x, const float *__restrict__ aff,
-                                                            f16 *__restrict__ y, int n, int HW, int C8, int ldc, int ldo) {
+                                                            f16 *__restrict__ y, int n, int HW, int C8, int ldc, int ldo, int lo_in,
+                                                            int lo_out, int dup) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * HW * C8) return;
     const int c8 = (int)(i % C8);
     const int64_t pix = i / C8;
     const int b = (int)(pix / HW);
-    const f16x8 v = *(const f16x8 *)(x + pix * ldc + c8 * 8);
+    float v[8];
+    ld8(x + pix * ldc + c8 * 8, lo_in, v);
     const float *a = aff + ((int64_t)b * C8 * 8 + c8 * 8) * 2;
-    f16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (f16)fmaxf((float)v[j] * a[j * 2] + a[j * 2 + 1], 0.f);
-    *(f16x8 *)(y + pix * ldo + c8 * 8) = o;
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * a[j * 2] + a[j * 2 + 1], 0.f);
+    f16 *dst = y + pix * ldo + c8 * 8;
+    st8(dst, lo_out, v);
+    if (dup) *(f16x8 *)(dst + dup) = *(const f16x8 *)dst;       // [hi | hi | lo] rows: the map is the B operand of a split GEMM (dynamic convolution)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -289,13 +320,17 @@ __global__ __launch_bounds__(256) void cls_points_nms_kernel(const float *__rest
     score[((int64_t)b * pts_total + off + cell) * C + c] = m == s ? s : 0.f;
 }
 
-// dst[k][cols] (fp16) = src[idx[k]][cols] (fp32); rows k >= count are zero
+// dst[k][cols] (fp16) = src[idx[k]][cols] (fp32); rows k >= count are zero; split: rows are [hi (cols) | lo (cols)]
 __global__ __launch_bounds__(256) void gather_rows_f16_kernel(const float *__restrict__ src, const int *__restrict__ idx,
-                                                              f16 *__restrict__ dst, int count, int rows_pad, int cols) {
+                                                              f16 *__restrict__ dst, int count, int rows_pad, int cols, int split) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)rows_pad * cols) return;
     const int c = (int)(i % cols), k = (int)(i / cols);
-    dst[i] = k < count ? (f16)src[(int64_t)idx[k] * cols + c] : (f16)0.f;
+    const float v = k < count ? src[(int64_t)idx[k] * cols + c] : 0.f;
+    const f16 h = (f16)v;
+    if (!split) { dst[i] = h; return; }
+    dst[(int64_t)k * 2 * cols + c] = h;
+    dst[(int64_t)k * 2 * cols + cols + c] = (f16)(v - (float)h);
 }
 
 // per candidate row of dynamic-conv logits [k][ld]: area = #(sigmoid > thr), soft = sum of sigmoid over those
@@ -454,19 +489,20 @@ __global__ __launch_bounds__(256) void band_accumulate_kernel(const float *__res
 }  // namespace
 
 int launch_mask_prep(hipStream_t s, const uint8_t *frames, int n, int H, int W, int nh, int nw, int Hp, int Wp, const int *xt,
-                     const int *yt, f16 *out, float *chw) {
+                     const int *yt, f16 *out, float *chw, int split) {
     hipLaunchKernelGGL(mask_prep_kernel, dim3(nblk((int64_t)n * Hp * Wp)), dim3(256), 0, s, frames, n, H, W, nh, nw, Hp, Wp,
-                       (const int4 *)xt, (const int4 *)yt, out, chw);
+                       (const int4 *)xt, (const int4 *)yt, out, chw, split ? 64 : 0);
     LAUNCH_CHECK();
 }
-int launch_maxpool3x3s2(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C) {
+int launch_maxpool3x3s2(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C, int split) {
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(nblk((int64_t)n * OH * OW * (C / 8))), dim3(256), 0, s, x, y, n, H, W, OH, OW, C / 8);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(nblk((int64_t)n * OH * OW * (C / 8))), dim3(256), 0, s, x, y, n, H, W, OH, OW, C / 8,
+                       split ? C : 0);
     LAUNCH_CHECK();
 }
-int launch_nearest_add(hipStream_t s, f16 *dst, const f16 *src, int n, int h, int w, int sh, int sw, int C) {
+int launch_nearest_add(hipStream_t s, f16 *dst, const f16 *src, int n, int h, int w, int sh, int sw, int C, int split) {
     hipLaunchKernelGGL(nearest_add_kernel, dim3(nblk((int64_t)n * h * w * (C / 8))), dim3(256), 0, s, dst, src, n, h, w, sh, sw, C / 8,
-                       (float)sh / (float)h, (float)sw / (float)w);
+                       (float)sh / (float)h, (float)sw / (float)w, split ? C : 0);
     LAUNCH_CHECK();
 }
 int launch_subsample2(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int C) {
@@ -474,36 +510,38 @@ int launch_subsample2(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, 
     hipLaunchKernelGGL(subsample2_kernel, dim3(nblk((int64_t)n * OH * OW * (C / 8))), dim3(256), 0, s, x, y, n, H, W, OH, OW, C / 8);
     LAUNCH_CHECK();
 }
-int launch_coord_concat(hipStream_t s, const f16 *x, f16 *y, int n, int h, int w, int C, int ldi) {
-    hipLaunchKernelGGL(coord_concat_kernel, dim3(nblk((int64_t)n * h * w * (C / 8 + 8))), dim3(256), 0, s, x, y, n, h, w, C / 8, ldi);
+int launch_coord_concat(hipStream_t s, const f16 *x, f16 *y, int n, int h, int w, int C, int ldi, int lo_in) {
+    hipLaunchKernelGGL(coord_concat_kernel, dim3(nblk((int64_t)n * h * w * (C / 8 + 8))), dim3(256), 0, s, x, y, n, h, w, C / 8, ldi, lo_in);
     LAUNCH_CHECK();
 }
 int launch_bilinear(hipStream_t s, const f16 *x, f16 *y, int n, int H, int W, int OH, int OW, int C, int ldi, int ldo,
-                    int accumulate) {
+                    int accumulate, int lo_in, int lo_out) {
     PB_CHECK(C % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0, -1, "bilinear: C=%d ldi=%d ldo=%d must be multiples of 8", C, ldi, ldo);
     hipLaunchKernelGGL(bilinear_kernel, dim3(nblk((int64_t)n * OH * OW * (C / 8))), dim3(256), 0, s, x, y, n, H, W, OH, OW, C / 8, ldi,
-                       ldo, (float)H / (float)OH, (float)W / (float)OW, accumulate);
+                       ldo, (float)H / (float)OH, (float)W / (float)OW, accumulate, lo_in, lo_out);
     LAUNCH_CHECK();
 }
 int gn_chunks(int HW) { return (HW + GN_CHUNK - 1) / GN_CHUNK; }
 int launch_gn_relu(hipStream_t s, const f16 *x, f16 *y, int n, int HW, int C, int ldc, int ldo, int groups, const float *gamma,
-                   const float *beta, float *stats, float *aff) {
+                   const float *beta, float *stats, float *aff, int lo_in, int lo_out, int dup) {
     const int C8 = C / 8;
     PB_CHECK(C % 8 == 0 && C8 <= 256 && 256 % C8 == 0 && C % groups == 0, -1, "group norm: C=%d groups=%d unsupported", C, groups);
     const int chunk = GN_CHUNK, nchunk = gn_chunks(HW);           // fixed: the partition must not depend on the batch
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, n), dim3(256), 0, s, x, HW, C8, ldc, stats, chunk);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, n), dim3(256), 0, s, x, HW, C8, ldc, stats, chunk, lo_in);
     const int cpg = C / groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((n * groups + 3) / 4), dim3(256), 0, s, stats, gamma, beta, aff, n, C, cpg, nchunk,
                        1.f / ((float)HW * (float)cpg));
-    hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(nblk((int64_t)n * HW * C8)), dim3(256), 0, s, x, aff, y, n, HW, C8, ldc, ldo);
+    hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(nblk((int64_t)n * HW * C8)), dim3(256), 0, s, x, aff, y, n, HW, C8, ldc, ldo, lo_in,
+                       lo_out, dup);
     LAUNCH_CHECK();
 }
 int launch_cls_points_nms(hipStream_t s, const float *logit, float *score, int n, int pts_total, int off, int g, int C) {
     hipLaunchKernelGGL(cls_points_nms_kernel, dim3(nblk((int64_t)n * g * g * C)), dim3(256), 0, s, logit, score, n, pts_total, off, g, C);
     LAUNCH_CHECK();
 }
-int launch_gather_rows_f16(hipStream_t s, const float *src, const int *idx, f16 *dst, int count, int rows_pad, int cols) {
-    hipLaunchKernelGGL(gather_rows_f16_kernel, dim3(nblk((int64_t)rows_pad * cols)), dim3(256), 0, s, src, idx, dst, count, rows_pad, cols);
+int launch_gather_rows_f16(hipStream_t s, const float *src, const int *idx, f16 *dst, int count, int rows_pad, int cols, int split) {
+    hipLaunchKernelGGL(gather_rows_f16_kernel, dim3(nblk((int64_t)rows_pad * cols)), dim3(256), 0, s, src, idx, dst, count, rows_pad, cols,
+                       split);
     LAUNCH_CHECK();
 }
 int launch_mask_stats(hipStream_t s, const float *logit, int rows, int HW, int64_t ld, float thr, float *out) {

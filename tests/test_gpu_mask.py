@@ -2,8 +2,9 @@
 
 The oracle for this band is PARITY UNPINNED (mmcv / cv2 / the model config are absent from the build container, see
 the oracle's header), so these tests show that the HIP path equals the restatement, not the reference itself.
-Tolerances: feature maps relative max / L2 as for the other bands (fp16 operands, fp32 accumulation); everything
-integer - the preprocessing bytes, the Matrix-NMS survivors and the mask image given the same soft inputs - exact."""
+Tolerances: every feature map 1e-3 of the stage's range (relative max) and 5e-4 relative L2, the bar of the other two bands (round 3:
+PB_PREC_SPLIT splits this band's activations too); the preprocessing bytes and the Matrix-NMS survivors exact; the id image
+against the fp32 oracle through `id_image_report` - equal, or every differing pixel counted and placed on the threshold it sits on."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +13,7 @@ from oracle import solov2_oracle as SO
 from prisma_amd import engine, synth
 
 pytestmark = pytest.mark.gpu
-TOL_RANGE, TOL_L2 = 4e-3, 2e-3
+TOL_RANGE, TOL_L2 = 1e-3, 5e-4
 KEEP = [synth.COCO_CLASSES.index(c) for c in synth.BAND_CLASSES]
 
 
@@ -66,9 +67,37 @@ def _oracle_post_from_engine(cfg, net, n, meta, b):
     kps = [torch.from_numpy(net.stage(f"kernel_pred{l}")) for l in range(5)]
     cps = [torch.from_numpy(net.stage(f"cls_logit{l}")) for l in range(5)]
     mf = torch.from_numpy(net.stage("mask_feats"))
-    # the engine multiplies fp16 kernels with the fp16 mask features
-    kps = [k.half().float() for k in kps]
+    if net.precision == engine._lib.PREC_F16:        # single fp16: the engine multiplies fp16 kernels with the fp16 mask features
+        kps = [k.half().float() for k in kps]
     return SO.get_results(cfg, kps, cps, mf, meta["img_shape"], meta["ori_shape"], img_id=b, return_debug=True)
+
+
+def id_image_report(tag, out_img, w, cfg, frame, confidence=0.5, soft_tol=2e-4):
+    """The band's id image against the fp32 oracle end to end (north_star: bit-exact ids).  Equal -> returns 0.  Otherwise every differing
+    pixel is counted and placed: with the same drawn instances on both sides a pixel can only differ at the last threshold
+    (resized sigmoid > mask_thr, solov2_head.py:748-759), and its distance from that threshold in the ORACLE's soft mask must lie inside
+    the soft outputs' tolerance; a different instance list is reported with the score that crossed 0.5 / --confidence and fails."""
+    x, meta = SO.preprocess(frame, cfg)
+    kps, cps, mf = SO.network(w, cfg, x)
+    sc, lb, mk, dbg = SO.get_results(cfg, kps, cps, mf, meta["img_shape"], meta["ori_shape"], return_debug=True)
+    ref = SO.band_mask(sc, lb, mk, synth.COCO_CLASSES, synth.BAND_CLASSES, confidence, meta["ori_shape"])
+    diff = out_img[..., 0] != ref[..., 0]
+    n = int(diff.sum())
+    if n == 0:
+        print("  %s: id image equals the fp32 oracle's (%d pixels, %d drawn)" % (tag, diff.size, int((ref[..., 0] != 0).sum())))
+        return 0
+    keep = np.array([synth.COCO_CLASSES[int(c)] in synth.BAND_CLASSES for c in lb.numpy()], bool)
+    drawn = np.nonzero(keep & (sc.numpy() > 0.5) & (sc.numpy() > confidence))[0]
+    assert len(drawn), "%s: %d pixels differ and the oracle draws nothing" % (tag, n)
+    margin = np.abs(dbg["soft"][drawn].numpy() - cfg.mask_thr).min(0)          # distance of the nearest drawn instance from mask_thr
+    at = margin[diff]
+    on_thr = int((at < soft_tol).sum())
+    near = np.sort(np.abs(sc.numpy()[keep] - 0.5))[:3]
+    print("  %s: %d of %d pixels differ from the fp32 oracle; %d sit on the mask threshold (|sigmoid - %.2f| < %.0e in the oracle's resized "
+          "soft mask, largest %.2e), %d elsewhere; instance scores nearest 0.5: %s" % (tag, n, diff.size, on_thr, cfg.mask_thr, soft_tol,
+                                                                                      float(at.max()), n - on_thr, np.round(near, 4)))
+    assert on_thr == n, "%s: %d differing pixels are not explained by the mask threshold (an instance-level decision flipped)" % (tag, n - on_thr)
+    return n
 
 
 def test_postprocess_exact_on_engine_outputs(tiny):
@@ -99,7 +128,15 @@ def test_end_to_end_mask_image_close_to_oracle(tiny):
     ref = SO.infer(w, cfg, frames[0], synth.COCO_CLASSES, synth.BAND_CLASSES, 0.5)
     mism = (out != ref).mean()
     print("  end-to-end mask image pixel mismatch vs fp32 oracle: %.3e (%d of %d pixels)" % (mism, int((out[..., 0] != ref[..., 0]).sum()), out[..., 0].size))
-    assert mism < 0.03          # discrete decisions on fp16-perturbed scores: instance boundaries and near-threshold cells
+    if net.precision == engine._lib.PREC_F16:
+        assert mism < 0.03          # discrete decisions on fp16-perturbed scores: instance boundaries and near-threshold cells
+        return
+    id_image_report("180x300 seed 8", out, w, cfg, frames[0])
+    for seed in (5, 21):
+        fr = synth.frames(2, 180, 300, seed=seed)
+        o2 = net.infer_batch(fr, 0.5, KEEP)
+        for b in range(2):
+            id_image_report("180x300 seed %d frame %d" % (seed, b), o2[b], w, cfg, fr[b])
 
 
 def test_mask_ids_do_not_depend_on_the_batch(tiny):
@@ -144,7 +181,8 @@ def test_r101_720p_against_oracle():
         got = net.stage(name)[1:2]
         a, b = relmax(got, ref.numpy()), rell2(got, ref.numpy())
         print("  %-13s relmax %.3e relL2 %.3e" % (name, a, b))
-        assert a < 2 * TOL_RANGE and b < 2 * TOL_L2, name
+        assert a < TOL_RANGE and b < TOL_L2, name
+    id_image_report("720p frame 1", out[1], w, cfg, frames[1])
     sc, lb, mk, dbg = _oracle_post_from_engine(cfg, net, 2, meta, 1)
     g_sc, g_lb, g_mk, g_cand = net.instances(1, with_masks=True)
     print("  %d candidates, %d instances, %d over 0.5" % (g_cand, len(g_sc), int((g_sc > 0.5).sum())))
@@ -175,7 +213,8 @@ def test_r101_1080p_batch_against_oracle():
         got = net.stage(name)[0:1]
         a, b = relmax(got, ref.numpy()), rell2(got, ref.numpy())
         print("  %-13s relmax %.3e relL2 %.3e" % (name, a, b))
-        assert a < 2 * TOL_RANGE and b < 2 * TOL_L2, name
+        assert a < TOL_RANGE and b < TOL_L2, name
+    id_image_report("1080p frame 2", out[2], w, cfg, frames[2])
     sc, lb, mk, dbg = _oracle_post_from_engine(cfg, net, 1, meta, 0)
     g_sc, g_lb, g_mk, g_cand = net.instances(2, with_masks=True)      # instance records are indexed by frame of the call
     assert g_cand == dbg["n_candidates"] and np.array_equal(g_lb, lb.numpy())
