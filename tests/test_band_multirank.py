@@ -13,8 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(script, args, ranks):
-    env = dict(os.environ, PRISMA_OVERWRITE="1", PRISMA_DIST_BACKEND="gloo", PRISMA_GPUS_PER_NODE="1", PRISMA_BATCH="2")
+def _run(script, args, ranks, nccl=False):
+    env = dict(os.environ, PRISMA_OVERWRITE="1", PRISMA_BATCH="2")
+    if nccl:        # one GPU per rank, torch.distributed "nccl" (= RCCL) and the native pb_comm / pb_gather_scalars path of shard.Ranks
+        env.pop("PRISMA_DIST_BACKEND", None); env.pop("PRISMA_GPUS_PER_NODE", None)
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    else:
+        env.update(PRISMA_DIST_BACKEND="gloo", PRISMA_GPUS_PER_NODE="1")
     cmd = [sys.executable]
     if ranks > 1:
         with socket.socket() as s:
@@ -59,3 +64,29 @@ def test_two_ranks_equal_one(tmp_path, script, extra, outputs):
             assert open(a / name).read() == open(b / name).read()
     ma, mb = json.load(open(a / "metadata.json")), json.load(open(b / "metadata.json"))
     assert ma == mb
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("script,extra,outputs", [
+    ("depth_anything.py", ["--encoder", "vits"], ["depth_anything.npy", "depth_anything_min.csv", "depth_anything_max.csv"]),
+    ("flow_raft.py", ["--iterations", "3", "--scale", "1.0"], ["flow_raft.npy", "flow_raft.csv"]),
+])
+def test_two_gpus_over_rccl_equal_one(tmp_path, script, extra, outputs):
+    """The same comparison with one GPU per rank on the nccl (= RCCL over xGMI) backend: the per-frame scalars travel through
+    `shard.Ranks.gather` on device buffers.  Needs two GPUs - skipped on the single-GPU boxes the suite usually runs on."""
+    if _gpus() < 2:
+        pytest.skip("needs 2 GPUs (this box has %d)" % _gpus())
+    from prisma_amd import synth
+    frames = synth.frame_pair_sequence(5, 176, 256, seed=6) if script.startswith("flow") else synth.frames(5, 180, 300, seed=5)
+    a, b = _clip(tmp_path, "one", frames), _clip(tmp_path, "two", frames)
+    _run(script, ["-i", str(a)] + extra, 1)
+    _run(script, ["-i", str(b)] + extra, 2, nccl=True)
+    for name in outputs:
+        if name.endswith(".npy"):
+            assert np.array_equal(np.load(a / name), np.load(b / name)), name
+        else:
+            assert open(a / name).read() == open(b / name).read()
