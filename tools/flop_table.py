@@ -27,7 +27,7 @@ def symbol(amode, epi, M, N, mx, halo=False):
         return f"gemm8_kernel<{amode}, {epi}, 0, true, {m}>"
     if epi == STD and N <= 64:
         if halo:                                         # 3x3, 64 -> 64, stride 1 on mx3 maps: the halo-tiled direct kernel (halo_conv.hip)
-            return "conv3x3_c64_mx_kernel<1>"
+            return "conv3x3_c64_mx2_kernel"
         return f"gemm_kernel<256, 64, 4, 1, {amode}, {epi}, true, 2, {m}>"
     return f"gemm_kernel<128, 128, 2, 2, {amode}, {epi}, true, 2, {m}>"
 
@@ -58,7 +58,7 @@ B_ALL, B = B, BD                                         # the depth rows below 
 # only the DPT head below is chunked (engine.hip run_chunk)
 Mv = B_ALL * ntp
 add("depth", (DENSE, PATCH), "patch embed (+ pos embed)", B_ALL * P, D, 588, mx=False, per_call=True)
-add("depth", (DENSE, QKV), "qkv", Mv, 3 * D, D, 24, per_call=True)
+add("depth", (DENSE, QKV), "qkv", Mv, 3 * D, D, 24, per_call=True, mx=False)       # round 3: qkv and fc1 run without a weight residual (PB_VIT_RES)
 add("depth", "attention", "softmax(QK^T)V, 16 heads", B_ALL * 16 * 2443, 2443, 64 * 2, 24, per_call=True)        # 4 n h t^2 d
 rows[-1] = rows[-1][:8] + (4.0 * B_ALL * 16 * 2443 * 64 * 2,)                                   # q, k, v in + o out, fp16
 add("depth", (DENSE, RESID), "proj (+ residual)", Mv, D, D, 24, out_b=8, per_call=True)
