@@ -115,7 +115,8 @@ int pb_struct_size(int which);
 int pb_device_count(void);
 
 /* init_model(): bands/depth_anything.py:48-76 (+ bands/d_anything/dpt.py:139-171).
- * band = "depth_anything".  Packs weights to fp16 MFMA layouts and uploads them. */
+ * band = "depth_anything" | "flow_raft" | "flow_gmflow" | "mask_mmdet" (the sections below).  Packs weights to fp16 MFMA layouts
+ * and uploads them. */
 int pb_create(pb_ctx **out, int device_id, const char *band, const pb_tensor *weights,
               int n_weights, const void *cfg, size_t cfg_bytes);
 void pb_destroy(pb_ctx *ctx);
@@ -193,7 +194,16 @@ int pb_flow_infer_sequence_masks_dev(pb_ctx *ctx, const uint8_t *frames, int F, 
                                      uint8_t *mask_out);
 int pb_flow_fwdbwd_mask(pb_ctx *ctx, const float *flows, int n, int sh, int sw, float alpha1, float alpha2,
                         uint8_t *mask_out);
-/* Stages of the last flow call: "fmap" [F,256,h/8,w/8], "flow_lo" [pairs*dirs, h/8*w/8, 2]. */
+/* flow_gmflow band (band = "flow_gmflow", cfg = pb_flow_cfg or NULL; weights: backbone.*, transformer.*, feature_flow_attn.*,
+ * upsampler.* of the GMFlow state dict).  Same entry points and output contract as flow_raft above (pb_flow_infer_sequence*,
+ * pb_flow_out_size; `iters` is ignored): replaces bands/flow_gmflow.py:60-118 infer (cv2.resize by --scale, InputPadder(16),
+ * GMFlow(attn_splits_list=[2], corr_radius_list=[-1], prop_radius_list=[-1], pred_bidir_flow per `backward`)) ->
+ * bands/gmflow/gmflow.py:12-170 (shared instance-norm encoder, position encoding, 6 transformer blocks with 2 x 2 shifted windows,
+ * global matching, self-attention propagation, convex upsampling) and the same write_flow / process_flow encode.  Only the band's
+ * default configuration is built (1 scale, 128 channels, 6 layers, 1 head, ffn x 4); the band script rejects other GMFlow flags. */
+/* Stages of the last flow call: "fmap" [F,256,h/8,w/8], "flow_lo" [pairs*dirs, h/8*w/8, 2]; flow_gmflow (token-major fp32, shape
+ * [n, tokens, channels, 1]): "feat" [F, h/8*w/8, 128] (encoder output), "block0" / "tfeat" [2 pairs, tokens, 128] (after the first / last
+ * transformer block; both images of every pair), "flow_match" / "flow_prop" [pairs*dirs, tokens, 2]. */
 int64_t pb_flow_get_stage(pb_ctx *ctx, const char *name, float *out, int64_t cap, int64_t shape_out[4]);
 
 /* mask_mmdet band (band = "mask_mmdet", cfg = pb_mask_cfg; weights: backbone.*, neck.*, mask_head.* in mmdet's
