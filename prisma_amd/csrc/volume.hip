@@ -25,6 +25,17 @@
 
 namespace {
 
+// Bare barriers: __syncthreads() carries a workgroup fence, for which the compiler drains vmcnt - with the LDS-DMA stages and the deferred
+// stores in flight that made every step wait for ALL of them (round 3: found in the ISA, `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of the
+// second barrier of a tile).  The counted waits below are what orders the DMAs; a wave's fragment reads are consumed by its MFMAs before it
+// reaches the next barrier.
+#define VOL_BAR()                               \
+    do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
+        asm volatile("s_barrier" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+
 constexpr int VBM = 128, VBN = 64, VNT = 256, VSTAGES = 4, VSTAGE_BYTES = 2 * VBN * 128;     // a stage = two K tiles of 64 columns
 
 __global__ __launch_bounds__(VNT, 2) void corr_volume_kernel(const f16 *__restrict__ A, int M, const f16 *__restrict__ W, int N, int w_rows,
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(VNT, 2) void corr_volume_kernel(const f16 *__restri
         // ---- step g: stages g and g + 1 must have landed; only stage g + 2 (4 DMAs) may stay in flight - and none of the stores ----
         if (g + 2 < G) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                        // ... for every wave; slot (g + 3) & 3 = (g - 1) & 3 is free
+        VOL_BAR();                                              // ... for every wave; slot (g + 3) & 3 = (g - 1) & 3 is free
         if (g + 3 < G) stage(g + 3);
         flush();                                                // the previous tile's results
         {
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(VNT, 2) void corr_volume_kernel(const f16 *__restri
             PB_VOL_HALF(0)
         }
         // ---- step g + 1: landed already (waited for above); the barrier frees slot g & 3 for stage g + 4 ----
-        __syncthreads();
+        VOL_BAR();
         if (g + 4 < G) stage(g + 4);
         {
             const char *sb = smem + ((g + 1) & (VSTAGES - 1)) * VSTAGE_BYTES;
