@@ -681,6 +681,13 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
     }
 }
 
+#define PB_BAR_GENERIC()                         \
+    do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
+        asm volatile("s_barrier" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+
 __device__ __forceinline__ void vm_wait_halftiles(int n) {
     if (n >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (n == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -852,7 +859,10 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         if (NS == 3 && kt + 1 < nk) vm_wait_halftiles((NA + NB) / 2);   // all but the newest stage (NA + NB DMAs) landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // NS == 3: a bare barrier - __syncthreads() carries a workgroup fence for which the compiler drains vmcnt, i.e. the stage the
+        // counted wait above leaves in flight (round 3: that is why the three-stage builds never beat the two-stage ones)
+        if constexpr (NS == 3) PB_BAR_GENERIC();
+        else __syncthreads();
         const char *sb = smem + cbuf * STAGE;
         load_frags(0, sb, 0);
         if constexpr (NS == 3) {
@@ -1353,6 +1363,9 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
         if (tile == TILE_256) return launch_g8<AMODE, EPI, MX>(s, a);
         if constexpr (EPI == EPI_STD) {
             if (tile == TILE_256x64) return launch_t<256, 64, 4, 1, AMODE, EPI, MX>(s, a);
+            // (round 3, measured and removed: launch_t<256, 128, 4, 2, AMODE, EPI, MX, false, 3> - 8 waves of 64 x 64, three LDS stages two K
+            // tiles ahead behind bare barriers, 144 KB, one workgroup per CU - against this tile's two workgroups per CU: update block 35.4 ->
+            // 36.7 ms, RAFT encoders 19.1 -> 20.0, DPT head 12.5 -> 13.4 on one box; these launches are not waiting on DMA latency)
         }
         return launch_t<128, 128, 2, 2, AMODE, EPI, MX>(s, a);
     }
