@@ -149,7 +149,7 @@ def process_video(a):
     first, last = rk.frames(n)
     lo, hi = [], []
     want_depth = bool(a.npy or a.subpath)
-    relay = shard.Relay(rk, a.output)
+    relay = shard.Relay(rk, a.output, est_bytes=(n - (last - first)) * h * w * 3)
 
     def emit(s, depth, rgb):
         # runs on the sink thread, chunk after chunk in order: video frames, .npy / .png dumps (reference :215-225)
@@ -175,10 +175,13 @@ def process_video(a):
     if rk.world > 1:
         # scalars first (every rank gets here when its own compute is done), then rank 0 muxes the other ranks' chunks while they
         # wait on a file signal in relay.close() - no collective is pending during the mux
+        # (with a bounded spool, PRISMA_SPOOL_MAX_CHUNKS, the drain has to run DURING the gather: Relay.drain_begin)
+        if rk.main:
+            relay.drain_begin(n, BATCH, lambda s, c: [out.write(f) for f in c["rgb"]])
         mm = rk.gather(np.asarray([lo, hi], np.float32).T.reshape(-1, 2), n, ctx=model)
         if rk.main:
             lo, hi = [float(v) for v in mm[:, 0]], [float(v) for v in mm[:, 1]]
-            relay.drain(n, BATCH, lambda s, c: [out.write(f) for f in c["rgb"]])
+            relay.drain_end()
     relay.close()
     if not rk.main:
         return

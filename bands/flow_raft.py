@@ -112,7 +112,8 @@ def process_video(args):
             fwd_mask_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output_mask)
             if args.backwards:
                 bwd_mask_video = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=mbase + "_bwd." + mext)
-    relay = shard.Relay(rk, args.output)
+    streams = (1 + bool(args.backwards)) * (1 + bool(args.output_mask))
+    relay = shard.Relay(rk, args.output, est_bytes=((n - 1) - (last - first)) * sh * sw * 3 * streams)
     mxs = []
 
     def write_chunk(_s, c):          # rank 0 only: one chunk of encoded pairs into every open video, in order
@@ -162,9 +163,13 @@ def process_video(args):
     sink.close()
     mx_all = np.asarray(mxs, np.float32)
     if rk.world > 1:
-        mx_all = rk.gather(mx_all, n - 1, ctx=model)         # before the drain: no collective pending while rank 0 muxes
+        # the gather comes before the drain: no collective pending while rank 0 muxes - unless the spool is bounded
+        # (PRISMA_SPOOL_MAX_CHUNKS), in which case the drain has to run during the gather (Relay.drain_begin)
         if rk.main:
-            relay.drain(n - 1, CHUNK, write_chunk)
+            relay.drain_begin(n - 1, CHUNK, write_chunk)
+        mx_all = rk.gather(mx_all, n - 1, ctx=model)
+        if rk.main:
+            relay.drain_end()
     relay.close()
     if not rk.main:
         return

@@ -101,7 +101,7 @@ def process_video(args):
         create_folder(args.subpath)
     first, last = rk.frames(n)
     out = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output) if rk.main else None
-    relay = shard.Relay(rk, args.output)
+    relay = shard.Relay(rk, args.output, est_bytes=(n - (last - first)) * h * w * 3)
 
     def emit(s, masks):              # sink thread, chunks in order
         done = np.stack([_finish(m_, args) for m_ in masks])

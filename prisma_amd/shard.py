@@ -83,36 +83,70 @@ class Relay:
     frame order, waiting for each file, muxing it and deleting it.  Memory is bounded by one chunk per rank.
 
     The spool is PER RUN: `<base>/prisma_spool.<basename(out)>.<token>` where the token is drawn by rank 0 and broadcast, so two
-    jobs (or two bands of one job) never share a namespace and nobody deletes anybody else's files.  `base` is PRISMA_SPOOL if
-    set, else /dev/shm when it exists (8 ranks x ~200 frames/s x 6.2 MB of 1080p frames is ~10 GB/s: memory, not the output
-    filesystem), else the output's folder.  It holds, at most, the other ranks' encoded shards until rank 0 gets to them; with
-    PRISMA_SPOOL_MAX_CHUNKS = K > 0 a producer waits while K of its chunks are unconsumed (bounded spool, but the producers then
-    finish one after the other at rank 0's mux speed: the default 0 keeps every GPU computing).
+    jobs (or two bands of one job) never share a namespace and nobody deletes anybody else's files.  It holds, at most, the other
+    ranks' encoded shards until rank 0 gets to them - (world - 1) / world of the uncompressed encoded video when nothing bounds it.
+    `base`: PRISMA_SPOOL if set; else /dev/shm when it is writable AND has room for `est_bytes` (what the caller
+    expects the other ranks to spool: 8 ranks x ~200 frames/s x 6.2 MB of 1080p frames is ~10 GB/s - memory, not the output
+    filesystem - but Docker's default /dev/shm is 64 MB and a bare-metal tmpfs competes with pinned buffers); else the output's
+    folder.  That folder is also every run's FALLBACK directory: a chunk that cannot be written to the primary spool (ENOSPC: the
+    estimate was wrong, or another job filled the tmpfs) goes there instead, and rank 0 looks in both.  Spool directories whose
+    owner (rank 0's pid, recorded in the directory) is dead are swept when a new run picks the same base.
 
-    End of a run: the scalar all-gather happens BEFORE the drain - every rank reaches it as soon as its own compute
-    is done - and the ranks > 0 then wait for rank 0's `done` FILE (wait_done), not inside a collective, so no communicator
-    watchdog runs while rank 0 muxes (world - 1) / world of the video."""
+    With PRISMA_SPOOL_MAX_CHUNKS = K > 0 a producer waits while K of its chunks are unconsumed (bounded spool, but the producers
+    then finish one after the other at rank 0's mux speed: the default 0 keeps every GPU computing).
 
-    def __init__(self, ranks: "Ranks", out_path: str, timeout_s: float = 0.0):
+    End of a run: `drain_begin` / scalar gather / `drain_end`.  Unbounded (K = 0): the gather comes first - every rank
+    reaches it as soon as its own compute is done - and rank 0 drains afterwards while the ranks > 0 wait for its `done` FILE
+    (close), not inside a collective.  Bounded (K > 0): the producers cannot finish - and so cannot reach the gather -
+    unless rank 0 consumes, so rank 0 drains on a worker thread WHILE it waits in the gather; draining only after the gather, as the
+    unbounded order does, would deadlock as soon as a shard has more than K (+ the sink's depth) chunks."""
+
+    def __init__(self, ranks: "Ranks", out_path: str, timeout_s: float = 0.0, est_bytes: int = 0):
         import os
         self.rk = ranks
         self.timeout = timeout_s or float(os.environ.get("PRISMA_RELAY_TIMEOUT_S", "21600"))
         self.max_chunks = int(os.environ.get("PRISMA_SPOOL_MAX_CHUNKS", "0"))
-        self.dir = ""
+        self.dir = self.dir2 = ""
         self._mine: List[str] = []
+        self._thread = None
+        self._thread_err = None
+        self._pending = None
         if ranks.world > 1:
             import uuid
             import torch.distributed as dist
-            base = os.environ.get("PRISMA_SPOOL") or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK)
-                                                      else os.path.dirname(os.path.abspath(out_path)))
-            box = [os.path.join(base, "prisma_spool.%s.%s" % (os.path.basename(out_path), uuid.uuid4().hex[:12])) if ranks.main else None]
+            box = [None]
+            if ranks.main:
+                out_dir = os.path.dirname(os.path.abspath(out_path))
+                base = os.environ.get("PRISMA_SPOOL") or _pick_spool_base(out_dir, est_bytes, self.max_chunks)
+                name = "prisma_spool.%s.%s" % (os.path.basename(out_path), uuid.uuid4().hex[:12])
+                box = [(os.path.join(base, name), os.path.join(out_dir, name), os.getpid())]
+                _sweep_stale_spools(base)
+                if out_dir != base:
+                    _sweep_stale_spools(out_dir)
             dist.broadcast_object_list(box, src=0)
-            self.dir = box[0]
+            self.dir, self.dir2, owner = box[0]
             os.makedirs(self.dir, exist_ok=True)
+            if ranks.main:
+                with open(os.path.join(self.dir, "owner.%d" % owner), "w") as f:
+                    f.write("%d\n" % owner)
 
-    def _path(self, start: int) -> str:
+    def _path(self, start: int, fallback: bool = False) -> str:
         import os
-        return os.path.join(self.dir, "chunk_%09d.npz" % start)
+        return os.path.join(self.dir2 if fallback else self.dir, "chunk_%09d.npz" % start)
+
+    def _write(self, path: str, arrays: dict):
+        import os
+        tmp = path + ".tmp.%d" % self.rk.rank
+        try:
+            with open(tmp, "wb") as f:
+                np.savez(f, **{k: np.ascontiguousarray(v) for k, v in arrays.items()})
+            os.replace(tmp, path)
+        except BaseException:
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
+            raise
 
     def put(self, start: int, arrays: dict):
         """rank > 0: publish the chunk whose first unit (frame / pair index) is `start`."""
@@ -125,28 +159,66 @@ class Relay:
                     raise TimeoutError(f"rank 0 did not consume rank {self.rk.rank}'s chunks within {self.timeout:.0f} s")
                 time.sleep(0.005)
             self._mine = [p for p in self._mine if os.path.exists(p)]
-        tmp = self._path(start) + ".tmp.%d" % self.rk.rank
-        with open(tmp, "wb") as f:
-            np.savez(f, **{k: np.ascontiguousarray(v) for k, v in arrays.items()})
-        os.replace(tmp, self._path(start))
-        self._mine.append(self._path(start))
+        path = self._path(start)
+        try:
+            self._write(path, arrays)
+        except OSError as e:
+            # the primary spool (a tmpfs, usually) is full or gone: this chunk goes to the output's folder, where rank 0 also looks
+            if self.dir2 == self.dir:
+                raise
+            import sys
+            print(f"[prisma] rank {self.rk.rank}: spool {self.dir} refused chunk {start} ({e}); falling back to {self.dir2}", file=sys.stderr)
+            os.makedirs(self.dir2, exist_ok=True)
+            path = self._path(start, True)
+            self._write(path, arrays)
+        self._mine.append(path)
 
     def drain(self, n_units: int, chunk: int, write):
-        """rank 0: for every other rank, in rank (= frame) order, for every chunk start of its shard: wait for the file, call
-        write(start, {name: array}), delete it."""
+        """rank 0: for every other rank, in rank (= frame) order, for every chunk start of its shard: wait for the file (primary
+        spool or the fallback directory), call write(start, {name: array}), delete it."""
         import os
         import time
         for r in range(1, self.rk.world):
             first, last = shard_range(n_units, r, self.rk.world)
             for s in range(first, last, chunk):
-                p, t0 = self._path(s), time.time()
-                while not os.path.exists(p):
+                cand, t0 = (self._path(s), self._path(s, True)), time.time()
+                while True:
+                    p = next((c for c in cand if os.path.exists(c)), None)
+                    if p:
+                        break
                     if time.time() - t0 > self.timeout:
                         raise TimeoutError(f"rank {r} did not deliver chunk {s} within {self.timeout:.0f} s")
                     time.sleep(0.005)
                 with np.load(p) as z:
                     write(s, {k: z[k] for k in z.files})
                 os.remove(p)
+
+    def drain_begin(self, n_units: int, chunk: int, write):
+        """rank 0, BEFORE the scalar gather.  Bounded spool: the drain starts now, on a worker thread (see the class docstring);
+        unbounded: it is only recorded and runs in drain_end, after the gather."""
+        self._pending = (n_units, chunk, write)
+        if self.max_chunks > 0:
+            import threading
+
+            def work():
+                try:
+                    self.drain(*self._pending)
+                except BaseException as e:      # noqa: BLE001 - re-raised by drain_end
+                    self._thread_err = e
+            self._thread = threading.Thread(target=work, name="relay-drain", daemon=True)
+            self._thread.start()
+
+    def drain_end(self):
+        """rank 0, AFTER the scalar gather: finishes (bounded) or runs (unbounded) the drain."""
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+            if self._thread_err is not None:
+                err, self._thread_err = self._thread_err, None
+                raise err
+        elif self._pending is not None:
+            self.drain(*self._pending)
+        self._pending = None
 
     def close(self):
         """rank 0: publish `done`; ranks > 0: wait for it (a file poll, no collective in flight), then the last one out removes the
@@ -169,11 +241,53 @@ class Relay:
         import torch.distributed as dist
         dist.barrier()                       # short: every rank is past its file wait
         if self.rk.main:
-            try:
-                os.remove(done)
-                os.rmdir(self.dir)
-            except OSError:
-                pass
+            import shutil
+            shutil.rmtree(self.dir, ignore_errors=True)
+            if self.dir2 != self.dir and os.path.isdir(self.dir2):
+                shutil.rmtree(self.dir2, ignore_errors=True)
+
+
+def _pick_spool_base(out_dir: str, est_bytes: int, max_chunks: int) -> str:
+    """/dev/shm when it is writable and has room for what the run may park there, else the output's folder.  With an
+    unknown estimate (0) a tmpfs is only trusted when it has 1 GiB free - Docker's default 64 MB /dev/shm never is."""
+    import os
+    import shutil
+    shm = "/dev/shm"
+    if not (os.path.isdir(shm) and os.access(shm, os.W_OK)):
+        return out_dir
+    try:
+        free = shutil.disk_usage(shm).free
+    except OSError:
+        return out_dir
+    need = int(est_bytes * 1.15) + (64 << 20) if est_bytes > 0 else (1 << 30)
+    floor = int(os.environ.get("PRISMA_SPOOL_MIN_FREE", "0"))
+    return shm if free >= max(need, floor) else out_dir
+
+
+def _sweep_stale_spools(base: str, min_age_s: float = 600.0):
+    """Remove `prisma_spool.*` directories under `base` left by a crashed run: the owner file names rank 0's pid; a directory whose
+    owner is dead (or that has no owner file) and that nobody touched for ten minutes is nobody's."""
+    import glob
+    import os
+    import shutil
+    import time
+    for d in glob.glob(os.path.join(base, "prisma_spool.*")):
+        try:
+            if not os.path.isdir(d) or time.time() - os.path.getmtime(d) < min_age_s:
+                continue
+            alive = False
+            for o in glob.glob(os.path.join(d, "owner.*")):
+                try:
+                    os.kill(int(o.rsplit(".", 1)[1]), 0)
+                    alive = True
+                except PermissionError:         # somebody else's live process
+                    alive = True
+                except (OSError, ValueError):
+                    pass
+            if not alive:
+                shutil.rmtree(d, ignore_errors=True)
+        except OSError:
+            pass
 
 
 class Ranks:

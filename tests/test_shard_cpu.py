@@ -78,9 +78,11 @@ def _relay_worker(rank, world, port, n, chunk, out_path, q):
         nonlocal peak_held
         peak_held = max(peak_held, c["rgb"].nbytes)
         muxed.extend(int(f[0, 0, 0]) for f in c["rgb"])
+    if rk.main:
+        relay.drain_begin(n, chunk, write)       # bounded spool (PRISMA_SPOOL_MAX_CHUNKS): drains on a thread during the gather
     mx = rk.gather(np.arange(first, last, dtype=np.float32), n)
     if rk.main:
-        relay.drain(n, chunk, write)
+        relay.drain_end()
     spool = relay.dir
     relay.close()
     if rk.main:
@@ -113,6 +115,99 @@ def test_relay_delivers_chunks_in_frame_order_with_bounded_memory(tmp_path, worl
     if os.path.isdir("/dev/shm") and not os.environ.get("PRISMA_SPOOL"):
         assert spool.startswith("/dev/shm/")
     assert mx == list(map(float, range(n)))
+
+
+@pytest.mark.parametrize("world,n,chunk", [(2, 120, 4), (3, 50, 2)])
+def test_bounded_spool_does_not_deadlock(tmp_path, monkeypatch, world, n, chunk):
+    """with PRISMA_SPOOL_MAX_CHUNKS = 1 a rank > 0 blocks in put() until rank 0 consumes, and the scalar gather needs
+    every rank to have finished - so rank 0 must drain WHILE it waits in the gather (Relay.drain_begin / drain_end).  15-25 chunks per
+    shard against a bound of one: the old gather-then-drain order hangs here until the relay timeout."""
+    monkeypatch.setenv("PRISMA_SPOOL_MAX_CHUNKS", "1")
+    monkeypatch.setenv("PRISMA_RELAY_TIMEOUT_S", "60")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_relay_worker, args=(r, world, port, n, chunk, str(tmp_path / "band.npy"), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    muxed, peak, _, spool, left, mx = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert muxed == [i % 251 for i in range(n)] and not left and mx == list(map(float, range(n)))
+
+
+def _fallback_worker(rank, world, port, out_path, primary, q):
+    import torch.distributed as dist      # noqa: F401
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      PRISMA_DIST_BACKEND="gloo", PRISMA_SPOOL=primary)
+    rk = shard.Ranks()
+    relay = shard.Relay(rk, out_path, timeout_s=60)
+    got = []
+    if not rk.main:
+        relay.put(4, {"rgb": np.full((2, 8, 8, 3), 4, np.uint8)})              # lands in the primary spool
+        import shutil
+        shutil.rmtree(relay.dir)                                               # the tmpfs "fills up": the directory is gone -> OSError
+        relay._mine = []
+        relay.put(4, {"rgb": np.full((2, 8, 8, 3), 4, np.uint8)})              # -> falls back to the output's folder
+        relay.put(6, {"rgb": np.full((2, 8, 8, 3), 6, np.uint8)})
+        os.makedirs(relay.dir, exist_ok=True)                                  # for close()'s done file
+    mx = rk.gather(np.zeros(4, np.float32), 8)
+    if rk.main:
+        relay.drain_begin(8, 2, lambda s, c: got.append((s, int(c["rgb"][0, 0, 0, 0]))))
+        relay.drain_end()
+    d1, d2 = relay.dir, relay.dir2
+    relay.close()
+    if rk.main:
+        q.put((got, d1, d2, os.path.exists(d1), os.path.exists(d2)))
+    rk.close()
+
+
+def test_spool_falls_back_to_the_output_folder(tmp_path):
+    """a chunk the primary spool refuses (ENOSPC on a small /dev/shm, or the directory vanished) goes to the run's fallback
+    directory next to the output; rank 0 looks in both and removes both at the end."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    primary = tmp_path / "shm"
+    primary.mkdir()
+    (tmp_path / "out").mkdir()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, str(tmp_path / "out" / "band.npy"), str(primary), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, d1, d2, left1, left2 = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == [(4, 4), (6, 6)]
+    assert d1.startswith(str(primary)) and d2.startswith(str(tmp_path / "out")) and not left1 and not left2
+
+
+def test_spool_base_and_stale_sweep(tmp_path, monkeypatch):
+    """/dev/shm is only chosen when it has room for the estimate (Docker's default is 64 MB); spool directories of dead
+    owners are swept, live or fresh ones are not."""
+    import shutil
+    out_dir = str(tmp_path)
+    free = shutil.disk_usage("/dev/shm").free if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else 0
+    if free:
+        assert shard._pick_spool_base(out_dir, free * 2, 0) == out_dir                    # too big for the tmpfs
+        assert shard._pick_spool_base(out_dir, 1 << 20, 0) == ("/dev/shm" if free > (80 << 20) else out_dir)
+        monkeypatch.setenv("PRISMA_SPOOL_MIN_FREE", str(free * 2))
+        assert shard._pick_spool_base(out_dir, 1 << 20, 0) == out_dir
+    dead, live, fresh = tmp_path / "prisma_spool.a.1", tmp_path / "prisma_spool.a.2", tmp_path / "prisma_spool.a.3"
+    for d in (dead, live, fresh):
+        d.mkdir()
+    (dead / "owner.999999999").write_text("x")           # no such pid
+    (dead / "chunk_000000000.npz").write_text("x")
+    (live / ("owner.%d" % os.getpid())).write_text("x")
+    old = __import__("time").time() - 3600
+    os.utime(dead, (old, old)); os.utime(live, (old, old))
+    shard._sweep_stale_spools(str(tmp_path))
+    assert not dead.exists() and live.exists() and fresh.exists()
 
 
 def test_two_concurrent_relays_do_not_share_a_spool(tmp_path, monkeypatch):
