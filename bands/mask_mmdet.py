@@ -63,28 +63,24 @@ def keep_ids():
     return [synth.COCO_CLASSES.index(c) for c in CLASSES]
 
 
-def get_sdf(masks_u8):
-    """reference :64-69 (snowy.generate_sdf on luminance != 0, remapped and clamped).  snowy 0.0.9 is absent:
-    signed Euclidean distance = distance to the mask outside it, minus distance to the background inside it."""
-    from scipy.ndimage import distance_transform_edt
-    inside = masks_u8[..., :3].astype(np.float64).mean(-1) != 0.0
-    sdf = distance_transform_edt(~inside) - distance_transform_edt(inside)
-    sdf = ((sdf + 127.0) / 255.0 - 0.25) * 2.0
-    return 1.0 - np.clip(sdf, 0.0, 1.0)
+def set_sdf(on):
+    """--sdf (reference :64-69,150-152; process.py passes it on every run): the engine writes the clamped signed distance field of
+    each id image into its green channel on the GPU (engine.MaskMMDet.set_sdf; the host restatement the tests compare it with is
+    oracle/solov2_oracle.py band_sdf)."""
+    model.set_sdf(bool(on))
 
 
-def _finish(masks_u8, args):
-    if args.sdf:
-        out = masks_u8.astype(np.float64)
-        out[..., 1] = get_sdf(masks_u8) * 255
-        return out.astype(np.uint8)
-    return masks_u8
+def _colmap(masks_u8):
+    """COLMAP wants black objects on white (reference :149-150 writes 255 - masks BEFORE the SDF goes into G): the id image has the
+    same byte in all three channels, so the pre-SDF image is its red channel three times."""
+    return 255 - np.repeat(masks_u8[..., :1], 3, axis=-1)
 
 
 def process_image(args):
     img = open_rgb(args.input)
+    set_sdf(args.sdf)
     masks = model.infer_batch(img[None], args.confidence, keep_ids())[0]
-    write_rgb(args.output, _finish(masks, args))
+    write_rgb(args.output, masks)
     data["bands"][BAND] = {"url": os.path.basename(args.output), "ids": CLASSES}
 
 
@@ -103,16 +99,17 @@ def process_video(args):
     out = VideoWriter(width=w, height=h, frame_rate=src.fps, filename=args.output) if rk.main else None
     relay = shard.Relay(rk, args.output, est_bytes=(n - (last - first)) * h * w * 3)
 
-    def emit(s, masks):              # sink thread, chunks in order
-        done = np.stack([_finish(m_, args) for m_ in masks])
+    set_sdf(args.sdf)
+
+    def emit(s, masks):              # sink thread, chunks in order (the SDF, if asked for, is already in G: set_sdf)
         if rk.main:
-            for f in done:
+            for f in masks:
                 out.write(f)
         else:
-            relay.put(s, {"mask": done})
-        if args.subpath:            # COLMAP wants black objects on white (reference :149-150)
+            relay.put(s, {"mask": masks})
+        if args.subpath:
             for j in range(len(masks)):
-                write_rgb(os.path.join(args.subpath, "{:05d}.png".format(s + j)), 255 - masks[j])
+                write_rgb(os.path.join(args.subpath, "{:05d}.png".format(s + j)), _colmap(masks[j]))
 
     sink = AsyncSink(depth=2)
     load = lambda s: np.stack([src[i] for i in range(s, min(last, s + BATCH))])      # noqa: E731

@@ -227,6 +227,17 @@ int pb_mask_infer_batch_dev(pb_ctx *ctx, const uint8_t *frames, int n, int H, in
 int pb_mask_get_instances(pb_ctx *ctx, int frame, int cap, float *scores_out, int32_t *labels_out, uint8_t *masks_out,
                           int32_t *candidates_out);
 int pb_mask_net_size(const pb_mask_cfg *cfg, int H, int W, int *nh, int *nw, int *Hp, int *Wp);
+/* --sdf (process.py passes it on every run, /root/reference/process.py:46-48,207; bands/mask_mmdet.py:64-69 getSDF, :150-152): the
+ * clamped signed distance field of the id image in its GREEN channel.  getSDF's byte is a function of the side of the mask a pixel is
+ * on and of its (integer) squared Euclidean distance n to the other side; the host tabulates it with the reference's own float64
+ * expression - tab_out[i] / tab_in[i] for n = i outside / inside the mask, the last entry (index n_tab - 1) for every n >= n_tab - 1
+ * (the remap saturates at sdf >= 64.25 and <= -63.25, so n_tab = 4130 holds every distinct byte; n_tab <= 4226) - and the library
+ * computes the exact n on the device (mask_kernels.hip sdf_*_kernel).
+ *   pb_mask_set_sdf : n_tab > 0 turns the green channel on for every following pb_mask_infer_batch* call of the ctx, 0 turns it off
+ *   pb_mask_sdf_green(_dev): the same pass on id images the caller holds ([n, H, W, 3] uint8, in place; host / device pointer) */
+int pb_mask_set_sdf(pb_ctx *ctx, const uint8_t *tab_out, const uint8_t *tab_in, int n_tab);
+int pb_mask_sdf_green(pb_ctx *ctx, uint8_t *masks, int n, int H, int W);
+int pb_mask_sdf_green_dev(pb_ctx *ctx, uint8_t *masks, int n, int H, int W);
 /* Stages of the last mask call as float32 NCHW: "input", "c2".."c5", "p2".."p6", "mask_feats",
  * "kernel_pred<l>", "cls_logit<l>" (l = 0..4). */
 int64_t pb_mask_get_stage(pb_ctx *ctx, const char *name, float *out, int64_t cap, int64_t shape_out[4]);

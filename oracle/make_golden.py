@@ -349,6 +349,39 @@ def gmflow_case(hgt=125, wid=157, seed=51, bidir=True, tag=None):
     np.savez_compressed(os.path.join(GOLD, f"gmflow_{tag or (str(hgt) + 'x' + str(wid))}.npz"), **keep)
 
 
+def gmflow_full_case(seed=61):
+    """flow_gmflow at the size the bench times it: one 1920x1080 pair at the band's default --scale 0.75
+    (810x1440 -> InputPadder(16) -> 816x1440: a 102 x 180 grid, 18 360 tokens, 18 360^2 global matching) through the REAL reference
+    GMFlow, forward direction, committed as 1/8-strided samples + float64 sums (as raft_full).  cv2 is absent here, so the reference
+    network is fed the oracle's 8-bit cubic resize (unpinned; GPU == oracle bit for bit) - the golden pins the network at that size."""
+    import time
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    from gmflow.gmflow import GMFlow
+    from common.flow import InputPadder
+    from oracle import raft_oracle as R
+    w = synth.gmflow_weights(seed=2468)
+    m = GMFlow(feature_channels=128, num_scales=1, upsample_factor=8, num_head=1, attention_type="swin", ffn_dim_expansion=4,
+               num_transformer_layers=6)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
+    big = synth.frame_pair_sequence(2, 1080, 1920, seed=seed)
+    a_u8, c_u8 = R.cv_resize_cubic_u8(big[0], 0.75), R.cv_resize_cubic_u8(big[1], 0.75)
+    assert a_u8.shape == (810, 1440, 3)
+    a = torch.from_numpy(np.ascontiguousarray(a_u8)).permute(2, 0, 1).float()[None]
+    c = torch.from_numpy(np.ascontiguousarray(c_u8)).permute(2, 0, 1).float()[None]
+    padder = InputPadder(a.shape, padding_factor=16)
+    p1, p2 = padder.pad(a, c)
+    assert tuple(p1.shape[-2:]) == (816, 1440)
+    t0 = time.time()
+    with torch.no_grad():
+        out = m(p1, p2, attn_splits_list=[2], corr_radius_list=[-1], prop_radius_list=[-1], pred_bidir_flow=False)["flow_preds"][-1]
+    f = padder.unpad(out[0]).permute(1, 2, 0).numpy()
+    print(f"[gmflow 1080p x0.75] reference forward {time.time() - t0:.1f} s, |flow| max {np.abs(f).max():.2f}, mean {f.reshape(-1, 2).mean(0)}", flush=True)
+    np.savez_compressed(os.path.join(GOLD, "gmflow_full.npz"), frame_seed=np.array(seed), fwd1080_s8=f[::8, ::8].copy(),
+                        sums1080=np.array([f[..., 0].astype(np.float64).sum(), f[..., 1].astype(np.float64).sum(),
+                                           np.abs(f.astype(np.float64)).sum()]),
+                        absmax=np.array(np.abs(f).max()))
+
+
 def raft_full_case(seed=41, iters=12):
     """BASELINE configs[2] / [4] at full size: the REAL reference RAFT + InputPadder on (a) 8 consecutive-frame pairs of a 9-frame
     1280x720 sequence, forward direction, 12 iterations (configs[2]: batch of 8 pairs, no --scale), committed as 1/8-strided
@@ -521,6 +554,8 @@ if __name__ == "__main__":
     if "gmflow" in which:
         gmflow_case()
         gmflow_case(216, 300, 52, False)   # pads to 224x304: a 28 x 38 grid, 14 x 19 windows, forward only
+    if "gmflow_full" in which:
+        gmflow_full_case()
     if "raft_full" in which:
         raft_full_case()
     if "raft" in which:

@@ -335,6 +335,22 @@ def band_mask(scores, labels, masks, class_names, keep_names, confidence: float,
     return (acc.astype(np.int64) & 255).astype(np.uint8)
 
 
+def band_sdf(masks_u8: np.ndarray) -> np.ndarray:
+    """getSDF + the green-channel store of the band (bands/mask_mmdet.py:64-69,150-152): uint8 HxWx3 id image -> the image the
+    band writes with --sdf.  snowy 0.0.9 (rgb_to_luminance, generate_sdf) is absent from the build container - parity unpinned for
+    it - so the signed distance is restated as scipy's exact Euclidean distance transform: distance to the mask outside it minus
+    distance to the background inside it; the remap, clip, x 255 and uint8 truncation are the reference's float64 expressions."""
+    from scipy.ndimage import distance_transform_edt
+    inside = masks_u8[..., :3].astype(np.float64).mean(-1) != 0.0
+    sdf = distance_transform_edt(~inside) - distance_transform_edt(inside)
+    sdf = (sdf + 127.0) / 255.0
+    sdf = (sdf - 0.25) * 2.0
+    sdf = 1.0 - np.clip(sdf, 0.0, 1.0)
+    out = masks_u8.astype(np.float64)
+    out[..., 1] = sdf * 255
+    return out.astype(np.uint8)
+
+
 def infer(w, cfg, frame_rgb: np.ndarray, class_names, keep_names, confidence: float = 0.5) -> np.ndarray:
     """The band's per-frame work (mask_mmdet.py:131-147) end to end."""
     x, meta = preprocess(frame_rgb, cfg)

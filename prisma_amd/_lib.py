@@ -78,6 +78,9 @@ SYMBOLS = {
     "pb_mask_net_size": (C.c_int, [C.POINTER(pb_mask_cfg), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_mask_get_stage": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "pb_mask_set_sdf": (C.c_int, [_P, _P, _P, C.c_int]),
+    "pb_mask_sdf_green": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
+    "pb_mask_sdf_green_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     "pb_flow_out_size": (C.c_int, [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_flow_infer_sequence": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
     "pb_flow_infer_sequence_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P]),

@@ -485,6 +485,31 @@ int pb_mask_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, f
     return 0;
 }
 
+int pb_mask_set_sdf(pb_ctx *c, const uint8_t *tab_out, const uint8_t *tab_in, int n_tab) {
+    PB_CHECK(c && c->mask, PB_ERR_STATE, "ctx has no mask_mmdet band");
+    PB_CHECK(n_tab <= 0 || (tab_out && tab_in && n_tab >= 2 && n_tab <= 4226), PB_ERR_ARG, "mask set_sdf: bad tables (n_tab = %d)", n_tab);
+    return c->mask->set_sdf(tab_out, tab_in, n_tab);
+}
+
+int pb_mask_sdf_green_dev(pb_ctx *c, uint8_t *masks, int n, int H, int W) {
+    PB_CHECK(c && c->mask, PB_ERR_STATE, "ctx has no mask_mmdet band");
+    return c->mask->sdf_green(masks, n, H, W);
+}
+
+int pb_mask_sdf_green(pb_ctx *c, uint8_t *masks, int n, int H, int W) {
+    PB_CHECK(c && c->mask, PB_ERR_STATE, "ctx has no mask_mmdet band");
+    PB_CHECK(masks && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "mask sdf: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * H * W * 3;
+    DevMem d;
+    PB_TRY(d.alloc(bytes));
+    PB_HIP(hipMemcpy(d.p, masks, bytes, hipMemcpyHostToDevice));
+    PB_TRY(c->mask->sdf_green(d.as<uint8_t>(), n, H, W));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(masks, d.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int pb_mask_get_instances(pb_ctx *c, int frame, int cap, float *scores_out, int32_t *labels_out, uint8_t *masks_out,
                           int32_t *candidates_out) {
     PB_CHECK(c && c->mask, PB_ERR_STATE, "ctx has no mask_mmdet band");

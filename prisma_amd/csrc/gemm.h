@@ -86,6 +86,10 @@ struct GemmArgs {
     // optional per-block timing stamps (8 x int64 per block): see gemm8_kernel
     long long *dbg = nullptr;
     int stagger = 0;                      // first-wave workgroups sleep ((id >> 3) & 7) * stagger * 64 cycles: see gemm.hip
+    // gemm8_kernel (set by its launcher): tiles of the launch - the grid is one persistent workgroup per CU - and whether a tile's
+    // first DMAs may be issued in front of the previous tile's epilogue
+    int ntiles = 0, prefetch = 1;
+    int ablate = 0;                       // PB_GEMM_ABL (timing only, wrong results): 1 no epilogue at all, 2 bare packed-fp16 buffer stores instead of it
 };
 
 // Launches the kernel on `stream`.  tile: TILE_AUTO picks from the shape.

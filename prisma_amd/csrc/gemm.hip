@@ -50,6 +50,7 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         if (small_tile < 0) { const char *e = getenv("PB_TILE_SMALL"); small_tile = e ? atoi(e) : TILE_128; }
         if (tile == TILE_128 && (epi == EPI_STD || epi == EPI_F32) && small_tile != TILE_128) tile = small_tile;
     }
+    if (epi == EPI_RESID) PB_CHECK(a.resid && (int64_t)a.M * a.ldr * 4 < (1LL << 32) - (1 << 20), -1, "residual epilogue: the stream (%d rows) must fit a 32-bit buffer resource", a.M);
     if (epi == EPI_QKV) PB_CHECK(a.D % (tile == TILE_128 ? 128 : 256) == 0 && a.ntp % 8 == 0, -1, "qkv epilogue: D=%d ntp=%d", a.D, a.ntp);
     const bool mx = a.nk16 > 0;
     // MX builds write / read split maps with e4m3 residual parts, fp16-only builds with fp16 residual parts

@@ -290,31 +290,47 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
 
 // EPI_RESID: X += A W'^T + b' with LayerScale pre-folded into W' and b'.  The accumulators START from the fp32
 // residual tile (loaded in the prologue, under the first DMAs' latency) and are stored straight back from the
-// MFMA layout (32 consecutive columns per half wave = 128-byte segments): no LDS transpose, no read in the epilogue.
+// MFMA layout: no LDS transpose, no read in the epilogue.  Round 4: the weight rows are fed in interleaved column order
+// (epi_interleaved), so a lane owns columns 2 li, 2 li + 1 of every row and moves them as ONE 8-byte access - a half wave
+// covers 256 contiguous bytes and a 128 x 64 wave tile takes 64 instructions instead of 128 - through a buffer resource over
+// the residual stream: the row term of the address is a scalar (soffset), the lane term one loop-invariant VGPR, where the
+// flat form spent a 64-bit multiply-add per access and kept 128 address pairs alive (profiles/r04a_store_probe.txt prices the patterns).
+// Rows >= M / columns >= N get an out-of-range offset: such loads return 0 and such stores are dropped.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int TM, bool STORE, bool CHECK>
+__device__ __forceinline__ void resid_io_impl(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int n = wave_n0 + 2 * li;
+    const bool nok = !CHECK || n < p.N;
+    const int nc = nok ? n : 0;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.resid, (unsigned)((int64_t)p.M * p.ldr * 4));
+    const int ldr = (int)p.ldr;
+    const unsigned voff = (unsigned)(((wave_m0 + 4 * lh) * ldr + nc) * 4);
+    float b0 = 0.f, b1 = 0.f;
+    if (!STORE) { b0 = p.bias[nc]; b1 = p.bias[nc + 1]; }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowc = tm * 32 + (r & 3) + 8 * (r >> 2);
+            const int soff = rowc * ldr * 4;
+            unsigned vo = voff;
+            if (CHECK) vo = (nok && wave_m0 + rowc + 4 * lh < p.M) ? voff : 0xFFFFFF00u;
+            if (STORE) {
+                const f32x2 o = {acc[tm][0][r], acc[tm][1][r]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs, (int)vo, soff, 0);
+            } else {
+                const f32x2 x = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)vo, soff, 0));
+                acc[tm][0][r] = x[0] + b0;
+                acc[tm][1][r] = x[1] + b1;
+            }
+        }
+}
 template <int TM, int TN, bool STORE>
 __device__ __forceinline__ void resid_io(const GemmArgs &p, f32x16 (&acc)[TM][TN], int wave_m0, int wave_n0, int lane) {
-    const int li = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = wave_n0 + tn * 32 + li;
-        const bool nok = n < p.N;
-        const int nc = nok ? n : p.N - 1;                   // loads are unconditional (clamped address): a per-element
-        const float b = STORE ? 0.f : p.bias[nc];           // conditional load would serialise on vmcnt(0) each
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = wave_m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (STORE) {
-                    if (nok && m < p.M) p.resid[(int64_t)m * p.ldr + n] = acc[tm][tn][r];
-                } else {
-                    // clamped row: keeps the load addresses distinct from the epilogue's store addresses - if the
-                    // compiler CSEs the two it keeps 128 address pairs live across the main loop and spills
-                    const int mc = m < p.M ? m : p.M - 1;
-                    acc[tm][tn][r] = p.resid[(int64_t)mc * p.ldr + nc] + b;
-                }
-            }
-    }
+    static_assert(TN == 2, "the residual epilogue is built for two 32-column MFMA tiles per wave");
+    if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) resid_io_impl<TM, STORE, false>(p, acc, wave_m0, wave_n0, lane);
+    else resid_io_impl<TM, STORE, true>(p, acc, wave_m0, wave_n0, lane);
 }
 
 // ---- interleaved output columns (fp16 epilogues, TN == 2) -----------------------------------------
@@ -327,7 +343,7 @@ __device__ __forceinline__ void resid_io(const GemmArgs &p, f32x16 (&acc)[TM][TN
 // the weight operand change; nothing moves between lanes.
 template <int EPI, int TN>
 __host__ __device__ constexpr bool epi_interleaved() {
-    return TN == 2 && (EPI == EPI_STD || EPI == EPI_QKV || EPI == EPI_PIXSHUF);
+    return TN == 2 && (EPI == EPI_STD || EPI == EPI_QKV || EPI == EPI_PIXSHUF || EPI == EPI_RESID);
 }
 __device__ __forceinline__ int col_map(int r, bool il) {        // tile-local B row -> tile-local output column
     return il ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;
@@ -943,6 +959,22 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
 
 // VAR != 0 are timing-only ablations (wrong results): 1 no DMA in the loop, 2 no vmcnt waits, 3 no ds_reads,
 // 5 DMA + barriers only (no ds_reads, no MFMAs), 6 MFMAs + barriers only.
+//
+// PERSISTENT WORKGROUPS (round 4).  The grid is one workgroup per CU (launch_g8_impl; PB_GEMM_PERSIST=0 restores one workgroup per
+// tile - the loop below then runs once) and a workgroup walks the tiles vb = blockIdx.x + k * gridDim.x of the same XCD-contiguous
+// order as before.  What that buys (profiles/r04a_store_probe.txt, r04a_gemm8_phase_cycles.log): a one-tile workgroup cannot end
+// before its 128-512 KB of output have left the CU, and with every CU reaching its epilogue at the same moment that is the whole
+// chip's write burst at HBM speed - 11-14k of a 54k-cycle fc1 tile - plus 3.4k cycles of prologue DMA latency in front of the next
+// workgroup's first MFMA.  A persistent workgroup only has to ISSUE its stores (2-3k cycles) and they drain under the next tile's
+// K loop; and the next tile's first six half tiles are requested BEFORE the epilogue (the staging buffers are dead by then), so they
+// have landed when the epilogue's last store has been issued:
+//   * vmcnt counts loads and stores in issue order and saturates at 63, so once >= PB_EPI_MIN_OPS (56) memory instructions have been
+//     issued behind the twelve prefetch DMAs, `s_waitcnt vmcnt(56)` certifies the DMAs without waiting for the newest 56 stores;
+//     only epilogues that use no LDS and issue that many stores on every lane take this path (`pf` below): interior tiles of the
+//     direct fp16 / fp32-residual epilogues.  Everything else runs the old order: epilogue, barrier, prologue.
+//   * K tile 0 of a prefetched tile skips its four counted waits (everything it reads was certified above; the waits would
+//     otherwise be the first thing to wait for ALL of the previous tile's stores); the first wait that needs those stores gone is
+//     K tile 1's, a whole K tile (~2.4k cycles) after the epilogue.
 template <int AMODE, int EPI, int VAR = 0, bool BUFP = false, bool MX = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     constexpr int BM = 256, BN = 256;
@@ -958,29 +990,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     if (p.dbg) { ts0 = __builtin_readcyclecounter(); tr0 = wall_clock64(); }
 
     const int tilesN = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    // Within an XCD's contiguous range, walk 8 (M) x GN (N) super-tiles so that the ~32 tiles in flight on
-    // the XCD share few A and W panels (fewer L2 misses -> less MALL/HBM traffic; loop time is unchanged).
-    int tile_m, tile_n;
-    {
-        const int GN = tilesN < 4 ? tilesN : 4;
-        const int per_band = 8 * tilesN;                 // tiles in a band of 8 M-panels
-        const int band = swz / per_band, rem = swz - band * per_band;
-        const int tilesM = nwg / tilesN;
-        const int bh = (tilesM - band * 8) < 8 ? (tilesM - band * 8) : 8;   // M-panels in this band
-        const int grp = rem / (bh * GN), r2 = rem - grp * bh * GN;
-        const int gw = (tilesN - grp * GN) < GN ? (tilesN - grp * GN) : GN; // N-panels in this group
-        tile_m = band * 8 + r2 / gw;
-        tile_n = grp * GN + r2 % gw;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nwg = p.ntiles > 0 ? p.ntiles : (int)gridDim.x;     // tiles of the launch (the grid may be smaller: persistent workgroups)
+    const int qd = nwg >> 3, rm = nwg & 7;
+    int m0 = 0, n0 = 0, swz = 0;
 
     // ---- staging geometry: half tile h in {A_0, A_1, B_0, B_1}, two DMAs (u = 0, 1) per thread ----
     // DMA (wave, u) covers the 8 LDS rows starting at row0; lane -> row0 + (lane >> 3), chunk lane & 7.
     const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
-    const int lrow = lane >> 3;
     int a_row0[2][2], b_row0[2][2];                  // [half][u], tile-local row of the DMA's first row
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
@@ -990,36 +1006,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             a_row0[hf][u] = (g < 8 ? 0 : 128) + hf * 64 + (g & 7) * 8;
             b_row0[hf][u] = (g >> 2) * 64 + hf * 32 + (g & 3) * 8;
         }
-    // swizzled global chunk of this lane's LDS slot: row0 is a multiple of 8 with (row0 >> 3) & 1 == u
-    int cgu[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) cgu[u] = (lane & 7) ^ ((4 * u + (lane >> 4)) & 7);
-
     const f16 *a_ptr[2][2];
-    int a_iy0[2][2], a_ix0[2][2];
-    bool a_ok[2][2];
+    // conv: the output pixel's first input row / column as (iy0 << 16) | (ix0 & 0xffff) - one register per DMA instead of two and a
+    // predicate; rows >= M carry iy0 = -20000, which fails every tap's range test (persistent workgroups keep all of this live
+    // across the epilogue of the previous tile: the kernel has no register to spare)
+    int a_yx[2][2];
     const f16 *b_ptr[2][2];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int m = m0 + a_row0[hf][u] + lrow;
-            if constexpr (AMODE == A_DENSE) {
-                const int mc = m < p.M ? m : p.M - 1;
-                a_ptr[hf][u] = p.A + (int64_t)mc * p.lda + cgu[u] * 8;
-                a_ok[hf][u] = true;
-                a_iy0[hf][u] = a_ix0[hf][u] = 0;
-            } else {
-                const int ohw = p.cOH * p.cOW;
-                const int b = m / ohw, rem = m - b * ohw;
-                const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
-                a_ok[hf][u] = m < p.M;
-                a_ptr[hf][u] = p.A + (int64_t)b * p.cH * p.cW * cld + cgu[u] * 8;
-                a_iy0[hf][u] = oy * p.cStride - p.cPad;
-                a_ix0[hf][u] = ox * p.cStride - padx;
-            }
-            b_ptr[hf][u] = p.W + (int64_t)(n0 + col_map(b_row0[hf][u] + lrow, epi_interleaved<EPI, 2>())) * p.K + cgu[u] * 8;
-        }
     const int nk = p.K >> 6;
     // BUFP: stage through the buffer path (`buffer_load_dwordx4 ... lds`) - measurably cheaper to issue than the flat
     // `global_load_lds` (8192^3: 1145 -> 1245 TF, qkv / fc1 shapes +14 ... +17 %).  The resource covers the whole operand
@@ -1030,38 +1022,87 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     unsigned a_voff[2][2], b_voff[2][2];
     if constexpr (BUFP) {
         rsW = make_rsrc(p.W, (unsigned)((int64_t)((p.N + 255) / 256 * 256) * p.K * 2));
-        if constexpr (AMODE == A_DENSE) {
-            rsA = make_rsrc(p.A, (unsigned)((int64_t)p.M * p.lda * 2));
-        } else {
-            const int ohw = p.cOH * p.cOW, nimg = p.M / ohw, b0 = p.bufmode == 2 ? m0 / ohw : 0;
-            const int64_t img = (int64_t)p.cH * p.cW * cld;
-            rsA = make_rsrc(p.A + b0 * img, (unsigned)((p.bufmode == 2 ? (nimg - b0 < 2 ? nimg - b0 : 2) : nimg) * img * 2));
-        }
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if constexpr (AMODE == A_DENSE) {
-                    a_voff[hf][u] = (unsigned)((a_ptr[hf][u] - p.A) * 2);
-                } else {
-                    const int ohw = p.cOH * p.cOW, b0 = p.bufmode == 2 ? m0 / ohw : 0;
-                    const int m = m0 + a_row0[hf][u] + lrow;
-                    a_voff[hf][u] = (unsigned)((int64_t)(m / ohw - b0) * p.cH * p.cW * cld * 2) + cgu[u] * 16;
-                }
-                b_voff[hf][u] = (unsigned)((b_ptr[hf][u] - p.W) * 2);
-            }
+        if constexpr (AMODE == A_DENSE) rsA = make_rsrc(p.A, (unsigned)((int64_t)p.M * p.lda * 2));
     }
-
     // staging past the last K tile re-reads the last one into a slot nobody reads any more: the loop stays branch free
     // and every phase can use the same counted wait
     // conv: each A half has its own tap cursor (ky, kx, c0) that steps one K tile per call - no divisions in the loop - and
     // the per-lane pixel offset of tap (0, 0) is precomputed, so a DMA costs one add, two range tests and a select
     int cur_ky[2] = {0, 0}, cur_kx[2] = {0, 0}, cur_c0[2] = {0, 0}, cur_kt[2] = {0, 0};
     int a_pix0[2][2];
+
+    // tile vb of the launch -> (m0, n0) and this thread's staging addresses.  XCD-contiguous remap (bijective for any tile count;
+    // workgroup b runs on XCD b % 8 and the persistent stride is a multiple of 8), then, within an XCD's contiguous range, a walk in
+    // 8 (M) x GN (N) super-tiles so that the ~32 tiles in flight on the XCD share few A and W panels (fewer L2 misses -> less
+    // MALL/HBM traffic; loop time is unchanged).
+    auto setup = [&](const GemmArgs &p, int vb) {
+        // everything lane dependent is derived from an opaque copy of the lane id, i.e. recomputed per tile instead of being kept in
+        // a dozen VGPRs across the K loops
+        int sl = lane;
+        asm volatile("" : "+v"(sl));
+        const int lrow = sl >> 3;
+        // swizzled global chunk of this lane's LDS slot: row0 is a multiple of 8 with (row0 >> 3) & 1 == u
+        int cgu[2];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
+        for (int u = 0; u < 2; ++u) cgu[u] = (sl & 7) ^ ((4 * u + (sl >> 4)) & 7);
+        const int xcd = vb & 7;
+        swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (vb >> 3);
+        int tile_m, tile_n;
+        {
+            const int GN = tilesN < 4 ? tilesN : 4;
+            const int per_band = 8 * tilesN;                 // tiles in a band of 8 M-panels
+            const int band = swz / per_band, rem = swz - band * per_band;
+            const int tilesM = nwg / tilesN;
+            const int bh = (tilesM - band * 8) < 8 ? (tilesM - band * 8) : 8;   // M-panels in this band
+            const int grp = rem / (bh * GN), r2 = rem - grp * bh * GN;
+            const int gw = (tilesN - grp * GN) < GN ? (tilesN - grp * GN) : GN; // N-panels in this group
+            tile_m = band * 8 + r2 / gw;
+            tile_n = grp * GN + r2 % gw;
+        }
+        m0 = tile_m * BM; n0 = tile_n * BN;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) a_pix0[hf][u] = AMODE == A_CONV ? (a_iy0[hf][u] * p.cW + a_ix0[hf][u]) * cld : 0;
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int m = m0 + a_row0[hf][u] + lrow;
+                if constexpr (AMODE == A_DENSE) {
+                    const int mc = m < p.M ? m : p.M - 1;
+                    a_ptr[hf][u] = p.A + (int64_t)mc * p.lda + cgu[u] * 8;
+                    a_yx[hf][u] = a_pix0[hf][u] = 0;
+                } else {
+                    const int ohw = p.cOH * p.cOW;
+                    const int b = m / ohw, rem = m - b * ohw;
+                    const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
+                    a_ptr[hf][u] = p.A + (int64_t)b * p.cH * p.cW * cld + cgu[u] * 8;
+                    const int iy0 = oy * p.cStride - p.cPad, ix0 = ox * p.cStride - padx;
+                    a_yx[hf][u] = (int)(((unsigned)(m < p.M ? iy0 : -20000) << 16) | ((unsigned)ix0 & 0xffffu));
+                    a_pix0[hf][u] = (iy0 * p.cW + ix0) * cld;
+                }
+                b_ptr[hf][u] = p.W + (int64_t)(n0 + col_map(b_row0[hf][u] + lrow, epi_interleaved<EPI, 2>())) * p.K + cgu[u] * 8;
+            }
+        if constexpr (BUFP) {
+            if constexpr (AMODE == A_CONV) {
+                const int ohw = p.cOH * p.cOW, nimg = p.M / ohw, b0 = p.bufmode == 2 ? m0 / ohw : 0;
+                const int64_t img = (int64_t)p.cH * p.cW * cld;
+                rsA = make_rsrc(p.A + b0 * img, (unsigned)((p.bufmode == 2 ? (nimg - b0 < 2 ? nimg - b0 : 2) : nimg) * img * 2));
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if constexpr (AMODE == A_DENSE) {
+                        a_voff[hf][u] = (unsigned)((a_ptr[hf][u] - p.A) * 2);
+                    } else {
+                        // byte offset of tap (0, 0) of this lane's pixel inside the resource (the pixel part may be "negative": only
+                        // in-range taps use the sum, and that sum is in range)
+                        const int ohw = p.cOH * p.cOW, b0 = p.bufmode == 2 ? m0 / ohw : 0;
+                        const int m = m0 + a_row0[hf][u] + lrow;
+                        a_voff[hf][u] = (unsigned)((int64_t)(m / ohw - b0) * p.cH * p.cW * cld * 2) + cgu[u] * 16 + (unsigned)(a_pix0[hf][u] * 2);
+                    }
+                    b_voff[hf][u] = (unsigned)((b_ptr[hf][u] - p.W) * 2);
+                }
+        }
+    };
     auto stage_a = [&](int hf, int kt_) {
         const int ktc = kt_ < nk ? kt_ : nk - 1;
         const int kt = (p.kwrap && ktc >= p.kwrap) ? ktc - p.kwrap : ktc;         // split-fp16 segments re-read A (gemm.h)
@@ -1076,13 +1117,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[hf][u], kt * 128, dst);
                 else glds16(a_ptr[hf][u] + kt * 64, dst);
             } else {
-                const bool ok = a_ok[hf][u] && (unsigned)(a_iy0[hf][u] + ky) < (unsigned)p.cH && (unsigned)(a_ix0[hf][u] + kx) < (unsigned)p.cW;
-                const int eo = a_pix0[hf][u] + tapoff;                      // element offset inside the image
+                const int iy = (a_yx[hf][u] >> 16) + ky, ix = ((int)((unsigned)a_yx[hf][u] << 16) >> 16) + kx;
+                // (bitwise &: a short-circuit && became an exec-masked branch in the K loop)
+                const bool ok = ((unsigned)iy < (unsigned)p.cH) & ((unsigned)ix < (unsigned)p.cW);
                 if constexpr (BUFP) {
                     const unsigned oob = ok ? 0u : 0xFFFFFF00u;            // any out-of-range offset reads zeros
-                    glds16_buf(rsA, (int)((a_voff[hf][u] + (unsigned)(eo * 2)) | oob), 0, dst);
+                    glds16_buf(rsA, (int)((a_voff[hf][u] + (unsigned)(tapoff * 2)) | oob), 0, dst);
                 } else {
-                    glds16(ok ? a_ptr[hf][u] + eo : p.zero, dst);
+                    glds16(ok ? a_ptr[hf][u] + (a_pix0[hf][u] + tapoff) : p.zero, dst);
                 }
             }
         }
@@ -1115,6 +1157,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             else glds16(b_ptr[hf][u] + kt * 64, base + ((g >> 2) * 64 + hf * 32 + (g & 3) * 8) * 128);
         }
     };
+    // a tile's first six half tiles: A_0(0) B_0(0) B_1(0) A_1(0) A_0(1) B_0(1)   (issuing these BEFORE the residual loads measured 5 % slower on proj)
+    auto prologue = [&]() {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) cur_ky[hf] = cur_kx[hf] = cur_c0[hf] = cur_kt[hf] = 0;
+        stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+        stage_a(0, 1); stage_b(0, 1);
+    };
 
     // ---- fragment addressing: chunk(ks) = (lh ^ fsw) ^ 2 ks  ->  byte offset = c0 ^ (32 ks) ----
     const int li = lane & 31, lh = lane >> 5;
@@ -1123,28 +1172,16 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     const int b_base = BOFF + (wc * 64 + li) * 128;      // + j*4096
 
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f16x8 fa[2][4], fb0[4], fb1[4];
-    if constexpr (EPI == EPI_RESID) resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-
-    // prologue: A_0(0) B_0(0) B_1(0) A_1(0) A_0(1) B_0(1)   (issuing these BEFORE the residual loads measured 5 % slower on proj)
-    stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
-    stage_a(0, 1); stage_b(0, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A_0(0), B_0(0) landed (this wave's share)
-    PB_BAR();
-    if (wr == 1) PB_BAR();                               // stagger the second wave group by one barrier
-    if (p.dbg) ts1 = __builtin_readcyclecounter();
 
     const int mxa = p.mx_scale_a * 0x01010101, mxb = p.mx_scale_b * 0x01010101;
     // one K tile; FP8 tiles hold 128 e4m3 bytes per row and go through the MX-scaled MFMA (gemm.h nk16): same staging, same fragment
-    // reads, 4 MFMAs of 64 cycles instead of 8 of 32 per phase - twice the K per tile at the same matrix-pipe time
-    auto tile = [&](auto fp8_tag, int t) {
+    // reads, 4 MFMAs of 64 cycles instead of 8 of 32 per phase - twice the K per tile at the same matrix-pipe time.
+    // FIRST (K tile 0) with `nw` set: the tile's operands were prefetched and certified before the loop (see the header), its four
+    // counted waits are skipped.
+    auto tile = [&](auto fp8_tag, auto first_tag, int t, bool nw) {
         constexpr bool FP8 = decltype(fp8_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
         const char *sb = smem + (t & 1) * BUF;
         // ================= p0 =================
         if ((VAR != 3 && VAR != 5 && VAR != 6) || t == 0) {
@@ -1156,7 +1193,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const f16x8 *)(sb + a_base + rt * 4096 + (c0 ^ (ks * 32)));
         }
         if (VAR != 1 && VAR != 6) stage_b(1, t + 1);
-        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (VAR == 0 || VAR == 3 || VAR == 5) { if (!(FIRST && nw)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
         if (VAR != 5) {
@@ -1182,7 +1219,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         for (int ks = 0; ks < 4; ++ks) fb1[ks] = *(const f16x8 *)(sb + b_base + 4096 + (c0 ^ (ks * 32)));
         }
         if (VAR != 1 && VAR != 6) stage_a(1, t + 1);
-        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (VAR == 0 || VAR == 3 || VAR == 5) { if (!(FIRST && nw)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
         if (VAR != 5) {
@@ -1210,7 +1247,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             for (int ks = 0; ks < 4; ++ks)
                 fa[rt][ks] = *(const f16x8 *)(sb + a_base + 8192 + rt * 4096 + (c0 ^ (ks * 32)));
         if (VAR != 1 && VAR != 6) stage_a(0, t + 2);
-        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (VAR == 0 || VAR == 3 || VAR == 5) { if (!(FIRST && nw)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
         if (VAR != 5) {
@@ -1232,7 +1269,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         PB_BAR();
         // ================= p3 =================
         if (VAR != 1 && VAR != 6) stage_b(0, t + 2);
-        if (VAR == 0 || VAR == 3 || VAR == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (VAR == 0 || VAR == 3 || VAR == 5) { if (!(FIRST && nw)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
         PB_BAR();
         __builtin_amdgcn_s_setprio(1);
         if (VAR != 5) {
@@ -1253,34 +1290,114 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);
         PB_BAR();
     };
-    if constexpr (!MX) {
-        for (int t = 0; t < nk; ++t) tile(std::false_type{}, t);
-    } else if constexpr (AMODE == A_DENSE) {     // [fp16 tiles | fp8 tiles] once
-        const int n16 = p.nk16 > 0 && p.nk16 < nk ? p.nk16 : nk;
-        for (int t = 0; t < n16; ++t) tile(std::false_type{}, t);
-        if constexpr (VAR == 0) {
-            for (int t = n16; t < nk; ++t) tile(std::true_type{}, t);
+
+    int vb = blockIdx.x;
+    setup(p, vb);
+    bool pf = false;                                     // this tile's prologue was issued before the previous tile's epilogue
+    if constexpr (EPI != EPI_RESID) prologue();
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if constexpr (EPI == EPI_RESID) {
+            resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+            if (!pf) prologue();
         }
-    } else {                                     // per tap (mx_period tiles): fp16 tiles, then fp8 tiles
-        const int per = p.mx_period > 0 ? p.mx_period : nk;
-        const int n16 = p.nk16 > 0 && p.nk16 < per ? p.nk16 : per;
-        for (int t0 = 0; t0 < nk; t0 += per) {
-            for (int t = t0; t < t0 + n16; ++t) tile(std::false_type{}, t);
-            for (int t = t0 + n16; t < t0 + per; ++t) tile(std::true_type{}, t);
+        if (pf) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");   // >= 56 stores were issued behind the twelve DMAs: they have landed
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A_0(0), B_0(0) landed (this wave's share)
+        PB_BAR();
+        if (wr == 1) PB_BAR();                               // stagger the second wave group by one barrier
+        if (p.dbg) ts1 = __builtin_readcyclecounter();
+
+        // K tile 0 is an fp16 tile in every layout (gemm.h nk16 >= 1 when MX tiles exist)
+        tile(std::false_type{}, std::true_type{}, 0, pf);
+        if constexpr (!MX) {
+            for (int t = 1; t < nk; ++t) tile(std::false_type{}, std::false_type{}, t, false);
+        } else if constexpr (AMODE == A_DENSE) {     // [fp16 tiles | fp8 tiles] once
+            const int n16 = p.nk16 > 0 && p.nk16 < nk ? p.nk16 : nk;
+            for (int t = 1; t < n16; ++t) tile(std::false_type{}, std::false_type{}, t, false);
+            if constexpr (VAR == 0) {
+                for (int t = n16; t < nk; ++t) tile(std::true_type{}, std::false_type{}, t, false);
+            }
+        } else {                                     // per tap (mx_period tiles): fp16 tiles, then fp8 tiles
+            const int per = p.mx_period > 0 ? p.mx_period : nk;
+            const int n16 = p.nk16 > 0 && p.nk16 < per ? p.nk16 : per;
+            for (int t0 = 0; t0 < nk; t0 += per) {
+                for (int t = t0 ? t0 : 1; t < t0 + n16; ++t) tile(std::false_type{}, std::false_type{}, t, false);
+                for (int t = t0 + n16; t < t0 + per; ++t) tile(std::true_type{}, std::false_type{}, t, false);
+            }
         }
-    }
-    if (wr == 0) PB_BAR();                               // re-align the two wave groups
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (p.dbg) ts2 = __builtin_readcyclecounter();
-    if constexpr (EPI == EPI_RESID) resid_io<4, 2, true>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-    else run_epilogue<EPI, 4, 2, MX>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, n0);
-    if (p.dbg && tid == 0) {
-        const long long t_issue = __builtin_readcyclecounter();      // all epilogue stores issued, none waited for
+        if (wr == 0) PB_BAR();                               // re-align the two wave groups
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long *d = p.dbg + (long long)blockIdx.x * 8;
-        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter(); d[4] = tr0; d[5] = wall_clock64();
-        d[6] = t_issue; d[7] = swz;
+        __syncthreads();
+        if (p.dbg) ts2 = __builtin_readcyclecounter();
+
+        // ---- this tile's epilogue, with the next tile's first DMAs in front of it where the epilogue allows ----
+        const int em0 = m0, en0 = n0, eswz = swz;
+        vb += gridDim.x;
+        const bool more = vb < nwg;
+        // epilogues that touch no LDS and issue >= PB_EPI_MIN_OPS stores on every lane: interior tiles of the direct fp16 epilogues
+        // (64+ stores; the V third of q/k/v transposes through LDS, a pixel-shuffle with ps_co % 64 != 0 takes the LDS path) and of
+        // the fp32 residual epilogue (128 stores)
+        bool lds_free = EPI == EPI_RESID || EPI == EPI_STD || EPI == EPI_QKV || EPI == EPI_PIXSHUF;
+        if constexpr (EPI == EPI_QKV) lds_free = en0 < 2 * p.D;
+        if constexpr (EPI == EPI_PIXSHUF) lds_free = (p.ps_co & 63) == 0;
+        pf = more && p.prefetch && lds_free && em0 + BM <= p.M && en0 + BN <= p.N;
+        // the epilogue and the tile set-up read the kernel arguments through an opaque copy of the kernarg segment pointer: their
+        // fields are s_load'ed per tile instead of being hoisted out of the tile loop, where ~100 of them would have to stay in
+        // SGPRs across the K loop (measured: 95-127 SGPRs spilled into VGPR lanes, 12-38 VGPRs spilled behind them)
+        typedef const __attribute__((address_space(4))) GemmArgs *kargs_t;
+        kargs_t ke = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ke));
+        const GemmArgs &pe = *(const GemmArgs *)ke;
+        if (pf) { setup(pe, vb); prologue(); }
+        // the epilogue sees an opaque copy of the lane id: nothing it derives from it is loop invariant, so the compiler does not hoist
+        // epilogue address arithmetic out of the tile loop and carry it (in VGPRs the K loop needs) across the MFMA phases
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        if (!MX && pe.ablate) {                  // (fp16-only builds: the MX builds have no register to spare for a diagnostic)
+            // timing-only ablations (PB_GEMM_ABL): what a tile costs with no epilogue at all (1) / with the cheapest imaginable one (2:
+            // 64 packed-fp16 buffer stores in the MFMA layout, no bias, no activation, no copies)
+            if (pe.ablate == 2 && pe.out) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(pe.out, (unsigned)((int64_t)pe.M * pe.ldo * 2));
+                const int ldo = (int)pe.ldo;
+                const unsigned voff = (unsigned)(((em0 + wr * 128 + 4 * (elane >> 5)) * ldo + en0 + wc * 64 + 2 * (elane & 31)) * 2);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        f16x2 o; o[0] = (f16)acc[tm][0][r]; o[1] = (f16)acc[tm][1][r];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs, (int)voff, (tm * 32 + (r & 3) + 8 * (r >> 2)) * ldo * 2, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+            }
+        } else if constexpr (EPI == EPI_RESID) resid_io<4, 2, true>(pe, acc, em0 + wr * 128, en0 + wc * 64, elane);
+        else run_epilogue<EPI, 4, 2, MX>(pe, acc, smem, wave, elane, em0 + wr * 128, en0 + wc * 64, en0);
+        if (p.dbg && tid == 0) {
+            // per TILE: start (kernel start or the previous tile's epilogue issued), loop start, loop end, epilogue issued (twice: a
+            // persistent workgroup never waits for its stores), wall clock at start / end, tile index
+            long long *d = p.dbg + (long long)eswz * 8;
+            const long long t_issue = __builtin_readcyclecounter();
+            d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = t_issue; d[4] = tr0; d[5] = wall_clock64();
+            d[6] = t_issue; d[7] = eswz;
+            ts0 = t_issue; tr0 = d[5];
+        }
+        if (!more) break;
+        // the next tile's staging addresses are (re)computed HERE rather than carried across the epilogue: with them live the epilogue
+        // spills (the kernel sits at 237-256 VGPRs); the opaque copy of vb keeps the compiler from re-using the values of the call above
+        asm volatile("" : "+s"(vb));
+        setup(pe, vb);
+        if (!pf) {
+            __syncthreads();                                 // the LDS patches of this tile's epilogue are dead
+            if constexpr (EPI != EPI_RESID) prologue();
+        }
     }
 }
 
@@ -1297,7 +1414,24 @@ int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
         attr_set = true;
     }
     const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), SMEM, stream, a);
+    // persistent workgroups: one per CU walks the tiles (gemm8_kernel header); PB_GEMM_PERSIST=0 launches one workgroup per tile,
+    // PB_GEMM_PREFETCH=0 keeps the persistent loop but issues every tile's prologue after the previous epilogue (A/B switches)
+    static int ncu = 0, persist = 1, prefetch = 1;
+    if (!ncu) {
+        int dev = 0;
+        PB_HIP(hipGetDevice(&dev));
+        PB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        persist = pb_env_int("PB_GEMM_PERSIST", 1);
+        prefetch = pb_env_int("PB_GEMM_PREFETCH", 1);
+    }
+    GemmArgs b = a;
+    b.ntiles = tilesM * tilesN;
+    b.prefetch = prefetch;
+    static int ablate = -1;
+    if (ablate < 0) ablate = pb_env_int("PB_GEMM_ABL", 0);
+    b.ablate = ablate;
+    const int grid = persist && b.ntiles > ncu ? ncu : b.ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM, stream, b);
     PB_HIP(hipGetLastError());
     return 0;
 }

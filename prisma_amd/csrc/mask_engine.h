@@ -15,6 +15,11 @@ class MaskEngine : public EngineBase {
     // frames: device uint8 [n, H, W, 3] RGB.  mask_out: device uint8 [n, H, W, 3] (the band's "mask ids" image).
     int infer(const uint8_t *frames, int n, int H, int W, float confidence, const int32_t *keep, int n_keep, uint8_t *mask_out);
     int64_t get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]);
+    // --sdf of the band (reference mask_mmdet.py:64-69,150-152): with tables set (n_tab = ncap + 1 bytes each; 0 turns it off) every
+    // infer() writes the clamped signed distance field of each frame's id image into its green channel before returning;
+    // sdf_green applies it to id images already on the device (mask_kernels.hip sdf_*_kernel)
+    int set_sdf(const uint8_t *tab_out, const uint8_t *tab_in, int n_tab);
+    int sdf_green(uint8_t *masks, int n, int H, int W);
     static void net_size(const pb_mask_cfg &cfg, int H, int W, int *nh, int *nw, int *Hp, int *Wp);
 
     // results of the last infer(): per frame, score-descending (what format_results would hand to the band)
@@ -91,6 +96,10 @@ class MaskEngine : public EngineBase {
     uint8_t *use_ = nullptr, *inst_ = nullptr;
     size_t inst_bytes_ = 0;
     std::vector<float> h_scores_;
+
+    uint8_t *sdf_tab_ = nullptr, *sdf_g_ = nullptr;      // [tab_out | tab_in], [gm | gb | cnt] scratch
+    int sdf_ncap_ = 0;
+    size_t sdf_px_ = 0;
 
     std::vector<Instances> results_;
     int last_n_ = 0;

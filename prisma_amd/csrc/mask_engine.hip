@@ -62,7 +62,7 @@ void MaskEngine::net_size(const pb_mask_cfg &cfg, int H, int W, int *nh, int *nw
 MaskEngine::~MaskEngine() {
     hipSetDevice(device);
     if (stream) hipStreamSynchronize(stream);
-    void *post[] = {pk_, bits_, plog_, pstat_, inter_, sig_, nmsf_, pidx_, nmsi_, use_, inst_};
+    void *post[] = {pk_, bits_, plog_, pstat_, inter_, sig_, nmsf_, pidx_, nmsi_, use_, inst_, sdf_tab_, sdf_g_};
     for (auto p : post)
         if (p) hipFree(p);
     for (int l = 0; l < 5; ++l) {
@@ -691,7 +691,40 @@ int MaskEngine::infer(const uint8_t *frames, int n, int H, int W, float confiden
         const int m = std::min(pB_, n - s);
         if ((r = run_chunk(frames + (int64_t)s * H * W * 3, m, s, confidence, keep_class, mask_out))) return r;
     }
+    if (sdf_ncap_ > 0) return sdf_green(mask_out, n, H, W);
     return 0;
+}
+
+int MaskEngine::set_sdf(const uint8_t *tab_out, const uint8_t *tab_in, int n_tab) {
+    PB_HIP(hipSetDevice(device));
+    if (n_tab <= 0) { sdf_ncap_ = 0; return 0; }
+    PB_CHECK(tab_out && tab_in && n_tab >= 2, PB_ERR_ARG, "set_sdf: bad tables");
+    PB_HIP(hipStreamSynchronize(stream));
+    if (sdf_tab_) { PB_HIP(hipFree(sdf_tab_)); sdf_tab_ = nullptr; }
+    PB_HIP(hipMalloc((void **)&sdf_tab_, (size_t)n_tab * 2));
+    PB_HIP(hipMemcpy(sdf_tab_, tab_out, n_tab, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(sdf_tab_ + n_tab, tab_in, n_tab, hipMemcpyHostToDevice));
+    sdf_ncap_ = n_tab - 1;
+    return 0;
+}
+
+int MaskEngine::sdf_green(uint8_t *masks, int n, int H, int W) {
+    PB_CHECK(sdf_ncap_ > 0, PB_ERR_STATE, "sdf_green: no tables set (pb_mask_set_sdf)");
+    PB_CHECK(masks && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "sdf_green: bad arguments");
+    PB_HIP(hipSetDevice(device));
+    const size_t px = (size_t)n * H * W;
+    if (px > sdf_px_) {
+        PB_HIP(hipStreamSynchronize(stream));
+        if (sdf_g_) { PB_HIP(hipFree(sdf_g_)); sdf_g_ = nullptr; }
+        PB_HIP(hipMalloc((void **)&sdf_g_, round_up(2 * px, 16) + 4 * 4096));
+        sdf_px_ = px;
+    }
+    PB_CHECK(n <= 4096, PB_ERR_ARG, "sdf_green: %d frames per call (at most 4096)", n);
+    tic(F_PP, 0, (double)px * 14.0);
+    const int r = launch_sdf_green(stream, masks, n, H, W, sdf_g_, sdf_g_ + px, (int *)(sdf_g_ + round_up(2 * sdf_px_, 16)), sdf_tab_,
+                                   sdf_tab_ + sdf_ncap_ + 1, sdf_ncap_);
+    toc();
+    return r;
 }
 
 int64_t MaskEngine::get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]) {

@@ -29,3 +29,7 @@ int launch_matrix_nms(hipStream_t s, const float *inter, int ld, const float *ar
 int launch_sigmoid_rows(hipStream_t s, const float *logit, int64_t ld, const int *idx, int count, int HW, float *sig);
 int launch_band_accumulate(hipStream_t s, const float *sig, int k, int fh, int fw, int h, int w, int H, int W, float thr,
                            const uint8_t *use, uint8_t *out, uint8_t *inst);
+// signed distance field of the id image into its green channel (mask_mmdet.py:64-69,150-152): gm / gb = n * H * W bytes of scratch each,
+// cnt = n ints, tab_out / tab_in = ncap + 1 bytes each (the byte for squared distance i outside / inside the mask; index ncap = saturated)
+int launch_sdf_green(hipStream_t s, uint8_t *masks, int n, int H, int W, uint8_t *gm, uint8_t *gb, int *cnt, const uint8_t *tab_out,
+                     const uint8_t *tab_in, int ncap);

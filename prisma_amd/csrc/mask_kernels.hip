@@ -574,6 +574,87 @@ int launch_sigmoid_rows(hipStream_t s, const float *logit, int64_t ld, const int
     hipLaunchKernelGGL(sigmoid_rows_kernel, dim3(nblk(HW / 4), count), dim3(256), 0, s, logit, ld, idx, HW, sig);
     LAUNCH_CHECK();
 }
+// ---- signed distance field of the band's id image -> its green channel (bands/mask_mmdet.py:64-69,150-152 of the reference) ----------
+// getSDF: inside = luminance != 0; sdf = distance to the mask (outside it) - distance to the background (inside it), remapped by
+// ((sdf + 127) / 255 - 0.25) * 2, clipped to [0, 1], inverted, x 255, truncated to uint8.  The remap saturates for sdf >= 64.25 and
+// sdf <= -63.25, so only SQUARED distances n <= 4128 (an integer: pixel offsets) matter - and the byte is a function of (side, n)
+// alone.  The host tabulates that function with the reference's own float64 expression (prisma_amd/engine.py sdf_tables); the two
+// kernels below compute the exact integer n of the Euclidean distance transform inside a +-64 window: a column scan for the vertical
+// distance to the nearest pixel of either class, then per pixel the minimum of dx^2 + g(x + dx)^2 over the row.  Bytes equal the host
+// restatement's (scipy distance_transform_edt) on every frame, including the degenerate ones: with no pixel of the other class in
+// the frame scipy's feature transform answers as if one sat at (row -1, column 0), and so does sdf_rows_kernel.
+enum { SDF_R = 64, SDF_FAR = 255 };
+
+__global__ __launch_bounds__(256) void sdf_columns_kernel(const uint8_t *__restrict__ masks, uint8_t *__restrict__ gm, uint8_t *__restrict__ gb,
+                                                          int *__restrict__ cnt, int n, int H, int W) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)n * W) return;
+    const int f = (int)(t / W), x = (int)(t - (int64_t)f * W);
+    const uint8_t *m = masks + ((int64_t)f * H * W + x) * 3;
+    uint8_t *pm = gm + (int64_t)f * H * W + x, *pb = gb + (int64_t)f * H * W + x;
+    int dm = SDF_FAR, db = SDF_FAR, inside_px = 0;         // vertical distance to the last mask / background pixel seen
+    for (int y = 0; y < H; ++y) {
+        const uint8_t *q = m + (int64_t)y * W * 3;
+        const bool in = (q[0] | q[1] | q[2]) != 0;
+        inside_px += in;
+        dm = in ? 0 : (dm < SDF_FAR ? dm + 1 : SDF_FAR);
+        db = in ? (db < SDF_FAR ? db + 1 : SDF_FAR) : 0;
+        pm[(int64_t)y * W] = (uint8_t)dm;
+        pb[(int64_t)y * W] = (uint8_t)db;
+    }
+    dm = db = SDF_FAR;
+    for (int y = H - 1; y >= 0; --y) {
+        const int um = pm[(int64_t)y * W], ub = pb[(int64_t)y * W];
+        dm = um == 0 ? 0 : (dm < SDF_FAR ? dm + 1 : SDF_FAR);
+        db = ub == 0 ? 0 : (db < SDF_FAR ? db + 1 : SDF_FAR);
+        if (dm < um) pm[(int64_t)y * W] = (uint8_t)dm;
+        if (db < ub) pb[(int64_t)y * W] = (uint8_t)db;
+    }
+    if (inside_px) atomicAdd(cnt + f, inside_px);
+}
+
+__global__ __launch_bounds__(256) void sdf_rows_kernel(uint8_t *__restrict__ masks, const uint8_t *__restrict__ gm, const uint8_t *__restrict__ gb,
+                                                       const int *__restrict__ cnt, const uint8_t *__restrict__ tab_out,
+                                                       const uint8_t *__restrict__ tab_in, int ncap, int H, int W) {
+    __shared__ uint8_t sm[256 + 2 * SDF_R], sb[256 + 2 * SDF_R];
+    const int f = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * 256;
+    const int64_t row = ((int64_t)f * H + y) * W;
+    for (int i = threadIdx.x; i < 256 + 2 * SDF_R; i += 256) {
+        const int x = x0 - SDF_R + i;
+        const bool ok = x >= 0 && x < W;
+        sm[i] = ok ? gm[row + x] : (uint8_t)SDF_FAR;
+        sb[i] = ok ? gb[row + x] : (uint8_t)SDF_FAR;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= W) return;
+    const bool in = sm[threadIdx.x + SDF_R] == 0;                  // a mask pixel: its own vertical distance to the mask is 0
+    const uint8_t *g = in ? sb : sm;                               // distances to the OTHER class
+    const int inside_px = cnt[f];
+    int best = ncap;
+    if (in ? inside_px == H * W : inside_px == 0) {
+        const int64_t v = (int64_t)(y + 1) * (y + 1) + (int64_t)x * x;      // scipy's answer when the other class is empty
+        best = v < ncap ? (int)v : ncap;
+    } else {
+#pragma unroll 4
+        for (int dx = -SDF_R; dx <= SDF_R; ++dx) {
+            const int gv = g[threadIdx.x + SDF_R + dx];
+            const int v = dx * dx + gv * gv;                       // SDF_FAR^2 > ncap: far columns never win
+            best = v < best ? v : best;
+        }
+    }
+    masks[(row + x) * 3 + 1] = in ? tab_in[best] : tab_out[best];
+}
+
+int launch_sdf_green(hipStream_t s, uint8_t *masks, int n, int H, int W, uint8_t *gm, uint8_t *gb, int *cnt, const uint8_t *tab_out,
+                     const uint8_t *tab_in, int ncap) {
+    PB_CHECK(ncap > 0 && ncap < SDF_FAR * SDF_FAR && ncap <= (SDF_R + 1) * (SDF_R + 1), -1, "sdf: table of %d entries does not fit the +-%d window", ncap + 1, SDF_R);
+    PB_HIP(hipMemsetAsync(cnt, 0, (size_t)n * sizeof(int), s));
+    hipLaunchKernelGGL(sdf_columns_kernel, dim3(nblk((int64_t)n * W)), dim3(256), 0, s, masks, gm, gb, cnt, n, H, W);
+    hipLaunchKernelGGL(sdf_rows_kernel, dim3((W + 255) / 256, H, n), dim3(256), 0, s, masks, gm, gb, cnt, tab_out, tab_in, ncap, H, W);
+    LAUNCH_CHECK();
+}
+
 int launch_band_accumulate(hipStream_t s, const float *sig, int k, int fh, int fw, int h, int w, int H, int W, float thr,
                            const uint8_t *use, uint8_t *out, uint8_t *inst) {
     hipLaunchKernelGGL(band_accumulate_kernel, dim3(nblk((int64_t)H * W)), dim3(256), 0, s, sig, k, fh, fw, h, w, H, W,

@@ -397,6 +397,24 @@ def mask_net_size(cfg: MaskCfg | str, H: int, W: int) -> Tuple[int, int, int, in
     return tuple(x.value for x in v)
 
 
+SDF_NTAB = 4130     # squared distances 0 .. 4128 are the ones getSDF's remap does not saturate on either side; entry 4129 = saturated
+
+
+def sdf_tables(n_tab: int = SDF_NTAB):
+    """(tab_out, tab_in): the byte `masks[..., 1] = sdf * 255 -> astype(uint8)` of the reference's getSDF (bands/mask_mmdet.py:64-69,
+    150-152) for a pixel outside / inside the mask whose squared Euclidean distance to the other side is i - evaluated with the
+    reference's own float64 numpy expression, so the device only has to deliver the exact integer i."""
+    d = np.sqrt(np.arange(n_tab, dtype=np.float64))
+    d[-1] = 1.0e6                                            # "at least this far": saturated on both sides
+    tabs = []
+    for sdf in (d, -d):
+        v = (sdf + 127.0) / 255.0
+        v = (v - 0.25) * 2.0
+        g = (1.0 - np.clip(v, 0.0, 1.0)) * 255
+        tabs.append(np.ascontiguousarray(g.astype(np.uint8)))
+    return tabs[0], tabs[1]
+
+
 class MaskMMDet(_Ctx):
     """SOLOv2 instance-mask band on one GPU (bands/mask_mmdet.py:36-39 init_model, :131-154 per-frame body).
 
@@ -431,6 +449,24 @@ class MaskMMDet(_Ctx):
         check(self.lib.pb_mask_infer_batch(self.ctx, _ptr(frames), n, H, W, C.c_float(confidence), _ptr(ids),
                                            0 if ids is None else len(ids), _ptr(out)))
         self._hw = (H, W)
+        return out
+
+    def set_sdf(self, on: bool = True):
+        """--sdf of the band (reference mask_mmdet.py:64-69,150-152): every following infer_batch* writes the clamped signed distance
+        field of the id image into its green channel, on the device.  The byte is tabulated here with the reference's float64
+        expression (sdf_tables) and looked up by the exact squared distance the library computes."""
+        if not on:
+            check(self.lib.pb_mask_set_sdf(self.ctx, None, None, 0))
+            return
+        to, ti = sdf_tables()
+        check(self.lib.pb_mask_set_sdf(self.ctx, _ptr(to), _ptr(ti), len(to)))
+
+    def sdf_green(self, masks: np.ndarray) -> np.ndarray:
+        """id images uint8 [n,H,W,3] -> the same with the SDF in the green channel (needs set_sdf)."""
+        out = np.ascontiguousarray(masks, np.uint8).copy()
+        n, H, W, ch = out.shape
+        assert ch == 3
+        check(self.lib.pb_mask_sdf_green(self.ctx, _ptr(out), n, H, W))
         return out
 
     def infer_batch_dev(self, frames_ptr: int, n: int, H: int, W: int, confidence: float, keep_classes, out_ptr: int):

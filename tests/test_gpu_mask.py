@@ -223,3 +223,63 @@ def test_r101_1080p_batch_against_oracle():
     assert (out[2] != ref_img).mean() < 5e-4 and out[2].any()
     assert np.array_equal(net.infer_batch(frames[2:3], 0.5, KEEP)[0], out[2])
     net.close()
+
+
+def _blob_masks(n, H, W, seed):
+    """id images like the band's: a few discs / rectangles / thin lines of 255 (and wrapped overlap counts) on black."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    out = np.zeros((n, H, W, 3), np.uint8)
+    for f in range(n):
+        acc = np.zeros((H, W), np.int64)
+        for _ in range(int(rng.integers(1, 7))):
+            cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(2, max(3, min(H, W) // 3))
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                acc += 255 * ((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r)
+            elif kind == 1:
+                acc += 255 * ((abs(yy - cy) <= r // 2) & (abs(xx - cx) <= r))
+            else:
+                acc += 255 * (abs((yy - cy) * 3 - (xx - cx) * 2) <= 2)
+        out[f] = (acc & 255).astype(np.uint8)[..., None]
+    return out
+
+
+@pytest.mark.parametrize("H,W,n", [(180, 300, 3), (720, 1280, 2), (1080, 1920, 2), (37, 53, 4)])
+def test_sdf_green_matches_the_restatement(tiny, H, W, n):
+    """the --sdf channel (reference mask_mmdet.py:64-69,150-152) is computed on the GPU - exact integer squared
+    distances inside a +-64 window, byte looked up in the table made with the reference's float64 expression - and equals the host
+    restatement (oracle band_sdf: scipy's exact EDT) byte for byte, including frames with no mask, no background, and one pixel."""
+    _, _, net = tiny
+    m = _blob_masks(n + 4, H, W, seed=H + n)
+    m[n] = 0                                                 # all-empty frame
+    m[n + 1] = 255                                           # all-full frame
+    m[n + 2] = 0
+    m[n + 2, H // 3, W // 2] = 255                           # one mask pixel
+    m[n + 3] = 255
+    m[n + 3, H - 1, 0] = 0                                   # one background pixel, in a corner
+    net.set_sdf(True)
+    try:
+        got = net.sdf_green(m)
+    finally:
+        net.set_sdf(False)
+    for f in range(len(m)):
+        want = SO.band_sdf(m[f])
+        bad = int((got[f] != want).sum())
+        assert bad == 0, f"frame {f} of {H}x{W}: {bad} bytes differ (first at {np.argwhere(got[f] != want)[0]})"
+
+
+def test_infer_batch_writes_the_sdf_when_asked(tiny):
+    """set_sdf: the band's product path - the id image comes back with the field already in G (R and B untouched)."""
+    cfg, w, net = tiny
+    frames = synth.frames(2, 180, 300, seed=5)
+    plain = net.infer_batch(frames, 0.5, KEEP)
+    net.set_sdf(True)
+    try:
+        withsdf = net.infer_batch(frames, 0.5, KEEP)
+    finally:
+        net.set_sdf(False)
+    assert np.array_equal(withsdf[..., 0], plain[..., 0]) and np.array_equal(withsdf[..., 2], plain[..., 2])
+    for f in range(2):
+        assert np.array_equal(withsdf[f], SO.band_sdf(plain[f]))
+    assert np.array_equal(net.infer_batch(frames, 0.5, KEEP), plain)          # off again

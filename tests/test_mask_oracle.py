@@ -148,6 +148,28 @@ def test_mask_band_host_helpers():
     assert band.BAND == "mask" and len(band.CLASSES) == 11 and band.keep_ids()[:3] == [0, 14, 15]
     m = np.zeros((40, 40, 3), np.uint8)
     m[10:30, 10:30] = 255
-    s = band.get_sdf(m)
-    assert s.shape == (40, 40) and s[0, 0] < s[9, 9] < s[10, 10] < s[20, 20]
-    assert abs(s[20, 20] - (1.0 - ((127.0 - 10.0) / 255.0 - 0.25) * 2.0)) < 1e-12        # 10 px inside the square
+    assert np.array_equal(band._colmap(m)[..., 1], 255 - m[..., 0])
+
+
+def test_band_sdf_restatement_and_tables():
+    """The --sdf image (reference mask_mmdet.py:64-69,150-152): oracle restatement on a square, and the (side, squared distance) ->
+    byte tables the engine looks up (prisma_amd.engine.sdf_tables) against it - every pixel of the restated image is the table entry
+    of its exact squared distance, which is all the device has to compute."""
+    from scipy.ndimage import distance_transform_edt
+    from prisma_amd.engine import SDF_NTAB, sdf_tables
+    m = np.zeros((200, 260, 3), np.uint8)
+    m[60:150, 80:200] = 255
+    m[0:5, 250:260] = 254                                   # a wrapped overlap count is still "inside"
+    img = SO.band_sdf(m)
+    g = img[..., 1].astype(int)
+    assert np.array_equal(img[..., 0], m[..., 0]) and np.array_equal(img[..., 2], m[..., 2])
+    assert g[0, 0] < g[59, 79] < g[60, 80] < g[100, 140]
+    assert g[70, 140] == int((1.0 - ((127.0 - 11.0) / 255.0 - 0.25) * 2.0) * 255)       # 11 px from the background, inside
+    to, ti = sdf_tables()
+    assert len(to) == len(ti) == SDF_NTAB and to[-1] == 0 and ti[-1] == 255
+    assert (to[4065:] == 0).all() and to[4064] > 0 and (ti[4001:] == 255).all() and ti[4000] < 255
+    inside = m[..., 0] != 0
+    n_out = np.rint(distance_transform_edt(~inside) ** 2).astype(np.int64)
+    n_in = np.rint(distance_transform_edt(inside) ** 2).astype(np.int64)
+    want = np.where(inside, ti[np.minimum(n_in, SDF_NTAB - 1)], to[np.minimum(n_out, SDF_NTAB - 1)])
+    assert np.array_equal(want, img[..., 1])
