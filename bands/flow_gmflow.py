@@ -86,13 +86,13 @@ def infer(args, image1, image2):
 
 def process_video(args):
     """The shared flow loop with this band's name, model, metadata and ranks."""
-    saved = (_loop.BAND, _loop.model, _loop.data, _loop.ranks)
-    _loop.BAND, _loop.model, _loop.data, _loop.ranks = BAND, model, data, ranks
+    saved = (_loop.BAND, _loop.model, _loop.data, _loop.ranks, _loop.SUBPATH_NEEDS_BOTH)
+    _loop.BAND, _loop.model, _loop.data, _loop.ranks, _loop.SUBPATH_NEEDS_BOTH = BAND, model, data, ranks, False
     args.iterations = 1                    # GMFlow is not iterative; the loop passes it through to the engine, which ignores it
     try:
         _loop.process_video(args)
     finally:                               # a process may run both flow bands (tests do): leave flow_raft's globals as they were
-        _loop.BAND, _loop.model, _loop.data, _loop.ranks = saved
+        _loop.BAND, _loop.model, _loop.data, _loop.ranks, _loop.SUBPATH_NEEDS_BOTH = saved
 
 
 def main(argv=None):

@@ -31,6 +31,7 @@ model = None
 data = None
 _SYNTH = [False]      # --synthetic
 ranks = None          # shard.Ranks(): one process per GPU under torchrun, world 1 otherwise
+SUBPATH_NEEDS_BOTH = True   # flow_gmflow's wrapper clears it around its call of process_video
 
 
 def load_weights(path):
@@ -97,7 +98,9 @@ def process_video(args):
     base = args.output.rsplit(".", 1)[0]
     ext = args.output.rsplit(".", 1)[1]
     want_mask = bool(args.output_mask or args.subpath_mask)
-    both = args.backwards or want_mask or bool(args.subpath)
+    # flow_gmflow predicts the backward flow only for --backwards / masks (reference flow_gmflow.py:86); with --subpath alone (what
+    # process.py passes) a second global matching would be computed and thrown away
+    both = args.backwards or want_mask or (SUBPATH_NEEDS_BOTH and bool(args.subpath))
     want_flow = bool(args.subpath or args.subpath_mask)
     if model is None:
         init_model(args, device=rk.device)

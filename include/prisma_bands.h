@@ -245,7 +245,9 @@ int64_t pb_mask_get_stage(pb_ctx *ctx, const char *name, float *out, int64_t cap
 /* Debug/parity: copy a named intermediate of the last pb_depth_infer_batch* call to the host
  * as float32 in the reference's layout ([n, C, h, w] for maps, [n, tokens, D] for tokens).
  * Names: "tokens", "block<i>", "feat<i>", "layer<i>_rn", "path<i>", "output_conv1", "net_depth".
- * shape_out receives up to 4 dims; returns the element count or a negative pb_status. */
+ * shape_out receives up to 4 dims; returns the element count or a negative pb_status.  shape_out[0] is the number of frames the
+ * stage holds: the whole call for the ViT's stages; for the DPT head's stages the LAST head chunk (the trailing shape_out[0] frames of
+ * the call) when the call was large enough for the head to run in several chunks (split precision: more than 16 frames of 1080p). */
 int64_t pb_depth_get_stage(pb_ctx *ctx, const char *name, float *out, int64_t cap, int64_t shape_out[4]);
 
 /* Device memory helpers so a Python host without torch can keep frames resident. */

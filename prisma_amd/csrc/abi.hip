@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "engine.h"
@@ -90,6 +91,12 @@ struct pb_ctx {
     int comm_rank = 0, comm_world = 0;
     float *comm_buf = nullptr;
     size_t comm_cap = 0;
+    // pb_depth_encode_still: its own stream and buffers, kept for the life of the ctx (the band calls it from its sink thread for
+    // every --subpath frame while the main thread's batches run on `stream`; a hipMalloc / hipFree pair per frame synchronised the device)
+    hipStream_t still_stream = nullptr;
+    char *still_buf = nullptr;
+    size_t still_cap = 0;
+    std::mutex still_mu;
 };
 
 namespace {
@@ -287,6 +294,8 @@ void pb_destroy(pb_ctx *c) {
     hipSetDevice(c->device);
     if (c->comm) { hipStreamSynchronize(c->stream); g_rccl.CommDestroy(c->comm); }
     if (c->comm_buf) hipFree(c->comm_buf);
+    if (c->still_stream) { hipStreamSynchronize(c->still_stream); hipStreamDestroy(c->still_stream); }
+    if (c->still_buf) hipFree(c->still_buf);
     c->pipe.release();
     if (c->depth) delete c->depth;
     if (c->raft) delete c->raft;
@@ -884,17 +893,26 @@ int pb_depth_encode_still(pb_ctx *c, const float *depth, int H, int W, int flip,
                           float *max_out) {
     PB_CHECK(c && depth && rgb_out && H > 0 && W > 0, PB_ERR_ARG, "depth_encode_still: bad arguments");
     PB_HIP(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lock(c->still_mu);
     const size_t px = (size_t)H * W;
-    DevMem dd, dr, dq, dm;
-    PB_TRY(dd.alloc(px * 4)); PB_TRY(dr.alloc(px * 3)); PB_TRY(dq.alloc(px)); PB_TRY(dm.alloc(64));
-    PB_HIP(hipMemcpy(dd.p, depth, px * 4, hipMemcpyHostToDevice));
-    unsigned *mm = dm.as<unsigned>();
-    PB_TRY(launch_still_encode(c->stream, dd.as<float>(), H, W, mm, mm + 2, dq.as<uint8_t>(), flip, encode_range, dr.as<uint8_t>(),
-                               (float *)(mm + 4)));
-    PB_HIP(hipStreamSynchronize(c->stream));
-    PB_HIP(hipMemcpy(rgb_out, dr.p, px * 3, hipMemcpyDeviceToHost));
+    // [depth f32 | rgb u8 x 3 | quantised u8 | 64 bytes of min / max words], each part 256-byte aligned
+    const size_t o_rgb = round_up(px * 4, 256), o_q = o_rgb + round_up(px * 3, 256), o_mm = o_q + round_up(px, 256), need = o_mm + 256;
+    if (!c->still_stream) PB_HIP(hipStreamCreateWithFlags(&c->still_stream, hipStreamNonBlocking));
+    if (need > c->still_cap) {
+        if (c->still_buf) { PB_HIP(hipStreamSynchronize(c->still_stream)); PB_HIP(hipFree(c->still_buf)); c->still_buf = nullptr; c->still_cap = 0; }
+        PB_HIP(hipMalloc((void **)&c->still_buf, need));
+        c->still_cap = need;
+    }
+    hipStream_t st = c->still_stream;
+    PB_HIP(hipMemsetAsync(c->still_buf + o_mm, 0, 256, st));
+    PB_HIP(hipMemcpyAsync(c->still_buf, depth, px * 4, hipMemcpyHostToDevice, st));
+    unsigned *mm = (unsigned *)(c->still_buf + o_mm);
+    PB_TRY(launch_still_encode(st, (const float *)c->still_buf, H, W, mm, mm + 2, (uint8_t *)(c->still_buf + o_q), flip, encode_range,
+                               (uint8_t *)(c->still_buf + o_rgb), (float *)(mm + 4)));
     float mnmx[2];
-    PB_HIP(hipMemcpy(mnmx, mm + 4, 8, hipMemcpyDeviceToHost));
+    PB_HIP(hipMemcpyAsync(rgb_out, c->still_buf + o_rgb, px * 3, hipMemcpyDeviceToHost, st));
+    PB_HIP(hipMemcpyAsync(mnmx, mm + 4, 8, hipMemcpyDeviceToHost, st));
+    PB_HIP(hipStreamSynchronize(st));
     if (min_out) *min_out = mnmx[0];
     if (max_out) *max_out = mnmx[1];
     return 0;

@@ -148,7 +148,7 @@ int DepthEngine::metric_head(int n) {
         p = nullptr;
         PB_HIP(hipMalloc((void **)&p, bytes));
         PB_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToDevice, stream));
-        stages_[name] = Stage{p, 0, 0, (int64_t)hh * ww, 1, 64, 64, (int64_t)hh * ww * 64};
+        stages_[name] = Stage{p, 0, last_n_, (int64_t)hh * ww, 1, 64, 64, (int64_t)hh * ww * 64};
         return 0;
     };
     const int Fp = 256 * hs_;            // row stride of the DPT head's maps ([hi | lo] per pixel in split-fp16 mode; hi is read)
@@ -198,6 +198,6 @@ int DepthEngine::metric_head(int n) {
     r = launch_logbinom_depth(stream, zpt_, 8, zbins_[cb], h, w, md_, n, nh_, nw_, 0.0212f, 50.f);
     toc();
     if (r) return r;
-    stages_["metric_net"] = Stage{md_, 2, 0, 1, nh_, nw_, 0, 0};
+    stages_["metric_net"] = Stage{md_, 2, last_n_, 1, nh_, nw_, 0, 0};
     return 0;
 }

@@ -89,6 +89,10 @@ struct GemmArgs {
     // gemm8_kernel (set by its launcher): tiles of the launch - the grid is one persistent workgroup per CU - and whether a tile's
     // first DMAs may be issued in front of the previous tile's epilogue
     int ntiles = 0, prefetch = 1;
+    // EPI_RESID on gemm8_kernel: 1 = the accumulators start from the bias alone and X += acc goes out as fire-and-forget fp32 atomic adds
+    // (executed in the XCD's L2; every element receives exactly one per launch, so the result is deterministic) instead of a residual
+    // tile load in front of the K loop and a store behind it (PB_RESID_ATOMIC)
+    int resid_atomic = 0;
     int ablate = 0;                       // PB_GEMM_ABL (timing only, wrong results): 1 no epilogue at all, 2 bare packed-fp16 buffer stores instead of it
 };
 

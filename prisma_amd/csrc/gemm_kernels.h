@@ -297,7 +297,7 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
 // flat form spent a 64-bit multiply-add per access and kept 128 address pairs alive (profiles/r04a_store_probe.txt prices the patterns).
 // Rows >= M / columns >= N get an out-of-range offset: such loads return 0 and such stores are dropped.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-template <int TM, bool STORE, bool CHECK>
+template <int TM, bool STORE, bool CHECK, bool ATOMIC = false>
 __device__ __forceinline__ void resid_io_impl(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     const int n = wave_n0 + 2 * li;
@@ -308,6 +308,13 @@ __device__ __forceinline__ void resid_io_impl(const GemmArgs &p, f32x16 (&acc)[T
     const unsigned voff = (unsigned)(((wave_m0 + 4 * lh) * ldr + nc) * 4);
     float b0 = 0.f, b1 = 0.f;
     if (!STORE) { b0 = p.bias[nc]; b1 = p.bias[nc + 1]; }
+    if constexpr (ATOMIC && !STORE) {                    // X += (b' + A W'^T): the accumulators start from the bias, nothing is loaded
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[tm][0][r] = b0; acc[tm][1][r] = b1; }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -316,7 +323,10 @@ __device__ __forceinline__ void resid_io_impl(const GemmArgs &p, f32x16 (&acc)[T
             const int soff = rowc * ldr * 4;
             unsigned vo = voff;
             if (CHECK) vo = (nok && wave_m0 + rowc + 4 * lh < p.M) ? voff : 0xFFFFFF00u;
-            if (STORE) {
+            if constexpr (ATOMIC) {
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[tm][0][r], rs, (int)vo, soff, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[tm][1][r], rs, (int)vo + 4, soff, 0);
+            } else if (STORE) {
                 const f32x2 o = {acc[tm][0][r], acc[tm][1][r]};
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs, (int)vo, soff, 0);
             } else {
@@ -331,6 +341,37 @@ __device__ __forceinline__ void resid_io(const GemmArgs &p, f32x16 (&acc)[TM][TN
     static_assert(TN == 2, "the residual epilogue is built for two 32-column MFMA tiles per wave");
     if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) resid_io_impl<TM, STORE, false>(p, acc, wave_m0, wave_n0, lane);
     else resid_io_impl<TM, STORE, true>(p, acc, wave_m0, wave_n0, lane);
+}
+// persistent workgroups: store this tile's residual rows and request the NEXT tile's into the same registers, access by access - the
+// write burst and the read burst of a tile boundary overlap in the memory system instead of following each other (the loads of a
+// separate pass queue behind every store: vmcnt is one in-order counter).  Interior tiles only (no out-of-range handling).
+template <int TM>
+__device__ __forceinline__ void resid_swap(const GemmArgs &p, f32x16 (&acc)[TM][2], int cur_m0, int cur_n0, int nxt_m0, int nxt_n0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.resid, (unsigned)((int64_t)p.M * p.ldr * 4));
+    const int ldr = (int)p.ldr;
+    const unsigned vc = (unsigned)(((cur_m0 + 4 * lh) * ldr + cur_n0 + 2 * li) * 4), vn = (unsigned)(((nxt_m0 + 4 * lh) * ldr + nxt_n0 + 2 * li) * 4);
+    const float b0 = p.bias[nxt_n0 + 2 * li], b1 = p.bias[nxt_n0 + 2 * li + 1];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int soff = (tm * 32 + (r & 3) + 8 * (r >> 2)) * ldr * 4;
+            const f32x2 o = {acc[tm][0][r], acc[tm][1][r]};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs, (int)vc, soff, 0);
+            const f32x2 x = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)vn, soff, 0));
+            acc[tm][0][r] = x[0];
+            acc[tm][1][r] = x[1];
+        }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[tm][0][r] += b0; acc[tm][1][r] += b1; }
+}
+template <int TM, int TN, bool STORE>
+__device__ __forceinline__ void resid_io_atomic(const GemmArgs &p, f32x16 (&acc)[TM][TN], int wave_m0, int wave_n0, int lane) {
+    if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) resid_io_impl<TM, STORE, false, true>(p, acc, wave_m0, wave_n0, lane);
+    else resid_io_impl<TM, STORE, true, true>(p, acc, wave_m0, wave_n0, lane);
 }
 
 // ---- interleaved output columns (fp16 epilogues, TN == 2) -----------------------------------------
@@ -567,6 +608,262 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
     }
 }
 
+// ---- round 4: the same epilogue through buffer resources (EPI_STD, EPI_QKV) ---------------------------------------------------------
+// profiles/r04c_gemm8_phase_cycles.log: of a 52.5k-cycle fc1 tile the flat epilogue above takes 13.2k cycles to ISSUE (16.9k with GELU),
+// 64 bare `buffer_store_dword` of the same bytes 4.4k.  The difference is address arithmetic: the flat form spends a 64-bit multiply-add
+// and shift-add per access and keeps eight 64-bit offsets, eight row indices and eight predicates per pass.  Here an access is
+//     resource (tensor base + the wave's first row: SGPRs)  +  lane offset (ONE loop-invariant VGPR per tensor layout)  +  row (scalar soffset)
+// so a pass computes no addresses at all.  Rows >= M / columns >= N (CHECK builds only) get an out-of-range lane offset: such stores are
+// dropped and such loads return 0.  Arithmetic, rounding and store order are those of direct_epilogue_f16_impl: the outputs are the same bits.
+struct BufT {                                   // one tensor as the epilogue addresses it
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned v;                                 // this lane's byte offset from the wave's first row
+};
+#define PB_POISON 0xFFFFFF00u
+__device__ __forceinline__ BufT buf_of(const void *base, int64_t first_row_bytes, unsigned lane_bytes) {
+    BufT t;
+    t.rs = make_rsrc((const char *)base + first_row_bytes, 0x80000000u);
+    t.v = lane_bytes;
+    return t;
+}
+__device__ __forceinline__ f16x2 bl_h2(const BufT &t, unsigned v, int soff) {
+    return __builtin_bit_cast(f16x2, __builtin_amdgcn_raw_buffer_load_b32(t.rs, (int)v, soff, 0));
+}
+__device__ __forceinline__ f32x2 bl_f2(const BufT &t, unsigned v, int soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rs, (int)v, soff, 0));
+}
+__device__ __forceinline__ void bs_h2(const BufT &t, unsigned v, int soff, f16x2 x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), t.rs, (int)v, soff, 0);
+}
+__device__ __forceinline__ void bs_f2(const BufT &t, unsigned v, int soff, f32x2 x) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), t.rs, (int)v, soff, 0);
+}
+__device__ __forceinline__ void bs_u16(const BufT &t, unsigned v, int soff, unsigned short x) {
+    __builtin_amdgcn_raw_buffer_store_b16(x, t.rs, (int)v, soff, 0);
+}
+__device__ __forceinline__ unsigned short bl_u16(const BufT &t, unsigned v, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b16(t.rs, (int)v, soff, 0);
+}
+
+// FAST >= 0: the activation is the compile-time constant FAST and the launch has no skip tensors, no ReLU'd copy and no pre-ReLU - the
+// pass loop is then straight-line code.  With the switches read at run time (FAST = -1) every 8-store pass hops through the uniform
+// branches of all the variants, ~1000 instructions apart in a kernel whose code is several times the instruction cache: measured as 7.0k
+// cycles for the 64 stores of a plain fp16 tile against 2.4k for the same stores in one run (profiles/r04d / r04e_gemm8_phase_cycles.log).
+template <int EPI, int TM, bool CHECK, int LOM, int FAST = -1>
+__device__ __forceinline__ void direct_epilogue_buf(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
+    static_assert(EPI == EPI_STD || EPI == EPI_QKV, "buffer-addressed direct epilogue: EPI_STD / EPI_QKV");
+    const int li = lane & 31, lh = lane >> 5;
+    const int n = wave_n0 + 2 * li;
+    const bool nok = !CHECK || n < p.N;
+    const int nc = nok ? n : 0;
+    float b0 = 0.f, b1 = 0.f;
+    if (p.bias) { b0 = p.bias[nc]; b1 = p.bias[nc + 1]; }
+    const int ldo = (int)p.ldo;
+    const int64_t row0 = (int64_t)wave_m0 * ldo * 2;                 // byte offset of the wave's first row in an [M, ldo] fp16 tensor
+    const unsigned vrow = (unsigned)(4 * lh * ldo * 2);              // the lane's row (4 lh) in such a tensor
+    const unsigned v16 = vrow + (unsigned)(nc * 2);                  // + its column pair
+    // EPI_QKV: q / k rows live at [b, head, t, 64]; a wave's 128 rows cross a batch boundary at most once and 8-aligned row groups never do
+    // (ntp % 8 == 0), so (b, t) of a row is a scalar and the lane only adds its half's 4 rows
+    int qk_t00 = 0, qk_b0 = 0;
+    float qs = 1.f;
+    BufT tq{};
+    if constexpr (EPI == EPI_QKV) {
+        const int which = wave_n0 / p.D, hn = wave_n0 - which * p.D;
+        qs = which == 0 ? p.qscale : 1.f;
+        qk_b0 = wave_m0 / p.ntp; qk_t00 = wave_m0 - qk_b0 * p.ntp;
+        tq = buf_of(which == 0 ? p.q : p.k, (int64_t)(hn >> 6) * p.ntp * 64 * 2, (unsigned)((4 * lh * 64 + 2 * li) * 2));
+    }
+    // lo8 (LOM 2): per pixel [hi fp16 (C) | hi8 (C bytes) | lo8 (C bytes)], C = lo_off; this lane's channel pair starts at byte 2 C + nc / 3 C + nc
+    const unsigned v8hi = vrow + (unsigned)(2 * p.lo_off + nc), v8lo = v8hi + (unsigned)p.lo_off;
+    const unsigned vlo16 = v16 + (unsigned)(p.lo_off * 2);          // LOM 1: the fp16 residual part
+    const unsigned vo8 = vrow + (unsigned)(p.o8_off + nc);          // LOM 3: fp8 copy behind the row's fp16 part
+    const float lo8_shi = __builtin_ldexpf(1.f, p.lo8_pa), lo8_slo = __builtin_ldexpf(1.f, p.lo8_pa + 12), lo8_inv = __builtin_ldexpf(1.f, -(p.lo8_pa + 12));
+    // FAST = act | add1 << 4 | add2 << 5 | out2 << 6 | pre_relu << 7 (the dispatcher's key): every switch is a compile-time constant
+    const int act = FAST >= 0 ? (FAST & 15) : p.act;
+    const bool gru_r = EPI == EPI_STD && act == ACT_GRU_ZR && wave_n0 >= 128;       // a wave's 64 columns are all z or all r
+#pragma unroll
+    for (int th = 0; th < TM * 2; ++th) {                   // 8 accumulator registers (= 16 rows) per pass
+        const int tm = th >> 1, r0 = (th & 1) * 8;
+        // tile-local row of register q (a compile-time constant) and, CHECK builds, the poisoned lane offsets of rows >= M
+        int rowc[8];
+        unsigned pz[8];                                     // 0 or PB_POISON: OR-ed into every lane offset of row q
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = r0 + q;
+            rowc[q] = tm * 32 + (r & 3) + 8 * (r >> 2);
+            pz[q] = (!CHECK || (nok && wave_m0 + rowc[q] + 4 * lh < p.M)) ? 0u : PB_POISON;
+        }
+        float v0[8], v1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { v0[q] = acc[tm][0][r0 + q] + b0; v1[q] = acc[tm][1][r0 + q] + b1; }
+        if constexpr (EPI == EPI_STD) {
+            if (FAST >= 0 ? ((FAST >> 7) & 1) != 0 : p.pre_relu != 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            }
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const f16 *addp = which == 0 ? p.add1 : p.add2;
+                if (FAST >= 0 ? ((FAST >> (4 + which)) & 1) == 0 : addp == nullptr) continue;
+                const BufT ta = buf_of(addp, row0, 0);
+                f16x2 a[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[q] = bl_h2(ta, v16 | pz[q], rowc[q] * ldo * 2);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                if constexpr (LOM == 2) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f32x2 l = __builtin_amdgcn_cvt_pk_f32_fp8((int)bl_u16(ta, v8lo | pz[q], rowc[q] * ldo * 2), false) * lo8_inv;
+                        v0[q] += l[0]; v1[q] += l[1];
+                    }
+                } else if constexpr (LOM == 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = bl_h2(ta, vlo16 | pz[q], rowc[q] * ldo * 2);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                }
+            }
+            if (FAST >= 0 ? ((FAST >> 6) & 1) != 0 : p.out2 != nullptr) {
+                const BufT t2 = buf_of(p.out2, row0, 0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    f16x2 o2;
+                    o2[0] = (f16)fmaxf(v0[q], 0.f); o2[1] = (f16)fmaxf(v1[q], 0.f);
+                    bs_h2(t2, v16 | pz[q], rowc[q] * ldo * 2, o2);
+                    if constexpr (LOM == 3) bs_u16(t2, vo8 | pz[q], rowc[q] * ldo * 2, pb_fp8x2((float)o2[0] * p.o8_scale, (float)o2[1] * p.o8_scale));
+                }
+                if constexpr (LOM == 1 || LOM == 2) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float r0f = fmaxf(v0[q], 0.f), r1f = fmaxf(v1[q], 0.f);
+                        if constexpr (LOM == 2) {
+                            const f16 h0 = (f16)r0f, h1 = (f16)r1f;
+                            bs_u16(t2, v8hi | pz[q], rowc[q] * ldo * 2, pb_fp8x2((float)h0 * lo8_shi, (float)h1 * lo8_shi));
+                            bs_u16(t2, v8lo | pz[q], rowc[q] * ldo * 2, pb_fp8x2((r0f - (float)h0) * lo8_slo, (r1f - (float)h1) * lo8_slo));
+                        } else {
+                            f16x2 o2;
+                            o2[0] = (f16)(r0f - (float)(f16)r0f); o2[1] = (f16)(r1f - (float)(f16)r1f);
+                            bs_h2(t2, vlo16 | pz[q], rowc[q] * ldo * 2, o2);
+                        }
+                    }
+                }
+            }
+            if (act == ACT_GELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) fast_gelu2(v0[q], v1[q]);
+            } else if (act == ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+            } else if (act == ACT_SIGMOID) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
+            } else if (act == ACT_TANH) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = tanhf(v0[q]); v1[q] = tanhf(v1[q]); }
+            } else if (act == ACT_GRU_ZR) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
+                if (gru_r) {                     // r columns: r * h -> gru_rh (the z columns fall through to the plain store below)
+                    const BufT th_ = buf_of(p.gru_h, (int64_t)wave_m0 * 128 * 4, 0);
+                    const BufT tr = buf_of(p.gru_rh, (int64_t)wave_m0 * p.gru_ld * 2, 0);
+                    const unsigned vh = (unsigned)((4 * lh * 128 + (nc - 128)) * 4), vr = (unsigned)((4 * lh * p.gru_ld + (nc - 128)) * 2);
+                    const unsigned vr8 = (unsigned)(4 * lh * p.gru_ld * 2 + p.o8_off + (nc - 128));
+                    f32x2 h[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) h[q] = bl_f2(th_, vh | pz[q], rowc[q] * 128 * 4);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        f16x2 o;
+                        o[0] = (f16)(v0[q] * h[q][0]); o[1] = (f16)(v1[q] * h[q][1]);
+                        bs_h2(tr, vr | pz[q], rowc[q] * p.gru_ld * 2, o);
+                        if constexpr (LOM == 3)       // fp8 twin of r * h for the q convolution's MX segment (o8_off = byte offset of the copy)
+                            bs_u16(tr, vr8 | pz[q], rowc[q] * p.gru_ld * 2, pb_fp8x2((float)o[0] * p.o8_scale, (float)o[1] * p.o8_scale));
+                    }
+                    continue;
+                }
+            } else if (act == ACT_GRU_Q) {
+                const BufT th_ = buf_of(p.gru_h, (int64_t)wave_m0 * 128 * 4, 0);
+                const BufT tz = buf_of(p.gru_z, (int64_t)wave_m0 * 256 * 2, 0);
+                const unsigned vh = (unsigned)((4 * lh * 128 + nc) * 4), vz = (unsigned)((4 * lh * 256 + nc) * 2);
+                f32x2 h[8];
+                f16x2 z[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    h[q] = bl_f2(th_, vh | pz[q], rowc[q] * 128 * 4);
+                    z[q] = bl_h2(tz, vz | pz[q], rowc[q] * 256 * 2);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float z0 = (float)z[q][0], z1 = (float)z[q][1];
+                    f32x2 hn;
+                    hn[0] = (1.f - z0) * h[q][0] + z0 * tanhf(v0[q]);
+                    hn[1] = (1.f - z1) * h[q][1] + z1 * tanhf(v1[q]);
+                    bs_f2(th_, vh | pz[q], rowc[q] * 128 * 4, hn);
+                    v0[q] = hn[0]; v1[q] = hn[1];
+                }
+            }
+        }
+        if (EPI != EPI_STD || p.out) {
+            BufT td;
+            if constexpr (EPI == EPI_QKV) td = tq; else td = buf_of(p.out, row0, 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f16x2 o;
+                o[0] = (f16)(v0[q] * qs); o[1] = (f16)(v1[q] * qs);
+                if constexpr (EPI == EPI_QKV) {
+                    int t = qk_t00 + rowc[q], b = qk_b0;
+                    if (t >= p.ntp) { t -= p.ntp; b += 1; }
+                    bs_h2(td, td.v | pz[q], (b * p.heads * p.ntp + t) * 64 * 2, o);
+                } else {
+                    bs_h2(td, v16 | pz[q], rowc[q] * ldo * 2, o);
+                }
+            }
+            if constexpr (EPI == EPI_STD && LOM == 3) {
+                if (act != ACT_GRU_ZR) {       // fp8 copy for a consumer's MX correction segment (gemm.h o8_off); z itself has none
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bs_u16(td, vo8 | pz[q], rowc[q] * ldo * 2, pb_fp8x2(v0[q] * p.o8_scale, v1[q] * p.o8_scale));
+                }
+            }
+            if constexpr (EPI == EPI_STD && (LOM == 1 || LOM == 2)) {       // split-fp16 consumers read [hi | lo] (or [hi | hi8 | lo8], gemm.h lo8)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if constexpr (LOM == 2) {
+                        const f16 h0 = (f16)v0[q], h1 = (f16)v1[q];
+                        bs_u16(td, v8hi | pz[q], rowc[q] * ldo * 2, pb_fp8x2((float)h0 * lo8_shi, (float)h1 * lo8_shi));
+                        bs_u16(td, v8lo | pz[q], rowc[q] * ldo * 2, pb_fp8x2((v0[q] - (float)h0) * lo8_slo, (v1[q] - (float)h1) * lo8_slo));
+                    } else {
+                        f16x2 o;
+                        o[0] = (f16)(v0[q] - (float)(f16)v0[q]); o[1] = (f16)(v1[q] - (float)(f16)v1[q]);
+                        bs_h2(td, vlo16 | pz[q], rowc[q] * ldo * 2, o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, int TM, bool CHECK, int LOM>
+__device__ __forceinline__ void direct_epilogue_any(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
+    if constexpr (EPI == EPI_STD) {
+        // interior tiles of the common launches take a straight-line copy of the epilogue (direct_epilogue_buf FAST): the plain / ReLU / GELU
+        // outputs of the linears and convolutions, the two GRU gates, and the DPT head's skip / ReLU'd-copy combinations
+        if (!CHECK) {
+            const int key = p.act | (p.add1 ? 16 : 0) | (p.add2 ? 32 : 0) | (p.out2 ? 64 : 0) | (p.pre_relu ? 128 : 0);
+#define PB_FAST_CASE(K) case K: direct_epilogue_buf<EPI, TM, false, LOM, K>(p, acc, wave_m0, wave_n0, lane); return;
+            switch (key) {
+                PB_FAST_CASE(ACT_NONE) PB_FAST_CASE(ACT_RELU) PB_FAST_CASE(ACT_GELU) PB_FAST_CASE(ACT_GRU_ZR) PB_FAST_CASE(ACT_GRU_Q)
+                PB_FAST_CASE(ACT_NONE | 64) PB_FAST_CASE(ACT_NONE | 16) PB_FAST_CASE(ACT_NONE | 16 | 32 | 64)
+                PB_FAST_CASE(ACT_GRU_ZR | 16) PB_FAST_CASE(ACT_GRU_Q | 16) PB_FAST_CASE(ACT_RELU | 16 | 128) PB_FAST_CASE(ACT_RELU | 64)
+                default: break;
+            }
+#undef PB_FAST_CASE
+        }
+        direct_epilogue_buf<EPI, TM, CHECK, LOM>(p, acc, wave_m0, wave_n0, lane);
+    } else if constexpr (EPI == EPI_QKV) direct_epilogue_buf<EPI, TM, CHECK, LOM>(p, acc, wave_m0, wave_n0, lane);
+    else direct_epilogue_f16_impl<EPI, TM, CHECK, LOM>(p, acc, wave_m0, wave_n0, lane);
+}
+
 template <int EPI, int TM, bool MX>
 __device__ __forceinline__ void direct_epilogue_f16(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
     // interior tiles (the common case) store without per-lane predicates: each predicate costs an exec-mask branch
@@ -575,20 +872,20 @@ __device__ __forceinline__ void direct_epilogue_f16(const GemmArgs &p, f32x16 (&
         if (p.lo_off) {
             // MX builds serve the e4m3-residual maps (lo8), fp16-only builds the fp16-residual maps
             const bool inner = wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N;
-            if (inner) direct_epilogue_f16_impl<EPI, TM, false, MX ? 2 : 1>(p, acc, wave_m0, wave_n0, lane);
-            else direct_epilogue_f16_impl<EPI, TM, true, MX ? 2 : 1>(p, acc, wave_m0, wave_n0, lane);
+            if (inner) direct_epilogue_any<EPI, TM, false, MX ? 2 : 1>(p, acc, wave_m0, wave_n0, lane);
+            else direct_epilogue_any<EPI, TM, true, MX ? 2 : 1>(p, acc, wave_m0, wave_n0, lane);
             return;
         }
     }
     if constexpr (MX && EPI == EPI_STD) {
         if (p.o8_off) {
-            if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false, 3>(p, acc, wave_m0, wave_n0, lane);
-            else direct_epilogue_f16_impl<EPI, TM, true, 3>(p, acc, wave_m0, wave_n0, lane);
+            if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_any<EPI, TM, false, 3>(p, acc, wave_m0, wave_n0, lane);
+            else direct_epilogue_any<EPI, TM, true, 3>(p, acc, wave_m0, wave_n0, lane);
             return;
         }
     }
-    if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_f16_impl<EPI, TM, false, 0>(p, acc, wave_m0, wave_n0, lane);
-    else direct_epilogue_f16_impl<EPI, TM, true, 0>(p, acc, wave_m0, wave_n0, lane);
+    if (wave_m0 + TM * 32 <= p.M && wave_n0 + 64 <= p.N) direct_epilogue_any<EPI, TM, false, 0>(p, acc, wave_m0, wave_n0, lane);
+    else direct_epilogue_any<EPI, TM, true, 0>(p, acc, wave_m0, wave_n0, lane);
 }
 
 // Accumulators -> per-wave LDS patch -> 8-column chunks -> fused store.  `smem` must be free of live
@@ -1182,6 +1479,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     auto tile = [&](auto fp8_tag, auto first_tag, int t, bool nw) {
         constexpr bool FP8 = decltype(fp8_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
+        // K tile 0 starts every accumulator from the inline constant 0 (no 128-register clear per tile); the residual epilogue starts
+        // them from the residual tile instead.  VAR != 0 ablations skip MFMAs, so they keep the explicit clear.
+        constexpr bool ZC = FIRST && EPI != EPI_RESID && VAR == 0;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const char *sb = smem + (t & 1) * BUF;
         // ================= p0 =================
         if ((VAR != 3 && VAR != 5 && VAR != 6) || t == 0) {
@@ -1208,7 +1509,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt)
-                        acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[rt][0], 0, 0, 0);
+                        acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], ZC && ks == 0 ? zero16 : acc[rt][0], 0, 0, 0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1234,7 +1535,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt)
-                        acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[rt][1], 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], ZC && ks == 0 ? zero16 : acc[rt][1], 0, 0, 0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1262,7 +1563,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt)
-                        acc[2 + rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], acc[2 + rt][1], 0, 0, 0);
+                        acc[2 + rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb1[ks], ZC && ks == 0 ? zero16 : acc[2 + rt][1], 0, 0, 0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1284,7 +1585,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt)
-                        acc[2 + rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], acc[2 + rt][0], 0, 0, 0);
+                        acc[2 + rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rt][ks], fb0[ks], ZC && ks == 0 ? zero16 : acc[2 + rt][0], 0, 0, 0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1294,16 +1595,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     int vb = blockIdx.x;
     setup(p, vb);
     bool pf = false;                                     // this tile's prologue was issued before the previous tile's epilogue
+    bool swapped = false;                                // EPI_RESID: this tile's residual rows were loaded by the previous tile's epilogue
     if constexpr (EPI != EPI_RESID) prologue();
     while (true) {
+        if constexpr (EPI != EPI_RESID && VAR != 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
         if constexpr (EPI == EPI_RESID) {
-            resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+            if (!swapped) {                                  // (after resid_swap the accumulators already hold this tile's residual rows)
+                if (p.resid_atomic) resid_io_atomic<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+                else resid_io<4, 2, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+            }
             if (!pf) prologue();
         }
         if (pf) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");   // >= 56 stores were issued behind the twelve DMAs: they have landed
@@ -1352,7 +1659,15 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         typedef const __attribute__((address_space(4))) GemmArgs *kargs_t;
         kargs_t ke = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ke));
-        const GemmArgs &pe = *(const GemmArgs *)ke;
+        // ... and through a by-value COPY of the struct (only the fields that are used get loaded, once): read through the pointer, every
+        // field would be re-loaded after every store of the epilogue (the stores may alias it as far as the compiler knows) - measured as
+        // 7.0k instead of 2.4k cycles for the 64 stores of a plain fp16 tile (profiles/r04d_gemm8_phase_cycles.log)
+        struct ArgWords { int w[sizeof(GemmArgs) / 4]; };
+        static_assert(sizeof(GemmArgs) % 4 == 0 && sizeof(ArgWords) == sizeof(GemmArgs), "GemmArgs is copied word by word");
+        ArgWords aw;
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(GemmArgs) / 4); ++i) aw.w[i] = ((const __attribute__((address_space(4))) int *)ke)[i];
+        const GemmArgs pe = __builtin_bit_cast(GemmArgs, aw);
         if (pf) { setup(pe, vb); prologue(); }
         // the epilogue sees an opaque copy of the lane id: nothing it derives from it is loop invariant, so the compiler does not hoist
         // epilogue address arithmetic out of the tile loop and carry it (in VGPRs the K loop needs) across the MFMA phases
@@ -1378,7 +1693,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
             }
-        } else if constexpr (EPI == EPI_RESID) resid_io<4, 2, true>(pe, acc, em0 + wr * 128, en0 + wc * 64, elane);
+        } else if constexpr (EPI == EPI_RESID) {
+            // pf implies that this tile is interior and that setup() already moved (m0, n0) to the next tile
+            swapped = pf && !pe.resid_atomic && m0 + BM <= pe.M && n0 + BN <= pe.N;
+            if (swapped) resid_swap<4>(pe, acc, em0 + wr * 128, en0 + wc * 64, m0 + wr * 128, n0 + wc * 64, elane);
+            else if (pe.resid_atomic) resid_io_atomic<4, 2, true>(pe, acc, em0 + wr * 128, en0 + wc * 64, elane);
+            else resid_io<4, 2, true>(pe, acc, em0 + wr * 128, en0 + wc * 64, elane);
+        }
         else run_epilogue<EPI, 4, 2, MX>(pe, acc, smem, wave, elane, em0 + wr * 128, en0 + wc * 64, en0);
         if (p.dbg && tid == 0) {
             // per TILE: start (kernel start or the previous tile's epilogue issued), loop start, loop end, epilogue issued (twice: a
@@ -1416,12 +1737,16 @@ int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
     const int tilesM = (a.M + 255) / 256, tilesN = (a.N + 255) / 256;
     // persistent workgroups: one per CU walks the tiles (gemm8_kernel header); PB_GEMM_PERSIST=0 launches one workgroup per tile,
     // PB_GEMM_PREFETCH=0 keeps the persistent loop but issues every tile's prologue after the previous epilogue (A/B switches)
-    static int ncu = 0, persist = 1, prefetch = 1;
+    static int ncu = 0, persist = 0, prefetch = 1;
     if (!ncu) {
         int dev = 0;
         PB_HIP(hipGetDevice(&dev));
         PB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        persist = pb_env_int("PB_GEMM_PERSIST", 1);
+        // default OFF: measured on the final epilogues (profiles/r04f_gemm8_phase_cycles.log) a one-tile workgroup is as fast or faster -
+        // fc1 45.1k against 46.9k cycles per tile, proj 77.7k against 81.6k: what a persistent workgroup saves in front of the K loop (the
+        // prefetched first DMAs) it pays inside the epilogue, whose own loads (bias, skip tensors, GRU state) wait behind those DMAs on
+        // the one in-order vmcnt counter.  The loop stays selectable (PB_GEMM_PERSIST=1) with its switches.
+        persist = pb_env_int("PB_GEMM_PERSIST", 0);
         prefetch = pb_env_int("PB_GEMM_PREFETCH", 1);
     }
     GemmArgs b = a;
@@ -1430,6 +1755,9 @@ int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
     static int ablate = -1;
     if (ablate < 0) ablate = pb_env_int("PB_GEMM_ABL", 0);
     b.ablate = ablate;
+    static int ratomic = -1;
+    if (ratomic < 0) ratomic = pb_env_int("PB_RESID_ATOMIC", 0);
+    b.resid_atomic = EPI == EPI_RESID ? ratomic : 0;
     const int grid = persist && b.ntiles > ncu ? ncu : b.ntiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM, stream, b);
     PB_HIP(hipGetLastError());

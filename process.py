@@ -8,9 +8,10 @@ field_of_view), same band order (mask -> depth -> flow -> camera, :205-290), sam
 default-band aliases (`depth`, `flow`, `flow_bwd`, `flow_mask`, `flow_mask_bwd`, :243-287).  It shells out to
 `bands/<band>.py` exactly like the reference's run() (:60-73), with `sys.executable` instead of a bare `python3`.
 
-Bands this repo builds: rgba, depth_anything, flow_raft, mask_mmdet.  The reference's defaults for
-still images (depth_patchfusion) and flow (flow_gmflow), and camera_colmap, are out of scope: a request
-for a band that is not built is reported and skipped; the defaults fall back to the built band of the same kind.
+Bands this repo builds: rgba, depth_anything, flow_raft, flow_gmflow (the reference's default flow band, :23 -
+and this script's), mask_mmdet.  The reference's default for still images (depth_patchfusion) and camera_colmap are out of scope
+(SURVEY section 2): a request for a band that is not built is reported and skipped; a default that is not built falls back to the
+built band of the same kind.
 """
 import argparse
 import os

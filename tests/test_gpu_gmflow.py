@@ -90,3 +90,19 @@ def test_fast_mode_runs(golden_dir):
     e = max(relmax(flow[0, 0], z["fwd"]), relmax(flow[0, 1], z["bwd"]))
     print("\n  single-pass fp16 gmflow 125x157: relmax %.3e (outside 1e-3 by design: DESIGN.md section 7)" % e)
     assert e < 5e-2
+
+
+def test_1080p_scaled_pair_against_reference_vectors(net, golden_dir):
+    """the size the bench times - a 1920x1080 pair at the band's default --scale 0.75 -> 810x1440 -> network
+    816x1440 (a 102 x 180 grid: 18 360 tokens, 18 360^2 global matching, 51 x 90 windows) against the REAL reference GMFlow fed the
+    same 8-bit cubic resize (tests/golden/gmflow_full.npz: 1/8-strided samples + float64 sums over every pixel)."""
+    z = np.load(os.path.join(golden_dir, "gmflow_full.npz"))
+    big = synth.frame_pair_sequence(2, 1080, 1920, seed=int(z["frame_seed"]))
+    flow, rgb, mx = net.infer_sequence(big, scale=0.75, backward=False)
+    assert flow.shape == (1, 1, 810, 1440, 2)
+    got, ref = flow[0, 0][::8, ::8], z["fwd1080_s8"]
+    print("\n  gmflow 1080p x0.75 relmax %.3e relL2 %.3e (|flow| max %.1f px)" % (relmax(got, ref), rell2(got, ref), float(z["absmax"])))
+    assert relmax(got, ref) < TOL[1][0] and rell2(got, ref) < TOL[1][1]
+    f64 = flow[0, 0].astype(np.float64)
+    sums = np.array([f64[..., 0].sum(), f64[..., 1].sum(), np.abs(f64).sum()])
+    assert np.all(np.abs(sums - z["sums1080"]) < TOL[1][1] * z["sums1080"][2])
