@@ -333,7 +333,9 @@ def main():
     ap.add_argument("--gemm-tile", type=int, default=0, help="A/B switch: 0 auto, 1 128x128, 2 ping-pong 256x256, 9 256x64")
     ap.add_argument("--conv-tile", type=int, default=0)
     ap.add_argument("--all-legs", action="store_true", help="also run the per-band legs below with their usual sizes (flow 720p, mask, pipeline, PCIe)")
-    ap.add_argument("--latency", action="store_true", help="also time one 1280x720 frame at batch 1 (BASELINE configs[1])")
+    ap.add_argument("--latency", action="store_true", default=True,
+                    help="also time one 1280x720 frame at batch 1 (BASELINE configs[1]; on by default since round 4: eight batch-1 calls, ~0.1 s)")
+    ap.add_argument("--no-latency", dest="latency", action="store_false")
     ap.add_argument("--host-chunks", type=int, default=0, help="batches pushed through the host-pointer API for the PCIe-inclusive rate")
     ap.add_argument("--pipeline-frames", type=int, default=0, help="frames per step of the three-band pipeline leg")
     ap.add_argument("--mask-frames", type=int, default=0, help="frames per step of the mask_mmdet leg")

@@ -214,6 +214,30 @@ def heavy_case():
                         fwd=fwd, bwd=bwd)
 
 
+def heavy_1080p_case():
+    """the heavy-tailed ViT-L weights on the frame the bench-shaped parity test reports (frame 13 of the 32-frame
+    1080p clip of seed 77), through the REAL reference model - so that the margin the per-layer residual assignment left (qkv and fc1
+    run one fp16 pass) is asserted at the timed size on outlier activations too."""
+    from d_anything.dpt import DPT_DINOv2
+    cfg = synth.DEPTH_CFGS["vitl"]
+    w = synth.depth_anything_weights_heavy(cfg, seed=1234)
+    m = DPT_DINOv2(encoder="vitl", features=cfg.features, out_channels=list(cfg.out_channels))
+    load_into(m, w)
+    m = m.eval()
+    frame = synth.frames(32, 1080, 1920, seed=77)[13]
+    x = O.preprocess(frame)[None]
+    with torch.no_grad():
+        d_net = m(torch.from_numpy(x))
+        d_ref = torch.nn.functional.interpolate(d_net[None], (1080, 1920), mode="bilinear", align_corners=False)[0, 0].numpy()
+    d_or = O.infer(w, frame, cfg.depth, cfg.heads)
+    e = relerr(d_or, d_ref)
+    print(f"[vitl heavy 1080p] oracle vs reference rel err {e:.2e}; depth {d_ref.min():.4f}..{d_ref.max():.4f} mean {d_ref.mean():.4f}")
+    assert e < 5e-5 and np.isfinite(d_ref).all() and d_ref.max() > d_ref.min() >= 0, e
+    np.savez_compressed(os.path.join(GOLD, "depth_vitl_heavy_1080p.npz"), frame_seed=np.array(77), frame_index=np.array(13),
+                        depth_s8=d_ref[::8, ::8].copy(),
+                        depth_sum=np.array([d_ref.astype(np.float64).sum(), np.abs(d_ref.astype(np.float64)).sum()]))
+
+
 def encode_case():
     sys.modules.setdefault("cv2", types.ModuleType("cv2"))   # common/encode.py:10 imports cv2 for Sobel only
     from common import encode as E
@@ -551,6 +575,8 @@ if __name__ == "__main__":
         full_case()
     if "heavy" in which:
         heavy_case()
+    if "heavy_1080p" in which:
+        heavy_1080p_case()
     if "gmflow" in which:
         gmflow_case()
         gmflow_case(216, 300, 52, False)   # pads to 224x304: a 28 x 38 grid, 14 x 19 windows, forward only

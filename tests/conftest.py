@@ -23,6 +23,10 @@ def golden_dir():
 # mode bench.py also reports) is held to what an 11-bit-mantissa operand rounding delivers on these models.
 TOL = {1: (1e-3, 1e-3),       # precision -> (max / range, L2)
        0: (2e-3, 1.1e-3)}
+# The depth band's split mode runs qkv and fc1 without a weight-residual pass (round 3: the per-layer assignment bought 10 ms of 150).
+# What that left of the 1e-3 is a TESTED quantity: at the bench's own shape - three frames of the 32 x 1080p batch
+# against the oracle, and the heavy-tailed weights on a 1080p frame against the real reference - the max-norm error stays below this.
+MARGIN_DEPTH_SPLIT = 7.5e-4
 
 # the band scripts refuse to run without a checkpoint unless seeded synthetic weights are asked for; tests ask
 os.environ.setdefault("PRISMA_SYNTH", "1")

@@ -78,6 +78,11 @@ def test_mask_loop(tmp_path, monkeypatch):
     folder, frames = _clip(tmp_path, 5)
 
     class Fake:
+        sdf = []
+
+        def set_sdf(self, on):           # --sdf is the engine's job now (green channel written on the GPU); the loop only switches it
+            Fake.sdf.append(bool(on))
+
         def infer_batch(self, fr, confidence, keep):
             return fr.copy()
 
@@ -87,7 +92,14 @@ def test_mask_loop(tmp_path, monkeypatch):
     monkeypatch.setattr(band, "data", {"bands": {"rgba": {"url": "rgba.npy"}}})
     a = types.SimpleNamespace(input=str(folder / "rgba.npy"), output=str(folder / "mask.npy"), confidence=0.5, sdf=False, subpath="")
     band.process_video(a)
-    assert np.array_equal(np.load(folder / "mask.npy")[:, 0, 0, 0], np.arange(5))
+    assert np.array_equal(np.load(folder / "mask.npy")[:, 0, 0, 0], np.arange(5)) and Fake.sdf == [False]
+    a.sdf, a.subpath = True, "colmap"
+    os.environ["PRISMA_OVERWRITE"] = "1"
+    band.process_video(a)
+    assert Fake.sdf == [False, True]
+    from PIL import Image
+    png = np.asarray(Image.open(folder / "colmap" / "00003.png"))        # COLMAP frames: 255 - the pre-SDF image (its red channel three times)
+    assert np.array_equal(png, 255 - np.repeat(frames[3][..., :1], 3, axis=-1))
 
 
 def test_flow_loop_pairs_and_halo(tmp_path, monkeypatch):

@@ -56,3 +56,14 @@ def test_roofline_flop_per_launch_is_the_table_entry():
     assert r["launches_per_step"] == n
     assert r["flop_per_launch"] == pytest.approx(flops / n, rel=5e-3)
     assert r["algorithmic_bytes"] == pytest.approx(by / n, rel=0.05)
+
+
+def test_no_family_of_a_committed_bench_line_exceeds_the_hardware():
+    """the bookkeeping the roofline rests on - no kernel family of the newest committed bench lines may claim more
+    than the HBM's 8 TB/s of algorithmic bytes or the 2.5 PFLOP/s dense fp16 MFMA peak (MI355X_MICROARCH.md)."""
+    for suffix in ("default_bench_line.json", "all_legs_bench_line.json"):
+        line = json.load(open(_newest(suffix)))
+        for k, v in line.get("kernel_algorithmic_tbps", {}).items():
+            assert 0 < v <= 8.0, (suffix, k, v)
+        for k, v in line.get("kernel_tflops", {}).items():
+            assert 0 <= v <= 2500.0, (suffix, k, v)

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import TOL
+from conftest import MARGIN_DEPTH_SPLIT, TOL
 from oracle import depth_oracle as O
 from prisma_amd import engine, synth
 
@@ -113,10 +113,14 @@ def test_vitl_batch_32_at_1080p_equals_single_frames(prec):
     for i in (0, 13, 31):
         d1, rgb1, mn1, mx1 = net.infer_batch(frames[i:i + 1])
         assert np.array_equal(d1[0], d[i]) and np.array_equal(rgb1[0], rgb[i]) and mn1[0] == mn[i] and mx1[0] == mx[i], i
-    ref = O.infer(w, frames[13], c.depth, c.heads)
-    report(f"b32[13] p{prec}", d[13], ref)
-    assert relmax(d[13], ref) < TOL[prec][0] and rell2(d[13], ref) < TOL[prec][1]
     net.close()
+    # the frames against the oracle: all three in the split mode, where the margin to the 1e-3 is asserted too (conftest MARGIN_DEPTH_SPLIT)
+    for i in ((0, 13, 31) if prec == 1 else (13,)):
+        ref = O.infer(w, frames[i], c.depth, c.heads)
+        report(f"b32[{i}] p{prec}", d[i], ref)
+        assert relmax(d[i], ref) < TOL[prec][0] and rell2(d[i], ref) < TOL[prec][1], i
+        if prec == 1:
+            assert relmax(d[i], ref) < MARGIN_DEPTH_SPLIT, (i, relmax(d[i], ref))
 
 
 def test_1080p_maps_to_same_network_and_runs():

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import TOL
+from conftest import MARGIN_DEPTH_SPLIT, TOL
 from prisma_amd import engine, synth
 
 pytestmark = pytest.mark.gpu
@@ -54,6 +54,24 @@ def test_depth_vitl_heavy_tailed_weights(golden_dir, monkeypatch):
     print("  ViT-L heavy-tailed 720p, single-pass fp16: relmax %.3e relL2 %.3e" % (relmax(d[::8, ::8], z["depth_s8"]), rell2(d[::8, ::8], z["depth_s8"])))
     e = res["shipped scales"]
     assert e[0] < TOL[1][0] and e[1] < TOL[1][1], res
+
+
+def test_depth_vitl_heavy_tailed_weights_at_1080p_keep_the_margin(golden_dir):
+    """the heavy-tailed weights at the bench's frame size (frame 13 of the 32 x 1080p clip) against what the REAL
+    reference returns on them (tests/golden/depth_vitl_heavy_1080p.npz) - inside the 1e-3, and inside the margin the per-layer residual
+    assignment is allowed to use (conftest MARGIN_DEPTH_SPLIT)."""
+    z = np.load(os.path.join(golden_dir, "depth_vitl_heavy_1080p.npz"))
+    c = synth.DEPTH_CFGS["vitl"]
+    w = synth.depth_anything_weights_heavy(c, seed=1234)
+    frame = synth.frames(32, 1080, 1920, seed=int(z["frame_seed"]))[int(z["frame_index"])]
+    net = engine.DepthAnything(w, c, device=0, max_batch=1, precision=1)
+    d = net.infer_batch(frame[None], want_rgb=False)[0][0]
+    net.close()
+    e = (relmax(d[::8, ::8], z["depth_s8"]), rell2(d[::8, ::8], z["depth_s8"]))
+    print("\n  ViT-L heavy-tailed 1080p (frame 13 of the bench clip): relmax %.3e relL2 %.3e" % e)
+    assert e[0] < MARGIN_DEPTH_SPLIT and e[1] < TOL[1][1], e
+    s = d.astype(np.float64)
+    assert abs(s.sum() - z["depth_sum"][0]) < TOL[1][1] * z["depth_sum"][1]
 
 
 def test_raft_heavy_tailed_weights(golden_dir, monkeypatch):

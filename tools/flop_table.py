@@ -45,7 +45,8 @@ def add(band, kind, name, M, N, K, n=1, in_b=2, out_b=2, mx=True, n_launch=None,
     a_bytes = in_b * M * stride * stride * (K / taps)
     if band == "depth" and not per_call:
         n *= ND                                          # the DPT head of a 32-frame call runs as ND chunks of BD frames (DepthEngine::batch_cap, split mode)
-    rows.append((band, fam, name, n, M, N, K, 2.0 * M * N * K, a_bytes + 2.0 * N * K + out_b * M * N))
+    out_bytes = 4.0 * M if (not isinstance(kind, str) and kind[1] == HEAD) else out_b * M * N      # the fused head writes one float per pixel
+    rows.append((band, fam, name, n, M, N, K, 2.0 * M * N * K, a_bytes + 2.0 * N * K + out_bytes))
 
 
 # ---- depth_anything ViT-L @ 518 x 924 (any 16:9 frame): 37 x 66 patches, 2443 tokens padded to 2448 rows per frame
