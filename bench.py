@@ -336,6 +336,7 @@ def main():
     ap.add_argument("--latency", action="store_true", default=True,
                     help="also time one 1280x720 frame at batch 1 (BASELINE configs[1]; on by default since round 4: eight batch-1 calls, ~0.1 s)")
     ap.add_argument("--no-latency", dest="latency", action="store_false")
+    ap.add_argument("--no-clock", action="store_true", help="skip the effective-clock probe behind roofline.effective_clock_ghz")
     ap.add_argument("--host-chunks", type=int, default=0, help="batches pushed through the host-pointer API for the PCIe-inclusive rate")
     ap.add_argument("--pipeline-frames", type=int, default=0, help="frames per step of the three-band pipeline leg")
     ap.add_argument("--mask-frames", type=int, default=0, help="frames per step of the mask_mmdet leg")
@@ -455,6 +456,26 @@ def main():
         return res
 
     main_res = run_mode(args.precision, args.steps, args.warmup, True)
+    # effective shader clock under the band's dominant GEMM shape: per-tile s_memtime / s_memrealtime stamps of one
+    # launch of the ping-pong kernel at the ViT's fc1 + GELU shape, right after the timed region (chip warm).  The 2.5 PF the fractions are
+    # quoted against assume 2.4 GHz; on data the part is power-limited (profiles/r04a_clock_mfma_peak.txt: 1.63-1.65 GHz in a bare MFMA loop).
+    clock_ghz = None
+    if rank == 0 and not args.no_clock:
+        try:
+            import tempfile
+            dump = os.path.join(tempfile.gettempdir(), "prisma_bench_gemm_dbg.%d.bin" % os.getpid())
+            os.environ["PB_GEMM_DBG"] = dump
+            ops = engine.Ops(local_rank)
+            ops.gemm_bench(B * 2448, 4096, 1024, tile=2, epi=1, iters=3)
+            ops.close()
+            d = np.fromfile(dump, dtype=np.int64).reshape(-1, 8)
+            d = d[d[:, 3] != 0]
+            clock_ghz = float(np.median((d[:, 3] - d[:, 0]) / np.maximum((d[:, 5] - d[:, 4]) * 10.0, 1.0)))
+            os.remove(dump)
+        except Exception as e:      # noqa: BLE001 - a diagnostic: the line is complete without it
+            print(f"[bench] clock probe skipped: {e}", file=sys.stderr)
+        finally:
+            os.environ.pop("PB_GEMM_DBG", None)
     # the other precision mode runs in a child process (single-GPU runs only): its launches then land in their own rocprofv3
     # per-process file, so the per-symbol averages of `rocprofv3 --stats -- python bench.py` stay those of ONE mode each
     other = None
@@ -529,6 +550,11 @@ def main():
                          "depth_frac_alone": round(band_fl["depth"] / main_res["depth_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
                          "flow_frac_alone": round(band_fl["flow"] / main_res["flow_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
                          "executed_frac": round(ach * exec_mult / PEAK_F16_TFLOPS, 4),
+                         "effective_clock_ghz": round(clock_ghz, 3) if clock_ghz else None,
+                         "frac_at_clock": round(ach / (PEAK_F16_TFLOPS * clock_ghz / 2.4), 4) if clock_ghz else None,
+                         "clock_note": "effective_clock_ghz = s_memtime cycles / s_memrealtime of the tiles of one fc1 + GELU launch of the ping-pong GEMM right after "
+                                       "the timed region; frac_at_clock = achieved / (peak x clock / 2.4 GHz) - beside, not instead of, `frac` "
+                                       "(profiles/r04a_clock_mfma_peak.txt: a bare MFMA loop holds 2.39 GHz on zeros and 1.63-1.65 GHz on random operands)",
                          "note": "flops are algorithmic multiply-adds (2 M N K of the layer; padding and the extra split-fp16 passes not counted) - executed_frac "
                                  "counts the MFMA work actually issued (x2 for weight-split, x3 for weight+activation-split layers); *_frac_alone = a "
                                  "band's flops / its wall time inside the step / peak; step_frac = all launches' flops / step wall time / peak"},
