@@ -55,8 +55,9 @@ def check_arch(args):
     bad = {k: getattr(args, k) for k, v in ARCH.items() if hasattr(args, k) and getattr(args, k) != v}
     if bad:
         raise SystemExit(f"[{BAND}] only the band's default GMFlow is built ({ARCH}); got {bad}")
-    if getattr(args, "inference_size", None):
-        raise SystemExit(f"[{BAND}] --inference_size (bilinear resize to a fixed network size, reference :76-80) is not built; use --scale")
+    isz = getattr(args, "inference_size", None)
+    if isz and (len(isz) != 2 or any(v < 32 or v % 16 for v in isz)):
+        raise SystemExit(f"[{BAND}] --inference_size takes H W, multiples of 16 (the reference's 2 x 2 window split of the 1/8 grid fails otherwise); got {isz}")
 
 
 def init_model(args=None, device=0):
@@ -65,6 +66,7 @@ def init_model(args=None, device=0):
         check_arch(args)
         _SYNTH[0] = bool(getattr(args, "synthetic", False))
     model = engine.FlowGMFlow(load_weights(getattr(args, "model", MODEL) if args else MODEL), device=device)
+    model.set_inference_size(getattr(args, "inference_size", None) if args is not None else None)      # reference :76-100
     return model
 
 

@@ -205,6 +205,10 @@ int pb_flow_fwdbwd_mask(pb_ctx *ctx, const float *flows, int n, int sh, int sw, 
  * [n, tokens, channels, 1]): "feat" [F, h/8*w/8, 128] (encoder output), "block0" / "tfeat" [2 pairs, tokens, 128] (after the first / last
  * transformer block; both images of every pair), "flow_match" / "flow_prop" [pairs*dirs, tokens, 2]. */
 int64_t pb_flow_get_stage(pb_ctx *ctx, const char *name, float *out, int64_t cap, int64_t shape_out[4]);
+/* flow_gmflow --inference_size (reference bands/flow_gmflow.py:76-100): with (h, w) > 0 - multiples of 16 - the network runs on
+ * F.interpolate(bilinear, align_corners = True) of the (scaled) frame to h x w instead of on the frame padded to /16, and the flow is
+ * resized back the same way with u * W' / w, v * H' / h.  (0, 0) turns it off.  flow_gmflow contexts only. */
+int pb_flow_set_inference_size(pb_ctx *ctx, int h, int w);
 
 /* mask_mmdet band (band = "mask_mmdet", cfg = pb_mask_cfg; weights: backbone.*, neck.*, mask_head.* in mmdet's
  * state_dict naming).  Replaces the per-frame body of bands/mask_mmdet.py:131-154: inference_detector

@@ -242,13 +242,24 @@ def gmflow_forward(w: Dict[str, np.ndarray], img0: np.ndarray, img1: np.ndarray,
     return up.numpy()
 
 
-def infer_pair(w, prev_u8: np.ndarray, curr_u8: np.ndarray, scale: float = 0.75, backward: bool = True):
+def infer_pair(w, prev_u8: np.ndarray, curr_u8: np.ndarray, scale: float = 0.75, backward: bool = True, inference_size=None):
     """bands/flow_gmflow.py:149-157 + infer (:66-118): two uint8 frames -> (fwd, bwd or None) float32 [H', W', 2] at the scaled
-    resolution (InputPadder(padding_factor=16), pred_bidir_flow when --backwards / masks are asked for)."""
+    resolution (InputPadder(padding_factor=16), pred_bidir_flow when --backwards / masks are asked for).  inference_size (H, W)
+    (:76-80, :92-97): no padding - bilinear (align_corners) to that size in, bilinear back out with u * W' / W and v * H' / H."""
     a = cv_resize_cubic_u8(prev_u8, scale) if scale != 1.0 else prev_u8
     c = cv_resize_cubic_u8(curr_u8, scale) if scale != 1.0 else curr_u8
     ta = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1).float()[None]
     tc = torch.from_numpy(np.ascontiguousarray(c)).permute(2, 0, 1).float()[None]
+    if inference_size is not None:
+        ori = ta.shape[-2:]
+        ia = F.interpolate(ta, size=tuple(inference_size), mode="bilinear", align_corners=True)
+        ic = F.interpolate(tc, size=tuple(inference_size), mode="bilinear", align_corners=True)
+        up = torch.from_numpy(gmflow_forward(w, ia.numpy(), ic.numpy(), bidir=backward))
+        up = F.interpolate(up, size=tuple(ori), mode="bilinear", align_corners=True)
+        up[:, 0] = up[:, 0] * ori[-1] / inference_size[-1]
+        up[:, 1] = up[:, 1] * ori[-2] / inference_size[-2]
+        up = up.numpy()
+        return np.ascontiguousarray(up[0].transpose(1, 2, 0)), (np.ascontiguousarray(up[1].transpose(1, 2, 0)) if backward else None)
     pad = pad_amounts(ta.shape[2], ta.shape[3])
     pa, pc = F.pad(ta, pad, mode="replicate"), F.pad(tc, pad, mode="replicate")
     up = gmflow_forward(w, pa.numpy(), pc.numpy(), bidir=backward)

@@ -373,6 +373,38 @@ def gmflow_case(hgt=125, wid=157, seed=51, bidir=True, tag=None):
     np.savez_compressed(os.path.join(GOLD, f"gmflow_{tag or (str(hgt) + 'x' + str(wid))}.npz"), **keep)
 
 
+def gmflow_isz_case(hgt=150, wid=210, seed=53, isz=(96, 160)):
+    """flow_gmflow --inference_size (bands/flow_gmflow.py:76-100): the REAL GMFlow wrapped exactly as the band's infer() wraps it - no
+    padder, F.interpolate(bilinear, align_corners=True) of the float frames to inference_size, the model, the flow resized back and
+    rescaled per axis - both directions; the oracle's infer_pair(inference_size=...) must return the same."""
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    import torch.nn.functional as Fn
+    from gmflow.gmflow import GMFlow
+    from oracle import gmflow_oracle as G
+    w = synth.gmflow_weights(seed=2468)
+    m = GMFlow(feature_channels=128, num_scales=1, upsample_factor=8, num_head=1, attention_type="swin", ffn_dim_expansion=4,
+               num_transformer_layers=6)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=True)
+    fr = synth.frame_pair_sequence(2, hgt, wid, seed=seed)
+    image1 = torch.from_numpy(fr[0]).permute(2, 0, 1).float()[None]
+    image2 = torch.from_numpy(fr[1]).permute(2, 0, 1).float()[None]
+    ori_size = image1.shape[-2:]
+    with torch.no_grad():
+        i1 = Fn.interpolate(image1, size=list(isz), mode="bilinear", align_corners=True)
+        i2 = Fn.interpolate(image2, size=list(isz), mode="bilinear", align_corners=True)
+        flow_pr = m(i1, i2, attn_splits_list=[2], corr_radius_list=[-1], prop_radius_list=[-1], pred_bidir_flow=True)["flow_preds"][-1]
+        flow_pr = Fn.interpolate(flow_pr, size=ori_size, mode="bilinear", align_corners=True)
+        flow_pr[:, 0] = flow_pr[:, 0] * ori_size[-1] / isz[-1]
+        flow_pr[:, 1] = flow_pr[:, 1] * ori_size[-2] / isz[-2]
+    fwd, bwd = flow_pr[0].permute(1, 2, 0).numpy(), flow_pr[1].permute(1, 2, 0).numpy()
+    f_o, b_o = G.infer_pair(w, fr[0], fr[1], scale=1.0, backward=True, inference_size=isz)
+    e = max(relerr(f_o, fwd), relerr(b_o, bwd))
+    print(f"[gmflow {hgt}x{wid} inference_size {isz}] oracle vs reference rel err {e:.2e}; |flow| max {np.abs(fwd).max():.2f} px")
+    assert e < 2e-4, e
+    np.savez_compressed(os.path.join(GOLD, "gmflow_isz_150x210.npz"), frame_seed=np.array(seed), hw=np.array([hgt, wid]), isz=np.array(isz),
+                        fwd=fwd, bwd=bwd)
+
+
 def gmflow_full_case(seed=61):
     """flow_gmflow at the size the bench times it: one 1920x1080 pair at the band's default --scale 0.75
     (810x1440 -> InputPadder(16) -> 816x1440: a 102 x 180 grid, 18 360 tokens, 18 360^2 global matching) through the REAL reference
@@ -580,6 +612,8 @@ if __name__ == "__main__":
     if "gmflow" in which:
         gmflow_case()
         gmflow_case(216, 300, 52, False)   # pads to 224x304: a 28 x 38 grid, 14 x 19 windows, forward only
+    if "gmflow_isz" in which:
+        gmflow_isz_case()
     if "gmflow_full" in which:
         gmflow_full_case()
     if "raft_full" in which:

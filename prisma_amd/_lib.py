@@ -78,6 +78,7 @@ SYMBOLS = {
     "pb_mask_net_size": (C.c_int, [C.POINTER(pb_mask_cfg), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_mask_get_stage": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "pb_flow_set_inference_size": (C.c_int, [_P, C.c_int, C.c_int]),
     "pb_mask_set_sdf": (C.c_int, [_P, _P, _P, C.c_int]),
     "pb_mask_sdf_green": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     "pb_mask_sdf_green_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),

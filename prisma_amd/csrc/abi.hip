@@ -543,6 +543,13 @@ int64_t pb_mask_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap, 
     return c->mask->get_stage(name, out, cap, shape_out);
 }
 
+int pb_flow_set_inference_size(pb_ctx *c, int h, int w) {
+    PB_CHECK(c && c->raft, PB_ERR_STATE, "ctx has no flow band");
+    GmflowEngine *g = dynamic_cast<GmflowEngine *>(c->raft);
+    PB_CHECK(g, PB_ERR_STATE, "--inference_size is a flow_gmflow option");
+    return g->set_inference_size(h, w);
+}
+
 int64_t pb_flow_get_stage(pb_ctx *c, const char *name, float *out, int64_t cap, int64_t shape_out[4]) {
     PB_CHECK(c && c->raft && name && out && shape_out, PB_ERR_ARG, "flow get_stage: bad arguments");
     PB_HIP(hipSetDevice(c->device));

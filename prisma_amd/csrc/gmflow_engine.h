@@ -15,6 +15,9 @@ class GmflowEngine : public RaftEngine {
     // fp32 stages of the last call as [n, rows, cols]: "feat" [F, P, 128], "block0" / "tfeat" [2 pairs, P, 128] (token stream after the
     // first / last transformer block), "flow_match" / "flow_prop" [pairs * dirs, P, 2]
     int64_t get_stage(const char *name, float *out, int64_t cap, int64_t shape[4]) override;
+    // --inference_size of the band (reference flow_gmflow.py:76-100): the network runs on a bilinear (align_corners) resize of the scaled frame to
+    // (h, w) - multiples of 16, no padding - and the flow is resized back and rescaled; (0, 0) = off (InputPadder(16), the default)
+    int set_inference_size(int h, int w);
 
   private:
     struct Layer {
@@ -33,6 +36,8 @@ class GmflowEngine : public RaftEngine {
     PackedW ffq_, ffk_, up0_, up2_;
     GmGeom g_{};
     int gF_ = 0, gH_ = 0, gW_ = 0, gD_ = 0;
+    int isz_h_ = 0, isz_w_ = 0;
+    float *gupi_ = nullptr;           // flow at the inference size, before the resize back
     float gS_ = 0.f;
     int ldvP_ = 0;
     float *feat_ = nullptr, *pos_ = nullptr, *X_ = nullptr, *Y1_ = nullptr, *Yq_ = nullptr, *Ow_ = nullptr, *M_ = nullptr, *Om_ = nullptr,

@@ -121,6 +121,11 @@ int GmflowEngine::prepare_g(int F, int H, int W, float scale, int dirs) {
     if (F <= gF_ && H == gH_ && W == gW_ && scale == gS_ && dirs <= gD_) return 0;
     PB_HIP(hipStreamSynchronize(stream));
     geometry(H, W, scale, 16);
+    if (isz_h_ > 0) {                 // --inference_size: the network's size is given, nothing is padded (sh_, sw_ stay the output size)
+        padl_ = padt_ = 0;
+        Hp_ = isz_h_; Wp_ = isz_w_;
+        h8_ = Hp_ / 8; w8_ = Wp_ / 8; P_ = h8_ * w8_;
+    }
     PB_CHECK(h8_ >= 4 && w8_ >= 4 && h8_ % 2 == 0 && w8_ % 2 == 0, PB_ERR_ARG, "flow_gmflow: %dx%d is too small", sh_, sw_);
     g_.h8 = h8_; g_.w8 = w8_; g_.P = P_; g_.wh = h8_ / 2; g_.ww = w8_ / 2; g_.Lw = g_.wh * g_.ww; g_.ldv = (int)round_up(g_.Lw, 32);
     ldvP_ = (int)round_up(P_, 32);
@@ -150,6 +155,7 @@ int GmflowEngine::prepare_g(int F, int H, int W, float scale, int dirs) {
         umap_ = (f16 *)carve((size_t)B * P_ * 384 * 2 + slack); u1_ = (f16 *)carve((size_t)round_up(B * P_, 256) * 512 * 2 + slack);
         gmask_ = (float *)carve((size_t)B * P_ * 576 * 4);
         gup_ = (float *)carve((size_t)B * sh_ * sw_ * 2 * 4);
+        gupi_ = isz_h_ > 0 ? (float *)carve((size_t)B * Hp_ * Wp_ * 2 * 4) : nullptr;
         gmaxd_ = (unsigned *)carve((size_t)B * 4);
         if (pass == 0) {
             const int rc = commit_arena("flow_gmflow");
@@ -202,6 +208,13 @@ int GmflowEngine::attention(const Attn128Args &a, double keys_per_query) {
     return r;
 }
 
+int GmflowEngine::set_inference_size(int h, int w) {
+    PB_CHECK((h == 0 && w == 0) || (h >= 32 && w >= 32 && h % 16 == 0 && w % 16 == 0), PB_ERR_ARG,
+             "flow_gmflow: --inference_size %d %d must be multiples of 16 (8 x the 2 x 2 window split; the reference fails in its window split otherwise)", h, w);
+    if (h != isz_h_ || w != isz_w_) { isz_h_ = h; isz_w_ = w; gF_ = 0; }      // re-plan on the next call
+    return 0;
+}
+
 int GmflowEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, int /*iters*/, int backward, float *flow_out,
                         uint8_t *rgb_out, float *maxdisp, uint8_t *mask_out, float alpha1, float alpha2) {
     PB_CHECK(frames && F >= 2 && H > 0 && W > 0 && scale > 0.f, PB_ERR_ARG, "flow_gmflow infer: bad arguments");
@@ -221,7 +234,7 @@ int GmflowEngine::infer(const uint8_t *frames, int F, int H, int W, float scale,
     // ---- frame prep (resize, replicate pad to /16, ImageNet normalisation) and the backbone, once per frame ----
     tic(F_PP, 0, (double)F * H * W * 3);
     r = launch_raft_prep(stream, frames, F, H, W, sh_, sw_, Hp_, Wp_, padl_, padt_, scale != 1.f, xi_, xc_, yi_, yc_, img_, nullptr, 1,
-                         split_w_ ? 64 : 0, -1, 1);
+                         split_w_ ? 64 : 0, -1, 1, isz_h_ > 0);
     toc();
     if (r) return r;
     const f16 *x = nullptr;
@@ -336,7 +349,12 @@ int GmflowEngine::infer(const uint8_t *frames, int F, int H, int W, float scale,
     if ((r = gemm32(u1_, 512, (int64_t)B * P, up2_, gmask_, 576))) return r;
     float *up = flow_out ? flow_out : gup_;
     tic(F_PP, 0, (double)B * sh_ * sw_ * 8);
-    r = launch_upsample(stream, flowp_, gmask_, B, h8_, w8_, padl_, padt_, sh_, sw_, up, gmaxd_);
+    if (isz_h_ > 0) {                 // convex upsampling at the inference size, then the bilinear resize back to the scaled frame
+        r = launch_upsample(stream, flowp_, gmask_, B, h8_, w8_, 0, 0, Hp_, Wp_, gupi_, gmaxd_);
+        if (!r) r = launch_flow_resize_back(stream, gupi_, B, Hp_, Wp_, sh_, sw_, up, gmaxd_);
+    } else {
+        r = launch_upsample(stream, flowp_, gmask_, B, h8_, w8_, padl_, padt_, sh_, sw_, up, gmaxd_);
+    }
     toc();
     if (r) return r;
     tic(F_PP, 0, (double)B * sh_ * sw_ * 11);

@@ -4,7 +4,8 @@
 
 int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, int sh, int sw, int Hp, int Wp, int pad_l,
                      int pad_t, int resize, const int *xi, const int *xc, const int *yi, const int *yc, f16 *out,
-                     uint8_t *scaled_out, int s2d = 0, int lo_off = 0, int lo8_pa = -1, int norm_mode = 0);     // norm_mode 1: ImageNet mean / std (GMFlow)
+                     uint8_t *scaled_out, int s2d = 0, int lo_off = 0, int lo8_pa = -1, int norm_mode = 0,      // norm_mode 1: ImageNet mean / std (GMFlow)
+                     int isz = 0);     // isz: (Hp, Wp) is flow_gmflow's --inference_size - bilinear (align_corners) of the scaled frame, no padding
 // ld: row stride of `out` in halfs (0 = Kp); o8: also store the row as e4m3 (unscaled) after its Kp halfs (gemm.h nk16)
 int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp, int ld = 0, int o8 = 0);
 int in_stats_chunks(int HW);
@@ -24,6 +25,8 @@ int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], co
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W, int split = 0);
 int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows, int ld = 384, int o8_off = 0, float o8_scale = 16.f,
                     int flow_off = 382);       // flow_off: channel offset of the two flow channels inside hx / hx2
+// flow_gmflow --inference_size: flow [N, ih, iw, 2] -> [N, sh, sw, 2], bilinear (align_corners), u * sw / iw, v * sh / ih; maxd as launch_upsample
+int launch_flow_resize_back(hipStream_t s, const float *in, int N, int ih, int iw, int sh, int sw, float *out, unsigned *maxd);
 int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, int h8, int w8, int pad_l, int pad_t, int sh,
                     int sw, float *out, unsigned *maxd);
 int launch_flow_encode(hipStream_t s, const float *flow, int N, int sh, int sw, const unsigned *maxd, uint8_t *rgb,

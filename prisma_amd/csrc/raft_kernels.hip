@@ -15,26 +15,16 @@ inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t
 // 2*(x/255)-1 -> fp16 [F][Hp][Wp][4] (channel 3 = 0).  One thread per padded pixel.
 // ------------------------------------------------------------------------------------------------
 // mode 0: RAFT 2 (x / 255) - 1 (raft.py:91-92); mode 1: GMFlow (x / 255 - mean) / std with the ImageNet statistics (gmflow/utils.py:53-58)
-__device__ __forceinline__ float prep_norm(int v, int c, int mode) {
-    if (mode == 0) return 2.f * ((float)v / 255.f) - 1.f;
+__device__ __forceinline__ float prep_norm(float v, int c, int mode) {
+    if (mode == 0) return 2.f * (v / 255.f) - 1.f;
     const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f), sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
-    return ((float)v / 255.f - mean) / sd;
+    return (v / 255.f - mean) / sd;
 }
 
-__global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restrict__ frames, int F, int H, int W, int sh,
-                                                        int sw, int Hp, int Wp, int pad_l, int pad_t, int resize,
-                                                        const int *__restrict__ xi, const int *__restrict__ xc,
-                                                        const int *__restrict__ yi, const int *__restrict__ yc,
-                                                        f16 *__restrict__ out, uint8_t *__restrict__ scaled_out, int s2d, int lo_off,
-                                                        int lo8_pa, int norm_mode) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)F * Hp * Wp) return;
-    const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), f = (int)(i / ((int64_t)Wp * Hp));
-    int sy = y - pad_t, sx = x - pad_l;                       // position in the scaled (unpadded) frame
-    sy = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
-    sx = sx < 0 ? 0 : (sx > sw - 1 ? sw - 1 : sx);
-    const uint8_t *img = frames + (int64_t)f * H * W * 3;
-    int v[3];
+// pixel (sy, sx) of the SCALED frame: cv2.resize(fx = fy = scale, INTER_CUBIC) on uint8 (fixed-point taps, common/flow.py / flow_raft.py:100)
+// or the frame itself
+__device__ __forceinline__ void scaled_px(const uint8_t *img, int W, int sy, int sx, int resize, const int *__restrict__ xi,
+                                          const int *__restrict__ xc, const int *__restrict__ yi, const int *__restrict__ yc, int (&v)[3]) {
     if (resize) {
         int acc[3] = {0, 0, 0};
 #pragma unroll
@@ -58,10 +48,51 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
         const uint8_t *px = img + ((int64_t)sy * W + sx) * 3;
         v[0] = px[0]; v[1] = px[1]; v[2] = px[2];
     }
+}
+
+__global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restrict__ frames, int F, int H, int W, int sh,
+                                                        int sw, int Hp, int Wp, int pad_l, int pad_t, int resize,
+                                                        const int *__restrict__ xi, const int *__restrict__ xc,
+                                                        const int *__restrict__ yi, const int *__restrict__ yc,
+                                                        f16 *__restrict__ out, uint8_t *__restrict__ scaled_out, int s2d, int lo_off,
+                                                        int lo8_pa, int norm_mode, int isz) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)F * Hp * Wp) return;
+    const int x = (int)(i % Wp), y = (int)((i / Wp) % Hp), f = (int)(i / ((int64_t)Wp * Hp));
+    const uint8_t *img = frames + (int64_t)f * H * W * 3;
+    int v[3];
+    float vf[3];
+    if (isz) {
+        // flow_gmflow --inference_size (reference flow_gmflow.py:76-80): the network input is F.interpolate(bilinear, align_corners = True) of
+        // the scaled frame as float - no padding; torch's arithmetic: src = dst * (in - 1) / (out - 1), weights (1 - l, l), rows of the
+        // horizontal blends
+        const float ry = Hp > 1 ? (float)(sh - 1) / (float)(Hp - 1) : 0.f, rx = Wp > 1 ? (float)(sw - 1) / (float)(Wp - 1) : 0.f;
+        const float fy = ry * (float)y, fx = rx * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        int p00[3], p01[3], p10[3], p11[3];
+        scaled_px(img, W, y0, x0, resize, xi, xc, yi, yc, p00);
+        scaled_px(img, W, y0, x1, resize, xi, xc, yi, yc, p01);
+        scaled_px(img, W, y1, x0, resize, xi, xc, yi, yc, p10);
+        scaled_px(img, W, y1, x1, resize, xi, xc, yi, yc, p11);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            vf[c] = (1.f - ly) * ((1.f - lx) * (float)p00[c] + lx * (float)p01[c]) + ly * ((1.f - lx) * (float)p10[c] + lx * (float)p11[c]);
+            v[c] = 0;
+        }
+    } else {
+        int sy = y - pad_t, sx = x - pad_l;                   // position in the scaled (unpadded) frame
+        sy = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        sx = sx < 0 ? 0 : (sx > sw - 1 ? sw - 1 : sx);
+        scaled_px(img, W, sy, sx, resize, xi, xc, yi, yc, v);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vf[c] = (float)v[c];
+    }
     f16x4 o, l;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float t = prep_norm(v[c], c, norm_mode);
+        const float t = prep_norm(vf[c], c, norm_mode);
         o[c] = (f16)t;
         l[c] = (f16)(t - (float)o[c]);
     }
@@ -75,7 +106,7 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
             const float shi = __builtin_ldexpf(1.f, lo8_pa), slo = __builtin_ldexpf(1.f, lo8_pa + 12);
             float t[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) t[c] = prep_norm(v[c], c, norm_mode);
+            for (int c = 0; c < 3; ++c) t[c] = prep_norm(vf[c], c, norm_mode);
             char *pb = (char *)(out + px - ((y & 3) * 4 + (x & 3)) * 4);
             const int col = ((y & 3) * 4 + (x & 3)) * 4;
             *(int *)(pb + 2 * lo_off + col) = pb_fp8x4((float)o[0] * shi, (float)o[1] * shi, (float)o[2] * shi, 0.f);
@@ -87,7 +118,7 @@ __global__ __launch_bounds__(256) void raft_prep_kernel(const uint8_t *__restric
         const int64_t oi = s2d ? ((((int64_t)f * (Hp >> 2) + (y >> 2)) * (Wp >> 2) + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)) : i;
         *(f16x4 *)(out + oi * 4) = o;
     }
-    if (scaled_out && y >= pad_t && y < pad_t + sh && x >= pad_l && x < pad_l + sw) {
+    if (scaled_out && !isz && y >= pad_t && y < pad_t + sh && x >= pad_l && x < pad_l + sw) {
         uint8_t *d = scaled_out + (((int64_t)f * sh + (y - pad_t)) * sw + (x - pad_l)) * 3;
         d[0] = (uint8_t)v[0]; d[1] = (uint8_t)v[1]; d[2] = (uint8_t)v[2];
     }
@@ -650,9 +681,9 @@ __global__ void fill_u32_kernel(unsigned *p, unsigned v, int n) {
 
 int launch_raft_prep(hipStream_t s, const uint8_t *frames, int F, int H, int W, int sh, int sw, int Hp, int Wp, int pad_l,
                      int pad_t, int resize, const int *xi, const int *xc, const int *yi, const int *yc, f16 *out,
-                     uint8_t *scaled_out, int s2d, int lo_off, int lo8_pa, int norm_mode) {
+                     uint8_t *scaled_out, int s2d, int lo_off, int lo8_pa, int norm_mode, int isz) {
     hipLaunchKernelGGL(raft_prep_kernel, dim3(nblk((int64_t)F * Hp * Wp)), dim3(256), 0, s, frames, F, H, W, sh, sw, Hp, Wp,
-                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d, lo_off, lo8_pa, norm_mode);
+                       pad_l, pad_t, resize, xi, xc, yi, yc, out, scaled_out, s2d, lo_off, lo8_pa, norm_mode, isz);
     LAUNCH_CHECK();
 }
 int launch_im2col7_flow(hipStream_t s, const float *x, int B, int H, int W, f16 *out, int Kp, int ld, int o8) {
@@ -708,6 +739,41 @@ int launch_upsample(hipStream_t s, const float *flow, const float *mask, int N, 
     hipLaunchKernelGGL(fill_u32_kernel, dim3(nblk(N)), dim3(256), 0, s, maxd, 0u, N);
     hipLaunchKernelGGL(upsample_kernel, dim3(std::min(nblk((int64_t)h8 * w8, 4), 256u), N), dim3(256), 0, s, flow, mask, h8, w8, pad_l, pad_t, sh,
                        sw, out, maxd);
+    LAUNCH_CHECK();
+}
+// flow_gmflow --inference_size, the way back (reference flow_gmflow.py:92-97): F.interpolate(bilinear, align_corners = True) of the flow from the
+// inference grid (ih, iw) to the scaled frame (sh, sw), u * sw / iw and v * sh / ih; the maximum displacement the encode needs is taken here
+__global__ __launch_bounds__(256) void flow_resize_back_kernel(const float *__restrict__ in, int ih, int iw, int sh, int sw,
+                                                               float *__restrict__ out, unsigned *__restrict__ maxd) {
+    const int n = blockIdx.y;
+    const float ry = sh > 1 ? (float)(ih - 1) / (float)(sh - 1) : 0.f, rx = sw > 1 ? (float)(iw - 1) / (float)(sw - 1) : 0.f;
+    float dmax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)sh * sw; i += (int64_t)gridDim.x * 256) {
+        const int y = (int)(i / sw), x = (int)(i - (int64_t)y * sw);
+        const float fy = ry * (float)y, fx = rx * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < ih - 1 ? 1 : 0), x1 = x0 + (x0 < iw - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float *b = in + (int64_t)n * ih * iw * 2;
+        float uv[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float p00 = b[((int64_t)y0 * iw + x0) * 2 + c], p01 = b[((int64_t)y0 * iw + x1) * 2 + c];
+            const float p10 = b[((int64_t)y1 * iw + x0) * 2 + c], p11 = b[((int64_t)y1 * iw + x1) * 2 + c];
+            const float v = (1.f - ly) * ((1.f - lx) * p00 + lx * p01) + ly * ((1.f - lx) * p10 + lx * p11);
+            uv[c] = c == 0 ? ex_fdiv(ex_fmul(v, (float)sw), (float)iw) : ex_fdiv(ex_fmul(v, (float)sh), (float)ih);
+        }
+        float *o = out + ((int64_t)n * sh * sw + i) * 2;
+        o[0] = uv[0]; o[1] = uv[1];
+        dmax = fmaxf(dmax, ex_fsqrt(ex_fadd(ex_fmul(uv[0], uv[0]), ex_fmul(uv[1], uv[1]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxd + n, f2ord_(dmax));
+}
+int launch_flow_resize_back(hipStream_t s, const float *in, int N, int ih, int iw, int sh, int sw, float *out, unsigned *maxd) {
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(nblk(N)), dim3(256), 0, s, maxd, 0u, N);
+    hipLaunchKernelGGL(flow_resize_back_kernel, dim3(std::min(nblk((int64_t)sh * sw), 512u), N), dim3(256), 0, s, in, ih, iw, sh, sw, out, maxd);
     LAUNCH_CHECK();
 }
 int launch_flow_encode(hipStream_t s, const float *flow, int N, int sh, int sw, const unsigned *maxd, uint8_t *rgb,

@@ -380,6 +380,12 @@ class FlowGMFlow(FlowRaft):
     [frames, tokens, 128], "flow_match", "flow_prop" as [pairs * dirs, tokens, 2]."""
     BAND = b"flow_gmflow"
 
+    def set_inference_size(self, size=None):
+        """--inference_size H W of the band (reference flow_gmflow.py:76-100): run the network on a bilinear (align_corners) resize of the
+        scaled frame to (H, W), multiples of 16, and resize the flow back; None / (0, 0) = off (pad to /16, the default)."""
+        h, w = (0, 0) if not size else (int(size[0]), int(size[1]))
+        check(self.lib.pb_flow_set_inference_size(self.ctx, h, w))
+
 
 def _mask_cfg(cfg: MaskCfg, max_batch: int, precision: int = 0) -> "_lib.pb_mask_cfg":
     return _lib.pb_mask_cfg((C.c_int32 * 4)(*cfg.blocks), cfg.scale_long, cfg.scale_short, cfg.num_classes, cfg.feat_channels,

@@ -136,6 +136,15 @@ def test_flow_gmflow_cli_video(tmp_path):
         band.main(["-i", str(folder), "--num_scales", "2"])
     band.model.close()
     band.model = None
+    # --inference_size H W (reference :76-100): another network size, same output size; bad sizes are refused before the model loads
+    first = out.copy()
+    band.main(["-i", str(folder), "--scale", "1.0", "--inference_size", "128", "192"])
+    out = np.load(folder / "flow_gmflow.npy")
+    assert out.shape == first.shape and not np.array_equal(out, first) and out[0].any() and not out[-1].any()
+    with pytest.raises(SystemExit, match="multiples of 16"):
+        band.main(["-i", str(folder), "--inference_size", "100", "192"])
+    band.model.close()
+    band.model = None
 
 
 def test_flow_file_writers(tmp_path):

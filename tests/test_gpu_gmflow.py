@@ -106,3 +106,29 @@ def test_1080p_scaled_pair_against_reference_vectors(net, golden_dir):
     f64 = flow[0, 0].astype(np.float64)
     sums = np.array([f64[..., 0].sum(), f64[..., 1].sum(), np.abs(f64).sum()])
     assert np.all(np.abs(sums - z["sums1080"]) < TOL[1][1] * z["sums1080"][2])
+
+
+def test_inference_size_against_reference_vectors(net, golden_dir):
+    """--inference_size (reference bands/flow_gmflow.py:76-100): bilinear (align_corners) resize of the frames to a fixed network size,
+    GMFlow, bilinear resize of the flow back with per-axis rescaling - against the REAL reference wrapped the way the band's infer()
+    wraps it (tests/golden/gmflow_isz_150x210.npz: 150x210 frames at inference_size 96x160, both directions)."""
+    z = np.load(os.path.join(golden_dir, "gmflow_isz_150x210.npz"))
+    h, w = [int(v) for v in z["hw"]]
+    fr = synth.frame_pair_sequence(2, h, w, seed=int(z["frame_seed"]))
+    net.set_inference_size([int(v) for v in z["isz"]])
+    try:
+        flow, rgb, mx = net.infer_sequence(fr, scale=1.0, backward=True)
+    finally:
+        net.set_inference_size(None)
+    assert flow.shape == (1, 2, h, w, 2) and rgb.shape == (1, 2, h, w, 3)
+    for k, g, ref in (("fwd", flow[0, 0], z["fwd"]), ("bwd", flow[0, 1], z["bwd"])):
+        print("\n  gmflow inference_size %-4s relmax %.3e relL2 %.3e" % (k, relmax(g, ref), rell2(g, ref)), end="")
+        assert relmax(g, ref) < TOL[1][0] and rell2(g, ref) < TOL[1][1], k
+    from oracle import raft_oracle as R
+    ref_rgb, ref_mx = R.process_flow(flow[0, 0], exact_atan2=True)
+    assert mx[0, 0] == ref_mx and np.array_equal(rgb[0, 0], ref_rgb)              # the encode sees the resized flow and ITS maximum
+    # off again: the padded path is back (same call, default size)
+    flow2, _, _ = net.infer_sequence(fr, scale=1.0, backward=False)
+    assert flow2.shape == (1, 1, h, w, 2) and relmax(flow2[0, 0], flow[0, 0]) > 1e-3
+    with pytest.raises(engine._lib.PrismaBandsError, match="multiples of 16"):
+        net.set_inference_size((100, 160))
