@@ -845,6 +845,13 @@ __device__ __forceinline__ void direct_epilogue_buf(const GemmArgs &p, f32x16 (&
 
 template <int EPI, int TM, bool CHECK, int LOM>
 __device__ __forceinline__ void direct_epilogue_any(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
+#ifdef PB_EPI_FLAT_STD      // A/B builds only (make EXTRA=-DPB_EPI_FLAT_STD): the round-3 flat-addressed epilogue for EPI_STD
+    if constexpr (EPI == EPI_STD) { direct_epilogue_f16_impl<EPI, TM, CHECK, LOM>(p, acc, wave_m0, wave_n0, lane); return; }
+#endif
+    // fp16-residual split maps ([hi | lo] pairs: the mask band) on the ping-pong kernel keep the flat-addressed epilogue: measured on the
+    // band's 1 x 1 ResNet convolutions (K = 64-512: the epilogue IS the kernel) 27.4 ms per 32 frames against 40.6 with the buffer-addressed one
+    // (profiles/r04j_mask_epilogue_ab.txt); every other format and the 128 x 128 tile measured equal or faster on the buffer path
+    if constexpr (EPI == EPI_STD && LOM == 1 && TM == 4) { direct_epilogue_f16_impl<EPI, TM, CHECK, LOM>(p, acc, wave_m0, wave_n0, lane); return; }
     if constexpr (EPI == EPI_STD) {
         // interior tiles of the common launches take a straight-line copy of the epilogue (direct_epilogue_buf FAST): the plain / ReLU / GELU
         // outputs of the linears and convolutions, the two GRU gates, and the DPT head's skip / ReLU'd-copy combinations
@@ -854,7 +861,7 @@ __device__ __forceinline__ void direct_epilogue_any(const GemmArgs &p, f32x16 (&
             switch (key) {
                 PB_FAST_CASE(ACT_NONE) PB_FAST_CASE(ACT_RELU) PB_FAST_CASE(ACT_GELU) PB_FAST_CASE(ACT_GRU_ZR) PB_FAST_CASE(ACT_GRU_Q)
                 PB_FAST_CASE(ACT_NONE | 64) PB_FAST_CASE(ACT_NONE | 16) PB_FAST_CASE(ACT_NONE | 16 | 32 | 64)
-                PB_FAST_CASE(ACT_GRU_ZR | 16) PB_FAST_CASE(ACT_GRU_Q | 16) PB_FAST_CASE(ACT_RELU | 16 | 128) PB_FAST_CASE(ACT_RELU | 64)
+                PB_FAST_CASE(ACT_GRU_ZR | 16) PB_FAST_CASE(ACT_GRU_Q | 16) PB_FAST_CASE(ACT_RELU | 16 | 128) PB_FAST_CASE(ACT_RELU | 64) PB_FAST_CASE(ACT_RELU | 16)
                 default: break;
             }
 #undef PB_FAST_CASE
