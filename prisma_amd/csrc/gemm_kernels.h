@@ -90,6 +90,14 @@ __device__ __forceinline__ float fast_gelu(float x) {
     return fmaxf(x, 0.f) - a * __builtin_amdgcn_exp2f(p);
 }
 
+// tanh as 1 - 2 / (1 + e^(2x)): one v_exp_f32, one v_rcp_f32 and three plain operations, saturating correctly at both ends (e^(2x) -> inf
+// gives 1, -> 0 gives -1).  The device library's tanhf is ~45 instructions with a divergent branch per element; the GRU's q gate evaluates
+// 73 M of them per launch.  Absolute error <= 2e-7 (cancellation near 0 costs RELATIVE accuracy only where tanh itself is ~0): far below the
+// fp16 rounding of the state that consumes it.
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x));
+}
+
 // two values per instruction where the ISA has a packed form (v_pk_fma_f32): the fc1 epilogue is VALU bound
 __device__ __forceinline__ void fast_gelu2(float &x0, float &x1) {
     // v_med3_f32 clamps without the canonicalising v_max that fminf / fmaxf put in front of every operand
@@ -193,7 +201,7 @@ __device__ __forceinline__ void epi_finish(const GemmArgs &p, int m, int n, floa
                 for (int j = 0; j < 8; ++j) r[j] = (f16)(1.f / (1.f + __expf(-v[j])));
             } else if (p.act == ACT_TANH) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = (f16)tanhf(v[j]);
+                for (int j = 0; j < 8; ++j) r[j] = (f16)fast_tanh(v[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) r[j] = (f16)v[j];
@@ -527,7 +535,7 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
             } else if (p.act == ACT_TANH) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { v0[q] = tanhf(v0[q]); v1[q] = tanhf(v1[q]); }
+                for (int q = 0; q < 8; ++q) { v0[q] = fast_tanh(v0[q]); v1[q] = fast_tanh(v1[q]); }
             } else if (p.act == ACT_GRU_ZR) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
@@ -560,8 +568,8 @@ __device__ __forceinline__ void direct_epilogue_f16_impl(const GemmArgs &p, f32x
                 for (int q = 0; q < 8; ++q) {
                     const float z0 = (float)z[q][0], z1 = (float)z[q][1];
                     f32x2 hn;
-                    hn[0] = (1.f - z0) * h[q][0] + z0 * tanhf(v0[q]);
-                    hn[1] = (1.f - z1) * h[q][1] + z1 * tanhf(v1[q]);
+                    hn[0] = (1.f - z0) * h[q][0] + z0 * fast_tanh(v0[q]);
+                    hn[1] = (1.f - z1) * h[q][1] + z1 * fast_tanh(v1[q]);
                     if (!CHECK || ok[q]) *(f32x2 *)(p.gru_h + (int64_t)mr[q] * 128 + nc) = hn;
                     v0[q] = hn[0]; v1[q] = hn[1];
                 }
@@ -760,7 +768,7 @@ __device__ __forceinline__ void direct_epilogue_buf(const GemmArgs &p, f32x16 (&
                 for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
             } else if (act == ACT_TANH) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { v0[q] = tanhf(v0[q]); v1[q] = tanhf(v1[q]); }
+                for (int q = 0; q < 8; ++q) { v0[q] = fast_tanh(v0[q]); v1[q] = fast_tanh(v1[q]); }
             } else if (act == ACT_GRU_ZR) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
@@ -797,8 +805,8 @@ __device__ __forceinline__ void direct_epilogue_buf(const GemmArgs &p, f32x16 (&
                 for (int q = 0; q < 8; ++q) {
                     const float z0 = (float)z[q][0], z1 = (float)z[q][1];
                     f32x2 hn;
-                    hn[0] = (1.f - z0) * h[q][0] + z0 * tanhf(v0[q]);
-                    hn[1] = (1.f - z1) * h[q][1] + z1 * tanhf(v1[q]);
+                    hn[0] = (1.f - z0) * h[q][0] + z0 * fast_tanh(v0[q]);
+                    hn[1] = (1.f - z1) * h[q][1] + z1 * fast_tanh(v1[q]);
                     bs_f2(th_, vh | pz[q], rowc[q] * 128 * 4, hn);
                     v0[q] = hn[0]; v1[q] = hn[1];
                 }
@@ -861,7 +869,7 @@ __device__ __forceinline__ void direct_epilogue_any(const GemmArgs &p, f32x16 (&
             switch (key) {
                 PB_FAST_CASE(ACT_NONE) PB_FAST_CASE(ACT_RELU) PB_FAST_CASE(ACT_GELU) PB_FAST_CASE(ACT_GRU_ZR) PB_FAST_CASE(ACT_GRU_Q)
                 PB_FAST_CASE(ACT_NONE | 64) PB_FAST_CASE(ACT_NONE | 16) PB_FAST_CASE(ACT_NONE | 16 | 32 | 64)
-                PB_FAST_CASE(ACT_GRU_ZR | 16) PB_FAST_CASE(ACT_GRU_Q | 16) PB_FAST_CASE(ACT_RELU | 16 | 128) PB_FAST_CASE(ACT_RELU | 64) PB_FAST_CASE(ACT_RELU | 16)
+                PB_FAST_CASE(ACT_GRU_ZR | 16 | 32) PB_FAST_CASE(ACT_GRU_Q | 16 | 32) PB_FAST_CASE(ACT_RELU | 16 | 128) PB_FAST_CASE(ACT_RELU | 64) PB_FAST_CASE(ACT_RELU | 16)
                 default: break;
             }
 #undef PB_FAST_CASE
