@@ -638,18 +638,26 @@ int pb_op_gemm_bench(pb_ctx *c, int M, int N, int K, int tile, int epi, int iter
     PB_TRY(launch_fill_random_f16(c->stream, w.as<f16>(), (int64_t)N * K, 2u, 0.05f));
     GemmArgs g;
     g.A = a.as<f16>(); g.lda = K; g.W = w.as<f16>(); g.K = K; g.M = M; g.N = N; g.zero = c->zero; g.bias = b.as<float>();
-    int e = EPI_STD;
+    int e = EPI_STD, amode = A_DENSE;
     if (epi == 2) { e = EPI_RESID; g.resid = r.as<float>(); g.ldr = N; g.gamma = b.as<float>(); }
     else { g.out = o.as<f16>(); g.ldo = N; g.act = epi == 1 ? ACT_GELU : ACT_NONE; }
+    if (epi >= 10) {                    // implicit-GEMM convolution over a [M / 18360, 102, 180, C] map (the RAFT update block's grid at 1080p x 0.75):
+        const int taps = epi == 12 ? 5 : 9;         // 10: 3 x 3 tap-major, 11: 3 x 3 slice-major, 12: 1 x 5 tap-major; K = taps * C
+        PB_CHECK(M % 18360 == 0 && K % (taps * 64) == 0, PB_ERR_ARG, "gemm_bench: conv modes need M = B * 102 * 180 and K = taps * C");
+        amode = A_CONV;
+        g.cH = g.cOH = 102; g.cW = g.cOW = 180; g.cC = K / taps; g.cStride = 1;
+        if (epi == 12) { g.cKW = 5; g.cPad = 0; g.cPadX = 2; g.cKH = 1; }
+        else { g.cKW = 3; g.cPad = 1; g.cKH = 3; g.cTapInner = epi == 11; }
+    }
     hipEvent_t e0, e1;
     PB_HIP(hipEventCreate(&e0)); PB_HIP(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) PB_TRY(launch_gemm(c->stream, A_DENSE, e, tile, g));
+    for (int i = 0; i < 2; ++i) PB_TRY(launch_gemm(c->stream, amode, e, tile, g));
     if (const char *dump = getenv("PB_GEMM_DBG")) {      // per-block stamps of one launch -> binary file
         const int nblk = (int)((Mp / 256) * (Np / 256));
         DevMem d;
         PB_TRY(d.alloc((size_t)nblk * 64));
         g.dbg = d.as<long long>();
-        PB_TRY(launch_gemm(c->stream, A_DENSE, e, tile, g));
+        PB_TRY(launch_gemm(c->stream, amode, e, tile, g));
         PB_HIP(hipStreamSynchronize(c->stream));
         std::vector<long long> h((size_t)nblk * 8);
         PB_HIP(hipMemcpy(h.data(), d.p, h.size() * 8, hipMemcpyDeviceToHost));
@@ -657,7 +665,7 @@ int pb_op_gemm_bench(pb_ctx *c, int M, int N, int K, int tile, int epi, int iter
         g.dbg = nullptr;
     }
     PB_HIP(hipEventRecord(e0, c->stream));
-    for (int i = 0; i < iters; ++i) PB_TRY(launch_gemm(c->stream, A_DENSE, e, tile, g));
+    for (int i = 0; i < iters; ++i) PB_TRY(launch_gemm(c->stream, amode, e, tile, g));
     PB_HIP(hipEventRecord(e1, c->stream));
     PB_HIP(hipStreamSynchronize(c->stream));
     float ms = 0;

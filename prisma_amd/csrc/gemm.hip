@@ -31,6 +31,10 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
     PB_CHECK(a.K > 0 && a.K % 64 == 0, -1, "gemm: K=%d must be a positive multiple of 64", a.K);
     PB_CHECK(a.M > 0 && a.N > 0 && a.N % 8 == 0, -1, "gemm: bad M=%d N=%d", a.M, a.N);
     if (amode == A_CONV) PB_CHECK(a.cC % 64 == 0 && a.cLd % 8 == 0 && a.zero, -1, "conv: channels %d (x64) / pixel stride %d (x8)", a.cC, a.cLd);
+    // gemm_kernel tests a tap against an 8 + 8 bit mask of the pixel (gemm_kernels.h tap_mask)
+    if (amode == A_CONV) PB_CHECK(a.K / 64 <= 512 && a.kshift % 8 == 0 && (int64_t)8 * a.cW * (a.cLd ? a.cLd : a.cC) * 2 < (1LL << 30), -1,
+                                  "conv: K walk table (K = %d, kshift = %d, row of %d pixels)", a.K, a.kshift, a.cW);
+    if (amode == A_CONV) PB_CHECK(a.cKW >= 1 && a.cKW <= 8 && a.K / (a.cKW * a.cC) <= 8, -1, "conv: kernel %d x %d (up to 8 x 8)", a.K / (a.cKW * a.cC), a.cKW);
     {   // experiment switch: PB_GEMM_STAGGER=<percent> de-phases the CUs by that share of 1/8 tile period per step
         static int env_st = -2;
         if (env_st == -2) { const char *e = getenv("PB_GEMM_STAGGER"); env_st = e ? atoi(e) : -1; }

@@ -394,6 +394,37 @@ template <int EPI, int TN>
 __host__ __device__ constexpr bool epi_interleaved() {
     return TN == 2 && (EPI == EPI_STD || EPI == EPI_QKV || EPI == EPI_PIXSHUF || EPI == EPI_RESID);
 }
+// implicit-GEMM convolution staging: which taps of a pixel lie inside the image, as bits - bit ky: input row iy0 + ky, bit 8 + kx: input
+// column ix0 + kx (kernels up to 8 x 8).  The K loop tests a tap with one AND + one compare against the scalar (1 << ky) | (256 << kx).
+__device__ __forceinline__ unsigned tap_range(int v0, int n) {          // bits t of [0, 8) with 0 <= v0 + t < n
+    const int lo = v0 < 0 ? -v0 : 0, hi = n - 1 - v0 < 7 ? n - 1 - v0 : 7;
+    return (hi >= lo && lo < 8) ? (((2u << (hi & 7)) - 1u) & ~((1u << (lo & 7)) - 1u)) : 0u;
+}
+__device__ __forceinline__ unsigned tap_mask(int iy0, int ix0, int H, int W) { return tap_range(iy0, H) | (tap_range(ix0, W) << 8); }
+
+// ... and the K walk of a convolution as a table in the LDS, one word per K tile, built once per workgroup: the tile's tap (ky, kx) in bits
+// [0, 6) and, above them, the byte offset / 16 of (tap, channel slice) relative to the pixel's tap (0, 0).  Both K orders (gemm.h cTapInner),
+// the split-fp16 wrap (kwrap / kshift) and the clamp past the last tile are in the table, so the K loop pays one broadcast ds_read, one
+// v_readfirstlane and five scalar instructions per K tile instead of the ~30 scalar instructions of a branch-free cursor step PER A HALF
+// (round 4, per-tile stamps: the 3 x 3 / 1 x 5 convolutions of the RAFT update block ran 3260 cycles per K tile against the dense GEMM's 2320 -
+// the ping-pong schedule has no room for ~100 extra instructions per K tile in the loading wave group's slots).
+constexpr int KTAB_BYTES = 2048;                                          // K <= 512 tiles (checked by the launchers)
+__device__ __forceinline__ unsigned conv_ktab_entry(const GemmArgs &p, int cld, int t) {
+    int ky, kx, c0;
+    if (p.cTapInner) {
+        const int per = p.cKH * p.cKW, sl = t / per, tp = t - sl * per;
+        ky = tp / p.cKW; kx = tp - ky * p.cKW; c0 = sl * 64;
+    } else {
+        const int cpt = p.cC >> 6, tp = t / cpt;
+        ky = tp / p.cKW; kx = tp - ky * p.cKW; c0 = (t - tp * cpt) * 64;
+    }
+    const int cs = (p.kwrap && c0 >= p.kwrap) ? c0 + p.kshift : c0;
+    const unsigned bytes = (unsigned)(((ky * p.cW + kx) * cld + cs) * 2);
+    return ((bytes >> 4) << 6) | (unsigned)(ky << 3) | (unsigned)kx;
+}
+__device__ __forceinline__ unsigned ktab_bytes(unsigned e) { return (e >> 6) << 4; }
+__device__ __forceinline__ unsigned ktab_sel(unsigned e) { return (1u << ((e >> 3) & 7)) | (256u << (e & 7)); }
+
 __device__ __forceinline__ int col_map(int r, bool il) {        // tile-local B row -> tile-local output column
     return il ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;
 }
@@ -689,17 +720,84 @@ __device__ __forceinline__ void direct_epilogue_buf(const GemmArgs &p, f32x16 (&
     // FAST = act | add1 << 4 | add2 << 5 | out2 << 6 | pre_relu << 7 (the dispatcher's key): every switch is a compile-time constant
     const int act = FAST >= 0 ? (FAST & 15) : p.act;
     const bool gru_r = EPI == EPI_STD && act == ACT_GRU_ZR && wave_n0 >= 128;       // a wave's 64 columns are all z or all r
+    // Everything a pass LOADS (skip tensors, GRU state and gate) is fetched by one lambda, and the straight-line copies (FAST >= 0) fetch pass
+    // th + 1 BEFORE pass th stores: loads and stores retire on one in-order counter, so loads issued behind a pass's 8-32 stores wait for those
+    // stores to reach memory first - eight serialised round trips per tile.  Issued in front of them the compiler's own counted wait
+    // (vmcnt = the stores issued since) lets them return while the stores drain.
+    struct Pre { f16x2 a1[8], l1[8], a2[8], l2[8]; unsigned short b1[8], b2[8]; f32x2 h[8]; f16x2 z[8]; };
+    // (fp16 builds only: with the e4m3 residual parts a pass of the skip-tensor variants already loads 32 registers' worth - two sets of them
+    // next to the 128 accumulators spill 260-290 VGPRs)
+    // measured (r04n, same box, two builds): no difference - update-block kernel 32.94 ms per step either way - so the prefetch is off by default
+    // (its registers would cost the 128 x 128 tile its second workgroup per CU); -DPB_EPI_PIPE builds it for the 256 x 256 tile
+#ifdef PB_EPI_PIPE
+    constexpr bool PIPE = FAST >= 0 && (LOM == 0 || LOM == 1) && TM == 4;
+#else
+    constexpr bool PIPE = false;
+#endif
+    const bool has_add1 = EPI == EPI_STD && (FAST >= 0 ? ((FAST >> 4) & 1) != 0 : p.add1 != nullptr);
+    const bool has_add2 = EPI == EPI_STD && (FAST >= 0 ? ((FAST >> 5) & 1) != 0 : p.add2 != nullptr);
+    const unsigned vh_r = (unsigned)((4 * lh * 128 + (nc - 128)) * 4), vh_q = (unsigned)((4 * lh * 128 + nc) * 4), vz_q = (unsigned)((4 * lh * 256 + nc) * 2);
+    auto rowinfo = [&](int th, int (&rowc)[8], unsigned (&pz)[8]) {
+        const int tm = th >> 1, r0 = (th & 1) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = r0 + q;
+            rowc[q] = tm * 32 + (r & 3) + 8 * (r >> 2);
+            pz[q] = (!CHECK || (nok && wave_m0 + rowc[q] + 4 * lh < p.M)) ? 0u : PB_POISON;
+        }
+    };
+    auto fetch = [&](int th, Pre &x, int parts) {            // parts: 1 add1, 2 add2, 4 the GRU's state / gate
+        if constexpr (EPI == EPI_STD) {
+            int rowc[8];
+            unsigned pz[8];
+            rowinfo(th, rowc, pz);
+            if ((parts & 1) && has_add1) {
+                const BufT ta = buf_of(p.add1, row0, 0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    x.a1[q] = bl_h2(ta, v16 | pz[q], rowc[q] * ldo * 2);
+                    if constexpr (LOM == 2) x.b1[q] = bl_u16(ta, v8lo | pz[q], rowc[q] * ldo * 2);
+                    if constexpr (LOM == 1) x.l1[q] = bl_h2(ta, vlo16 | pz[q], rowc[q] * ldo * 2);
+                }
+            }
+            if ((parts & 2) && has_add2) {
+                const BufT ta = buf_of(p.add2, row0, 0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    x.a2[q] = bl_h2(ta, v16 | pz[q], rowc[q] * ldo * 2);
+                    if constexpr (LOM == 2) x.b2[q] = bl_u16(ta, v8lo | pz[q], rowc[q] * ldo * 2);
+                    if constexpr (LOM == 1) x.l2[q] = bl_h2(ta, vlo16 | pz[q], rowc[q] * ldo * 2);
+                }
+            }
+            if ((parts & 4) && gru_r) {
+                const BufT th_ = buf_of(p.gru_h, (int64_t)wave_m0 * 128 * 4, 0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x.h[q] = bl_f2(th_, vh_r | pz[q], rowc[q] * 128 * 4);
+            }
+            if ((parts & 4) && act == ACT_GRU_Q) {
+                const BufT th_ = buf_of(p.gru_h, (int64_t)wave_m0 * 128 * 4, 0);
+                const BufT tz = buf_of(p.gru_z, (int64_t)wave_m0 * 256 * 2, 0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    x.h[q] = bl_f2(th_, vh_q | pz[q], rowc[q] * 128 * 4);
+                    x.z[q] = bl_h2(tz, vz_q | pz[q], rowc[q] * 256 * 2);
+                }
+            }
+        }
+    };
+    Pre nxt;
+    if constexpr (PIPE) fetch(0, nxt, 7);
 #pragma unroll
     for (int th = 0; th < TM * 2; ++th) {                   // 8 accumulator registers (= 16 rows) per pass
         const int tm = th >> 1, r0 = (th & 1) * 8;
         // tile-local row of register q (a compile-time constant) and, CHECK builds, the poisoned lane offsets of rows >= M
         int rowc[8];
         unsigned pz[8];                                     // 0 or PB_POISON: OR-ed into every lane offset of row q
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int r = r0 + q;
-            rowc[q] = tm * 32 + (r & 3) + 8 * (r >> 2);
-            pz[q] = (!CHECK || (nok && wave_m0 + rowc[q] + 4 * lh < p.M)) ? 0u : PB_POISON;
+        rowinfo(th, rowc, pz);
+        Pre cur;
+        if constexpr (PIPE) {
+            cur = nxt;
+            if (th + 1 < TM * 2) fetch(th + 1, nxt, 7);
         }
         float v0[8], v1[8];
 #pragma unroll
@@ -709,27 +807,28 @@ __device__ __forceinline__ void direct_epilogue_buf(const GemmArgs &p, f32x16 (&
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
             }
+            if constexpr (!PIPE) fetch(th, cur, 1);          // (not pipelined: each part is loaded where it is consumed, one register set at a time)
+            if (has_add1) {
 #pragma unroll
-            for (int which = 0; which < 2; ++which) {
-                const f16 *addp = which == 0 ? p.add1 : p.add2;
-                if (FAST >= 0 ? ((FAST >> (4 + which)) & 1) == 0 : addp == nullptr) continue;
-                const BufT ta = buf_of(addp, row0, 0);
-                f16x2 a[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) a[q] = bl_h2(ta, v16 | pz[q], rowc[q] * ldo * 2);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                for (int q = 0; q < 8; ++q) { v0[q] += (float)cur.a1[q][0]; v1[q] += (float)cur.a1[q][1]; }
                 if constexpr (LOM == 2) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const f32x2 l = __builtin_amdgcn_cvt_pk_f32_fp8((int)bl_u16(ta, v8lo | pz[q], rowc[q] * ldo * 2), false) * lo8_inv;
-                        v0[q] += l[0]; v1[q] += l[1];
-                    }
+                    for (int q = 0; q < 8; ++q) { const f32x2 l = __builtin_amdgcn_cvt_pk_f32_fp8((int)cur.b1[q], false) * lo8_inv; v0[q] += l[0]; v1[q] += l[1]; }
                 } else if constexpr (LOM == 1) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) a[q] = bl_h2(ta, vlo16 | pz[q], rowc[q] * ldo * 2);
+                    for (int q = 0; q < 8; ++q) { v0[q] += (float)cur.l1[q][0]; v1[q] += (float)cur.l1[q][1]; }
+                }
+            }
+            if constexpr (!PIPE) fetch(th, cur, 2);
+            if (has_add2) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { v0[q] += (float)a[q][0]; v1[q] += (float)a[q][1]; }
+                for (int q = 0; q < 8; ++q) { v0[q] += (float)cur.a2[q][0]; v1[q] += (float)cur.a2[q][1]; }
+                if constexpr (LOM == 2) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const f32x2 l = __builtin_amdgcn_cvt_pk_f32_fp8((int)cur.b2[q], false) * lo8_inv; v0[q] += l[0]; v1[q] += l[1]; }
+                } else if constexpr (LOM == 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { v0[q] += (float)cur.l2[q][0]; v1[q] += (float)cur.l2[q][1]; }
                 }
             }
             if (FAST >= 0 ? ((FAST >> 6) & 1) != 0 : p.out2 != nullptr) {
@@ -757,6 +856,7 @@ __device__ __forceinline__ void direct_epilogue_buf(const GemmArgs &p, f32x16 (&
                     }
                 }
             }
+            if constexpr (!PIPE) fetch(th, cur, 4);
             if (act == ACT_GELU) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) fast_gelu2(v0[q], v1[q]);
@@ -773,17 +873,13 @@ __device__ __forceinline__ void direct_epilogue_buf(const GemmArgs &p, f32x16 (&
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { v0[q] = __frcp_rn(1.f + __expf(-v0[q])); v1[q] = __frcp_rn(1.f + __expf(-v1[q])); }
                 if (gru_r) {                     // r columns: r * h -> gru_rh (the z columns fall through to the plain store below)
-                    const BufT th_ = buf_of(p.gru_h, (int64_t)wave_m0 * 128 * 4, 0);
                     const BufT tr = buf_of(p.gru_rh, (int64_t)wave_m0 * p.gru_ld * 2, 0);
-                    const unsigned vh = (unsigned)((4 * lh * 128 + (nc - 128)) * 4), vr = (unsigned)((4 * lh * p.gru_ld + (nc - 128)) * 2);
+                    const unsigned vr = (unsigned)((4 * lh * p.gru_ld + (nc - 128)) * 2);
                     const unsigned vr8 = (unsigned)(4 * lh * p.gru_ld * 2 + p.o8_off + (nc - 128));
-                    f32x2 h[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) h[q] = bl_f2(th_, vh | pz[q], rowc[q] * 128 * 4);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         f16x2 o;
-                        o[0] = (f16)(v0[q] * h[q][0]); o[1] = (f16)(v1[q] * h[q][1]);
+                        o[0] = (f16)(v0[q] * cur.h[q][0]); o[1] = (f16)(v1[q] * cur.h[q][1]);
                         bs_h2(tr, vr | pz[q], rowc[q] * p.gru_ld * 2, o);
                         if constexpr (LOM == 3)       // fp8 twin of r * h for the q convolution's MX segment (o8_off = byte offset of the copy)
                             bs_u16(tr, vr8 | pz[q], rowc[q] * p.gru_ld * 2, pb_fp8x2((float)o[0] * p.o8_scale, (float)o[1] * p.o8_scale));
@@ -792,22 +888,13 @@ __device__ __forceinline__ void direct_epilogue_buf(const GemmArgs &p, f32x16 (&
                 }
             } else if (act == ACT_GRU_Q) {
                 const BufT th_ = buf_of(p.gru_h, (int64_t)wave_m0 * 128 * 4, 0);
-                const BufT tz = buf_of(p.gru_z, (int64_t)wave_m0 * 256 * 2, 0);
-                const unsigned vh = (unsigned)((4 * lh * 128 + nc) * 4), vz = (unsigned)((4 * lh * 256 + nc) * 2);
-                f32x2 h[8];
-                f16x2 z[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    h[q] = bl_f2(th_, vh | pz[q], rowc[q] * 128 * 4);
-                    z[q] = bl_h2(tz, vz | pz[q], rowc[q] * 256 * 2);
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float z0 = (float)z[q][0], z1 = (float)z[q][1];
+                    const float z0 = (float)cur.z[q][0], z1 = (float)cur.z[q][1];
                     f32x2 hn;
-                    hn[0] = (1.f - z0) * h[q][0] + z0 * fast_tanh(v0[q]);
-                    hn[1] = (1.f - z1) * h[q][1] + z1 * fast_tanh(v1[q]);
-                    bs_f2(th_, vh | pz[q], rowc[q] * 128 * 4, hn);
+                    hn[0] = (1.f - z0) * cur.h[q][0] + z0 * fast_tanh(v0[q]);
+                    hn[1] = (1.f - z1) * cur.h[q][1] + z1 * fast_tanh(v1[q]);
+                    bs_f2(th_, vh_q | pz[q], rowc[q] * 128 * 4, hn);
                     v0[q] = hn[0]; v1[q] = hn[1];
                 }
             }
@@ -1055,24 +1142,25 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     const int srow = tid >> 3;                              // + i * (NT/8)
     const int cg = (tid & 7) ^ ((tid >> 4) & 7);            // swizzled global chunk for this LDS slot
     const f16 *a_ptr[NA];
-    int a_iy0[NA], a_ix0[NA];
-    bool a_ok[NA];
+    // conv: a_msk = tap_mask of the row's pixel (0 for rows >= M), a_pix0 = element offset of its tap (0, 0) inside the image (may be negative)
+    unsigned a_msk[NA];
+    int a_pix0[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + srow + i * (NT / 8);
         if constexpr (AMODE == A_DENSE) {
             const int mc = m < p.M ? m : p.M - 1;
             a_ptr[i] = p.A + (int64_t)mc * p.lda + cg * 8;
-            a_ok[i] = true;
-            a_iy0[i] = a_ix0[i] = 0;
+            a_msk[i] = 0u;
+            a_pix0[i] = 0;
         } else {
             const int ohw = p.cOH * p.cOW;
             const int b = m / ohw, rem = m - b * ohw;
             const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
-            a_ok[i] = m < p.M;
+            const int iy0 = oy * p.cStride - p.cPad, ix0 = ox * p.cStride - padx;
+            a_msk[i] = m < p.M ? tap_mask(iy0, ix0, p.cH, p.cW) : 0u;
+            a_pix0[i] = (iy0 * p.cW + ix0) * cld;
             a_ptr[i] = p.A + (int64_t)b * p.cH * p.cW * cld + cg * 8;
-            a_iy0[i] = oy * p.cStride - p.cPad;
-            a_ix0[i] = ox * p.cStride - padx;
         }
     }
     const f16 *b_ptr[NB];
@@ -1080,8 +1168,18 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     for (int i = 0; i < NB; ++i)
         b_ptr[i] = p.W + (int64_t)(n0 + col_map(srow + i * (NT / 8), epi_interleaved<EPI, TN>())) * p.K + cg * 8;
 
-    int c_ky = 0, c_kx = 0, c_c0 = 0;                       // conv tap state of the NEXT stage call
+    int c_ky = 0, c_kx = 0, c_c0 = 0;                       // conv tap state of the NEXT stage call (!KT builds)
     const int nk = p.K >> 6;
+    // KT: the K walk comes from the table in the LDS (conv_ktab_entry).  The 256 x 64 tile keeps the cursor: its two workgroups per CU
+    // use the LDS to the last byte.
+    constexpr bool KT = AMODE == A_CONV && BN != 64;
+    const unsigned *ktab = (const unsigned *)(smem + NS * STAGE);
+    unsigned e_nxt = 0;                                     // table word of the next stage call, read one call ahead
+    if constexpr (KT) {
+        for (int t = tid; t < nk; t += NT) ((unsigned *)(smem + NS * STAGE))[t] = conv_ktab_entry(p, cld, t);
+        __syncthreads();
+        e_nxt = ktab[0];
+    }
     // BUFP: LDS-DMA through the buffer path (see gemm8_kernel); p.bufmode 1 = whole operand, 2 = two-image window (conv)
     __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, 0u), rsW = make_rsrc(p.W, 0u);
     unsigned a_voff[NA], b_voff[NB];
@@ -1100,7 +1198,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if constexpr (AMODE == A_DENSE) a_voff[i] = (unsigned)((a_ptr[i] - p.A) * 2);
-            else a_voff[i] = (unsigned)((int64_t)((m0 + srow + i * (NT / 8)) / (p.cOH * p.cOW) - b0) * p.cH * p.cW * cld * 2) + cg * 16;
+            else a_voff[i] = (unsigned)((int64_t)((m0 + srow + i * (NT / 8)) / (p.cOH * p.cOW) - b0) * p.cH * p.cW * cld * 2) + cg * 16 + (unsigned)(a_pix0[i] * 2);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) b_voff[i] = (unsigned)((b_ptr[i] - p.W) * 2);
@@ -1111,19 +1209,25 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
         char *sB = smem + buf * STAGE + A_BYTES + wave * 1024;
         const int ka = (p.kwrap && kt >= p.kwrap) ? kt - p.kwrap : kt;            // split-fp16 segments re-read A (gemm.h)
         const int cs = (p.kwrap && c_c0 >= p.kwrap) ? c_c0 + p.kshift : c_c0;
+        // scalar per K tile: the tap's element offset and its two bits of tap_mask - a DMA then costs an AND, a compare, an add and a select
+        // (round 4: the per-DMA (iy * W + ix) * ld was a 64-bit mad + a 32-bit multiply, ~70 VALU cycles per DMA, 4 DMAs per 16 MFMAs)
+        unsigned tapoff2 = (unsigned)(((c_ky * p.cW + c_kx) * cld + cs) * 2), tapsel = (1u << c_ky) | (256u << c_kx);
+        if constexpr (KT) {
+            const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)e_nxt);
+            e_nxt = ktab[kt + 1 < nk ? kt + 1 : nk - 1];
+            tapoff2 = ktab_bytes(e); tapsel = ktab_sel(e);
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if constexpr (AMODE == A_DENSE) {
                 if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[i], ka * 128, sA + i * (NT * 16));
                 else glds16(a_ptr[i] + ka * 64, sA + i * (NT * 16));
             } else {
-                const int iy = a_iy0[i] + c_ky, ix = a_ix0[i] + c_kx;
-                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
-                if constexpr (BUFP) {      // branch-free: OR-ing all ones into the offset makes it out of range -> the load returns zeros
-                    const unsigned oob = ok ? 0u : 0xFFFFFF00u;
-                    glds16_buf(rsA, (int)((a_voff[i] + (unsigned)(((iy * p.cW + ix) * cld + cs) * 2)) | oob), 0, sA + i * (NT * 16));
+                const bool ok = (a_msk[i] & tapsel) == tapsel;
+                if constexpr (BUFP) {      // branch-free: an out-of-range offset makes the load return zeros
+                    glds16_buf(rsA, (int)(ok ? a_voff[i] + tapoff2 : 0xFFFFFF00u), 0, sA + i * (NT * 16));
                 } else {
-                    glds16(ok ? a_ptr[i] + ((iy * p.cW + ix) * cld + cs) : p.zero, sA + i * (NT * 16));
+                    glds16(ok ? a_ptr[i] + (a_pix0[i] + (int)(tapoff2 >> 1)) : p.zero, sA + i * (NT * 16));
                 }
             }
         }
@@ -1132,7 +1236,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             if constexpr (BUFP) glds16_buf(rsW, (int)b_voff[i], kt * 128, sB + i * (NT * 16));
             else glds16(b_ptr[i] + kt * 64, sB + i * (NT * 16));
         }
-        if constexpr (AMODE == A_CONV) {
+        if constexpr (AMODE == A_CONV && !KT) {
             // one branch-free step for both K orders (gemm.h cTapInner): tap-major walks (ky, kx, c), slice-major (c, ky, kx)
             const int ti = p.cTapInner;
             int c1 = c_c0 + (ti ? 0 : 64);
@@ -1179,12 +1283,15 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     static_assert(NS == 2 || (NS == 3 && (NA + NB == 8 || NA + NB == 6 || NA + NB == 4)), "stage count / DMAs per stage");
     const int mxper = MX && p.mx_period > 0 ? p.mx_period : nk;
     const int n16 = MX && p.nk16 > 0 && p.nk16 < mxper ? p.nk16 : mxper;
-    int kphase = 0;                              // kt % mxper
     const int mxa = p.mx_scale_a * 0x01010101, mxb = p.mx_scale_b * 0x01010101;
     stage(0, 0);
     if constexpr (NS == 3) { if (nk > 1) stage(1, 1); }
     int cbuf = 0;                                           // buffer of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
+    // one K tile (fp16, or - MX builds - 128 e4m3 bytes per row).  The two kinds run in loops of their own below: with one loop and a branch
+    // per tile the register allocator carried the accumulators across the back edge in VGPRs and copied all 64 of them into the AGPRs
+    // and back EVERY K tile (128 v_accvgpr moves per 16-24 MFMAs in the MX build of the 128 x 128 tile - round 4, found in the ISA).
+    auto ktile = [&](auto fp8_tag, int kt) {
+        constexpr bool FP8 = decltype(fp8_tag)::value;
         if (NS == 3 && kt + 1 < nk) vm_wait_halftiles((NA + NB) / 2);   // all but the newest stage (NA + NB DMAs) landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // NS == 3: a bare barrier - __syncthreads() carries a workgroup fence for which the compiler drains vmcnt, i.e. the stage the
@@ -1201,12 +1308,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             if (kt + 1 < nk) stage(cbuf ^ 1, kt + 1);
             cbuf ^= 1;
         }
-        bool is8 = false;
-        if constexpr (MX) {
-            is8 = kphase >= n16;
-            kphase = kphase + 1 == mxper ? 0 : kphase + 1;
-        }
-        if (MX && is8) {
+        if constexpr (FP8) {
             // MX-fp8 tile (gemm.h nk16): the fragments of k-steps 2q, 2q + 1 are the 32-byte operands of one scaled MFMA
             // the second MFMA group's fragments are read from the LDS under the first group's MFMAs
             constexpr int FB = MX ? 2 : 0;
@@ -1225,18 +1327,27 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = mfma_mx8(af[FB][i], af[FB + 1][i], bf[FB][j], bf[FB + 1][j], acc[i][j], mxa, mxb);
             __builtin_amdgcn_sched_barrier(0);
-            continue;
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) load_frags((ks + 1) & 1, sb, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) load_frags((ks + 1) & 1, sb, ks + 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (!MX) {
+        for (int kt = 0; kt < nk; ++kt) ktile(std::false_type{}, kt);
+    } else {
+        for (int t0 = 0; t0 < nk; t0 += mxper) {
+            const int e16 = t0 + n16 < nk ? t0 + n16 : nk, e8 = t0 + mxper < nk ? t0 + mxper : nk;
+            for (int kt = t0; kt < e16; ++kt) ktile(std::false_type{}, kt);
+            for (int kt = e16; kt < e8; ++kt) ktile(std::true_type{}, kt);
         }
     }
     __syncthreads();            // staging buffers are dead; reuse LDS for the epilogue patches
@@ -1319,9 +1430,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             b_row0[hf][u] = (g >> 2) * 64 + hf * 32 + (g & 3) * 8;
         }
     const f16 *a_ptr[2][2];
-    // conv: the output pixel's first input row / column as (iy0 << 16) | (ix0 & 0xffff) - one register per DMA instead of two and a
-    // predicate; rows >= M carry iy0 = -20000, which fails every tap's range test (persistent workgroups keep all of this live
-    // across the epilogue of the previous tile: the kernel has no register to spare)
+    // conv: which taps of the output pixel lie inside the image (tap_mask; 0 for rows >= M) - one register per DMA, tested against the
+    // K tile's two tap bits with an AND and a compare
     int a_yx[2][2];
     const f16 *b_ptr[2][2];
     const int nk = p.K >> 6;
@@ -1340,7 +1450,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     // and every phase can use the same counted wait
     // conv: each A half has its own tap cursor (ky, kx, c0) that steps one K tile per call - no divisions in the loop - and
     // the per-lane pixel offset of tap (0, 0) is precomputed, so a DMA costs one add, two range tests and a select
-    int cur_ky[2] = {0, 0}, cur_kx[2] = {0, 0}, cur_c0[2] = {0, 0}, cur_kt[2] = {0, 0};
+    // (round 4: the walk is a table in the LDS, conv_ktab_entry; A_0(k) fetches K tile k's word, A_1(k) - always the next stage_a call - re-uses it)
+    const unsigned *ktab = (const unsigned *)(smem + 2 * BUF);
+    unsigned e_nxt = 0, e_cur = 0;
     int a_pix0[2][2];
 
     // tile vb of the launch -> (m0, n0) and this thread's staging addresses.  XCD-contiguous remap (bijective for any tile count;
@@ -1387,7 +1499,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                     const int oy = rem / p.cOW, ox = rem - oy * p.cOW;
                     a_ptr[hf][u] = p.A + (int64_t)b * p.cH * p.cW * cld + cgu[u] * 8;
                     const int iy0 = oy * p.cStride - p.cPad, ix0 = ox * p.cStride - padx;
-                    a_yx[hf][u] = (int)(((unsigned)(m < p.M ? iy0 : -20000) << 16) | ((unsigned)ix0 & 0xffffu));
+                    a_yx[hf][u] = (int)(m < p.M ? tap_mask(iy0, ix0, p.cH, p.cW) : 0u);
                     a_pix0[hf][u] = (iy0 * p.cW + ix0) * cld;
                 }
                 b_ptr[hf][u] = p.W + (int64_t)(n0 + col_map(b_row0[hf][u] + lrow, epi_interleaved<EPI, 2>())) * p.K + cgu[u] * 8;
@@ -1419,8 +1531,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         const int ktc = kt_ < nk ? kt_ : nk - 1;
         const int kt = (p.kwrap && ktc >= p.kwrap) ? ktc - p.kwrap : ktc;         // split-fp16 segments re-read A (gemm.h)
         char *base = smem + (kt_ & 1) * BUF;
-        const int ky = cur_ky[hf], kx = cur_kx[hf], c0 = cur_c0[hf];
-        const int tapoff = (ky * p.cW + kx) * cld + ((p.kwrap && c0 >= p.kwrap) ? c0 + p.kshift : c0);
+        unsigned tapoff2 = 0, tapsel = 0;
+        if constexpr (AMODE == A_CONV) {
+            if (hf == 0) {
+                e_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)e_nxt);
+                e_nxt = ktab[ktc + 1 < nk ? ktc + 1 : nk - 1];
+            }
+            tapoff2 = ktab_bytes(e_cur); tapsel = ktab_sel(e_cur);
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int g = wave * 2 + u;
@@ -1429,34 +1547,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 if constexpr (BUFP) glds16_buf(rsA, (int)a_voff[hf][u], kt * 128, dst);
                 else glds16(a_ptr[hf][u] + kt * 64, dst);
             } else {
-                const int iy = (a_yx[hf][u] >> 16) + ky, ix = ((int)((unsigned)a_yx[hf][u] << 16) >> 16) + kx;
-                // (bitwise &: a short-circuit && became an exec-masked branch in the K loop)
-                const bool ok = ((unsigned)iy < (unsigned)p.cH) & ((unsigned)ix < (unsigned)p.cW);
+                const bool ok = ((unsigned)a_yx[hf][u] & tapsel) == tapsel;            // tap_mask: an AND and a compare per DMA
                 if constexpr (BUFP) {
-                    const unsigned oob = ok ? 0u : 0xFFFFFF00u;            // any out-of-range offset reads zeros
-                    glds16_buf(rsA, (int)((a_voff[hf][u] + (unsigned)(tapoff * 2)) | oob), 0, dst);
+                    glds16_buf(rsA, (int)(ok ? a_voff[hf][u] + tapoff2 : 0xFFFFFF00u), 0, dst);      // any out-of-range offset reads zeros
                 } else {
-                    glds16(ok ? a_ptr[hf][u] + (a_pix0[hf][u] + tapoff) : p.zero, dst);
+                    glds16(ok ? a_ptr[hf][u] + (a_pix0[hf][u] + (int)(tapoff2 >> 1)) : p.zero, dst);
                 }
             }
-        }
-        if constexpr (AMODE == A_CONV) {
-            // branch-free step; past the end the cursor stays on the last K tile
-            const int adv = cur_kt[hf] < nk - 1 ? 1 : 0;
-            cur_kt[hf] += adv;
-            // one step for both K orders (gemm.h cTapInner): tap-major walks (ky, kx, c), slice-major (c, ky, kx); scalar selects only -
-            // a branch here costs the 256 x 256 MX kernel its register allocation (128 VGPRs spilled)
-            const int ti = p.cTapInner;
-            int c1 = cur_c0[hf] + (ti ? 0 : 64 * adv);
-            const int wc = (!ti && c1 >= p.cC) ? 1 : 0;
-            c1 = wc ? 0 : c1;
-            const int x1 = cur_kx[hf] + (ti ? adv : 0) + wc;
-            const int wx = x1 == p.cKW ? 1 : 0;
-            cur_kx[hf] = wx ? 0 : x1;
-            const int y1 = cur_ky[hf] + wx;
-            const int wy = (ti && y1 == p.cKH) ? 1 : 0;
-            cur_ky[hf] = wy ? 0 : y1;
-            cur_c0[hf] = c1 + 64 * wy;
         }
     };
     auto stage_b = [&](int hf, int kt_) {
@@ -1471,8 +1568,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     };
     // a tile's first six half tiles: A_0(0) B_0(0) B_1(0) A_1(0) A_0(1) B_0(1)   (issuing these BEFORE the residual loads measured 5 % slower on proj)
     auto prologue = [&]() {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) cur_ky[hf] = cur_kx[hf] = cur_c0[hf] = cur_kt[hf] = 0;
+        if constexpr (AMODE == A_CONV) e_nxt = ktab[0];
         stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
         stage_a(0, 1); stage_b(0, 1);
     };
@@ -1607,6 +1703,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         PB_BAR();
     };
 
+    if constexpr (AMODE == A_CONV) {                     // the K walk of the launch (conv_ktab_entry), once per workgroup
+        for (int t = tid; t < nk; t += 512) ((unsigned *)(smem + 2 * BUF))[t] = conv_ktab_entry(p, cld, t);
+        __syncthreads();
+    }
     int vb = blockIdx.x;
     setup(p, vb);
     bool pf = false;                                     // this tile's prologue was issued before the previous tile's epilogue
@@ -1739,7 +1839,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 
 template <int AMODE, int EPI, bool MX, bool BUFP>
 int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
-    constexpr int SMEM = 131072;
+    constexpr int SMEM = 131072 + (AMODE == A_CONV ? KTAB_BYTES : 0);
     auto kern = gemm8_kernel<AMODE, EPI, 0, BUFP, MX>;
     static char name[96];
     if (!name[0]) snprintf(name, sizeof(name), "gemm8_kernel<%d, %d, 0, %s, %s>", AMODE, EPI, BUFP ? "true" : "false", MX ? "true" : "false");
@@ -1809,7 +1909,8 @@ int launch_t(hipStream_t stream, const GemmArgs &a) {
     constexpr int TN = BN / WN / 32;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * (TN * 32 + 4) * 4;
-    constexpr int SMEM = NS * STAGE > WM * WN * EPIB ? NS * STAGE : WM * WN * EPIB;
+    constexpr int STG = NS * STAGE + (AMODE == A_CONV && BN != 64 ? KTAB_BYTES : 0);          // (+ the conv K-walk table, gemm_kernel KT)
+    constexpr int SMEM = STG > WM * WN * EPIB ? STG : WM * WN * EPIB;
     if constexpr (!BUFP && ((BM == 128 && BN == 128) || NS == 3 || BN == 64)) {       // the small tiles also have a buffer-path build
         GemmArgs b = a;
         b.bufmode = buffer_mode(AMODE, a, BM);

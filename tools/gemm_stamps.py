@@ -1,7 +1,7 @@
 """Per-tile timing breakdown of the ping-pong GEMM (PB_GEMM_DBG stamps; gemm8_kernel writes one record per TILE: start = kernel start or
 the previous tile's epilogue issued, loop start, loop end, epilogue issued).  Environment switches of the kernel apply
 (PB_GEMM_PERSIST, PB_GEMM_PREFETCH, PB_GEMM_ABL, PB_GEMM_STAGGER); `python tools/gemm_stamps.py [shape ...]` with shapes out of
-fc1 fc1-gelu proj fc2 sq8k (default: all)."""
+fc1 fc1-gelu proj fc2 sq8k conv3x3 conv3x3-slice conv1x5-gru dense-k2304 (default: all)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,11 @@ os.environ["PB_GEMM_DBG"] = "/tmp/gemm_dbg.bin"
 from prisma_amd import engine
 ops = engine.Ops(0)
 SHAPES = {"fc1": (78336, 4096, 1024, 0), "fc1-gelu": (78336, 4096, 1024, 1), "proj": (78336, 1024, 1024, 2), "fc2": (78336, 1024, 4096, 2),
-          "sq8k": (8192, 8192, 8192, 0)}
+          "sq8k": (8192, 8192, 8192, 0),
+          # implicit-GEMM convolutions on the RAFT update block's grid (31 pairs x 102 x 180 rows): 3 x 3 256 -> 256 tap-major / slice-major,
+          # the GRU's 1 x 5 over 384 channels, and the dense GEMM of the same M, N, K beside them
+          "conv3x3": (31 * 18360, 256, 2304, 10), "conv3x3-slice": (31 * 18360, 256, 2304, 11), "conv1x5-gru": (31 * 18360, 256, 1920, 12),
+          "dense-k2304": (31 * 18360, 256, 2304, 0)}
 want = sys.argv[1:] or list(SHAPES)
 print("# switches:", {k: v for k, v in os.environ.items() if k.startswith("PB_GEMM_") and k != "PB_GEMM_DBG"})
 for name in want:

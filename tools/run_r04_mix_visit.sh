@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-4 visit: pytest subset, then per-tile stamps and bench legs under switches.
+# (STAMP_SHAPES="conv3x3 dense-k2304 ..." picks the shapes of tools/gemm_stamps.py)
 # usage: bash tools/run_r04_mix_visit.sh <tag> "<pytest args>" "<stamps cfgs separated by ;>" "<bench cfgs separated by ;>"
 set -u
 T=$1; PYT=$2; SC=$3; BC=$4
@@ -15,7 +16,7 @@ fi
 IFS=';' read -ra SCS <<< "$SC"
 for cfg in "${SCS[@]}"; do
   [ -z "$cfg" ] && continue
-  env $cfg timeout 300 python tools/gemm_stamps.py fc1 fc1-gelu proj fc2 >> $O/${T}_gemm8_phase_cycles.log 2>&1
+  env $cfg timeout 300 python tools/gemm_stamps.py ${STAMP_SHAPES:-fc1 fc1-gelu proj fc2} >> $O/${T}_gemm8_phase_cycles.log 2>&1
 done
 cat $O/${T}_gemm8_phase_cycles.log
 IFS=';' read -ra BCS <<< "$BC"
