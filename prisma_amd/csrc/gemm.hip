@@ -46,6 +46,12 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         // 256x256 needs wide N and enough tiles to fill 256 CUs; the q/k/v split needs D % BN == 0
         const bool wide = a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256;
         tile = wide && (epi != EPI_QKV || a.D % 256 == 0) ? TILE_256 : TILE_128;
+        // N = 192 (RAFT's convc2): two 128-wide tiles of which the second is half empty, or one 256-wide tile that is a quarter empty - the
+        // ping-pong kernel's K loop runs ~2460 cycles per 256 x 256 x 64 against the generic tile's ~1000 per 128 x 128 x 64.  Measured (r04p, one box):
+        // flow band 147.4 -> 145.3 ms with N = 192 on the wide tile, 157.8 with N = 128 on it too.  PB_TILE_WIDE=<min columns of the last tile>, 0 = off
+        static int wide_min = -1;
+        if (wide_min < 0) { const char *e = getenv("PB_TILE_WIDE"); wide_min = e ? atoi(e) : 192; }
+        if (tile == TILE_128 && epi == EPI_STD && wide_min > 0 && a.N % 256 >= wide_min && (int64_t)(a.M / 256) * ((a.N + 255) / 256) >= 256) tile = TILE_256;
         // N <= 64 (RAFT / ResNet stems and first stages): a 128-wide tile spends half its MFMAs and B loads on padding columns
         static int n64_tile = -1;
         if (n64_tile < 0) { const char *e = getenv("PB_TILE_N64"); n64_tile = e ? atoi(e) : TILE_256x64; }

@@ -112,12 +112,13 @@ int RaftEngine::load(const pb_tensor *w, int n) {
         if ((r = pack_conv(en + ".conv2", true, nullptr, nullptr, E.out, 1))) return r;
     }
     const std::string u = "update_block.";
-    // the update block's activations carry an fp8 copy ([a16 | a8] per pixel) and its weight residuals are e4m3 (PackedW::mx2)
-    // ... as an opt-in (PB_MX_UPD=1) only: measured on MI355X it buys 1 % of the band (1080p x 0.75, 31 pairs: 174.7 -> 172.9 ms; 720p:
-    // 177.8 -> 175.7 ms - these convolutions are not bound by the matrix pipe, and the fp8 copies add traffic) while the e4m3 copies of
-    // the recurrent state eat the parity margin (720p x 8 pairs, worst pair: 5.8e-4 -> 1.1e-3 max-norm).  The default keeps the two
-    // fp16 passes (w_hi, w_lo) here.
-    pack_mx2_ = mx_ && getenv("PB_MX_UPD") && getenv("PB_MX_UPD")[0] == '1';
+    // the update block's activations carry an fp8 copy ([a16 | a8] per pixel) and its weight residuals are e4m3 (PackedW::mx2): the residual
+    // pass a8 x w_lo8 runs on the MX-scaled MFMA at half the matrix-pipe time of the second fp16 pass it replaces.  History: rounds 2-3 kept
+    // this off (it bought 1 % of the band: the MX build of the 128 x 128 tile copied its accumulators through VGPRs every K tile, and the
+    // variant excluded the context hoist below); round 4 fixed both - 31 pairs 1080p x 0.75: flow band 150.4 -> 142.2 ms on one box - and the
+    // parity figures do not move (720p x 8 pairs 4.1e-4 ... 5.4e-4 max, 3.4e-4 ... 3.5e-4 L2 against 4.1e-4 ... 6.6e-4 / 3.4e-4 with two fp16
+    // passes; heavy-tailed weights 5.8e-4 against 6.3e-4): the e4m3 rounding only ever enters a residual term.  PB_MX_UPD=0: two fp16 passes.
+    pack_mx2_ = mx_ && !(getenv("PB_MX_UPD") && getenv("PB_MX_UPD")[0] == '0');
     upd8_ = pack_mx2_;
     // slice-major K order (gemm.h cTapInner) for the 3x3 / 1x5 / 5x1 convolutions over the 128 ... 384-channel maps of the update block:
     // tap-major order overflows the XCD L2 there.  PB_TAPIN=0 turns it off, 2 also applies it to the encoders (A/B runs).
@@ -139,7 +140,7 @@ int RaftEngine::load(const pb_tensor *w, int n) {
                 for (int tp = 0; tp < 49; ++tp) g[(size_t)o * 98 + tp * 2 + c] = wt[((size_t)o * 2 + c) * 49 + tp];
         if ((r = pack(g.data(), 128, 98, 128, convf1_, (const float *)ib->second->data))) return r;
     }
-    // Context hoist (default; PB_GRU_HOIST=0 or PB_MX_UPD=1 turn it off): the GRU's input is cat(h, inp, motion) and `inp` - the context
+    // Context hoist (default; PB_GRU_HOIST=0 turns it off): the GRU's input is cat(h, inp, motion) and `inp` - the context
     // features - does not change over the iterations (raft.py:112-115, update.py:131).  A convolution is linear in its input channels, so
     // the inp share of every gate's pre-activation is computed ONCE per call (bias-free, stored as an fp16 hi plane + an fp16 lo plane: ~22
     // bits) and the per-iteration convolutions run on [h | motion] alone (K = 5 x 256 instead of 5 x 384), adding the two planes as the
@@ -148,7 +149,7 @@ int RaftEngine::load(const pb_tensor *w, int n) {
     // ate half of what the smaller K saved; as an fp32 read in the GRU epilogues it cost every EPI_STD kernel its register allocation.)
     {
         const char *e = getenv("PB_GRU_HOIST");
-        hoist_ = !upd8_ && !(e && e[0] == '0');
+        hoist_ = !(e && e[0] == '0');
     }
     for (int half = 0; half < 2; ++half) {
         // z and r gates share their input: one GEMM with N = 256 ([z | r]); q separately
@@ -187,14 +188,20 @@ int RaftEngine::load(const pb_tensor *w, int n) {
             fill(gi, 0, 128, 0, wz, 128, 128);
             fill(gi, 128, 128, 0, wr, 128, 128);
             if ((r = pack(g.data(), 256, 5 * 256, 5 * 256, zr_[half], bb.data(), 5))) return r;
-            if ((r = pack(gi.data(), 256, 5 * 128, 5 * 128, zr_in_[half], nullptr, 5))) return r;
+            pack_mx2_ = 0;                                  // the once-per-call share runs two fp16 passes into an fp16 hi + lo plane
+            r = pack(gi.data(), 256, 5 * 128, 5 * 128, zr_in_[half], nullptr, 5);
+            pack_mx2_ = upd8_;
+            if (r) return r;
         }
         {
             std::vector<float> g((size_t)128 * 5 * 256, 0.f), gi((size_t)128 * 5 * 128, 0.f);
             fill(g, 0, 256, 0, wq, 0, 128); fill(g, 0, 256, 128, wq, 256, 128);
             fill(gi, 0, 128, 0, wq, 128, 128);
             if ((r = pack(g.data(), 128, 5 * 256, 5 * 256, q_[half], (const float *)bq->data, 5))) return r;
-            if ((r = pack(gi.data(), 128, 5 * 128, 5 * 128, q_in_[half], nullptr, 5))) return r;
+            pack_mx2_ = 0;
+            r = pack(gi.data(), 128, 5 * 128, 5 * 128, q_in_[half], nullptr, 5);
+            pack_mx2_ = upd8_;
+            if (r) return r;
         }
     }
     if ((r = pack_conv(u + "flow_head.conv1", true, nullptr, nullptr, fh1_))) return r;
@@ -507,7 +514,7 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         // HX = [h | inp | motion] feeds the z / r convs, HX2 = [r * h | inp | motion] the q conv: the motion features are
         // written to both by the producing conv (its ReLU'd second output), r * h and the state update by the GRU epilogues
         ConvFuse dup; dup.out2 = hx2_ + mot;
-        if ((r = conv(corflo_, 256, L256, ND, h8_, w8_, 3, 3, 1, convm_, hx_ + mot, Lhx, ACT_RELU, 0, nullptr, &dup, 0, 0, upd8_ ? 768 - 256 : 0))) return r;
+        if ((r = conv(corflo_, 256, L256, ND, h8_, w8_, 3, 3, 1, convm_, hx_ + mot, Lhx, ACT_RELU, 0, nullptr, &dup, 0, 0, upd8_ ? 768 - mot : 0))) return r;
         tic(F_ELT, 0, 0);
         r = launch_put_flow(stream, flow_, hx_, hx2_, rows, Lhx, upd8_ ? 768 : 0, s8, mot + 126);
         toc();
@@ -517,9 +524,12 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
             const int kh = half == 0 ? 1 : 5, kw = half == 0 ? 5 : 1;
             const int gc = hoist_ ? 256 : 384;               // channels the per-iteration convolutions read: [h | motion] (+ inp without the hoist)
             ConvFuse fz; fz.gru_h = h32_; fz.gru_rh = hx2_; fz.gru_ld = Lhx; fz.add2 = hoist_ ? gz_[half] + rows * 256 : nullptr;
-            if ((r = conv(hx_, gc, Lhx, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_GRU_ZR, 0, hoist_ ? gz_[half] : nullptr, &fz, 0, 0, upd8_ ? 768 : 0))) return r;
+            // (upd8_: the fp8 copy of the [h | motion] slice starts 384 halfs after the pixel's first channel - conv()'s a8_rel - and the
+            // epilogues store the new copies of r * h / h at byte 768 of the row)
+            const int a8 = upd8_ && hoist_ ? 384 : 0;
+            if ((r = conv(hx_, gc, Lhx, ND, h8_, w8_, kh, kw, 1, zr_[half], zrb_, 256, ACT_GRU_ZR, 0, hoist_ ? gz_[half] : nullptr, &fz, 0, a8, upd8_ ? 768 : 0))) return r;
             ConvFuse fq; fq.gru_h = h32_; fq.gru_z = zrb_; fq.add2 = hoist_ ? gq_[half] + rows * Lhx : nullptr;
-            if ((r = conv(hx2_, gc, Lhx, ND, h8_, w8_, kh, kw, 1, q_[half], hx_, Lhx, ACT_GRU_Q, 0, hoist_ ? gq_[half] : nullptr, &fq, 0, 0, upd8_ ? 768 : 0))) return r;
+            if ((r = conv(hx2_, gc, Lhx, ND, h8_, w8_, kh, kw, 1, q_[half], hx_, Lhx, ACT_GRU_Q, 0, hoist_ ? gq_[half] : nullptr, &fq, 0, a8, upd8_ ? 768 : 0))) return r;
         }
         // FlowHead -> delta_flow (fp32), coords1 += delta (the h slice's fp8 copy sits 384 halfs after it)
         if ((r = conv(hx_, 128, Lhx, ND, h8_, w8_, 3, 3, 1, fh1_, fh_, 256, ACT_RELU, 0, nullptr, nullptr, 0, upd8_ ? 384 : 0))) return r;

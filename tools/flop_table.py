@@ -1,7 +1,7 @@
 """Per-launch algorithmic FLOPs / bytes of the bench's GEMM-shaped launches, from the layer shapes alone,
 so that bench.py's `roofline.flop_per_launch` and per-family totals can be re-derived by hand.  A bench family is
 `<band>/<kernel symbol as rocprofv3 prints it>`; the symbol of a layer follows from launch_gemm's rule (csrc/gemm.hip): the 256 x 256
-ping-pong kernel when N % 256 == 0 and there are >= 256 tiles, the 256 x 64 tile for N <= 64 (round 3: the halo-tiled direct kernel for the
+ping-pong kernel when N % 256 == 0 (or, round 4, >= 192) and there are >= 256 tiles, the 256 x 64 tile for N <= 64 (round 3: the halo-tiled direct kernel for the
 3x3 64 -> 64 layers on mx3 maps), else the 128 x 128 tile; the last
 template parameter says whether the launch carries MX-fp8 residual tiles (split mode; always false in the f16 mode).
 FLOPs = 2 M N K of the layer (real channels: padding and the residual passes not counted); bytes = A once + W once + output once.
@@ -24,6 +24,8 @@ def symbol(amode, epi, M, N, mx, halo=False):
     if epi == PATCH:                                     # engine.hip launches the patch embed on the 128 x 128 tile
         return f"gemm_kernel<128, 128, 2, 2, 0, 4, true, 2, {m}>"
     if N % 256 == 0 and (M // 256) * (N // 256) >= 256:
+        return f"gemm8_kernel<{amode}, {epi}, 0, true, {m}>"
+    if epi == STD and N % 256 >= 192 and (M // 256) * ((N + 255) // 256) >= 256:      # round 4: N = 192 (RAFT convc2) on the wide tile (PB_TILE_WIDE)
         return f"gemm8_kernel<{amode}, {epi}, 0, true, {m}>"
     if epi == STD and N <= 64:
         if halo:                                         # 3x3, 64 -> 64, stride 1 on mx3 maps: the halo-tiled direct kernel (halo_conv.hip)
@@ -112,20 +114,22 @@ for l, (a, b) in enumerate(lv):
     add("flow", "corr_volume_kernel", f"correlation volume level {l} (per pair; volume.hip, row stride {vol_stride(a, b)})", Pp, a * b, 256, pairs)
 Mu = pairs * Pp
 it = 12
-add("flow", (CONV, STD), "convc1 1x1 324->256 (a 1 x 1 conv launch on the channel slice)", Mu, 256, 324, it, mx=False)
-add("flow", (CONV, STD), "convc2 3x3 256->192", Mu, 192, 9 * 256, it, mx=False)
-add("flow", (DENSE, STD), "convf1 7x7 2->128 (im2col GEMM)", Mu, 128, 98, it, mx=False)
-add("flow", (CONV, STD), "convf2 3x3 128->64", Mu, 64, 9 * 128, it, mx=False)
-add("flow", (CONV, STD), "motion conv 3x3 256->126", Mu, 126, 9 * 256, it, mx=False)
+add("flow", (CONV, STD), "convc1 1x1 324->256 (a 1 x 1 conv launch on the channel slice)", Mu, 256, 324, it)
+add("flow", (CONV, STD), "convc2 3x3 256->192", Mu, 192, 9 * 256, it)
+add("flow", (DENSE, STD), "convf1 7x7 2->128 (im2col GEMM)", Mu, 128, 98, it)
+add("flow", (CONV, STD), "convf2 3x3 128->64", Mu, 64, 9 * 128, it)
+add("flow", (CONV, STD), "motion conv 3x3 256->126", Mu, 126, 9 * 256, it)
+# (round 4: the update block's maps carry e4m3 copies and its launches MX residual tiles - PB_MX_UPD, default on; the once-per-call context
+# shares below and the fp32-output mask.2 keep two fp16 passes)
 # round 3, context hoist (raft_engine.hip load()): the context features' 128 of the GRU's 384 input channels do not change over the
 # iterations - their share of every gate is computed once per call, the per-iteration convolutions read [h | motion] (256 channels)
 add("flow", (CONV, STD), "GRU z|r context share 1x5 / 5x1 128->256 (once per call)", Mu, 256, 5 * 128, 2, mx=False)
 add("flow", (CONV, STD), "GRU q context share 1x5 / 5x1 128->128 (once per call)", Mu, 128, 5 * 128, 2, mx=False)
-add("flow", (CONV, STD), "GRU z|r 1x5 / 5x1 [h | motion] 256->256", Mu, 256, 5 * 256, 2 * it, mx=False)
-add("flow", (CONV, STD), "GRU q 1x5 / 5x1 [r h | motion] 256->128", Mu, 128, 5 * 256, 2 * it, mx=False)
-add("flow", (CONV, STD), "flow head conv1 3x3 128->256", Mu, 256, 9 * 128, it, mx=False)
+add("flow", (CONV, STD), "GRU z|r 1x5 / 5x1 [h | motion] 256->256", Mu, 256, 5 * 256, 2 * it)
+add("flow", (CONV, STD), "GRU q 1x5 / 5x1 [r h | motion] 256->128", Mu, 128, 5 * 256, 2 * it)
+add("flow", (CONV, STD), "flow head conv1 3x3 128->256", Mu, 256, 9 * 128, it)
 add("flow", "flow_head2_kernel<true>", "flow head conv2 3x3 256->2 (direct kernel)", Mu, 2, 9 * 256, it)
-add("flow", (CONV, STD), "mask.0 3x3 128->256 (last iteration)", Mu, 256, 9 * 128, mx=False)
+add("flow", (CONV, STD), "mask.0 3x3 128->256 (last iteration)", Mu, 256, 9 * 128)
 add("flow", (DENSE, F32), "mask.2 1x1 256->576", Mu, 576, 256, out_b=4, mx=False)
 
 
