@@ -32,6 +32,10 @@ class RaftEngine : public EngineBase {
     int prepare(int F, int H, int W, float scale, int dirs);
     Enc fnet_, cnet_;
     PackedW convc1_, convc2_, convf1_, convf2_, convm_, zr_[2], q_[2], fh1_, fh2_, mk0_, mk2_;
+    // convf1 as a direct kernel on the fp32 flow field (raft_kernels.hip convf1_kernel; PB_CONVF1_DIRECT=0: im2col + GEMM as in rounds 1-3)
+    f16 *f1w_ = nullptr;
+    int f1_passes_ = 1;
+    bool f1_direct_ = true;
     // context hoist (raft_engine.hip load()): zr_ / q_ then cover [h | motion] only, zr_in_ / q_in_ the context features' 128 channels
     PackedW zr_in_[2], q_in_[2];
     int hoist_ = 0;

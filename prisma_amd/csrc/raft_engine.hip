@@ -139,6 +139,18 @@ int RaftEngine::load(const pb_tensor *w, int n) {
             for (int c = 0; c < 2; ++c)
                 for (int tp = 0; tp < 49; ++tp) g[(size_t)o * 98 + tp * 2 + c] = wt[((size_t)o * 2 + c) * 49 + tp];
         if ((r = pack(g.data(), 128, 98, 128, convf1_, (const float *)ib->second->data))) return r;
+        {
+            const char *e = getenv("PB_CONVF1_DIRECT");
+            f1_direct_ = !(e && e[0] == '0');
+            f1_passes_ = split_w_ ? 2 : 1;
+            std::vector<f16> hw((size_t)convf1_packed_halfs(f1_passes_));
+            convf1_pack(wt, f1_passes_, hw.data());
+            void *pw = nullptr;
+            PB_HIP(hipMalloc(&pw, hw.size() * 2));
+            owned_.push_back(pw);
+            PB_HIP(hipMemcpy(pw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+            f1w_ = (f16 *)pw;
+        }
     }
     // Context hoist (default; PB_GRU_HOIST=0 turns it off): the GRU's input is cat(h, inp, motion) and `inp` - the context
     // features - does not change over the iterations (raft.py:112-115, update.py:131).  A convolution is linear in its input channels, so
@@ -505,11 +517,19 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
         // store the fp8 copy too (o8 = its byte offset from the output row: 2 Ctot - slice offset) and the MX segments read it
         if ((r = conv(corr_, 384, Lhx, ND, h8_, w8_, 1, 1, 1, convc1_, c1_, L256, ACT_RELU, 0, nullptr, nullptr, 0, 0, upd8_ ? 512 : 0))) return r;
         if ((r = conv(c1_, 256, L256, ND, h8_, w8_, 3, 3, 1, convc2_, corflo_, L256, ACT_RELU, 0, nullptr, nullptr, 0, 0, upd8_ ? 512 : 0))) return r;
-        tic(F_ELT, 0, 0);
-        r = launch_im2col7_flow(stream, flow_, ND, h8_, w8_, fa_, 128, L128, upd8_);
-        toc();
-        if (r) return r;
-        if ((r = dense(fa_, L128, rows, convf1_, f1_, L128, ACT_RELU, nullptr, upd8_ ? 256 : 0, 0))) return r;     // flow is in pixels: its fp8 copy is unscaled
+        if (f1_direct_) {
+            tic(F_CONV, 2.0 * rows * 128.0 * 98.0, 8.0 * rows + 256.0 * rows, (double)f1_passes_);
+            r = launch_convf1(stream, flow_, f1w_, convf1_.bias, f1_, rows, P_, h8_, w8_, L128, upd8_ ? 256 : 0, (float)(1 << kMx2Pa), f1_passes_);
+            if (timer.enabled && !r) timer.recs[open_.back()].name = "convf1_kernel";
+            toc();
+            if (r) return r;
+        } else {
+            tic(F_ELT, 0, 0);
+            r = launch_im2col7_flow(stream, flow_, ND, h8_, w8_, fa_, 128, L128, upd8_);
+            toc();
+            if (r) return r;
+            if ((r = dense(fa_, L128, rows, convf1_, f1_, L128, ACT_RELU, nullptr, upd8_ ? 256 : 0, 0))) return r;     // flow is in pixels: its fp8 copy is unscaled
+        }
         if ((r = conv(f1_, 128, L128, ND, h8_, w8_, 3, 3, 1, convf2_, corflo_ + 192, L256, ACT_RELU, 0, nullptr, nullptr, 0, 0, upd8_ ? 512 - 192 : 0))) return r;
         // HX = [h | inp | motion] feeds the z / r convs, HX2 = [r * h | inp | motion] the q conv: the motion features are
         // written to both by the producing conv (its ReLU'd second output), r * h and the state update by the GRU epilogues

@@ -22,6 +22,11 @@ int launch_corr_tile(hipStream_t s, const f16 *x, f16 *y, int F, int h, int w, i
 int launch_corr_volume(hipStream_t s, const f16 *A, int M, const f16 *W, int N, int w_rows, f16 *out, int64_t ldo);
 int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], const int w[4], const int wp[4], const int ld[4],
                        const float *flow, int P, int w8, f16 *out, int64_t rows, int ldo = 384, int o8_off = 0, float o8_scale = 16.f);
+// convf1 (7 x 7, 2 -> 128, ReLU) straight from the fp32 flow field (raft_kernels.hip convf1_kernel)
+int convf1_packed_halfs(int passes);
+void convf1_pack(const float *w, int passes, f16 *dst);
+int launch_convf1(hipStream_t s, const float *flow, const f16 *wpk, const float *bias, f16 *out, int64_t rows, int P, int h8, int w8, int ldo,
+                  int o8_off, float o8_scale, int passes);
 int launch_flow_head2(hipStream_t s, const f16 *x, const f16 *w, const float *bias, float *flow, int n, int H, int W, int split = 0);
 int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows, int ld = 384, int o8_off = 0, float o8_scale = 16.f,
                     int flow_off = 382);       // flow_off: channel offset of the two flow channels inside hx / hx2

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void corr_tile_kernel(const f16 *__restrict__ 
     *(f16x8 *)(y + ((int64_t)f * npad + row) * 256 + c * 8) = o;
 }
 
-struct PyrPtrs { const f16 *lv[4]; int h[4], w[4], wp[4], ld[4]; };
+struct PyrPtrs { const f16 *lv[4]; int h[4], w[4], wp[4], ld[4], hp8[4]; };      // hp8 = ld / wp: padded target rows of the level
 
 // CorrBlock.__call__ (corr.py:29-50): 9 x 9 bilinear window on each of the 4 levels around coords / 2^l, zero outside.
 // A block covers 7 pixels, i.e. 28 (pixel, level) windows:
@@ -416,12 +416,15 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const floa
     for (int idx = t; idx < 28 * 33; idx += 256) {
         const int seg = idx % 3, row = (idx / 3) % 11, pl = idx / 33, l = pl & 3, pr = pl >> 2;
         const int64_t r = r0 + pr < rows ? r0 + pr : rows - 1;
-        const int hp8 = py.ld[l] / py.wp[l], wt = py.wp[l] >> 3;
+        const int hp8 = py.hp8[l], wt = py.wp[l] >> 3;
         const int y = ci[pl * 18 + 9] + row, tx = (ci[pl * 18] >> 3) + seg;
         f16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
-        if ((unsigned)y < (unsigned)hp8 && (unsigned)tx < (unsigned)wt)
+        // the third segment is only read by the blend when the window's last column + 1 reaches it, i.e. when the first column sits on the
+        // last target of its tile (1 window in 8): skipping it otherwise takes a quarter of the kernel's fetches away
+        const bool need = seg < 2 || ci[pl * 18 + 8] + 1 - (ci[pl * 18] & ~7) >= 16;
+        if (need && (unsigned)y < (unsigned)hp8 && (unsigned)tx < (unsigned)wt)
             v = *(const f16x8 *)(py.lv[l] + r * (int64_t)py.ld[l] + ((y >> 3) * wt + tx) * 64 + (y & 7) * 8);
         *(f16x8 *)(win + (pl * 11 + row) * 24 + seg * 8) = v;
     }
@@ -720,8 +723,109 @@ int launch_corr_tile(hipStream_t s, const f16 *x, f16 *y, int F, int h, int w, i
 int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], const int w[4], const int wp[4], const int ld[4],
                        const float *flow, int P, int w8, f16 *out, int64_t rows, int ldo, int o8_off, float o8_scale) {
     PyrPtrs py;
-    for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; py.wp[i] = wp[i]; py.ld[i] = ld[i]; }
+    for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; py.wp[i] = wp[i]; py.ld[i] = ld[i]; py.hp8[i] = ld[i] / wp[i]; }
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)((rows + 6) / 7)), dim3(256), 0, s, py, flow, P, w8, out, rows, ldo, o8_off, o8_scale);
+    LAUNCH_CHECK();
+}
+// BasicMotionEncoder.convf1 (update.py:88: 7 x 7, 2 -> 128, ReLU) as a direct kernel on the fp32 flow field.  As an im2col GEMM it cost a 130 MB
+// [rows, 128] operand written and read back per iteration for 14 GFLOP (im2col7 0.19 ms + GEMM 0.10 ms per launch at 31 pairs 1080p x 0.75).
+// Here a wave owns 32 consecutive pixels: the A fragments (k = tap * 2 + channel, 98 -> 112 = 7 k-steps) are gathered straight from the flow
+// field - 4.5 MB, L2 resident; lane (li, lh) needs taps 8 ks + 4 lh .. + 3 of pixel li, i.e. four 8-byte loads per k-step - and rounded to fp16
+// exactly as the GEMM path's operand was; the weights [w_hi | w_lo] (fp16 pair, `passes` = 2 in the split mode) sit in the LDS for the
+// kernel's lifetime, rows interleaved (LDS row g * 64 + tn * 32 + li <-> channel g * 64 + 2 li + tn) so a lane owns two adjacent channels and half
+// a wave stores one contiguous 128-byte line per pixel.  Output as the GEMM epilogue's: relu(v + bias) as fp16 (+ its e4m3 copy at byte o8_off).
+constexpr int F1_LD = 120;                     // halfs per weight row in the LDS (240 bytes: 16-byte fragment reads of 16 lanes hit 64 distinct banks)
+__global__ __launch_bounds__(256, 2) void convf1_kernel(const float *__restrict__ flow, const f16 *__restrict__ wpk, const float *__restrict__ bias,
+                                                         f16 *__restrict__ out, int64_t rows, int P, int h8, int w8, int ldo, int o8_off, float o8_scale,
+                                                         int passes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int nw16 = passes * 128 * F1_LD / 8;                         // 16-byte chunks of the packed weights
+    for (int i = tid; i < nw16; i += 256) ((f16x8 *)smem)[i] = ((const f16x8 *)wpk)[i];
+    __syncthreads();
+    // taps of this lane's fragment chunk: t = 8 ks + 4 lh + e -> (ky, kx) offsets relative to the pixel, 49.. = padding
+    float b2[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) { b2[g][0] = bias[g * 64 + 2 * li]; b2[g][1] = bias[g * 64 + 2 * li + 1]; }
+    const int64_t ntiles = (rows + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (tid >> 6); tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t m = tile * 32 + li;
+        const int64_t mc = m < rows ? m : rows - 1;
+        const int64_t n = mc / P;
+        const int rem = (int)(mc - n * P), y = rem / w8, x = rem - y * w8;
+        const float *fb = flow + n * P * 2;
+        f16x8 a[7];
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            f32x2 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = 8 * ks + 4 * lh + e;
+                const int ky = (t * 37) >> 8, kx = t - 7 * ky;          // t / 7 for t < 64
+                const int iy = y + ky - 3, ix = x + kx - 3;
+                const bool ok = t < 49 && (unsigned)iy < (unsigned)h8 && (unsigned)ix < (unsigned)w8;
+                const f32x2 z = {0.f, 0.f};
+                v[e] = ok ? *(const f32x2 *)(fb + ((int64_t)iy * w8 + ix) * 2) : z;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[ks][2 * e] = (f16)v[e][0]; a[ks][2 * e + 1] = (f16)v[e][1]; }
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int ps = 0; ps < passes; ++ps) {
+            const char *wb = smem + ps * 128 * F1_LD * 2 + li * (F1_LD * 2) + lh * 16;
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f16x8 b = *(const f16x8 *)(wb + j * 32 * (F1_LD * 2) + ks * 32);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], b, acc[j], 0, 0, 0);
+                }
+        }
+        // acc[g * 2 + tn][r]: pixel (r & 3) + 8 (r >> 2) + 4 lh of the tile, channel g * 64 + 2 li + tn
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t mr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (mr < rows) {
+                f16 *row = out + mr * ldo;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    f16x2 o;
+                    o[0] = (f16)fmaxf(acc[g * 2][r] + b2[g][0], 0.f); o[1] = (f16)fmaxf(acc[g * 2 + 1][r] + b2[g][1], 0.f);
+                    *(f16x2 *)(row + g * 64 + 2 * li) = o;
+                    if (o8_off) *(unsigned short *)((char *)row + o8_off + g * 64 + 2 * li) = pb_fp8x2((float)o[0] * o8_scale, (float)o[1] * o8_scale);
+                }
+            }
+        }
+    }
+}
+
+int convf1_packed_halfs(int passes) { return passes * 128 * F1_LD; }
+// host side of the layout above: w [128][2][7][7] fp32 -> [pass][LDS row][F1_LD] fp16 (pass 0: hi, pass 1: the fp16 rounding residual)
+void convf1_pack(const float *w, int passes, f16 *dst) {
+    for (int i = 0; i < passes * 128 * F1_LD; ++i) dst[i] = (f16)0.f;
+    for (int row = 0; row < 128; ++row) {
+        const int g = row >> 6, tn = (row >> 5) & 1, l = row & 31, ch = g * 64 + 2 * l + tn;
+        for (int c = 0; c < 2; ++c)
+            for (int tp = 0; tp < 49; ++tp) {
+                const float v = w[((size_t)ch * 2 + c) * 49 + tp];
+                const f16 hi = (f16)v;
+                dst[(size_t)row * F1_LD + tp * 2 + c] = hi;
+                if (passes > 1) dst[(size_t)(128 + row) * F1_LD + tp * 2 + c] = (f16)(v - (float)hi);
+            }
+    }
+}
+int launch_convf1(hipStream_t s, const float *flow, const f16 *wpk, const float *bias, f16 *out, int64_t rows, int P, int h8, int w8, int ldo,
+                  int o8_off, float o8_scale, int passes) {
+    const int smem = passes * 128 * F1_LD * 2;
+    static bool attr = false;
+    if (!attr) { PB_HIP(hipFuncSetAttribute((const void *)convf1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * F1_LD * 2)); attr = true; }
+    const int64_t ntiles = (rows + 31) / 32;
+    const int grid = (int)std::min<int64_t>((ntiles + 3) / 4, 512);
+    hipLaunchKernelGGL(convf1_kernel, dim3(grid), dim3(256), smem, s, flow, wpk, bias, out, rows, P, h8, w8, ldo, o8_off, o8_scale, passes);
     LAUNCH_CHECK();
 }
 int launch_put_flow(hipStream_t s, const float *flow, f16 *hx, f16 *hx2, int64_t rows, int ld, int o8_off, float o8_scale, int flow_off) {

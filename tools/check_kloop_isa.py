@@ -37,8 +37,34 @@ def check(path, quiet=False):
     return bad
 
 
+def acc_shuffles(path):
+    """Round 4: every MX build of the generic GEMM tile carried its accumulators across the K loop's back edge in VGPRs and copied all 64 of
+    them into the AGPRs and back each K tile (64 v_accvgpr_read + 128 v_accvgpr_write per 24 MFMAs; two tile kinds as branches of ONE loop did
+    it) - invisible in the resource remarks, 15-25 % of those kernels' time.  Returns [(symbol, mfmas, moves)] for every loop (backward branch
+    span) of under 1000 lines that holds MFMAs and at least twice as many accumulator moves; a tile loop that contains a whole epilogue (the
+    halo kernels) is longer and reads each accumulator once, which is not this."""
+    out = []
+    for name, body in kernels(path):
+        labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"\.LBB\d+_\d+:", l)}
+        worst = None
+        for i, l in enumerate(body):
+            m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+            if not m or labels.get(m.group(1), i) >= i:
+                continue
+            seg = body[labels[m.group(1)]:i + 1]
+            nm, na = sum("v_mfma" in x for x in seg), sum("v_accvgpr" in x for x in seg)
+            if nm and len(seg) < 1000 and na >= 2 * nm and (worst is None or na > worst[2]):
+                worst = (name, nm, na)
+        if worst:
+            out.append(worst)
+    return out
+
+
 if __name__ == "__main__":
     allbad = []
     for p in sys.argv[1:]:
         allbad += check(p)
+        for sym, nm, na in acc_shuffles(p):
+            print(f"{sym}: {na} accumulator moves beside {nm} MFMAs in one loop")
+            allbad.append(sym)
     sys.exit(1 if allbad else 0)

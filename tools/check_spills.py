@@ -44,6 +44,9 @@ isa = sorted(glob.glob(os.path.join(bdir, "gemm_i*-gfx950.s")))
 for f in isa:
     for sym in check_kloop_isa.check(f, quiet=True):
         bad.append((sym, "scratch access between the first and last MFMA (%s)" % os.path.basename(f)))
+for f in sorted(glob.glob(os.path.join(bdir, "*-gfx950.s"))):
+    for sym, nm, na in check_kloop_isa.acc_shuffles(f):
+        bad.append((sym, "%d accumulator moves beside %d MFMAs in one loop (%s): the accumulators cross the back edge in VGPRs" % (na, nm, os.path.basename(f))))
 if not isa:
     bad.append(("gemm_i*.hip", "no ISA files under %s: the Makefile keeps them with -save-temps=obj" % bdir))
 if bad:

@@ -116,7 +116,7 @@ Mu = pairs * Pp
 it = 12
 add("flow", (CONV, STD), "convc1 1x1 324->256 (a 1 x 1 conv launch on the channel slice)", Mu, 256, 324, it)
 add("flow", (CONV, STD), "convc2 3x3 256->192", Mu, 192, 9 * 256, it)
-add("flow", (DENSE, STD), "convf1 7x7 2->128 (im2col GEMM)", Mu, 128, 98, it)
+add("flow", "convf1_kernel", "convf1 7x7 2->128 (direct kernel on the fp32 flow field, round 4)", Mu, 128, 98, it)
 add("flow", (CONV, STD), "convf2 3x3 128->64", Mu, 64, 9 * 128, it)
 add("flow", (CONV, STD), "motion conv 3x3 256->126", Mu, 126, 9 * 256, it)
 # (round 4: the update block's maps carry e4m3 copies and its launches MX residual tiles - PB_MX_UPD, default on; the once-per-call context
