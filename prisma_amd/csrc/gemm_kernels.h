@@ -1705,7 +1705,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 
     if constexpr (AMODE == A_CONV) {                     // the K walk of the launch (conv_ktab_entry), once per workgroup
         for (int t = tid; t < nk; t += 512) ((unsigned *)(smem + 2 * BUF))[t] = conv_ktab_entry(p, cld, t);
-        __syncthreads();
+        __syncthreads();                                 // (moving this barrier behind the tile set-up measured slower: start -> loop 9.9k -> 11.7k cycles, r04w)
     }
     int vb = blockIdx.x;
     setup(p, vb);
@@ -1857,11 +1857,13 @@ int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
         int dev = 0;
         PB_HIP(hipGetDevice(&dev));
         PB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        // default OFF: measured on the final epilogues (profiles/r04f_gemm8_phase_cycles.log) a one-tile workgroup is as fast or faster -
-        // fc1 45.1k against 46.9k cycles per tile, proj 77.7k against 81.6k: what a persistent workgroup saves in front of the K loop (the
-        // prefetched first DMAs) it pays inside the epilogue, whose own loads (bias, skip tensors, GRU state) wait behind those DMAs on
-        // the one in-order vmcnt counter.  The loop stays selectable (PB_GEMM_PERSIST=1) with its switches.
-        persist = pb_env_int("PB_GEMM_PERSIST", 0);
+        // default ON since the end of round 4.  History: on the first straight-line epilogues the per-tile stamps had a one-tile workgroup as
+        // fast or faster (profiles/r04f_gemm8_phase_cycles.log: fc1 45.1k against 46.9k cycles per tile, proj 77.7k against 81.6k - what a
+        // persistent workgroup saves in front of the K loop it pays inside the epilogue, whose own loads wait behind the prefetched DMAs on the
+        // one in-order vmcnt counter) and the bench saw no difference; on the final tree the bench does (r04w, alternating on one box:
+        // 120.55 -> 121.17 frames/s; proj + fc2 28.2 -> 27.6 ms, the update block's convolutions 35.5 -> 34.9, fc1 19.5 -> 19.4) although a
+        // tile's own stamps are still ~3 % longer: launch ramp and tail, which the stamps do not see, shrink.  PB_GEMM_PERSIST=0: one workgroup per tile.
+        persist = pb_env_int("PB_GEMM_PERSIST", 1);
         prefetch = pb_env_int("PB_GEMM_PREFETCH", 1);
     }
     GemmArgs b = a;
