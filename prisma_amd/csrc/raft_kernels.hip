@@ -371,7 +371,22 @@ __global__ __launch_bounds__(256) void corr_tile_kernel(const f16 *__restrict__ 
     *(f16x8 *)(y + ((int64_t)f * npad + row) * 256 + c * 8) = o;
 }
 
-struct PyrPtrs { const f16 *lv[4]; int h[4], w[4], wp[4], ld[4], hp8[4]; };      // hp8 = ld / wp: padded target rows of the level
+struct PyrPtrs { const f16 *lv[4]; int h[4], w[4], wp[4], ld[4], hp8[4]; };
+// a per-LANE level index into the kernel-argument arrays above compiles to loads from the kernarg segment (and a wait for every load in flight
+// in front of each use); four-way selects on the scalar registers keep the level's geometry out of memory
+// (as bit selects: nested ?: on the lane's level became exec-masked branches)
+__device__ __forceinline__ unsigned sel4u(unsigned a0, unsigned a1, unsigned a2, unsigned a3, int l) {
+    const unsigned m1 = 0u - (unsigned)(l & 1), m2 = 0u - (unsigned)((l >> 1) & 1);
+    const unsigned lo = (a0 & ~m1) | (a1 & m1), hi = (a2 & ~m1) | (a3 & m1);
+    return (lo & ~m2) | (hi & m2);
+}
+__device__ __forceinline__ int sel4(const int (&a)[4], int l) { return (int)sel4u((unsigned)a[0], (unsigned)a[1], (unsigned)a[2], (unsigned)a[3], l); }
+__device__ __forceinline__ const f16 *sel4(const f16 *const (&a)[4], int l) {
+    const unsigned long long p0 = (unsigned long long)a[0], p1 = (unsigned long long)a[1], p2 = (unsigned long long)a[2], p3 = (unsigned long long)a[3];
+    const unsigned lo = sel4u((unsigned)p0, (unsigned)p1, (unsigned)p2, (unsigned)p3, l);
+    const unsigned hi = sel4u((unsigned)(p0 >> 32), (unsigned)(p1 >> 32), (unsigned)(p2 >> 32), (unsigned)(p3 >> 32), l);
+    return (const f16 *)(((unsigned long long)hi << 32) | lo);
+}      // hp8 = ld / wp: padded target rows of the level
 
 // CorrBlock.__call__ (corr.py:29-50): 9 x 9 bilinear window on each of the 4 levels around coords / 2^l, zero outside.
 // A block covers 7 pixels, i.e. 28 (pixel, level) windows:
@@ -391,42 +406,64 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(PyrPtrs py, const floa
     __shared__ float ca[28 * 18];
     const int t = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * 7;
-    for (int idx = t; idx < 28 * 18; idx += 256) {
-        const int k = idx % 18, pl = idx / 18, l = pl & 3, pr = pl >> 2;
-        const int64_t r = r0 + pr < rows ? r0 + pr : rows - 1;
-        const int p = (int)(r % P);
-        const float inv = 1.f / (float)(1 << l);
-        float v;
-        if (k < 9) {
-            const float cx = (float)(p % w8) + flow[r * 2];
-            const int w = py.w[l];
-            // reproduce grid_sample's round trip: normalise then un-normalise (align_corners=True)
-            v = ((2.f * (cx * inv + (float)(k - 4)) / (float)(w - 1) - 1.f) + 1.f) * 0.5f * (float)(w - 1);
-        } else {
-            const float cy = (float)(p / w8) + flow[r * 2 + 1];
-            const int h = py.h[l];
-            v = ((2.f * (cy * inv + (float)(k - 13)) / (float)(h - 1) - 1.f) + 1.f) * 0.5f * (float)(h - 1);
+    {   // two coordinates per thread; both flow loads are issued before either is used (one round trip instead of two to four)
+        f32x2 fl[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = t + 256 * u, idc = idx < 28 * 18 ? idx : 0;
+            const int pr = (idc / 18) >> 2;
+            const int64_t r = r0 + pr < rows ? r0 + pr : rows - 1;
+            fl[u] = *(const f32x2 *)(flow + r * 2);
         }
-        const float f = floorf(v);
-        // far out-of-range samples are all zero anyway: clamp so that the integer arithmetic below cannot overflow
-        ci[idx] = (int)fminf(fmaxf(f, -65536.f), 65536.f);
-        ca[idx] = v - f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = t + 256 * u, idc = idx < 28 * 18 ? idx : 0;
+            const int k = idc % 18, pl = idc / 18, l = pl & 3, pr = pl >> 2;
+            const int64_t r = r0 + pr < rows ? r0 + pr : rows - 1;
+            const int p = (int)((unsigned)r % (unsigned)P);           // rows < 2^31 (launcher check): a 32-bit remainder, not the 64-bit library one
+            const float inv = 1.f / (float)(1 << l);
+            const bool isx = k < 9;
+            // x samples k = 0..8 around column p % w8, y samples k = 9..17 around row p / w8; the same expression for both
+            const float c = (float)(isx ? p % w8 : p / w8) + (isx ? fl[u][0] : fl[u][1]);
+            const int dim = isx ? sel4(py.w, l) : sel4(py.h, l);
+            // reproduce grid_sample's round trip: normalise then un-normalise (align_corners=True)
+            const float v = ((2.f * (c * inv + (float)(isx ? k - 4 : k - 13)) / (float)(dim - 1) - 1.f) + 1.f) * 0.5f * (float)(dim - 1);
+            const float f = floorf(v);
+            if (idx < 28 * 18) {
+                // far out-of-range samples are all zero anyway: clamp so that the integer arithmetic below cannot overflow
+                ci[idx] = (int)fminf(fmaxf(f, -65536.f), 65536.f);
+                ca[idx] = v - f;
+            }
+        }
     }
     __syncthreads();
-    for (int idx = t; idx < 28 * 33; idx += 256) {
-        const int seg = idx % 3, row = (idx / 3) % 11, pl = idx / 33, l = pl & 3, pr = pl >> 2;
-        const int64_t r = r0 + pr < rows ? r0 + pr : rows - 1;
-        const int hp8 = py.hp8[l], wt = py.wp[l] >> 3;
-        const int y = ci[pl * 18 + 9] + row, tx = (ci[pl * 18] >> 3) + seg;
-        f16x8 v;
+    // all of a thread's (up to four) window loads are issued before the first one is consumed: as a plain loop every iteration waited for its
+    // own load in front of its LDS store - four HBM round trips in a row per block (round 4: the kernel moved 1.3 TB/s with 24 waves per CU)
+    {
+        f16x8 wv[4];
+        int wdst[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
-        // the third segment is only read by the blend when the window's last column + 1 reaches it, i.e. when the first column sits on the
-        // last target of its tile (1 window in 8): skipping it otherwise takes a quarter of the kernel's fetches away
-        const bool need = seg < 2 || ci[pl * 18 + 8] + 1 - (ci[pl * 18] & ~7) >= 16;
-        if (need && (unsigned)y < (unsigned)hp8 && (unsigned)tx < (unsigned)wt)
-            v = *(const f16x8 *)(py.lv[l] + r * (int64_t)py.ld[l] + ((y >> 3) * wt + tx) * 64 + (y & 7) * 8);
-        *(f16x8 *)(win + (pl * 11 + row) * 24 + seg * 8) = v;
+        for (int u = 0; u < 4; ++u) {
+            const int idx = t + 256 * u;
+            const int idc = idx < 28 * 33 ? idx : 0;
+            const int seg = idc % 3, row = (idc / 3) % 11, pl = idc / 33, l = pl & 3, pr = pl >> 2;
+            const int64_t r = r0 + pr < rows ? r0 + pr : rows - 1;
+            const int hp8 = sel4(py.hp8, l), wt = sel4(py.wp, l) >> 3;
+            const int y = ci[pl * 18 + 9] + row, tx = (ci[pl * 18] >> 3) + seg;
+            // the third segment is only read by the blend when the window's last column + 1 reaches it, i.e. when the first column sits on the
+            // last target of its tile (1 window in 8): skipping it otherwise takes a quarter of the kernel's fetches away
+            const bool need = seg < 2 || ci[pl * 18 + 8] + 1 - (ci[pl * 18] & ~7) >= 16;
+            const bool ok = idx < 28 * 33 && need && (unsigned)y < (unsigned)hp8 && (unsigned)tx < (unsigned)wt;
+            // branch-free: an out-of-range window row reads the level's first 16 bytes and is zeroed afterwards (zeros = padding_mode='zeros')
+            const f16 *src = sel4(py.lv, l) + (ok ? r * (int64_t)sel4(py.ld, l) + ((y >> 3) * wt + tx) * 64 + (y & 7) * 8 : 0);
+            const f16x8 ld = *(const __attribute__((address_space(1))) f16x8 *)(unsigned long long)src;      // (a global, not a flat load: the pointer went through integers)
+            const f16x8 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+            wv[u] = ok ? ld : z;
+            wdst[u] = idx < 28 * 33 ? (pl * 11 + row) * 24 + seg * 8 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (wdst[u] >= 0) *(f16x8 *)(win + wdst[u]) = wv[u];
     }
     __syncthreads();
     if (t < 252) {
@@ -724,6 +761,7 @@ int launch_corr_lookup(hipStream_t s, const f16 *const lv[4], const int h[4], co
                        const float *flow, int P, int w8, f16 *out, int64_t rows, int ldo, int o8_off, float o8_scale) {
     PyrPtrs py;
     for (int i = 0; i < 4; ++i) { py.lv[i] = lv[i]; py.h[i] = h[i]; py.w[i] = w[i]; py.wp[i] = wp[i]; py.ld[i] = ld[i]; py.hp8[i] = ld[i] / wp[i]; }
+    PB_CHECK(rows < (1LL << 31), -1, "corr_lookup: %lld rows", (long long)rows);
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)((rows + 6) / 7)), dim3(256), 0, s, py, flow, P, w8, out, rows, ldo, o8_off, o8_scale);
     LAUNCH_CHECK();
 }
