@@ -10,9 +10,6 @@ namespace {
 // reference: nn.LayerNorm(eps=1e-6) in dinov2 blocks (block.py:82-107) and the final norm
 // applied to the 4 taps (vision_transformer.py:297-321).
 // ------------------------------------------------------------------------------------------------
-// PRE (PB_LN_PRELOAD=1, prepared at the end of round 4 and NOT yet measured): the gain / bias vectors are requested together with the row instead of
-// inside the output loop, where each of their loads sat behind both reductions and a vmcnt(0) (ISA audit); same arithmetic.
-template <bool PRE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                         const float *__restrict__ bt, f16 *__restrict__ y, int B,
                                                         int ntp, int ntok, int D, float eps, int drop_cls, int ldy,
@@ -25,14 +22,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     const float *xr = x + ((int64_t)b * ntp + t) * D;
     f16 *yr = drop_cls ? y + ((int64_t)b * (ntok - 1) + (t - 1)) * ldy : y + ((int64_t)b * ntp + t) * ldy;
     f32x4 v[4];
-    f32x4 pg[PRE ? 4 : 1], pb[PRE ? 4 : 1];
-    if constexpr (PRE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = lane * 4 + 256 * j;
-            if (c < D) { pg[j] = *(const f32x4 *)(g + c); pb[j] = *(const f32x4 *)(bt + c); }
-        }
-    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -60,9 +49,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     for (int j = 0; j < 4; ++j) {
         const int c = lane * 4 + 256 * j;
         if (c < D) {
-            f32x4 gg, bb;
-            if constexpr (PRE) { gg = pg[j]; bb = pb[j]; }
-            else { gg = *(const f32x4 *)(g + c); bb = *(const f32x4 *)(bt + c); }
+            const f32x4 gg = *(const f32x4 *)(g + c), bb = *(const f32x4 *)(bt + c);
             f16x4 o, l;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -466,12 +453,8 @@ inline unsigned nblk(int64_t n, int t = 256) { return (unsigned)((n + t - 1) / t
 int launch_layernorm(hipStream_t s, const float *x, const float *g, const float *b, f16 *y, int B, int ntp, int ntok,
                      int D, float eps, int drop_cls, int ldy, int lo_off, int o8_off, float o8_scale, int lo8_pa) {
     PB_CHECK(D % 4 == 0 && D <= 1024, -1, "layernorm: D=%d unsupported", D);
-    static int pre = -1;
-    if (pre < 0) pre = pb_env_int("PB_LN_PRELOAD", 0);
-    if (pre) hipLaunchKernelGGL(layernorm_kernel<true>, dim3(nblk((int64_t)B * ntok, 4)), dim3(256), 0, s, x, g, b, y, B, ntp, ntok,
-                                D, eps, drop_cls, ldy ? ldy : D, lo_off, o8_off, o8_scale, lo8_pa);
-    else hipLaunchKernelGGL(layernorm_kernel<false>, dim3(nblk((int64_t)B * ntok, 4)), dim3(256), 0, s, x, g, b, y, B, ntp, ntok,
-                            D, eps, drop_cls, ldy ? ldy : D, lo_off, o8_off, o8_scale, lo8_pa);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(nblk((int64_t)B * ntok, 4)), dim3(256), 0, s, x, g, b, y, B, ntp, ntok,
+                       D, eps, drop_cls, ldy ? ldy : D, lo_off, o8_off, o8_scale, lo8_pa);
     PB_HIP(hipGetLastError());
     return 0;
 }
