@@ -394,36 +394,11 @@ template <int EPI, int TN>
 __host__ __device__ constexpr bool epi_interleaved() {
     return TN == 2 && (EPI == EPI_STD || EPI == EPI_QKV || EPI == EPI_PIXSHUF || EPI == EPI_RESID);
 }
-// implicit-GEMM convolution staging: which taps of a pixel lie inside the image, as bits - bit ky: input row iy0 + ky, bit 8 + kx: input
-// column ix0 + kx (kernels up to 8 x 8).  The K loop tests a tap with one AND + one compare against the scalar (1 << ky) | (256 << kx).
-__device__ __forceinline__ unsigned tap_range(int v0, int n) {          // bits t of [0, 8) with 0 <= v0 + t < n
-    const int lo = v0 < 0 ? -v0 : 0, hi = n - 1 - v0 < 7 ? n - 1 - v0 : 7;
-    return (hi >= lo && lo < 8) ? (((2u << (hi & 7)) - 1u) & ~((1u << (lo & 7)) - 1u)) : 0u;
-}
-__device__ __forceinline__ unsigned tap_mask(int iy0, int ix0, int H, int W) { return tap_range(iy0, H) | (tap_range(ix0, W) << 8); }
-
-// ... and the K walk of a convolution as a table in the LDS, one word per K tile, built once per workgroup: the tile's tap (ky, kx) in bits
-// [0, 6) and, above them, the byte offset / 16 of (tap, channel slice) relative to the pixel's tap (0, 0).  Both K orders (gemm.h cTapInner),
-// the split-fp16 wrap (kwrap / kshift) and the clamp past the last tile are in the table, so the K loop pays one broadcast ds_read, one
-// v_readfirstlane and five scalar instructions per K tile instead of the ~30 scalar instructions of a branch-free cursor step PER A HALF
-// (round 4, per-tile stamps: the 3 x 3 / 1 x 5 convolutions of the RAFT update block ran 3260 cycles per K tile against the dense GEMM's 2320 -
-// the ping-pong schedule has no room for ~100 extra instructions per K tile in the loading wave group's slots).
+#include "conv_walk.h"      // tap_range / tap_mask / conv_ktab_word / ktab_bytes / ktab_sel: plain C++, also compiled on the host by tests/test_conv_walk_cpu.py
 constexpr int KTAB_BYTES = 2048;                                          // K <= 512 tiles (checked by the launchers)
 __device__ __forceinline__ unsigned conv_ktab_entry(const GemmArgs &p, int cld, int t) {
-    int ky, kx, c0;
-    if (p.cTapInner) {
-        const int per = p.cKH * p.cKW, sl = t / per, tp = t - sl * per;
-        ky = tp / p.cKW; kx = tp - ky * p.cKW; c0 = sl * 64;
-    } else {
-        const int cpt = p.cC >> 6, tp = t / cpt;
-        ky = tp / p.cKW; kx = tp - ky * p.cKW; c0 = (t - tp * cpt) * 64;
-    }
-    const int cs = (p.kwrap && c0 >= p.kwrap) ? c0 + p.kshift : c0;
-    const unsigned bytes = (unsigned)(((ky * p.cW + kx) * cld + cs) * 2);
-    return ((bytes >> 4) << 6) | (unsigned)(ky << 3) | (unsigned)kx;
+    return conv_ktab_word(p.cTapInner, p.cKH, p.cKW, p.cC, p.cW, cld, p.kwrap, p.kshift, t);
 }
-__device__ __forceinline__ unsigned ktab_bytes(unsigned e) { return (e >> 6) << 4; }
-__device__ __forceinline__ unsigned ktab_sel(unsigned e) { return (1u << ((e >> 3) & 7)) | (256u << (e & 7)); }
 
 __device__ __forceinline__ int col_map(int r, bool il) {        // tile-local B row -> tile-local output column
     return il ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;
