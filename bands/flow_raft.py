@@ -225,6 +225,8 @@ def main(argv=None):
     ap.add_argument("--iterations", help="number of iterations", type=int, default=ITERATIONS)
     ap.add_argument("--model", "-m", help="model path", type=str, default=MODEL)
     ap.add_argument("--scale", type=float, default=0.75, help="scale factor")
+    # reference :184: parsed and never read (init_model loads args.model, :40) - accepted so a reference command line runs unchanged
+    ap.add_argument("--raft_model", default="models/raft-things.pth", help="[RAFT] restore checkpoint (unused by the reference as well)")
     ap.add_argument("--small", action="store_true", help="use small model")
     ap.add_argument("--mixed_precision", action="store_true", help="use mixed precision")
     ap.add_argument("--alternate_corr", action="store_true", help="use efficent correlation implementation")

@@ -339,10 +339,15 @@ def band_sdf(masks_u8: np.ndarray) -> np.ndarray:
     """getSDF + the green-channel store of the band (bands/mask_mmdet.py:64-69,150-152): uint8 HxWx3 id image -> the image the
     band writes with --sdf.  snowy 0.0.9 (rgb_to_luminance, generate_sdf) is absent from the build container - parity unpinned for
     it - so the signed distance is restated as scipy's exact Euclidean distance transform: distance to the mask outside it minus
-    distance to the background inside it; the remap, clip, x 255 and uint8 truncation are the reference's float64 expressions."""
+    distance to the background inside it; the remap, clip, x 255 and uint8 truncation are the reference's float64 expressions.
+    When one class is empty snowy's unsigned transform keeps its INF = 1e20 start value (distance 1e10, the remap saturates: G = 0 on a
+    frame without a mask, 255 on an all-mask frame); scipy's feature transform would answer as if a pixel sat at (row -1, column 0)."""
     from scipy.ndimage import distance_transform_edt
     inside = masks_u8[..., :3].astype(np.float64).mean(-1) != 0.0
-    sdf = distance_transform_edt(~inside) - distance_transform_edt(inside)
+    if not inside.any() or inside.all():
+        sdf = np.full(inside.shape, -1.0e10 if inside.all() else 1.0e10)
+    else:
+        sdf = distance_transform_edt(~inside) - distance_transform_edt(inside)
     sdf = (sdf + 127.0) / 255.0
     sdf = (sdf - 0.25) * 2.0
     sdf = 1.0 - np.clip(sdf, 0.0, 1.0)

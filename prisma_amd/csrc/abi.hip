@@ -649,6 +649,7 @@ int pb_op_gemm_bench(pb_ctx *c, int M, int N, int K, int tile, int epi, int iter
         if (epi == 12) { g.cKW = 5; g.cPad = 0; g.cPadX = 2; g.cKH = 1; }
         else { g.cKW = 3; g.cPad = 1; g.cKH = 3; g.cTapInner = epi == 11; }
     }
+    g.ablate = pb_env_int("PB_GEMM_ABL", 0);       // timing-only epilogue ablations (wrong results): this tool op only, never an engine launch
     hipEvent_t e0, e1;
     PB_HIP(hipEventCreate(&e0)); PB_HIP(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i) PB_TRY(launch_gemm(c->stream, amode, e, tile, g));

@@ -1844,9 +1844,7 @@ int launch_g8_impl(hipStream_t stream, const GemmArgs &a) {
     GemmArgs b = a;
     b.ntiles = tilesM * tilesN;
     b.prefetch = prefetch;
-    static int ablate = -1;
-    if (ablate < 0) ablate = pb_env_int("PB_GEMM_ABL", 0);
-    b.ablate = ablate;
+    // b.ablate: timing-only switch of the microbenchmark op (pb_op_gemm_bench reads PB_GEMM_ABL); engine launches leave it 0
     static int ratomic = -1;
     if (ratomic < 0) ratomic = pb_env_int("PB_RESID_ATOMIC", 0);
     b.resid_atomic = EPI == EPI_RESID ? ratomic : 0;

@@ -581,8 +581,9 @@ int launch_sigmoid_rows(hipStream_t s, const float *logit, int64_t ld, const int
 // alone.  The host tabulates that function with the reference's own float64 expression (prisma_amd/engine.py sdf_tables); the two
 // kernels below compute the exact integer n of the Euclidean distance transform inside a +-64 window: a column scan for the vertical
 // distance to the nearest pixel of either class, then per pixel the minimum of dx^2 + g(x + dx)^2 over the row.  Bytes equal the host
-// restatement's (scipy distance_transform_edt) on every frame, including the degenerate ones: with no pixel of the other class in
-// the frame scipy's feature transform answers as if one sat at (row -1, column 0), and so does sdf_rows_kernel.
+// restatement's on every frame.  Degenerate frames (no pixel of the other class anywhere) follow the reference's snowy.generate_sdf: its
+// unsigned transform starts from INF = 1e20, so the distance is ~1e10 and the remap saturates - G = 0 on a frame without a mask, 255 on
+// an all-mask frame (scipy's feature transform would instead answer as if a pixel sat at (row -1, column 0)).
 enum { SDF_R = 64, SDF_FAR = 255 };
 
 __global__ __launch_bounds__(256) void sdf_columns_kernel(const uint8_t *__restrict__ masks, uint8_t *__restrict__ gm, uint8_t *__restrict__ gb,
@@ -632,10 +633,7 @@ __global__ __launch_bounds__(256) void sdf_rows_kernel(uint8_t *__restrict__ mas
     const uint8_t *g = in ? sb : sm;                               // distances to the OTHER class
     const int inside_px = cnt[f];
     int best = ncap;
-    if (in ? inside_px == H * W : inside_px == 0) {
-        const int64_t v = (int64_t)(y + 1) * (y + 1) + (int64_t)x * x;      // scipy's answer when the other class is empty
-        best = v < ncap ? (int)v : ncap;
-    } else {
+    if (!(in ? inside_px == H * W : inside_px == 0)) {                // other class empty: saturated (snowy's INF), best stays ncap
 #pragma unroll 4
         for (int dx = -SDF_R; dx <= SDF_R; ++dx) {
             const int gv = g[threadIdx.x + SDF_R + dx];

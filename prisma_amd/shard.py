@@ -117,7 +117,7 @@ class Relay:
             box = [None]
             if ranks.main:
                 out_dir = os.path.dirname(os.path.abspath(out_path))
-                base = os.environ.get("PRISMA_SPOOL") or _pick_spool_base(out_dir, est_bytes, self.max_chunks)
+                base = os.environ.get("PRISMA_SPOOL") or _pick_spool_base(out_dir, est_bytes)
                 name = "prisma_spool.%s.%s" % (os.path.basename(out_path), uuid.uuid4().hex[:12])
                 box = [(os.path.join(base, name), os.path.join(out_dir, name), os.getpid())]
                 _sweep_stale_spools(base)
@@ -126,9 +126,9 @@ class Relay:
             dist.broadcast_object_list(box, src=0)
             self.dir, self.dir2, owner = box[0]
             os.makedirs(self.dir, exist_ok=True)
+            self._owner = owner
             if ranks.main:
-                with open(os.path.join(self.dir, "owner.%d" % owner), "w") as f:
-                    f.write("%d\n" % owner)
+                _write_owner(self.dir, owner)
 
     def _path(self, start: int, fallback: bool = False) -> str:
         import os
@@ -148,15 +148,29 @@ class Relay:
                 pass
             raise
 
+    def _check_abort(self):
+        """rank 0's drain failed: it left an `abort` file so that producers blocked in put() / close() fail with its message
+        instead of waiting out the relay timeout while rank 0 sits in the gather."""
+        import os
+        p = os.path.join(self.dir, "abort")
+        if os.path.exists(p):
+            try:
+                msg = open(p).read().strip()
+            except OSError:
+                msg = "?"
+            raise RuntimeError(f"rank 0 aborted the relay: {msg}")
+
     def put(self, start: int, arrays: dict):
         """rank > 0: publish the chunk whose first unit (frame / pair index) is `start`."""
         import os
         import time
+        self._check_abort()
         if self.max_chunks > 0:
             t0 = time.time()
             while sum(os.path.exists(p) for p in self._mine) >= self.max_chunks:
                 if time.time() - t0 > self.timeout:
                     raise TimeoutError(f"rank 0 did not consume rank {self.rk.rank}'s chunks within {self.timeout:.0f} s")
+                self._check_abort()
                 time.sleep(0.005)
             self._mine = [p for p in self._mine if os.path.exists(p)]
         path = self._path(start)
@@ -169,6 +183,7 @@ class Relay:
             import sys
             print(f"[prisma] rank {self.rk.rank}: spool {self.dir} refused chunk {start} ({e}); falling back to {self.dir2}", file=sys.stderr)
             os.makedirs(self.dir2, exist_ok=True)
+            _write_owner(self.dir2, self._owner)       # the fallback directory names its owner too: a sweep must not take it for a dead run's
             path = self._path(start, True)
             self._write(path, arrays)
         self._mine.append(path)
@@ -205,8 +220,19 @@ class Relay:
                     self.drain(*self._pending)
                 except BaseException as e:      # noqa: BLE001 - re-raised by drain_end
                     self._thread_err = e
+                    self._abort(e)              # producers blocked in put() must not wait for a consumer that is gone
             self._thread = threading.Thread(target=work, name="relay-drain", daemon=True)
             self._thread.start()
+
+    def _abort(self, err):
+        import os
+        try:
+            tmp = os.path.join(self.dir, "abort.tmp")
+            with open(tmp, "w") as f:
+                f.write("%s: %s\n" % (type(err).__name__, err))
+            os.replace(tmp, os.path.join(self.dir, "abort"))
+        except OSError:
+            pass
 
     def drain_end(self):
         """rank 0, AFTER the scalar gather: finishes (bounded) or runs (unbounded) the drain."""
@@ -237,6 +263,7 @@ class Relay:
             while not os.path.exists(done):
                 if time.time() - t0 > self.timeout:
                     raise TimeoutError(f"rank 0 did not finish muxing within {self.timeout:.0f} s")
+                self._check_abort()
                 time.sleep(0.02)
         import torch.distributed as dist
         dist.barrier()                       # short: every rank is past its file wait
@@ -247,7 +274,18 @@ class Relay:
                 shutil.rmtree(self.dir2, ignore_errors=True)
 
 
-def _pick_spool_base(out_dir: str, est_bytes: int, max_chunks: int) -> str:
+def _write_owner(d: str, pid: int):
+    """owner.<pid> holding `<host> <pid>`: who may be asked whether this spool is still in use (_sweep_stale_spools)."""
+    import os
+    import socket
+    p = os.path.join(d, "owner.%d" % pid)
+    if not os.path.exists(p):
+        with open(p + ".tmp", "w") as f:
+            f.write("%s %d\n" % (socket.gethostname(), pid))
+        os.replace(p + ".tmp", p)
+
+
+def _pick_spool_base(out_dir: str, est_bytes: int) -> str:
     """/dev/shm when it is writable and has room for what the run may park there, else the output's folder.  With an
     unknown estimate (0) a tmpfs is only trusted when it has 1 GiB free - Docker's default 64 MB /dev/shm never is."""
     import os
@@ -264,28 +302,52 @@ def _pick_spool_base(out_dir: str, est_bytes: int, max_chunks: int) -> str:
     return shm if free >= max(need, floor) else out_dir
 
 
-def _sweep_stale_spools(base: str, min_age_s: float = 600.0):
-    """Remove `prisma_spool.*` directories under `base` left by a crashed run: the owner file names rank 0's pid; a directory whose
-    owner is dead (or that has no owner file) and that nobody touched for ten minutes is nobody's."""
+def _sweep_stale_spools(base: str, min_age_s: float = 600.0, unknown_age_s: float = 86400.0):
+    """Remove `prisma_spool.*` directories under `base` left by a crashed run.  The owner file names rank 0's host and pid: a
+    directory whose owner is a dead process OF THIS HOST and in which nothing changed for ten minutes is nobody's.  A directory with no
+    owner file, or one written on another host (output folders are often shared file systems, and `kill(pid, 0)` only speaks for this
+    host's pid namespace), is presumed alive and only swept after a day without a change.  Age = the newest mtime of the
+    directory and of the files in it - chunks waiting for rank 0 do not touch the directory entry."""
     import glob
     import os
     import shutil
+    import socket
     import time
+    host = socket.gethostname()
     for d in glob.glob(os.path.join(base, "prisma_spool.*")):
         try:
-            if not os.path.isdir(d) or time.time() - os.path.getmtime(d) < min_age_s:
+            if not os.path.isdir(d):
                 continue
-            alive = False
-            for o in glob.glob(os.path.join(d, "owner.*")):
+            newest = os.path.getmtime(d)
+            for e in os.scandir(d):
                 try:
-                    os.kill(int(o.rsplit(".", 1)[1]), 0)
+                    newest = max(newest, e.stat().st_mtime)
+                except OSError:
+                    pass
+            age = time.time() - newest
+            if age < min_age_s:
+                continue
+            alive = unknown = False
+            owners = glob.glob(os.path.join(d, "owner.*"))
+            owners = [o for o in owners if not o.endswith(".tmp")]
+            if not owners:
+                unknown = True
+            for o in owners:
+                try:
+                    txt = open(o).read().split()
+                    pid = int(o.rsplit(".", 1)[1])
+                    if len(txt) >= 2 and txt[0] != host:
+                        unknown = True              # another host's run: cannot ask
+                        continue
+                    os.kill(pid, 0)
                     alive = True
-                except PermissionError:         # somebody else's live process
+                except PermissionError:             # somebody else's live process
                     alive = True
                 except (OSError, ValueError):
                     pass
-            if not alive:
-                shutil.rmtree(d, ignore_errors=True)
+            if alive or (unknown and age < unknown_age_s):
+                continue
+            shutil.rmtree(d, ignore_errors=True)
         except OSError:
             pass
 

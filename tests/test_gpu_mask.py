@@ -263,6 +263,8 @@ def test_sdf_green_matches_the_restatement(tiny, H, W, n):
         got = net.sdf_green(m)
     finally:
         net.set_sdf(False)
+    # degenerate frames saturate like snowy's INF-initialised transform: no corner gradient
+    assert (got[n, ..., 1] == 0).all() and (got[n + 1, ..., 1] == 255).all()
     for f in range(len(m)):
         want = SO.band_sdf(m[f])
         bad = int((got[f] != want).sum())

@@ -173,3 +173,6 @@ def test_band_sdf_restatement_and_tables():
     n_in = np.rint(distance_transform_edt(inside) ** 2).astype(np.int64)
     want = np.where(inside, ti[np.minimum(n_in, SDF_NTAB - 1)], to[np.minimum(n_out, SDF_NTAB - 1)])
     assert np.array_equal(want, img[..., 1])
+    # degenerate frames: snowy.generate_sdf keeps its INF = 1e20 start value when a class is empty, the remap saturates
+    assert (SO.band_sdf(np.zeros((40, 50, 3), np.uint8))[..., 1] == 0).all()
+    assert (SO.band_sdf(np.full((40, 50, 3), 255, np.uint8))[..., 1] == 255).all()

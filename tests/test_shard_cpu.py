@@ -194,20 +194,80 @@ def test_spool_base_and_stale_sweep(tmp_path, monkeypatch):
     out_dir = str(tmp_path)
     free = shutil.disk_usage("/dev/shm").free if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else 0
     if free:
-        assert shard._pick_spool_base(out_dir, free * 2, 0) == out_dir                    # too big for the tmpfs
-        assert shard._pick_spool_base(out_dir, 1 << 20, 0) == ("/dev/shm" if free > (80 << 20) else out_dir)
+        assert shard._pick_spool_base(out_dir, free * 2) == out_dir                    # too big for the tmpfs
+        assert shard._pick_spool_base(out_dir, 1 << 20) == ("/dev/shm" if free > (80 << 20) else out_dir)
         monkeypatch.setenv("PRISMA_SPOOL_MIN_FREE", str(free * 2))
-        assert shard._pick_spool_base(out_dir, 1 << 20, 0) == out_dir
-    dead, live, fresh = tmp_path / "prisma_spool.a.1", tmp_path / "prisma_spool.a.2", tmp_path / "prisma_spool.a.3"
-    for d in (dead, live, fresh):
-        d.mkdir()
-    (dead / "owner.999999999").write_text("x")           # no such pid
-    (dead / "chunk_000000000.npz").write_text("x")
-    (live / ("owner.%d" % os.getpid())).write_text("x")
-    old = __import__("time").time() - 3600
-    os.utime(dead, (old, old)); os.utime(live, (old, old))
+        assert shard._pick_spool_base(out_dir, 1 << 20) == out_dir
+    # an owner file names host + pid; a directory without one (a run's fallback directory used to have none) or written on
+    # another host is presumed alive until a day has passed; the age is the newest mtime INSIDE the directory (waiting chunks)
+    import socket as _socket
+    host = _socket.gethostname()
+    names = ("dead", "live", "fresh", "noowner", "foreign", "busy", "ancient")
+    d = {k: tmp_path / ("prisma_spool.a.%d" % i) for i, k in enumerate(names)}
+    for v in d.values():
+        v.mkdir()
+    (d["dead"] / "owner.999999999").write_text("%s 999999999\n" % host)           # no such pid on this host
+    (d["dead"] / "chunk_000000000.npz").write_text("x")
+    (d["live"] / ("owner.%d" % os.getpid())).write_text("%s %d\n" % (host, os.getpid()))
+    (d["foreign"] / "owner.999999999").write_text("some-other-host 999999999\n")
+    (d["busy"] / "owner.999999999").write_text("%s 999999999\n" % host)
+    (d["busy"] / "chunk_000000004.npz").write_text("x")                             # written just now: the directory is in use
+    (d["ancient"] / "chunk_000000000.npz").write_text("x")                          # no owner, untouched for two days
+    now = __import__("time").time()
+    for k, age in (("dead", 3600), ("live", 3600), ("noowner", 3600), ("foreign", 3600), ("busy", 3600), ("ancient", 2 * 86400)):
+        for f in [d[k]] + [e for e in d[k].iterdir() if not (k == "busy" and e.name.startswith("chunk"))]:
+            os.utime(f, (now - age, now - age))
     shard._sweep_stale_spools(str(tmp_path))
-    assert not dead.exists() and live.exists() and fresh.exists()
+    left = {k for k, v in d.items() if v.exists()}
+    assert left == {"live", "fresh", "noowner", "foreign", "busy"}, left
+
+
+def _abort_worker(rank, world, port, out_path, q):
+    import torch.distributed as dist      # noqa: F401
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      PRISMA_DIST_BACKEND="gloo", PRISMA_SPOOL_MAX_CHUNKS="1")
+    rk = shard.Ranks()
+    relay = shard.Relay(rk, out_path, timeout_s=120)
+    if rk.main:
+        def bad_write(s, c):
+            raise IOError("VideoWriter died at chunk %d" % s)
+        relay.drain_begin(8, 2, bad_write)          # the drain thread fails on the first chunk it gets
+        relay._thread.join(60)
+        q.put(("main", type(relay._thread_err).__name__, os.path.exists(os.path.join(relay.dir, "abort"))))
+    else:
+        import time
+        t0 = time.time()
+        try:
+            for s in (4, 6):                          # bound of one chunk: the second put() blocks until rank 0 consumes - or aborts
+                relay.put(s, {"rgb": np.zeros((2, 4, 4, 3), np.uint8)})
+            q.put(("producer", "no error", time.time() - t0))
+        except RuntimeError as e:
+            q.put(("producer", str(e), time.time() - t0))
+    import shutil
+    import torch.distributed as dist
+    dist.barrier()
+    if rk.main:
+        shutil.rmtree(relay.dir, ignore_errors=True)
+    dist.destroy_process_group()
+
+
+def test_failed_drain_aborts_the_producers(tmp_path):
+    """in bounded-spool mode a drain thread that raises used to leave the producers blocked in put() until the relay timeout
+    (6 h by default); now it leaves an `abort` file that put() / close() poll."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_abort_worker, args=(r, 2, port, str(tmp_path / "band.npy"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((k, (a, b)) for k, a, b in (q.get(timeout=120), q.get(timeout=120)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got["main"] == ("OSError", True)
+    assert "aborted the relay" in got["producer"][0] and "VideoWriter died" in got["producer"][0] and got["producer"][1] < 60
 
 
 def test_two_concurrent_relays_do_not_share_a_spool(tmp_path, monkeypatch):

@@ -28,8 +28,9 @@ for r, n in zip(rows, names):
     # the persistent ping-pong kernel (round 4) is one loop body of set-up, K loop and epilogue to the register allocator: a few spills
     # around the epilogue are the price of keeping the next tile's set-up out of the K loop's registers - allowed up to 48 VGPRs as long as
     # the ISA shows none of them between the kernel's first and last MFMA (checked below); every other GEMM kernel: none
-    # (the flat-addressed builds - 4th template argument false - are the fallback for operands beyond a buffer resource's 4 GB: 96)
-    lim = (48 if re.match(r"gemm8_kernel<\d+, \d+, \d+, true", n) else 96) if "gemm8_kernel" in n else 2
+    # (the flat-addressed builds - 4th template argument false - are the fallback for operands beyond a buffer resource's 4 GB).
+    # Limits = the measured values of the committed tree (15 buffer-addressed, 25 flat: build/resource_usage.txt) plus a small margin
+    lim = (20 if re.match(r"gemm8_kernel<\d+, \d+, \d+, true", n) else 32) if "gemm8_kernel" in n else 2
     if ("gemm8_kernel" in n or "gemm_kernel" in n) and r.get("vspill", 0) > lim:
         bad.append((n, "%d VGPRs spilled" % r.get("vspill")))
     # the 128 x 128 / 256 x 64 / 256 x 32 tiles are built to run TWO workgroups per CU (4 waves each, <= 256 registers per lane), the ping-pong
