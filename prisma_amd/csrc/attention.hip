@@ -45,9 +45,19 @@ struct AttnArgs {
 // the matrix pipe never waits for an LDS round trip (without it hipcc keeps one fragment in flight to save registers).
 // NW waves per workgroup (4 or 8): 32 * NQB * NW query rows share one K / Vt stream, so the LDS-DMA instructions per
 // wave and tile (the issue cost of which is ~15 % of the loop at NW = 4) go down as 8 / NW.
-template <int NQB, int OCC, int ABL = 0, bool PF = false, int NW = 4>
+// NBUF = 3 (round 5, the schedule of attention128.hip): three K / Vt buffers, tile t + 2 requested at the top of tile t, ONE counted
+// `s_waitcnt vmcnt` per tile that leaves the newest stage in flight, and a bare `s_barrier` (__syncthreads() drains vmcnt and with it
+// the stage the loop is trying to keep in flight).  NBUF = 2 is the round-1 loop: vmcnt(0) + __syncthreads() per tile, one tile ahead.
+#define ATT_BAR()                               \
+    do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
+        asm volatile("s_barrier" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+
+template <int NQB, int OCC, int ABL = 0, bool PF = false, int NW = 4, int NBUF = 2>
 __global__ __launch_bounds__(64 * NW, OCC) void attnq_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // 2 x (K tile 8 KB + Vt tile 8 KB)
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 16384];   // NBUF x (K tile 8 KB + Vt tile 8 KB)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -69,6 +79,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void attnq_kernel(const AttnArgs p) {
         const int qrc = qrow[qb] < p.ntp ? qrow[qb] : p.ntp - 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[qb][s] = *(const f16x8 *)(Q + (int64_t)qrc * 64 + 16 * s + 8 * lh);
+    }
+    if constexpr (NBUF == 3) {
+        // pin the Q loads here: the compiler's wait for them at their first use INSIDE the loop would (loads return in order) also
+        // drain the DMA stages the loop keeps in flight
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[qb][s]));
     }
 
     constexpr int CH = 8 / NW;                               // 16-byte chunks of K (and of Vt) per thread and tile
@@ -119,13 +137,28 @@ __global__ __launch_bounds__(64 * NW, OCC) void attnq_kernel(const AttnArgs p) {
 
     const int nt = (p.ntok + 63) >> 6;
     stage(0, 0);
+    if constexpr (NBUF == 3) stage(1, nt > 1 ? 1 : 0);
+    int bcur = 0;                                            // NBUF = 3: buffer of tile t
     for (int t = 0; t < nt; ++t) {
-        if constexpr (ABL != 5) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        const char *sK;
+        if constexpr (NBUF == 3) {
+            // tile t has landed when at most the newer stage's 2 CH DMAs are outstanding (nothing else is in flight); the stage issued
+            // below overwrites the buffer tile t - 1 was read from, which every wave has left once it is past the barrier
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
+            ATT_BAR();
+            int bn = bcur + 2;
+            bn = bn >= 3 ? bn - 3 : bn;
+            stage(bn, t + 2 < nt ? t + 2 : nt - 1);          // (past the end: a valid tile again, so the wait count stays uniform)
+            sK = smem + bcur * 16384;
+            bcur = bcur == 2 ? 0 : bcur + 1;
+        } else {
+            if constexpr (ABL != 5) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            if constexpr (ABL != 4 && ABL != 5) stage((t + 1) & 1, t + 1 < nt ? t + 1 : t);
+            sK = smem + (t & 1) * 16384;
         }
-        if constexpr (ABL != 4 && ABL != 5) stage((t + 1) & 1, t + 1 < nt ? t + 1 : t);
-        const char *sK = smem + (t & 1) * 16384;
         const char *sV = sK + 8192;
 
         // ---- S^T = K Q^T - m, keys >= ntok pushed to -30000 (2^-30000 = 0) by the same extra k-step: the K-side
@@ -245,6 +278,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attnq_kernel(const AttnArgs p) {
             }
     }
 
+    if constexpr (NBUF == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two stages past the end
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         const float ltot = lrun[qb] + __shfl_xor(lrun[qb], 32);
@@ -275,9 +309,10 @@ int launch_attention(hipStream_t stream, const f16 *q, const f16 *k, const f16 *
     if (env_variant < 0) { const char *e = getenv("PB_ATTN_VARIANT"); env_variant = e ? atoi(e) : 0; }
     if (variant <= 0) variant = env_variant;
     // variants (tools/attn_bench.py): 0 default = 8 waves x 1 block; 2 = 4 waves x 1 block; 3 = 4 waves x 2 blocks;
-    // 4 = 4 waves x 1 block with fragment prefetch; 5 = 8 waves x 2 blocks; 11 .. 16 = ablations 1 .. 6 of variant 2
-    const int nqb = variant == 3 || variant == 5 ? 2 : 1;
-    const int nw = variant == 0 || variant == 1 || variant == 5 ? 8 : 4;
+    // 4 = 4 waves x 1 block with fragment prefetch; 5 = 8 waves x 2 blocks; 11 .. 16 = ablations 1 .. 6 of variant 2;
+    // 6 = 8 waves x 1 block on three buffers (round 5), 7 = 8 waves x 2 blocks on three buffers; 21 / 23 = ablations 1 / 3 of variant 6
+    const int nqb = variant == 3 || variant == 5 || variant == 7 ? 2 : 1;
+    const int nw = variant == 0 || variant == 1 || variant == 5 || variant == 6 || variant == 7 || variant == 21 || variant == 23 ? 8 : 4;
     const int nq = (ntok + 32 * nw * nqb - 1) / (32 * nw * nqb);
     AttnArgs a{q, k, vt, o, ntp, ntok, heads, ldo, nq, B, o8_off, o8_scale};
     dim3 grid(8 * nq * ((B * heads + 7) / 8));
@@ -287,6 +322,11 @@ int launch_attention(hipStream_t stream, const f16 *q, const f16 *k, const f16 *
     case 3: hipLaunchKernelGGL((attnq_kernel<2, 2, 0, false, 4>), grid, dim3(256), 0, stream, a); break;
     case 4: hipLaunchKernelGGL((attnq_kernel<1, 3, 0, true, 4>), grid, dim3(256), 0, stream, a); break;
     case 5: hipLaunchKernelGGL((attnq_kernel<2, 1, 0, false, 8>), grid, dim3(512), 0, stream, a); break;
+    // (the second launch-bound argument is waves per SIMD: 4 = two 8-wave workgroups per CU, i.e. at most 128 registers)
+    case 6: hipLaunchKernelGGL((attnq_kernel<1, 4, 0, false, 8, 3>), grid, dim3(512), 0, stream, a); break;
+    case 7: hipLaunchKernelGGL((attnq_kernel<2, 2, 0, false, 8, 3>), grid, dim3(512), 0, stream, a); break;
+    case 21: hipLaunchKernelGGL((attnq_kernel<1, 4, 1, false, 8, 3>), grid, dim3(512), 0, stream, a); break;
+    case 23: hipLaunchKernelGGL((attnq_kernel<1, 4, 3, false, 8, 3>), grid, dim3(512), 0, stream, a); break;
     case 11: hipLaunchKernelGGL((attnq_kernel<1, 4, 1, false, 4>), grid, dim3(256), 0, stream, a); break;
     case 12: hipLaunchKernelGGL((attnq_kernel<1, 4, 2, false, 4>), grid, dim3(256), 0, stream, a); break;
     case 13: hipLaunchKernelGGL((attnq_kernel<1, 4, 3, false, 4>), grid, dim3(256), 0, stream, a); break;
