@@ -7,7 +7,8 @@ enum { EPI_STD = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_PIXSHUF = 3, EPI_PATCH = 4, 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4,
        ACT_GRU_ZR = 5,     // N = 256 = [z | r]: z = sigmoid -> out; r = sigmoid, r * gru_h -> gru_rh (ld 384), nothing to out
        ACT_GRU_Q = 6 };    // N = 128: q = tanh; h = (1 - z) h + z q with z from gru_z (ld 256), h in gru_h (fp32, ld 128); h -> out
-enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256x64 = 9 };      // (4, 5, 7, 8, 10: round-1 variants, measured slower, removed)
+enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256x64 = 9,       // (4, 5, 7, 8, 10: round-1 variants, measured slower, removed)
+       TILE_256x128 = 11 };   // round 5: the ping-pong schedule for N <= 128 (gemm_n128.h; EPI_STD only)
 
 struct GemmArgs {
     // operands: A row-major fp16 [M, lda] (dense) or NHWC image (conv); W fp16 [Npad, K], K % 64 == 0

@@ -21,6 +21,11 @@ int pb_gemm_conv_pixshuf_f16(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_pixshuf_mx(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_head_f16(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_head_mx(hipStream_t s, int tile, const GemmArgs &a);
+// gemm_i7.hip: the 256 x 128 ping-pong kernel (gemm_n128.h), EPI_STD
+int pb_gemm_n128_dense_f16(hipStream_t s, const GemmArgs &a);
+int pb_gemm_n128_dense_mx(hipStream_t s, const GemmArgs &a);
+int pb_gemm_n128_conv_f16(hipStream_t s, const GemmArgs &a);
+int pb_gemm_n128_conv_mx(hipStream_t s, const GemmArgs &a);
 
 static thread_local const char *g_last_kernel = "";
 const char *pb_gemm_last_kernel() { return g_last_kernel; }
@@ -56,6 +61,10 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         static int n64_tile = -1;
         if (n64_tile < 0) { const char *e = getenv("PB_TILE_N64"); n64_tile = e ? atoi(e) : TILE_256x64; }
         if (tile == TILE_128 && epi == EPI_STD && a.N <= 64 && n64_tile != TILE_128) tile = n64_tile;
+        // 64 < N <= 128 with enough rows to fill the chip: the 256 x 128 ping-pong kernel (gemm_n128.h).  PB_TILE_N128=<min tiles>, 0 = off
+        static int n128_min = -1;
+        if (n128_min < 0) { const char *e = getenv("PB_TILE_N128"); n128_min = e ? atoi(e) : 0; }
+        if (tile == TILE_128 && epi == EPI_STD && n128_min > 0 && a.N > 64 && a.N <= 128 && (a.M + 255) / 256 >= n128_min) tile = TILE_256x128;
         static int small_tile = -1;
         if (small_tile < 0) { const char *e = getenv("PB_TILE_SMALL"); small_tile = e ? atoi(e) : TILE_128; }
         if (tile == TILE_128 && (epi == EPI_STD || epi == EPI_F32) && small_tile != TILE_128) tile = small_tile;
@@ -66,6 +75,11 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
     // MX builds write / read split maps with e4m3 residual parts, fp16-only builds with fp16 residual parts
     PB_CHECK(!a.lo_off || (a.lo8 != 0) == mx, -1, "gemm: split-map format (lo8 = %d) does not match the weights' (nk16 = %d)", a.lo8, a.nk16);
     PB_CHECK(!a.o8_off || mx, -1, "gemm: an fp8 output copy needs an MX build");
+    if (tile == TILE_256x128) {
+        PB_CHECK(epi == EPI_STD, -1, "gemm: the 256 x 128 tile is built for EPI_STD only (epilogue %d)", epi);
+        if (amode == A_DENSE) return mx ? pb_gemm_n128_dense_mx(stream, a) : pb_gemm_n128_dense_f16(stream, a);
+        return mx ? pb_gemm_n128_conv_mx(stream, a) : pb_gemm_n128_conv_f16(stream, a);
+    }
     if (amode == A_DENSE && epi == EPI_STD) return mx ? pb_gemm_dense_std_mx(stream, tile, a) : pb_gemm_dense_std_f16(stream, tile, a);
     if (amode == A_DENSE && epi == EPI_RESID) return mx ? pb_gemm_dense_resid_mx(stream, tile, a) : pb_gemm_dense_resid_f16(stream, tile, a);
     if (amode == A_DENSE && epi == EPI_QKV) return mx ? pb_gemm_dense_qkv_mx(stream, tile, a) : pb_gemm_dense_qkv_f16(stream, tile, a);

@@ -35,6 +35,9 @@ def ops():
     (256, 256, 64, 0, 2), (2448, 3072, 1024, 0, 2), (777, 512, 4096, 2, 2), (513, 64, 128, 0, 1),
     (300, 256, 128, 0, 2), (1000, 512, 192, 1, 2), (515, 768, 576, 0, 2), (4096, 1024, 640, 0, 2),
     (2448, 1024, 1024, 0, 4), (640, 256, 320, 2, 4),
+    # 256 x 128 ping-pong tile (gemm_n128.h): one K tile, ragged M / N, K tiles around the three-buffer ring's period, every activation
+    (256, 128, 64, 0, 11), (300, 128, 128, 1, 11), (1000, 96, 192, 0, 11), (2448, 128, 1024, 2, 11), (777, 384, 448, 0, 11),
+    (4096, 72, 2304, 1, 11), (515, 256, 320, 0, 11),
 ])
 def test_gemm(ops, M, N, K, act, tile):
     g = np.random.default_rng(M + N + K)
@@ -107,12 +110,13 @@ def test_conv2d(ops, B, Ci, H, W, Co, ks, stride, relu_in, relu_out):
     assert relmax(out, ref.numpy()) < 1.5e-3, relmax(out, ref.numpy())
 
 
-@pytest.mark.parametrize("tile", [2, 4])
+@pytest.mark.parametrize("tile", [2, 4, 11])
 def test_conv2d_wide_tiles(ops, tile):
     ops.set_option("conv_tile", tile)
     try:
         g = np.random.default_rng(tile)
-        for (B, Ci, H, W, Co, stride) in [(1, 256, 37, 49, 256, 1), (2, 128, 24, 40, 512, 1), (1, 320, 33, 21, 256, 2)]:
+        for (B, Ci, H, W, Co, stride) in [(1, 256, 37, 49, 256, 1), (2, 128, 24, 40, 512, 1), (1, 320, 33, 21, 256, 2), (3, 128, 19, 31, 128, 1),
+                                          (1, 64, 40, 56, 96, 2)]:
             x = h(g.standard_normal((B, Ci, H, W)))
             w = h(g.standard_normal((Co, Ci, 3, 3)) / np.sqrt(Ci * 9))
             b = g.standard_normal(Co).astype(np.float32)
