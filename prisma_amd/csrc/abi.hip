@@ -31,19 +31,23 @@ struct HostPipe {
     void *h_in[2] = {}, *h_depth[2] = {}, *h_rgb[2] = {}, *h_mm[2] = {};
     void *d_in[2] = {}, *d_depth[2] = {}, *d_rgb[2] = {}, *d_mm[2] = {};
     size_t cap_in = 0, cap_d = 0, cap_r = 0, cap_m = 0;
-    int grow(void **h, void **d, size_t &cap, size_t need) {
-        if (need <= cap) return 0;
+    // device slots always; the pinned staging halves only for callers whose own buffers are pageable (`host`)
+    int grow(void **h, void **d, size_t &cap, size_t need, bool host = true) {
+        if (need <= cap && (!host || h[0] || !need)) return 0;
+        const size_t want = need > cap ? need : cap;
         for (int i = 0; i < 2; ++i) {
-            if (h[i]) PB_HIP(hipHostFree(h[i]));
-            if (d[i]) PB_HIP(hipFree(d[i]));
-            h[i] = d[i] = nullptr;
-            PB_HIP(hipHostMalloc(&h[i], need, hipHostMallocDefault));
-            PB_HIP(hipMalloc(&d[i], need));
+            if (need > cap) {
+                if (h[i]) PB_HIP(hipHostFree(h[i]));
+                if (d[i]) PB_HIP(hipFree(d[i]));
+                h[i] = d[i] = nullptr;
+                PB_HIP(hipMalloc(&d[i], want));
+            }
+            if (host && !h[i]) PB_HIP(hipHostMalloc(&h[i], want, hipHostMallocDefault));
         }
-        cap = need;
+        cap = want;
         return 0;
     }
-    int ensure(size_t in_b, size_t d_b, size_t r_b, size_t m_b) {
+    int ensure(size_t in_b, size_t d_b, size_t r_b, size_t m_b, bool host_in = true, bool host_d = true, bool host_r = true) {
         if (!s_in) {
             PB_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
             PB_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
@@ -54,8 +58,8 @@ struct HostPipe {
             }
         }
         int r;
-        if ((r = grow(h_in, d_in, cap_in, in_b)) || (r = grow(h_depth, d_depth, cap_d, d_b)) || (r = grow(h_rgb, d_rgb, cap_r, r_b)) ||
-            (r = grow(h_mm, d_mm, cap_m, m_b)))
+        if ((r = grow(h_in, d_in, cap_in, in_b, host_in)) || (r = grow(h_depth, d_depth, cap_d, d_b, host_d)) ||
+            (r = grow(h_rgb, d_rgb, cap_r, r_b, host_r)) || (r = grow(h_mm, d_mm, cap_m, m_b)))
             return r;
         return 0;
     }
@@ -76,6 +80,64 @@ struct HostPipe {
     }
 };
 
+// The caller's buffer is page-locked host memory (hipHostMalloc / hipHostRegister / torch pin_memory): the copy engines can address it
+// directly, so the host-pointer entry points skip their own pinned staging copies (a 1080p clip of 32 frames is 199 MB each way: ~20 ms of
+// one core per memcpy, which the pipeline can only hide while a LATER chunk computes)
+static bool pb_is_pinned(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+// pb_flow_infer_sequence: the same three-stage pipeline over chunks of frame pairs (a chunk = its pairs' frames + one halo frame)
+struct FlowPipe {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_h2d[2] = {}, ev_comp[2] = {}, ev_d2h[2] = {};
+    void *h[4][2] = {}, *d[4][2] = {};        // 0 frames in, 1 flow out, 2 rgb out, 3 max displacement out
+    size_t cap[4] = {};
+    int grow(int k, size_t need, bool host) {
+        if (need <= cap[k] && (!host || h[k][0])) return 0;
+        const size_t want = need > cap[k] ? need : cap[k];
+        for (int i = 0; i < 2; ++i) {
+            if (need > cap[k]) {
+                if (d[k][i]) PB_HIP(hipFree(d[k][i]));
+                d[k][i] = nullptr;
+                PB_HIP(hipMalloc(&d[k][i], want));
+                if (h[k][i]) { PB_HIP(hipHostFree(h[k][i])); h[k][i] = nullptr; }
+            }
+            if (host && !h[k][i]) PB_HIP(hipHostMalloc(&h[k][i], want, hipHostMallocDefault));
+        }
+        cap[k] = want;
+        return 0;
+    }
+    int ensure_streams() {
+        if (s_in) return 0;
+        PB_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+        PB_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            PB_HIP(hipEventCreateWithFlags(&ev_h2d[i], hipEventDisableTiming));
+            PB_HIP(hipEventCreateWithFlags(&ev_comp[i], hipEventDisableTiming));
+            PB_HIP(hipEventCreateWithFlags(&ev_d2h[i], hipEventDisableTiming));
+        }
+        return 0;
+    }
+    void release() {
+        if (s_in) { hipStreamSynchronize(s_in); hipStreamSynchronize(s_out); }
+        for (int k = 0; k < 4; ++k)
+            for (int i = 0; i < 2; ++i) {
+                if (h[k][i]) hipHostFree(h[k][i]);
+                if (d[k][i]) hipFree(d[k][i]);
+            }
+        for (int i = 0; i < 2; ++i) {
+            if (ev_h2d[i]) hipEventDestroy(ev_h2d[i]);
+            if (ev_comp[i]) hipEventDestroy(ev_comp[i]);
+            if (ev_d2h[i]) hipEventDestroy(ev_d2h[i]);
+        }
+        if (s_in) { hipStreamDestroy(s_in); hipStreamDestroy(s_out); }
+    }
+};
+
 struct pb_ctx {
     int device = 0;
     DepthEngine *depth = nullptr;
@@ -85,7 +147,9 @@ struct pb_ctx {
     f16 *zero = nullptr;
     bool own_stream = false;
     int gemm_tile = TILE_AUTO, conv_tile = TILE_AUTO;
+    int host_chunk = 0;             // pb_set_option("host_chunk"): frames (depth) / frame pairs (flow) per chunk of the host-pointer pipelines, 0 = default
     HostPipe pipe;
+    FlowPipe fpipe;
     // pb_comm_init: RCCL communicator of the ranks (one process per GPU) for pb_gather_scalars
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -297,6 +361,7 @@ void pb_destroy(pb_ctx *c) {
     if (c->still_stream) { hipStreamSynchronize(c->still_stream); hipStreamDestroy(c->still_stream); }
     if (c->still_buf) hipFree(c->still_buf);
     c->pipe.release();
+    c->fpipe.release();
     if (c->depth) delete c->depth;
     if (c->raft) delete c->raft;
     if (c->mask) delete c->mask;
@@ -330,17 +395,19 @@ int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, 
     PB_CHECK(frames && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "infer: bad arguments");
     PB_HIP(hipSetDevice(c->device));
     const size_t px = (size_t)H * W;
-    const int cap = std::min(n, c->depth->max_batch());
+    const int cap = std::min(n, c->host_chunk > 0 ? std::min(c->host_chunk, c->depth->max_batch()) : c->depth->max_batch());
     HostPipe &hp = c->pipe;
     const size_t in_b = (size_t)cap * px * 3, d_b = depth_out ? (size_t)cap * px * 4 : 0, r_b = rgb_out ? in_b : 0,
                  m_b = (size_t)cap * 8;
-    PB_TRY(hp.ensure(in_b, d_b, r_b, m_b));
+    // page-locked caller buffers are read / written by the copy engines directly (no staging memcpy on this thread)
+    const bool pin_in = pb_is_pinned(frames), pin_d = pb_is_pinned(depth_out), pin_r = pb_is_pinned(rgb_out);
+    PB_TRY(hp.ensure(in_b, d_b, r_b, m_b, !pin_in, !pin_d, !pin_r));
     const int chunks = (n + cap - 1) / cap;
     auto finish = [&](int i) -> int {           // results of chunk i: pinned -> caller
         const int slot = i & 1, s0 = i * cap, m = std::min(cap, n - s0);
         PB_HIP(hipEventSynchronize(hp.ev_d2h[slot]));
-        if (depth_out) memcpy(depth_out + (size_t)s0 * px, hp.h_depth[slot], (size_t)m * px * 4);
-        if (rgb_out) memcpy(rgb_out + (size_t)s0 * px * 3, hp.h_rgb[slot], (size_t)m * px * 3);
+        if (depth_out && !pin_d) memcpy(depth_out + (size_t)s0 * px, hp.h_depth[slot], (size_t)m * px * 4);
+        if (rgb_out && !pin_r) memcpy(rgb_out + (size_t)s0 * px * 3, hp.h_rgb[slot], (size_t)m * px * 3);
         const float *mm = (const float *)hp.h_mm[slot];
         if (min_out) memcpy(min_out + s0, mm, (size_t)m * 4);
         if (max_out) memcpy(max_out + s0, mm + cap, (size_t)m * 4);
@@ -349,8 +416,9 @@ int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, 
     for (int i = 0; i < chunks; ++i) {
         const int slot = i & 1, s0 = i * cap, m = std::min(cap, n - s0);
         if (i >= 2) PB_TRY(finish(i - 2));       // frees this slot's pinned output and (through ev_d2h) its device buffers
-        memcpy(hp.h_in[slot], frames + (size_t)s0 * px * 3, (size_t)m * px * 3);
-        PB_HIP(hipMemcpyAsync(hp.d_in[slot], hp.h_in[slot], (size_t)m * px * 3, hipMemcpyHostToDevice, hp.s_in));
+        const void *src = frames + (size_t)s0 * px * 3;
+        if (!pin_in) { memcpy(hp.h_in[slot], src, (size_t)m * px * 3); src = hp.h_in[slot]; }
+        PB_HIP(hipMemcpyAsync(hp.d_in[slot], src, (size_t)m * px * 3, hipMemcpyHostToDevice, hp.s_in));
         PB_HIP(hipEventRecord(hp.ev_h2d[slot], hp.s_in));
         PB_HIP(hipStreamWaitEvent(c->stream, hp.ev_h2d[slot], 0));
         float *mn = (float *)hp.d_mm[slot], *mx = mn + cap;
@@ -358,8 +426,8 @@ int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, 
                                (uint8_t *)(r_b ? hp.d_rgb[slot] : nullptr), mn, mx, flip));
         PB_HIP(hipEventRecord(hp.ev_comp[slot], c->stream));
         PB_HIP(hipStreamWaitEvent(hp.s_out, hp.ev_comp[slot], 0));
-        if (d_b) PB_HIP(hipMemcpyAsync(hp.h_depth[slot], hp.d_depth[slot], (size_t)m * px * 4, hipMemcpyDeviceToHost, hp.s_out));
-        if (r_b) PB_HIP(hipMemcpyAsync(hp.h_rgb[slot], hp.d_rgb[slot], (size_t)m * px * 3, hipMemcpyDeviceToHost, hp.s_out));
+        if (d_b) PB_HIP(hipMemcpyAsync(pin_d ? (void *)(depth_out + (size_t)s0 * px) : hp.h_depth[slot], hp.d_depth[slot], (size_t)m * px * 4, hipMemcpyDeviceToHost, hp.s_out));
+        if (r_b) PB_HIP(hipMemcpyAsync(pin_r ? (void *)(rgb_out + (size_t)s0 * px * 3) : hp.h_rgb[slot], hp.d_rgb[slot], (size_t)m * px * 3, hipMemcpyDeviceToHost, hp.s_out));
         PB_HIP(hipMemcpyAsync(hp.h_mm[slot], hp.d_mm[slot], m_b, hipMemcpyDeviceToHost, hp.s_out));
         PB_HIP(hipEventRecord(hp.ev_d2h[slot], hp.s_out));
     }
@@ -397,6 +465,11 @@ int pb_flow_infer_sequence_dev(pb_ctx *c, const uint8_t *frames, int F, int H, i
     return c->raft->infer(frames, F, H, W, scale, iters, backward, flow_out, rgb_out, maxdisp_out);
 }
 
+// Host-pointer variant (reference loop bands/flow_raft.py:98-113: a decoded frame pair per iteration): a three-stage pipeline over chunks of
+// PB_FLOW_HOST_PAIRS (16) frame pairs - frames of chunk i + 1 to HBM on a copy stream, chunk i on the ctx stream, results of chunk i - 1 to the
+// host on a second copy stream; two slots per stage ordered by events, device / pinned buffers kept on the ctx (round 4 allocated, cleared and
+// freed ~0.5 GB per call).  A chunk carries one halo frame, so the frame it shares with its neighbour is encoded twice (1 / 16 of the encoders'
+// work); every pair's flow is that of one whole-sequence call (pairs do not interact).  Page-locked caller buffers are used directly.
 int pb_flow_infer_sequence(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
                            float *flow_out, uint8_t *rgb_out, float *maxdisp_out) {
     PB_CHECK(c && c->raft, PB_ERR_STATE, "ctx has no flow_raft band");
@@ -404,18 +477,45 @@ int pb_flow_infer_sequence(pb_ctx *c, const uint8_t *frames, int F, int H, int W
     PB_HIP(hipSetDevice(c->device));
     int sh, sw;
     RaftEngine::out_size(H, W, scale, &sh, &sw);
-    const size_t nd = (size_t)(F - 1) * (backward ? 2 : 1), px = (size_t)sh * sw;
-    DevMem dF, dO, dR, dM;
-    PB_TRY(dF.alloc((size_t)F * H * W * 3));
-    if (flow_out) PB_TRY(dO.alloc(nd * px * 8));
-    if (rgb_out) PB_TRY(dR.alloc(nd * px * 3));
-    PB_TRY(dM.alloc(nd * 4));
-    PB_HIP(hipMemcpy(dF.p, frames, (size_t)F * H * W * 3, hipMemcpyHostToDevice));
-    PB_TRY(c->raft->infer(dF.as<uint8_t>(), F, H, W, scale, iters, backward, dO.as<float>(), dR.as<uint8_t>(), dM.as<float>()));
-    PB_HIP(hipStreamSynchronize(c->stream));
-    if (flow_out) PB_HIP(hipMemcpy(flow_out, dO.p, nd * px * 8, hipMemcpyDeviceToHost));
-    if (rgb_out) PB_HIP(hipMemcpy(rgb_out, dR.p, nd * px * 3, hipMemcpyDeviceToHost));
-    if (maxdisp_out) PB_HIP(hipMemcpy(maxdisp_out, dM.p, nd * 4, hipMemcpyDeviceToHost));
+    const int dirs = backward ? 2 : 1, pairs = F - 1;
+    static const int env_cp = pb_env_int("PB_FLOW_HOST_PAIRS", 16);
+    int cp = c->host_chunk > 0 ? c->host_chunk : (env_cp > 0 ? env_cp : 16);
+    if (pairs <= cp + cp / 4) cp = pairs;                       // a short tail is not worth a chunk of its own
+    const int chunks = (pairs + cp - 1) / cp;
+    const size_t fpx = (size_t)H * W * 3, px = (size_t)sh * sw;
+    FlowPipe &fp = c->fpipe;
+    const bool pin_in = pb_is_pinned(frames), pin_f = pb_is_pinned(flow_out), pin_r = pb_is_pinned(rgb_out);
+    PB_TRY(fp.ensure_streams());
+    PB_TRY(fp.grow(0, (size_t)(cp + 1) * fpx, !pin_in));
+    if (flow_out) PB_TRY(fp.grow(1, (size_t)cp * dirs * px * 8, !pin_f));
+    if (rgb_out) PB_TRY(fp.grow(2, (size_t)cp * dirs * px * 3, !pin_r));
+    PB_TRY(fp.grow(3, (size_t)cp * dirs * 4 + 256, true));
+    auto finish = [&](int i) -> int {           // results of chunk i: pinned staging -> caller (page-locked caller buffers were written directly)
+        const int slot = i & 1, p0 = i * cp, m = std::min(cp, pairs - p0);
+        PB_HIP(hipEventSynchronize(fp.ev_d2h[slot]));
+        if (flow_out && !pin_f) memcpy(flow_out + (size_t)p0 * dirs * px * 2, fp.h[1][slot], (size_t)m * dirs * px * 8);
+        if (rgb_out && !pin_r) memcpy(rgb_out + (size_t)p0 * dirs * px * 3, fp.h[2][slot], (size_t)m * dirs * px * 3);
+        if (maxdisp_out) memcpy(maxdisp_out + (size_t)p0 * dirs, fp.h[3][slot], (size_t)m * dirs * 4);
+        return 0;
+    };
+    for (int i = 0; i < chunks; ++i) {
+        const int slot = i & 1, p0 = i * cp, m = std::min(cp, pairs - p0);
+        if (i >= 2) PB_TRY(finish(i - 2));       // frees this slot's staging and (through ev_d2h) its device buffers
+        const void *src = frames + (size_t)p0 * fpx;
+        if (!pin_in) { memcpy(fp.h[0][slot], src, (size_t)(m + 1) * fpx); src = fp.h[0][slot]; }
+        PB_HIP(hipMemcpyAsync(fp.d[0][slot], src, (size_t)(m + 1) * fpx, hipMemcpyHostToDevice, fp.s_in));
+        PB_HIP(hipEventRecord(fp.ev_h2d[slot], fp.s_in));
+        PB_HIP(hipStreamWaitEvent(c->stream, fp.ev_h2d[slot], 0));
+        PB_TRY(c->raft->infer((const uint8_t *)fp.d[0][slot], m + 1, H, W, scale, iters, backward, (float *)(flow_out ? fp.d[1][slot] : nullptr),
+                              (uint8_t *)(rgb_out ? fp.d[2][slot] : nullptr), (float *)fp.d[3][slot]));
+        PB_HIP(hipEventRecord(fp.ev_comp[slot], c->stream));
+        PB_HIP(hipStreamWaitEvent(fp.s_out, fp.ev_comp[slot], 0));
+        if (flow_out) PB_HIP(hipMemcpyAsync(pin_f ? (void *)(flow_out + (size_t)p0 * dirs * px * 2) : fp.h[1][slot], fp.d[1][slot], (size_t)m * dirs * px * 8, hipMemcpyDeviceToHost, fp.s_out));
+        if (rgb_out) PB_HIP(hipMemcpyAsync(pin_r ? (void *)(rgb_out + (size_t)p0 * dirs * px * 3) : fp.h[2][slot], fp.d[2][slot], (size_t)m * dirs * px * 3, hipMemcpyDeviceToHost, fp.s_out));
+        PB_HIP(hipMemcpyAsync(fp.h[3][slot], fp.d[3][slot], (size_t)m * dirs * 4, hipMemcpyDeviceToHost, fp.s_out));
+        PB_HIP(hipEventRecord(fp.ev_d2h[slot], fp.s_out));
+    }
+    for (int i = std::max(0, chunks - 2); i < chunks; ++i) PB_TRY(finish(i));
     return 0;
 }
 
@@ -562,6 +662,7 @@ int pb_set_option(pb_ctx *c, const char *key, int value) {
     int *v = c->depth ? &c->depth->conv_tile : (c->raft ? &c->raft->conv_tile : (c->mask ? &c->mask->conv_tile : &c->conv_tile));
     if (!strcmp(key, "gemm_tile")) *g = value;
     else if (!strcmp(key, "conv_tile")) *v = value;
+    else if (!strcmp(key, "host_chunk")) c->host_chunk = value;
     else PB_CHECK(false, PB_ERR_ARG, "unknown option '%s'", key);
     return 0;
 }

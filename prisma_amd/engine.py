@@ -248,13 +248,18 @@ class DepthAnything(_Ctx):
                                  C.sizeof(c)))
         self.max_batch = max_batch
 
-    def infer_batch(self, frames: np.ndarray, want_depth: bool = True, want_rgb: bool = True, flip: bool = True):
-        """frames uint8 [n,H,W,3] RGB -> (depth f32 [n,H,W] | None, rgb u8 [n,H,W,3] | None, min [n], max [n])."""
+    def infer_batch(self, frames: np.ndarray, want_depth: bool = True, want_rgb: bool = True, flip: bool = True,
+                    out_depth: Optional[np.ndarray] = None, out_rgb: Optional[np.ndarray] = None):
+        """frames uint8 [n,H,W,3] RGB -> (depth f32 [n,H,W] | None, rgb u8 [n,H,W,3] | None, min [n], max [n]).
+        out_depth / out_rgb: caller-owned result arrays (e.g. views of page-locked memory, which the library's copy engines then
+        write directly - no staging copy)."""
         frames = np.ascontiguousarray(frames, np.uint8)
         n, H, W, ch = frames.shape
         assert ch == 3
-        depth = np.empty((n, H, W), np.float32) if want_depth else None
-        rgb = np.empty((n, H, W, 3), np.uint8) if want_rgb else None
+        depth = (out_depth if out_depth is not None else np.empty((n, H, W), np.float32)) if want_depth else None
+        rgb = (out_rgb if out_rgb is not None else np.empty((n, H, W, 3), np.uint8)) if want_rgb else None
+        assert depth is None or (depth.dtype == np.float32 and depth.shape == (n, H, W) and depth.flags.c_contiguous)
+        assert rgb is None or (rgb.dtype == np.uint8 and rgb.shape == (n, H, W, 3) and rgb.flags.c_contiguous)
         mn, mx = np.empty(n, np.float32), np.empty(n, np.float32)
         check(self.lib.pb_depth_infer_batch(self.ctx, _ptr(frames), n, H, W, _ptr(depth), _ptr(rgb), _ptr(mn),
                                             _ptr(mx), int(flip)))
@@ -316,15 +321,19 @@ class FlowRaft(_Ctx):
         check(self.lib.pb_create(C.byref(self.ctx), device, self.BAND, arr, len(keep), C.byref(fc), C.sizeof(fc)))
 
     def infer_sequence(self, frames: np.ndarray, scale: float = 0.75, iters: int = 12, backward: bool = False,
-                       want_flow: bool = True, want_rgb: bool = True):
-        """frames uint8 [F,H,W,3] -> (flow f32 [F-1,dirs,sh,sw,2] | None, rgb u8 [F-1,dirs,sh,sw,3] | None, maxdisp [F-1,dirs])."""
+                       want_flow: bool = True, want_rgb: bool = True, out_flow: Optional[np.ndarray] = None,
+                       out_rgb: Optional[np.ndarray] = None):
+        """frames uint8 [F,H,W,3] -> (flow f32 [F-1,dirs,sh,sw,2] | None, rgb u8 [F-1,dirs,sh,sw,3] | None, maxdisp [F-1,dirs]).
+        out_flow / out_rgb: caller-owned result arrays (page-locked ones are written by the copy engines directly)."""
         frames = np.ascontiguousarray(frames, np.uint8)
         F, H, W, ch = frames.shape
         assert ch == 3 and F >= 2
         sh, sw = flow_out_size(H, W, scale)
         d = 2 if backward else 1
-        flow = np.empty((F - 1, d, sh, sw, 2), np.float32) if want_flow else None
-        rgb = np.empty((F - 1, d, sh, sw, 3), np.uint8) if want_rgb else None
+        flow = (out_flow if out_flow is not None else np.empty((F - 1, d, sh, sw, 2), np.float32)) if want_flow else None
+        rgb = (out_rgb if out_rgb is not None else np.empty((F - 1, d, sh, sw, 3), np.uint8)) if want_rgb else None
+        assert flow is None or (flow.dtype == np.float32 and flow.shape == (F - 1, d, sh, sw, 2) and flow.flags.c_contiguous)
+        assert rgb is None or (rgb.dtype == np.uint8 and rgb.shape == (F - 1, d, sh, sw, 3) and rgb.flags.c_contiguous)
         mx = np.empty((F - 1, d), np.float32)
         check(self.lib.pb_flow_infer_sequence(self.ctx, _ptr(frames), F, H, W, C.c_float(scale), iters, int(backward),
                                               _ptr(flow), _ptr(rgb), _ptr(mx)))

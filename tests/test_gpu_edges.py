@@ -115,3 +115,23 @@ def test_bench_nccl_path_under_torch_distributed_run():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and "roofline" in line
+
+
+def test_depth_host_pipeline_with_page_locked_buffers(depth):
+    """pb_depth_infer_batch reads page-locked caller frames and writes page-locked result arrays directly (no staging copy); chunked by
+    the host_chunk option.  Same bytes as the pageable path."""
+    import torch
+    fr = synth.frames(5, 90, 120, seed=3)
+    d0, r0, mn0, mx0 = depth.infer_batch(fr)
+    depth.set_option("host_chunk", 2)
+    try:
+        hf = torch.from_numpy(fr).pin_memory()
+        od = torch.empty(d0.shape, dtype=torch.float32).pin_memory()
+        og = torch.empty(r0.shape, dtype=torch.uint8).pin_memory()
+        d1, r1, mn1, mx1 = depth.infer_batch(hf.numpy(), out_depth=od.numpy(), out_rgb=og.numpy())
+        assert d1.ctypes.data == od.data_ptr()
+        assert np.array_equal(d1, d0) and np.array_equal(r1, r0) and np.array_equal(mn1, mn0) and np.array_equal(mx1, mx0)
+        d2, r2, _, _ = depth.infer_batch(fr)                     # pageable again, chunked
+        assert np.array_equal(d2, d0) and np.array_equal(r2, r0)
+    finally:
+        depth.set_option("host_chunk", 0)

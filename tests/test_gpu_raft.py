@@ -241,3 +241,28 @@ def test_volume_kernel_is_bit_identical_to_the_generic_gemm(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-800:]
     assert np.array_equal(np.load(out), flow)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_pipeline_chunks_equal_one_call(net, pinned):
+    """pb_flow_infer_sequence is a three-stage pipeline over chunks of frame pairs (H2D of chunk i + 1, the band on chunk i, D2H of chunk
+    i - 1; a chunk re-encodes its halo frame): flows, encodes and maximum displacements must be those of one whole-sequence call, bit for
+    bit, whatever the chunk size, from pageable arrays (pinned staging inside the library) and from page-locked ones (used directly)."""
+    import torch
+    fr = synth.frame_pair_sequence(8, 136, 168, seed=21)
+    net.set_option("host_chunk", 64)
+    flow1, rgb1, mx1 = net.infer_sequence(fr, scale=1.0, iters=3, backward=True)
+    try:
+        for chunk in (2, 3):
+            net.set_option("host_chunk", chunk)
+            if pinned:
+                hf = torch.from_numpy(fr).pin_memory()
+                of = torch.empty(flow1.shape, dtype=torch.float32).pin_memory()
+                og = torch.empty(rgb1.shape, dtype=torch.uint8).pin_memory()
+                flow, rgb, mx = net.infer_sequence(hf.numpy(), scale=1.0, iters=3, backward=True, out_flow=of.numpy(), out_rgb=og.numpy())
+                assert flow.ctypes.data == of.data_ptr() and rgb.ctypes.data == og.data_ptr()
+            else:
+                flow, rgb, mx = net.infer_sequence(fr, scale=1.0, iters=3, backward=True)
+            assert np.array_equal(flow, flow1) and np.array_equal(rgb, rgb1) and np.array_equal(mx, mx1), (chunk, pinned)
+    finally:
+        net.set_option("host_chunk", 0)

@@ -26,5 +26,5 @@ for name in want:
     pro, loop, epi_c, tot = d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2], d[:, 3] - d[:, 0]
     real = (d[:, 5] - d[:, 4]) / 100.0
     print(f"{name}: " + " | ".join(row) + f" || tile 11 stamps ({len(d)} tiles): start->loop {np.median(pro):.0f} loop {np.median(loop):.0f} "
-          f"epilogue {np.median(epi_c):.0f} total {np.median(tot):.0f} cycles, loop / K tile {np.median(loop) / (k // 64):.0f} (MFMA bound 1024), "
+          f"epilogue {np.median(epi_c):.0f} total {np.median(tot):.0f} cycles, loop / K tile {np.median(loop) / (k // 64):.0f} (MFMA bound 1536), "
           f"clock ~{np.median(tot / np.maximum(real, 1e-3)) / 1e3:.2f} GHz", flush=True)
