@@ -18,6 +18,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, _p)
 
 from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_rgb  # noqa: E402
+from common.ckpt import load_checkpoint  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
 from common.pipe import AsyncSink, prefetch  # noqa: E402
 from prisma_amd import engine, shard, synth  # noqa: E402
@@ -49,12 +50,7 @@ def load_weights(encoder, path=""):
                                  os.path.join("models", f"depth_anything_{encoder}14.pth")]
     for c in cands:
         if c and os.path.exists(c):
-            if c.endswith(".npz"):
-                z = np.load(c)
-                return {k: z[k].astype(np.float32) for k in z.files}
-            import torch
-            sd = torch.load(c, map_location="cpu")
-            return {k: v.float().numpy() for k, v in sd.items()}
+            return load_checkpoint(c)
     if not shard.synthetic_allowed(getattr(args, "synthetic", False)):
         raise SystemExit(f"[{BAND}] no checkpoint found ({cands}); pass --weights, or --synthetic / PRISMA_SYNTH=1 for seeded synthetic weights")
     print(f"[{BAND}] no checkpoint found ({cands}); using seeded synthetic weights (--synthetic)", file=sys.stderr)
@@ -77,13 +73,7 @@ def init_model(encoder=None, weights="", device=0, max_batch=BATCH):
 def load_metric_weights(path):
     """ZoeDepth state dict (`core.core.*` + the metric head); `model_io.load_state_from_resource` keeps it under 'model'."""
     if path and os.path.exists(path):
-        if path.endswith(".npz"):
-            z = np.load(path)
-            return {k: z[k].astype(np.float32) for k in z.files}
-        import torch
-        sd = torch.load(path, map_location="cpu")
-        sd = sd.get("model", sd)
-        return {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "numpy")}
+        return load_checkpoint(path, wrappers=("model",))
     if not shard.synthetic_allowed(getattr(args, "synthetic", False)):
         raise SystemExit(f"[{BAND}] metric checkpoint {path!r} not found; pass --weights, or --synthetic / PRISMA_SYNTH=1")
     print(f"[{BAND}] metric checkpoint {path!r} not found; using seeded synthetic weights (--synthetic)", file=sys.stderr)

@@ -20,6 +20,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 import flow_raft as _loop  # noqa: E402  (process_video and its writers; its module globals carry this band's model / metadata)
 from common.io import check_overwrite  # noqa: E402
+from common.ckpt import load_checkpoint  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
 from prisma_amd import engine, shard, synth  # noqa: E402
 
@@ -38,13 +39,7 @@ _SYNTH = [False]
 def load_weights(path):
     """reference :57-61: torch.load(checkpoint)['model'] if present, else the dict itself."""
     if path and os.path.exists(path):
-        if path.endswith(".npz"):
-            z = np.load(path)
-            return {k: z[k] for k in z.files}
-        import torch
-        sd = torch.load(path, map_location="cpu")
-        sd = sd["model"] if "model" in sd else sd
-        return {k: v.numpy() for k, v in sd.items()}
+        return load_checkpoint(path, wrappers=("model",))
     if not shard.synthetic_allowed(_SYNTH[0]):
         raise SystemExit(f"[{BAND}] checkpoint {path!r} not found; pass --model, or --synthetic / PRISMA_SYNTH=1 for seeded synthetic weights")
     print(f"[{BAND}] checkpoint {path!r} not found; using seeded synthetic weights (--synthetic)", file=sys.stderr)

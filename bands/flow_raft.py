@@ -18,6 +18,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, _p)
 
 from common.io import FrameReader, VideoWriter, check_overwrite, write_flo, write_flow_png  # noqa: E402
+from common.ckpt import load_checkpoint  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
 from common.pipe import AsyncSink, prefetch  # noqa: E402
 from prisma_amd import engine, shard, synth  # noqa: E402
@@ -37,13 +38,7 @@ SUBPATH_NEEDS_BOTH = True   # flow_gmflow's wrapper clears it around its call of
 def load_weights(path):
     """Checkpoint keys carry a `module.` prefix from DataParallel (reference :42-44): strip it."""
     if path and os.path.exists(path):
-        if path.endswith(".npz"):
-            z = np.load(path)
-            sd = {k: z[k] for k in z.files}
-        else:
-            import torch
-            sd = {k: v.numpy() for k, v in torch.load(path, map_location="cpu").items()}
-        return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        return load_checkpoint(path, strip_prefix="module.")
     if not shard.synthetic_allowed(_SYNTH[0]):
         raise SystemExit(f"[{BAND}] checkpoint {path!r} not found; pass --model, or --synthetic / PRISMA_SYNTH=1 for seeded synthetic weights")
     print(f"[{BAND}] checkpoint {path!r} not found; using seeded synthetic weights (--synthetic)", file=sys.stderr)

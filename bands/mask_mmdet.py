@@ -19,6 +19,7 @@ for _p in (_ROOT, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, _p)
 
 from common.io import FrameReader, VideoWriter, check_overwrite, create_folder, open_rgb, write_rgb  # noqa: E402
+from common.ckpt import load_checkpoint  # noqa: E402
 from common.meta import get_target, get_url, is_video, load_metadata, write_metadata  # noqa: E402
 from common.pipe import AsyncSink, prefetch  # noqa: E402
 from prisma_amd import engine, shard, synth  # noqa: E402
@@ -38,13 +39,7 @@ ranks = None          # shard.Ranks(): one process per GPU under torchrun, world
 def load_weights(path, cfg):
     """mmdet checkpoints keep the tensors under 'state_dict'."""
     if path and os.path.exists(path):
-        if path.endswith(".npz"):
-            z = np.load(path)
-            return {k: z[k] for k in z.files}
-        import torch
-        sd = torch.load(path, map_location="cpu")
-        sd = sd.get("state_dict", sd)
-        return {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "numpy")}
+        return load_checkpoint(path, wrappers=("state_dict",))
     if not shard.synthetic_allowed(_SYNTH[0]):
         raise SystemExit(f"[{BAND}] checkpoint {path!r} not found; pass --weights, or --synthetic / PRISMA_SYNTH=1 for seeded synthetic weights")
     print(f"[{BAND}] checkpoint {path!r} not found; using seeded synthetic weights (--synthetic)", file=sys.stderr)
