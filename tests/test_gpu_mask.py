@@ -112,11 +112,14 @@ def test_postprocess_exact_on_engine_outputs(tiny):
         assert g_cand == dbg["n_candidates"] and len(g_sc) == len(sc) > 0
         assert np.array_equal(g_lb, lb.numpy())
         assert np.allclose(g_sc, sc.numpy(), rtol=2e-3, atol=1e-6)      # a pixel on the 0.5 edge may flip an area by one
-        diff = (g_mk != mk.numpy()).mean()
-        print("  instance-mask pixel mismatch %.2e" % diff)
-        assert diff < 2e-4
+        diff = int((g_mk != mk.numpy()).sum())
+        print("  instance-mask pixels that differ: %d" % diff)
+        # round 5 (tools/mask_final_stage.py, profiles/r05e_mask_final_stage.txt): the engine's final stage IS the oracle's final stage on the
+        # same inputs - every instance mask and the id image bit for bit at this size and at 720p; what separates the id image from the
+        # end-to-end fp32 oracle's is upstream of it (id_image_report)
+        assert diff == 0
         ref_img = SO.band_mask(sc, lb, mk, synth.COCO_CLASSES, synth.BAND_CLASSES, 0.5, meta["ori_shape"])
-        assert (out[b] != ref_img).mean() < 5e-4
+        assert np.array_equal(out[b], ref_img)
         assert out[b].max() > 0, "the synthetic detector must draw something"
         assert np.array_equal(out[b][..., 0], out[b][..., 1]) and np.array_equal(out[b][..., 0], out[b][..., 2])
 
@@ -188,9 +191,9 @@ def test_r101_720p_against_oracle():
     print("  %d candidates, %d instances, %d over 0.5" % (g_cand, len(g_sc), int((g_sc > 0.5).sum())))
     assert g_cand == dbg["n_candidates"] and np.array_equal(g_lb, lb.numpy())
     assert np.allclose(g_sc, sc.numpy(), rtol=2e-3, atol=1e-6)      # a pixel on the 0.5 edge may flip an area by one
-    assert (g_mk != mk.numpy()).mean() < 2e-4
     ref_img = SO.band_mask(sc, lb, mk, synth.COCO_CLASSES, synth.BAND_CLASSES, 0.5, meta["ori_shape"])
-    assert (out[1] != ref_img).mean() < 5e-4 and out[1].any()
+    # the oracle's final stage on the engine's own soft outputs reproduces the engine's id image exactly (0 of 921 600 pixels, r05e)
+    assert np.array_equal(out[1], ref_img) and out[1].any()
     st = {s["name"]: s for s in net.kernel_stats()}
     print("  kernel ms (2 frames):", {k: round(v["ms"], 2) for k, v in st.items()})
     net.close()
