@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import MARGIN_DEPTH_SPLIT, TOL
+from conftest import MARGIN_DEPTH_SPLIT, TOL, pw
 from oracle import depth_oracle as O
 from prisma_amd import engine, synth
 
@@ -28,7 +28,7 @@ def rell2(a, b):
 
 
 def report(tag, a, b):
-    print(f"  {tag:14s} relmax {relmax(a, b):.3e}  relL2 {rell2(a, b):.3e}")
+    print(f"  {tag:14s} relmax {relmax(a, b):.3e}  relL2 {rell2(a, b):.3e}  {pw(a, b)}")
 
 
 @pytest.mark.parametrize("prec", [1, 0])

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import TOL
+from conftest import TOL, pw
 from oracle import raft_oracle as R
 from prisma_amd import engine, synth
 
@@ -86,7 +86,7 @@ def test_pair_against_reference_vectors(net, golden_dir):
     print("  flow_lo   relmax %.3e relL2 %.3e" % (relmax(flo, lo), rell2(flo, lo)))
     assert relmax(fmap, st["fmap1"]) < TOL_RANGE and relmax(flo, lo) < TOL_RANGE and relmax(flo, z["flow_lo"]) < TOL_RANGE
     for name, got, ref in (("fwd", flow[0, 0], z["fwd"]), ("bwd", flow[0, 1], z["bwd"])):
-        print("  %s/golden relmax %.3e relL2 %.3e  max|flow| %.2f" % (name, relmax(got, ref), rell2(got, ref), np.abs(ref).max()))
+        print("  %s/golden relmax %.3e relL2 %.3e  max|flow| %.2f  %s" % (name, relmax(got, ref), rell2(got, ref), np.abs(ref).max(), pw(got, ref)))
         assert relmax(got, ref) < TOL_RANGE and rell2(got, ref) < TOL_L2
     # encode: max displacement and colours are functions of the engine's own flow
     ref_rgb, ref_mx = R.process_flow(flow[0, 0], exact_atan2=True)
@@ -123,7 +123,7 @@ def test_720p_batch_of_8_pairs_against_reference_vectors(golden_dir, prec):
     tol = TOL[1] if prec == 1 else FAST_TOL
     for i in range(8):
         got, ref = flow[i, 0][::8, ::8], z["fwd720_s8"][i]
-        print("\n  p%d pair %d relmax %.3e relL2 %.3e" % (prec, i, relmax(got, ref), rell2(got, ref)), end="")
+        print("\n  p%d pair %d relmax %.3e relL2 %.3e  %s" % (prec, i, relmax(got, ref), rell2(got, ref), pw(got, ref)), end="")      # (1/8-strided samples of the reference's flow)
         assert relmax(got, ref) < tol[0] and rell2(got, ref) < tol[1], i
         f64 = flow[i, 0].astype(np.float64)
         sums = np.array([f64[..., 0].sum(), f64[..., 1].sum(), np.abs(f64).sum()])
@@ -159,7 +159,7 @@ def test_1080p_scaled_pair_against_reference_vectors(golden_dir, prec):
     assert flow.shape == (1, 1, 810, 1440, 2)
     tol = TOL[1] if prec == 1 else FAST_TOL
     got, ref = flow[0, 0][::8, ::8], z["fwd1080_s8"]
-    print("\n  p%d 1080p x0.75 relmax %.3e relL2 %.3e" % (prec, relmax(got, ref), rell2(got, ref)))
+    print("\n  p%d 1080p x0.75 relmax %.3e relL2 %.3e  %s" % (prec, relmax(got, ref), rell2(got, ref), pw(got, ref)))
     assert relmax(got, ref) < tol[0] and rell2(got, ref) < tol[1]
     f64 = flow[0, 0].astype(np.float64)
     sums = np.array([f64[..., 0].sum(), f64[..., 1].sum(), np.abs(f64).sum()])
@@ -173,7 +173,7 @@ def test_scaled_sequence_matches_oracle(net):
     w = synth.raft_weights(seed=4321)
     for i in range(2):
         fwd, _ = R.infer_pair(w, fr[i], fr[i + 1], scale=0.75, iters=6)
-        print("\n  pair %d relmax %.3e relL2 %.3e" % (i, relmax(flow[i, 0], fwd), rell2(flow[i, 0], fwd)))
+        print("\n  pair %d relmax %.3e relL2 %.3e  %s" % (i, relmax(flow[i, 0], fwd), rell2(flow[i, 0], fwd), pw(flow[i, 0], fwd)))
         assert relmax(flow[i, 0], fwd) < TOL_RANGE and rell2(flow[i, 0], fwd) < TOL_L2
 
 
