@@ -48,9 +48,10 @@ def load_weights(path):
 def init_model(args=None, device=0):
     global model
     if args is not None and getattr(args, "small", False):
-        # reference raft.py:30-36,52-53 (hidden 96, corr radius 3, SmallEncoder / SmallUpdateBlock, its own checkpoint raft-small.pth):
-        # another network, not another code path of this one - its weights cannot be loaded into the basic model
-        raise SystemExit(f"[{BAND}] --small (RAFT-small: a different network and checkpoint) is not built; drop the flag to run the basic model")
+        # reference raft.py:28-53: both `if args.small:` branches sit inside string literals (dead code) - RAFT(args) builds BasicEncoder /
+        # BasicUpdateBlock (hidden 128, corr radius 4, 5.26 M parameters) whatever the flag says, and loads args.model into it.  Drop-in
+        # behaviour is therefore: accept the flag, run the basic model (round 4 refused it as "another network"; it never was one here)
+        print(f"[{BAND}] --small: the reference builds the basic RAFT regardless (bands/raft/raft.py:28-53, the small branches are commented out); flag ignored", file=sys.stderr)
     if args is not None and getattr(args, "alternate_corr", False):
         # reference raft.py:103-106: AlternateCorrBlock computes the same correlations on the fly (memory saving, needs the alt_cuda_corr
         # extension); results are those of CorrBlock, and the volume is no memory problem in 288 GB - run the normal path

@@ -126,7 +126,9 @@ def test_flow_raft_cli_on_a_pth_checkpoint(tmp_path, monkeypatch):
     p = str(tmp_path / "raft-sintel.pth")
     raft_ckpt(p)
     monkeypatch.setenv("PRISMA_SYNTH", "0")                                               # a missing checkpoint would now be an error
-    band.main(["-i", str(folder), "--iterations", "3", "--scale", "1.0", "--model", p, "--raft_model", "models/raft-things.pth"])
+    # --small / --raft_model: parsed by the reference and without effect there (raft.py:28-53 builds the basic model regardless; init_model
+    # loads args.model) - a reference command line carrying them runs unchanged
+    band.main(["-i", str(folder), "--iterations", "3", "--scale", "1.0", "--model", p, "--raft_model", "models/raft-things.pth", "--small"])
     assert np.array_equal(np.load(folder / "flow_raft.npy"), want) and open(folder / "flow_raft.csv").read() == want_csv
     band.model.close(); band.model = None
 
