@@ -63,8 +63,11 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         if (tile == TILE_128 && epi == EPI_STD && a.N <= 64 && n64_tile != TILE_128) tile = n64_tile;
         // 64 < N <= 128 with enough rows to fill the chip: the 256 x 128 ping-pong kernel (gemm_n128.h).  PB_TILE_N128=<min tiles>, 0 = off
         static int n128_min = -1;
-        if (n128_min < 0) { const char *e = getenv("PB_TILE_N128"); n128_min = e ? atoi(e) : 0; }
-        if (tile == TILE_128 && epi == EPI_STD && n128_min > 0 && a.N > 64 && a.N <= 128 && (a.M + 255) / 256 >= n128_min) tile = TILE_256x128;
+        // Default 2048 tiles of 384 rows (M >= 786 k: the DPT head's output_conv1, 2.5 M rows).  Measured (r05c, same box): that layer 426 -> 528 TF/s;
+        // the RAFT update block's and encoders' N <= 128 layers (M = 569 k) 34.5 -> 35.6 ms per step ON this kernel - its one-tile workgroups pay
+        // ~11 k cycles of set-up per 40-85 k-cycle tile that the generic tile's second workgroup per CU hides - so those stay on the generic tile.
+        if (n128_min < 0) { const char *e = getenv("PB_TILE_N128"); n128_min = e ? atoi(e) : 2048; }
+        if (tile == TILE_128 && epi == EPI_STD && n128_min > 0 && a.N > 64 && a.N <= 128 && (a.M + 383) / 384 >= n128_min) tile = TILE_256x128;
         static int small_tile = -1;
         if (small_tile < 0) { const char *e = getenv("PB_TILE_SMALL"); small_tile = e ? atoi(e) : TILE_128; }
         if (tile == TILE_128 && (epi == EPI_STD || epi == EPI_F32) && small_tile != TILE_128) tile = small_tile;
