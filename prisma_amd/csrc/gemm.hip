@@ -63,10 +63,12 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         if (tile == TILE_128 && epi == EPI_STD && a.N <= 64 && n64_tile != TILE_128) tile = n64_tile;
         // 64 < N <= 128 with enough rows to fill the chip: the 256 x 128 ping-pong kernel (gemm_n128.h).  PB_TILE_N128=<min tiles>, 0 = off
         static int n128_min = -1;
-        // Default 2048 tiles of 384 rows (M >= 786 k: the DPT head's output_conv1, 2.5 M rows).  Measured (r05c, same box): that layer 426 -> 528 TF/s;
-        // the RAFT update block's and encoders' N <= 128 layers (M = 569 k) 34.5 -> 35.6 ms per step ON this kernel - its one-tile workgroups pay
-        // ~11 k cycles of set-up per 40-85 k-cycle tile that the generic tile's second workgroup per CU hides - so those stay on the generic tile.
-        if (n128_min < 0) { const char *e = getenv("PB_TILE_N128"); n128_min = e ? atoi(e) : 2048; }
+        // Off by default.  Measured on one box (profiles/r05c_*, r05f_*): the DPT head's output_conv1 (2.5 M rows) 426 -> 528 TF/s, but the depth band's
+        // N <= 128 launches together 10.02 -> 10.0 ms; the RAFT encoders' 1/4-resolution layers (2.35 M rows, N = 96) 13.1 -> 14.5 ms and the update
+        // block's (569 k rows) 34.5 -> 35.6 ms: the K loop is faster (2200 cycles per 384 x 128 x 64 against the generic tile's ~2 x 1300 for the
+        // same work) and the one-tile workgroups give it back - ~11 k cycles of set-up per 40-85 k-cycle tile that the generic tile's second
+        // workgroup per CU hides.  Kept as a tested kernel (tile id 11) for the persistent variant that would make it pay.
+        if (n128_min < 0) { const char *e = getenv("PB_TILE_N128"); n128_min = e ? atoi(e) : 0; }
         if (tile == TILE_128 && epi == EPI_STD && n128_min > 0 && a.N > 64 && a.N <= 128 && (a.M + 383) / 384 >= n128_min) tile = TILE_256x128;
         static int small_tile = -1;
         if (small_tile < 0) { const char *e = getenv("PB_TILE_SMALL"); small_tile = e ? atoi(e) : TILE_128; }
