@@ -17,6 +17,10 @@
 // deferred (2.4 TB/s of volume written).  Per tile the matrix pipe and the LDS fragment reads need ~1000 cycles each; the steps (two per
 // tile, 512 MFMA cycles) are short against their barrier + wait.  Tried and measured slower: a 3-slot ring at three workgroups per CU
 // (13.6 ms); a fifth, load-only producer wave so that the compute waves never wait on their stores (28 ms).
+// Round 5, measured slower as well (profiles/r05g_volume_64row_waves.txt): 64 source rows per wave against 32-column tiles - half the LDS
+// fragment traffic per MFMA, a lane then owns one column, neighbouring lanes swap a register per row pair and store dwords, 16 lanes
+// covering 64 contiguous bytes of a row: bit-identical volume, 12.5 -> 17.6 ms per step.  The kernel is bound by its stores (half-line
+// segments cost more than the LDS reads they saved), not by the LDS like the GEMM kernels (gemm_n128.h).
 #include "common.h"
 #include "raft_kernels.h"
 #include "../../include/prisma_bands.h"
