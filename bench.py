@@ -476,8 +476,10 @@ def main():
                 h_rgb = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
                 h_frgb = torch.empty((B - 1, 1, sh, sw, 3), dtype=torch.uint8).pin_memory()
                 h_scal = [None, None]
+                # depth in two chunks (its H2D / D2H then also overlap its own kernels); flow as ONE chunk: its launches keep the shapes of the
+                # timed region, so the per-symbol averages of `rocprofv3 --stats -- python bench.py` stay those of the roofline object
                 dn.set_option("host_chunk", max(1, B // 2))
-                fn.set_option("host_chunk", 16)
+                fn.set_option("host_chunk", B)
                 errs = []
 
                 def band(fn_):

@@ -308,6 +308,9 @@ int launch_attention(hipStream_t stream, const f16 *q, const f16 *k, const f16 *
     static int env_variant = -1;
     if (env_variant < 0) { const char *e = getenv("PB_ATTN_VARIANT"); env_variant = e ? atoi(e) : 0; }
     if (variant <= 0) variant = env_variant;
+    // a small batch does not fill the chip with 8-wave workgroups (one 720p frame: 16 heads x 10 blocks of 256 rows = 160): the 4-wave
+    // geometry (128 rows per workgroup, same per-wave arithmetic - bit-identical output) puts twice as many on it
+    if (variant == 0 && (int64_t)((ntok + 255) / 256) * ((B * heads + 7) / 8) * 8 < 384) variant = 2;
     // variants (tools/attn_bench.py): 0 default = 8 waves x 1 block; 2 = 4 waves x 1 block; 3 = 4 waves x 2 blocks;
     // 4 = 4 waves x 1 block with fragment prefetch; 5 = 8 waves x 2 blocks; 11 .. 16 = ablations 1 .. 6 of variant 2;
     // 6 = 8 waves x 1 block on three buffers (round 5), 7 = 8 waves x 2 blocks on three buffers; 21 / 23 = ablations 1 / 3 of variant 6

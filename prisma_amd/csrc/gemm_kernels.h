@@ -1886,7 +1886,7 @@ int launch_t(hipStream_t stream, const GemmArgs &a) {
     constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * (TN * 32 + 4) * 4;
     constexpr int STG = NS * STAGE + (AMODE == A_CONV && BN != 64 ? KTAB_BYTES : 0);          // (+ the conv K-walk table, gemm_kernel KT)
     constexpr int SMEM = STG > WM * WN * EPIB ? STG : WM * WN * EPIB;
-    if constexpr (!BUFP && ((BM == 128 && BN == 128) || NS == 3 || BN == 64)) {       // the small tiles also have a buffer-path build
+    if constexpr (!BUFP && ((BM == 128 && BN == 128) || NS == 3 || BN == 64)) {       // the small tiles also have a buffer-path build (BN == 64: 256 x 64 and 64 x 64)
         GemmArgs b = a;
         b.bufmode = buffer_mode(AMODE, a, BM);
         if (b.bufmode) return launch_t<BM, BN, WM, WN, AMODE, EPI, MX, true, NS>(stream, b);
@@ -1920,6 +1920,9 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
             // tiles ahead behind bare barriers, 144 KB, one workgroup per CU - against this tile's two workgroups per CU: update block 35.4 ->
             // 36.7 ms, RAFT encoders 19.1 -> 20.0, DPT head 12.5 -> 13.4 on one box; these launches are not waiting on DMA latency)
         }
+        // (round 5, measured and removed: one-wave 64 x 64 workgroups for the residual GEMMs of ONE frame - 624 instead of 160 workgroups on 256 CUs:
+        // proj + fc2 2.79 -> 2.42 ms of a 9.0 ms call (profiles/r05h_latency_batch1.txt); the staging swizzle below also assumes NT / 8 rows per
+        // DMA step is a multiple of 16, which a 64-thread block breaks)
         return launch_t<128, 128, 2, 2, AMODE, EPI, MX>(s, a);
     }
 }

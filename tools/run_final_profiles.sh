@@ -16,7 +16,7 @@ for f in $(ls $O/${T}_bench/*/*kernel_stats.csv | sort -V); do
   if [ $i -eq 0 ]; then cp $f $O/${T}_default_bench_kernel_stats.csv; else cp $f $O/${T}_default_bench_other_precision_kernel_stats.csv; fi
   i=$((i+1))
 done
-D="--steps 1 --warmup 1 --no-cpu-baseline --one-precision"
+D="--steps 1 --warmup 1 --no-cpu-baseline --one-precision --host-clips 0 --no-latency --no-clock"
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${T}_pmc_fetch --output-format csv -- python bench.py $D > $O/${T}_pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${T}_pmc_write --output-format csv -- python bench.py $D > $O/${T}_pmc_write.log 2>&1
 python tools/pmc_summary.py $O/${T}_pmc_fetch $O/${T}_pmc_write $O/${T}_pmc_traffic.json > $O/${T}_pmc_traffic.txt 2>&1
