@@ -470,7 +470,7 @@ def main():
             # on chunk i and D2H of chunk i - 1 on three streams) - from page-locked frames into page-locked result arrays, the two bands
             # called from two threads (ctypes drops the GIL) so that one band's PCIe traffic also runs under the other's kernels.
             # Steady state over args.host_clips clips after one untimed clip; results are compared byte for byte with the HBM-resident leg's.
-            if args.host_clips > 0:
+            if args.host_clips > 0 and world == 1:       # (one-GPU runs: with several ranks the host's PCIe / memory paths are shared and only rank 0 would be measuring)
                 import threading
                 hf = torch.from_numpy(frames).pin_memory()
                 h_rgb = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
@@ -636,6 +636,10 @@ def main():
                           "value": round(world * (B - 1) * args.steps / main_res["flow_s"], 3), "unit": "pairs/s",
                           "ms_per_step": round(main_res["flow_s"] / args.steps * 1e3, 3)},
             "pcie_inclusive_fps": round(main_res["host_fps"], 2) if "host_fps" in main_res else None,
+            "pcie_inclusive_note": "the same clip through the host-pointer entry points (pb_depth_infer_batch, pb_flow_infer_sequence) from page-locked frames into "
+                                   "page-locked result arrays, both bands called from two threads; results byte-identical to the HBM-resident leg's.  It can exceed "
+                                   "`value`: there the bands run one after the other with a device sync between them, here their kernels overlap "
+                                   "(the three-band `pipeline` leg of --all-legs shows the same effect)",
             "latency_720p_batch1_ms": round(main_res["lat_b1"], 3) if "lat_b1" in main_res else None,
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(fam.items())},
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items()
