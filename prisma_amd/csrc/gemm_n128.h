@@ -21,8 +21,16 @@
 //     RAW: a slot staged in phase P is certified by both groups' waits of phase P + 2 and first read in phase >= P + 3.
 //     WAR: a slot is re-staged two phases (four barrier segments) after the phase that read it.
 //
-// One workgroup per tile (no persistent loop: it bought gemm8_kernel 0.5 %); operands, swizzle, K walk, MX-fp8 tiles and epilogues are
-// gemm8_kernel's / gemm_kernel's (gemm_kernels.h), so every EPI_STD launch kind of the bands runs unchanged.
+// PERSISTENT workgroups, one per CU, walk the tiles vb = blockIdx.x + k gridDim.x of the XCD-contiguous order.  The first version ran one
+// workgroup per tile and lost to the generic tile although its K loop is faster (profiles/r05c_n128_384_tile_stamps.txt: 2200 cycles per
+// 384 x 128 x 64 against ~2 x 1300 for the same work): a tile spent 10-12.7 k cycles between launch and its first MFMA - the K-walk table, two
+// integer divisions per staging slot, eleven DMAs and their way from the HBM with every CU asking at once - and 2.7 k in the epilogue, around
+// a 40-85 k-cycle K loop; the generic tile hides the same costs behind its second workgroup per CU.  Here the table is built once, and the next
+// tile's addresses and first eleven DMAs are issued BEFORE the epilogue (the staging buffers are dead by then; EPI_STD tiles that store
+// straight from the accumulators touch no LDS), so they land while the stores are issued; one `s_waitcnt vmcnt(0)` in front of the next
+// K loop then covers them and the stores (PB_G8N_PERSIST=0: one workgroup per tile, for A/B runs).
+// Operands, swizzle, K walk, MX-fp8 tiles and epilogues are gemm8_kernel's / gemm_kernel's (gemm_kernels.h), so every EPI_STD launch kind of
+// the bands runs unchanged.
 #pragma once
 #include "gemm_kernels.h"
 
@@ -43,13 +51,12 @@ __global__ __launch_bounds__(512) void gemm8n_kernel(const GemmArgs p) {
     long long ts0 = 0, ts1 = 0, ts2 = 0, tr0 = 0;
     if (p.dbg) { ts0 = __builtin_readcyclecounter(); tr0 = wall_clock64(); }
 
-    // ---- tile id with XCD-contiguous remap (bijective for any grid size) ----
+    // ---- tiles of the launch (the grid may be smaller: persistent workgroups), XCD-contiguous remap (bijective for any tile count;
+    //      workgroup b runs on XCD b % 8 and the persistent stride is a multiple of 8) ----
     const int tilesN = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    const int tile_m = swz / tilesN, tile_n = swz - tile_m * tilesN;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nwg = p.ntiles > 0 ? p.ntiles : (int)gridDim.x;
+    const int qd = nwg >> 3, rm = nwg & 7;
+    int m0 = 0, n0 = 0, swz = 0;
 
     // ---- staging geometry.  LDS A rows are ordered by slot: row (g * 3 + rt) * 64 + wm * 32 + i holds tile row g * 192 + wm * 96 + rt * 32 + i;
     //      this wave's DMA of slot (g, rt) covers LDS rows (g * 3 + rt) * 64 + 8 wave .. + 7.  B slot j covers the LDS rows
@@ -63,17 +70,22 @@ __global__ __launch_bounds__(512) void gemm8n_kernel(const GemmArgs p) {
     int a_yx[2][3], a_pix0[2][3];
     unsigned a_voff[2][3], b_voff[2];
     __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, 0u), rsW = make_rsrc(p.W, 0u);
-    int bimg0 = 0;
     if constexpr (BUFP) {
         rsW = make_rsrc(p.W, (unsigned)((int64_t)((p.N + 255) / 256 * 256) * p.K * 2));
-        if constexpr (AMODE == A_DENSE) {
-            rsA = make_rsrc(p.A, (unsigned)((int64_t)p.M * p.lda * 2));
-        } else {
-            const int ohw = p.cOH * p.cOW, nimg = p.M / ohw;
-            const int64_t img = (int64_t)p.cH * p.cW * cld;
-            bimg0 = p.bufmode == 2 ? m0 / ohw : 0;
-            rsA = make_rsrc(p.A + bimg0 * img, (unsigned)((p.bufmode == 2 ? (nimg - bimg0 < 2 ? nimg - bimg0 : 2) : nimg) * img * 2));
-        }
+        if constexpr (AMODE == A_DENSE) rsA = make_rsrc(p.A, (unsigned)((int64_t)p.M * p.lda * 2));
+    }
+    // tile vb of the launch -> (m0, n0) and this thread's staging addresses
+    auto setup = [&](int vb) {
+    const int xcd = vb & 7;
+    swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (vb >> 3);
+    const int tile_m = swz / tilesN, tile_n = swz - tile_m * tilesN;
+    m0 = tile_m * BM; n0 = tile_n * BN;
+    int bimg0 = 0;
+    if constexpr (BUFP && AMODE == A_CONV) {
+        const int ohw = p.cOH * p.cOW, nimg = p.M / ohw;
+        const int64_t img = (int64_t)p.cH * p.cW * cld;
+        bimg0 = p.bufmode == 2 ? m0 / ohw : 0;
+        rsA = make_rsrc(p.A + bimg0 * img, (unsigned)((p.bufmode == 2 ? (nimg - bimg0 < 2 ? nimg - bimg0 : 2) : nimg) * img * 2));
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g)
@@ -103,6 +115,7 @@ __global__ __launch_bounds__(512) void gemm8n_kernel(const GemmArgs p) {
         b_ptr[j] = p.W + (int64_t)(n0 + col_map(r, epi_interleaved<EPI, 2>())) * p.K + cgw * 8;
         b_voff[j] = (unsigned)((b_ptr[j] - p.W) * 2);
     }
+    };
 
     const unsigned *ktab = (const unsigned *)(smem + NBUF * BUF);
     unsigned e_nxt = 0, e_cur = 0;
@@ -148,29 +161,21 @@ __global__ __launch_bounds__(512) void gemm8n_kernel(const GemmArgs p) {
     const int b_base = BOFF + (wn * 64 + li) * 128;         // + j * 4096
 
     f32x16 acc[3][2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f16x8 fa[4], fb0[4], fb1[4];
     const int mxa = p.mx_scale_a * 0x01010101, mxb = p.mx_scale_b * 0x01010101;
 
     if constexpr (AMODE == A_CONV) {                     // the K walk of the launch (conv_ktab_entry), once per workgroup
         for (int t = tid; t < nk; t += 512) ((unsigned *)(smem + NBUF * BUF))[t] = conv_ktab_entry(p, cld, t);
         __syncthreads();
-        e_nxt = ktab[0];
     }
-    // prologue: what the phases -3, -2, -1 of the steady state would have staged, behind K tile 0's first slots (eleven DMAs per thread)
-    stage_a(0, 0); stage_b(0, 0);
-    stage_a(0, 1); stage_b(0, 1);
-    stage_a(0, 2);
-    stage_a(1, 0); stage_b(1, 0);
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");        // A[.][0], B[0], A[.][1], B[1] of K tile 0 landed (this wave's share)
-    PB_BAR();
-    if (wr == 1) PB_BAR();                                   // stagger the second wave group by one barrier
-    if (p.dbg) ts1 = __builtin_readcyclecounter();
+    // a tile's prologue: what the phases -3, -2, -1 of the steady state would have staged, behind K tile 0's first slots (eleven DMAs per thread)
+    auto prologue = [&]() {
+        if constexpr (AMODE == A_CONV) e_nxt = ktab[0];
+        stage_a(0, 0); stage_b(0, 0);
+        stage_a(0, 1); stage_b(0, 1);
+        stage_a(0, 2);
+        stage_a(1, 0); stage_b(1, 0);
+    };
 
     // the 8 MFMAs of one phase: row tile RT against both column tiles
     auto mm = [&](auto fp8_tag, auto rt_tag) {
@@ -224,6 +229,22 @@ __global__ __launch_bounds__(512) void gemm8n_kernel(const GemmArgs p) {
         PB_BAR();
     };
 
+    int vb = blockIdx.x;
+    setup(vb);
+    prologue();
+    bool pf = false;                                         // this tile's prologue was issued in front of the previous tile's epilogue
+    while (true) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (pf) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the eleven DMAs and, behind them, the previous tile's stores
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");        // A[.][0], B[0], A[.][1], B[1] of K tile 0 landed (this wave's share)
+    PB_BAR();
+    if (wr == 1) PB_BAR();                                   // stagger the second wave group by one barrier
+    if (p.dbg) ts1 = __builtin_readcyclecounter();
     if constexpr (!MX) {
         for (int t = 0; t < nk; ++t) tile(std::false_type{}, t);
     } else {                                         // per period (mx_period tiles; 0 = the whole K axis): fp16 tiles, then fp8 tiles
@@ -240,12 +261,27 @@ __global__ __launch_bounds__(512) void gemm8n_kernel(const GemmArgs p) {
     __syncthreads();                                         // staging buffers are dead; the epilogue may use the LDS
     if (p.dbg) ts2 = __builtin_readcyclecounter();
 
-    run_epilogue<EPI, 3, 2, MX>(p, acc, smem, wave, lane, m0 + wr * 192 + wm * 96, n0 + wn * 64, n0);
-    if (p.dbg && tid == 0) {                                 // same record as gemm8_kernel's (tools/gemm_stamps.py)
-        long long *d = p.dbg + (long long)swz * 8;
+    // ---- this tile's epilogue, with the next tile's addresses and first DMAs in front of it where the epilogue touches no LDS: interior tiles of
+    //      the direct fp16 epilogue (run_epilogue: EPI_STD with interleaved columns stores straight from the accumulators) ----
+    const int em0 = m0, en0 = n0, eswz = swz;
+    vb += gridDim.x;
+    const bool more = vb < nwg;
+    pf = more && p.prefetch && EPI == EPI_STD && em0 + BM <= p.M && en0 + BN <= p.N;
+    if (pf) { setup(vb); prologue(); }
+    run_epilogue<EPI, 3, 2, MX>(p, acc, smem, wave, lane, em0 + wr * 192 + wm * 96, en0 + wn * 64, en0);
+    if (p.dbg && tid == 0) {                                 // per TILE, same record as gemm8_kernel's (tools/gemm_stamps.py)
+        long long *d = p.dbg + (long long)eswz * 8;
         const long long t_issue = __builtin_readcyclecounter();
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = t_issue; d[4] = tr0; d[5] = wall_clock64();
-        d[6] = t_issue; d[7] = swz;
+        d[6] = t_issue; d[7] = eswz;
+        ts0 = t_issue; tr0 = d[5];
+    }
+    if (!more) break;
+    if (!pf) {
+        __syncthreads();                                     // the LDS patches of this tile's epilogue are dead
+        setup(vb);
+        prologue();
+    }
     }
 }
 
@@ -262,7 +298,19 @@ int launch_g8n_impl(hipStream_t stream, const GemmArgs &a) {
         attr_set = true;
     }
     const int tilesM = (a.M + G8N_BM - 1) / G8N_BM, tilesN = (a.N + 127) / 128;
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), SMEM, stream, a);
+    static int ncu = 0, persist = 1;
+    if (!ncu) {
+        int dev = 0;
+        PB_HIP(hipGetDevice(&dev));
+        PB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        persist = pb_env_int("PB_G8N_PERSIST", 1);
+    }
+    GemmArgs b = a;
+    b.ntiles = tilesM * tilesN;
+    static const int prefetch = pb_env_int("PB_G8N_PREFETCH", 1);
+    b.prefetch = prefetch;
+    const int grid = persist && b.ntiles > ncu ? ncu : b.ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM, stream, b);
     PB_HIP(hipGetLastError());
     return 0;
 }
