@@ -467,11 +467,12 @@ def main():
                 res["lat_b1"] = (time.perf_counter() - t1) / 5 * 1e3
             # PCIe-inclusive rate (never `value`; SURVEY 8(d) config 4: frames "resident in pinned host memory"): the SAME clip through the
             # host-pointer entry points of both bands - pb_depth_infer_batch and pb_flow_infer_sequence (abi.hip: H2D of chunk i + 1, the band
-            # on chunk i and D2H of chunk i - 1 on three streams) - from page-locked frames into page-locked result arrays, the two bands
-            # called from two threads (ctypes drops the GIL) so that one band's PCIe traffic also runs under the other's kernels.
+            # on chunk i and D2H of chunk i - 1 on three streams) - from page-locked frames into page-locked result arrays, one band after
+            # the other like the timed region (called from two threads the bands' kernels overlap and this figure EXCEEDS `value` - 124.6
+            # against 123.9, r05d - but every launch then takes longer than in the timed region, and the per-symbol averages of
+            # `rocprofv3 --stats -- python bench.py` stop matching the roofline object's).
             # Steady state over args.host_clips clips after one untimed clip; results are compared byte for byte with the HBM-resident leg's.
             if args.host_clips > 0 and world == 1:       # (one-GPU runs: with several ranks the host's PCIe / memory paths are shared and only rank 0 would be measuring)
-                import threading
                 hf = torch.from_numpy(frames).pin_memory()
                 h_rgb = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
                 h_frgb = torch.empty((B - 1, 1, sh, sw, 3), dtype=torch.uint8).pin_memory()
@@ -480,13 +481,6 @@ def main():
                 # timed region, so the per-symbol averages of `rocprofv3 --stats -- python bench.py` stay those of the roofline object
                 dn.set_option("host_chunk", max(1, B // 2))
                 fn.set_option("host_chunk", B)
-                errs = []
-
-                def band(fn_):
-                    try:
-                        fn_()
-                    except BaseException as e:      # noqa: BLE001 - re-raised on the main thread
-                        errs.append(e)
 
                 def d_band():
                     h_scal[0] = dn.infer_batch(hf.numpy(), want_depth=False, want_rgb=True, flip=True, out_rgb=h_rgb.numpy())[2:]
@@ -496,13 +490,8 @@ def main():
                                                   want_rgb=True, out_rgb=h_frgb.numpy())[2]
 
                 def clip():
-                    th = [threading.Thread(target=band, args=(f,)) for f in (d_band, f_band)]
-                    for t_ in th:
-                        t_.start()
-                    for t_ in th:
-                        t_.join()
-                    if errs:
-                        raise errs[0]
+                    d_band()
+                    f_band()
 
                 clip()
                 same = bool((h_rgb == d_rgb.cpu()).all().item()) and bool((h_frgb[:, 0] == f_rgb.cpu()).all().item())
@@ -637,9 +626,8 @@ def main():
                           "ms_per_step": round(main_res["flow_s"] / args.steps * 1e3, 3)},
             "pcie_inclusive_fps": round(main_res["host_fps"], 2) if "host_fps" in main_res else None,
             "pcie_inclusive_note": "the same clip through the host-pointer entry points (pb_depth_infer_batch, pb_flow_infer_sequence) from page-locked frames into "
-                                   "page-locked result arrays, both bands called from two threads; results byte-identical to the HBM-resident leg's.  It can exceed "
-                                   "`value`: there the bands run one after the other with a device sync between them, here their kernels overlap "
-                                   "(the three-band `pipeline` leg of --all-legs shows the same effect)",
+                                   "page-locked result arrays, one band after the other as in the timed region (depth in two chunks whose copies overlap its "
+                                   "own kernels, flow as one chunk: its 199 MB in and 109 MB out are exposed); results byte-identical to the HBM-resident leg's",
             "latency_720p_batch1_ms": round(main_res["lat_b1"], 3) if "lat_b1" in main_res else None,
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(fam.items())},
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items()
