@@ -2,15 +2,17 @@
 //
 // Why it exists.  The generic 128 x 128 tile (gemm_kernel: four waves of 64 x 64, two workgroups per CU) keeps the matrix pipe busy 41 % of
 // the time on the RAFT update block's and encoders' N <= 128 convolutions and on the DPT head's output_conv1: 43 ms of a 258 ms step.
-// What bounds these launches is the LDS, not the L2 -> LDS transport and not latency (profiles/r05b_dma_probe.txt: a CU moves 59.5 bytes per
-// cycle from the L2 by any route; the GEMM kernels all sit at 27-31): per MFMA a 64 x 64 wave tile reads 1 KB of fragments and stages 0.5 KB,
-// i.e. 192 bytes per cycle and CU at full matrix rate against the LDS's 128.  gemm8_kernel's 128 x 64 wave tile needs 0.75 + 0.25 KB
-// per MFMA = exactly 128, which is why it runs at 88 % and nothing narrower does.  A first ping-pong kernel of 256 x 128 with 64 x 64 wave tiles
-// (profiles/r05a_n128_tile_stamps.txt: 1764-1869 cycles per K tile against 1024 MFMA-bound) confirmed it: the staggered wave groups remove
-// the issue stalls, and the loading group's fragment reads + DMA writes (44 KB per segment) then take 1.75x the partner's MFMA segment.
+// What a ping-pong K loop costs (profiles/r05b_dma_probe.txt, r05m_lds_read_probe.txt): its K tile's fragment reads at the
+// LDS read ports' 256 bytes per cycle and CU PLUS its LDS-DMA pieces at ~41 (one 1 KB piece per ~25 cycles and CU while the loading wave
+// group issues them) - 3.9 cycles per KB read + 24.6 per KB staged predicts gemm8_kernel's K tile to a cycle (2323 / 2324 against 2048
+// MFMA-bound).  Neither the L2 -> LDS transport (59.5 bytes per cycle and CU when alone) nor LDS bandwidth as such is the bound.  A first
+// ping-pong kernel of 256 x 128 with 64 x 64 wave tiles (128 KB read + 48 KB staged per K tile: 1680 predicted, 1764-1869 measured against
+// 1024 MFMA-bound, profiles/r05a_n128_tile_stamps.txt) confirmed it: the staggered wave groups remove the issue stalls of the generic tile,
+// and the loading group's reads + DMA issue then take 1.75x the partner's MFMA segment.
 //
 // This kernel: BN = 128 with a 96 x 64 wave tile (3 x 2 MFMA tiles, 96 accumulator registers), i.e. 0.83 KB of fragment reads and 0.33 KB of
-// DMA per MFMA (149 bytes per cycle and CU at full rate), in gemm8_kernel's schedule:
+// DMA per MFMA (160 + 64 KB per K tile: 2198 cycles predicted, 2200-2370 measured against 1536 MFMA-bound - the DMA term alone is 1574, which
+// is why ~70 % is what BN = 128 can reach), in gemm8_kernel's schedule:
 //   * 8 waves = 2 wave groups (rows 0-191 / 192-383) staggered by one barrier, 2 x 2 waves of 96 x 64 each;
 //   * a K tile is three phases of 8 MFMAs per wave, one per 32-row tile rt:
 //         p0: read B(j0)[4] B(j1)[4] A(0)[4] | mfma (0, *)      p1: read A(1)[4] | mfma (1, *)      p2: read A(2)[4] | mfma (2, *)

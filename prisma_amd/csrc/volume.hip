@@ -20,7 +20,7 @@
 // Round 5, measured slower as well (profiles/r05g_volume_64row_waves.txt): 64 source rows per wave against 32-column tiles - half the LDS
 // fragment traffic per MFMA, a lane then owns one column, neighbouring lanes swap a register per row pair and store dwords, 16 lanes
 // covering 64 contiguous bytes of a row: bit-identical volume, 12.5 -> 17.6 ms per step.  The kernel is bound by its stores (half-line
-// segments cost more than the LDS reads they saved), not by the LDS like the GEMM kernels (gemm_n128.h).
+// segments cost more than the fragment reads they saved), not by what its K tiles move through the LDS like the GEMM kernels (gemm_n128.h).
 #include "common.h"
 #include "raft_kernels.h"
 #include "../../include/prisma_bands.h"

@@ -6,6 +6,9 @@
 //   V2  buffer_load_dwordx4 -> VGPRs -> ds_write_b128
 //   V3  V0 with half of the waves reading the LDS (ds_read_b128) instead of loading   (fragment-read traffic beside the DMA)
 //   V4  V0 with `mf` MFMAs per wave between bursts (matrix pipe busy beside the DMA)
+//   V5  no global traffic at all: every wave issues ds_read_b128 (1 KB per wave instruction, conflict-free) back to back - what the LDS itself delivers
+//   V6  V5 with half of the waves issuing LDS-DMA instead (fragment reads beside DMA writes, the GEMM kernels' mix)
+//   V7  V6 with the loading waves going through registers (buffer_load -> VGPRs -> ds_write_b128) instead of LDS-DMA
 // Geometry: one workgroup of NW waves per CU, each workgroup walks its own S-byte window of an L2-resident buffer (S * 32 CUs < 4 MB per XCD),
 // `per` loads per wave back to back, then one wait; T rounds.  Prints bytes per cycle and CU (s_memtime) and GB/s (wall).
 // build: hipcc --offload-arch=gfx950 -O3 tools/probe/dma_probe.hip -o tools/probe/dma_probe.bin
@@ -38,8 +41,26 @@ __global__ __launch_bounds__(512) void probe(const char *src, int S, int T, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = (float)(lane + r);
     f32x4 keep = {0.f, 0.f, 0.f, 0.f};
-    const bool reader = V == 3 && (wave & 1);
-    const int loaders = V == 3 ? nw / 2 : nw, lw = V == 3 ? wave >> 1 : wave;
+    const bool reader = (V == 3 || V == 6 || V == 7) && (wave & 1);
+    const int loaders = (V == 3 || V == 6 || V == 7) ? nw / 2 : nw, lw = (V == 3 || V == 6 || V == 7) ? wave >> 1 : wave;
+    if constexpr (V == 5 || V == 6 || V == 7) {
+        if (V == 5 || reader) {
+            // PER ds_read_b128 per round, straight into registers nobody reads (asm volatile: they are issued), one wait per round
+            const unsigned a0 = (unsigned)(size_t)(smem) + lane * 16 + wave * 1024;
+            const long long t0 = __builtin_readcyclecounter();
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    f32x4 v;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a0), "n"((i & 7) * 4096));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            const long long t1 = __builtin_readcyclecounter();
+            if (tid == 64 * (V == 5 ? 0 : 1)) { stamps[blockIdx.x * 2] = t0; stamps[blockIdx.x * 2 + 1] = t1; }
+            return;
+        }
+    }
     __syncthreads();
     const long long t0 = __builtin_readcyclecounter();
     int off = lw * PER * 1024;                               // this wave's first byte of the round
@@ -50,7 +71,7 @@ __global__ __launch_bounds__(512) void probe(const char *src, int S, int T, int 
                 const f32x4 v = *(const f32x4 *)(smem + ((i * 8 + wave) & 63) * 1024 + lane * 16);
                 keep += v;
             }
-        } else if constexpr (V == 0 || V == 3 || V == 4) {
+        } else if constexpr (V == 0 || V == 3 || V == 4 || V == 6) {
 #pragma unroll
             for (int i = 0; i < PER; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(smem + ((i * nw + wave) & 63) * 1024), 16,
@@ -60,7 +81,7 @@ __global__ __launch_bounds__(512) void probe(const char *src, int S, int T, int 
             f32x4 v[PER];
 #pragma unroll
             for (int i = 0; i < PER; ++i) v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, off + i * 1024, 0));
-            if constexpr (V == 2) {
+            if constexpr (V == 2 || V == 7) {
 #pragma unroll
                 for (int i = 0; i < PER; ++i) *(f32x4 *)(smem + ((i * nw + wave) & 63) * 1024 + lane * 16) = v[i];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -79,7 +100,7 @@ __global__ __launch_bounds__(512) void probe(const char *src, int S, int T, int 
         off = off + loaders * PER * 1024 > S ? lw * PER * 1024 : off;
     }
     const long long t1 = __builtin_readcyclecounter();
-    if (tid == 0) { stamps[blockIdx.x * 2] = t0; stamps[blockIdx.x * 2 + 1] = t1; }
+    if (tid == 0 && V != 6 && V != 7) { stamps[blockIdx.x * 2] = t0; stamps[blockIdx.x * 2 + 1] = t1; }
     float s = keep[0] + keep[1] + keep[2] + keep[3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][5];
@@ -104,7 +125,7 @@ void run(const char *name, const char *src, int S, int nw, int T, int mf, long l
     std::vector<double> cyc;
     for (int i = 0; i < ncu; ++i) cyc.push_back((double)(st[2 * i + 1] - st[2 * i]));
     std::sort(cyc.begin(), cyc.end());
-    const int loaders = V == 3 ? nw / 2 : nw;
+    const int loaders = (V == 3 || V == 6 || V == 7) ? nw / 2 : nw;       // (V6: the stamps are a READER wave's; its share = the other half of the waves)
     const double bytes = (double)T * loaders * PER * 1024;
     printf("%-34s waves %d per %2d mf %3d: %6.1f B/cycle/CU (median WG, %7.0f cycles / round), %7.1f GB/s chip, %.3f ms\n", name, nw, PER, mf,
            bytes / cyc[ncu / 2], cyc[ncu / 2] / T, bytes * ncu / (ms * 1e-3) / 1e9, ms);
@@ -130,6 +151,10 @@ int main(int argc, char **argv) {
         run<2, 8>("V2 load -> vgpr -> ds_write", src, S, nw, T, 0, d_st, d_sink, ncu);
         run<3, 4>("V3 lds-dma | half the waves ds_read", src, S, nw, T, 0, d_st, d_sink, ncu);
         run<3, 8>("V3 lds-dma | half the waves ds_read", src, S, nw, T, 0, d_st, d_sink, ncu);
+        run<5, 8>("V5 ds_read_b128 only", src, S, nw, T, 0, d_st, d_sink, ncu);
+        run<5, 16>("V5 ds_read_b128 only", src, S, nw, T, 0, d_st, d_sink, ncu);
+        run<6, 8>("V6 ds_read_b128 (counted) | half the waves lds-dma", src, S, nw, T, 0, d_st, d_sink, ncu);
+        run<7, 8>("V7 ds_read_b128 (counted) | half the waves load -> vgpr -> ds_write", src, S, nw, T, 0, d_st, d_sink, ncu);
         run<4, 2>("V4 lds-dma + mfma", src, S, nw, T, 8, d_st, d_sink, ncu);
         run<4, 3>("V4 lds-dma + mfma", src, S, nw, T, 8, d_st, d_sink, ncu);
         run<4, 4>("V4 lds-dma + mfma", src, S, nw, T, 16, d_st, d_sink, ncu);
