@@ -382,16 +382,6 @@ def main():
         weights = synth.cached_weights("depth", cfg, 1234)
         rweights = synth.cached_weights("raft", 4321)
     B, H, W = args.batch, args.height, args.width
-    # CPU baseline (rank 0 of a one-GPU run): the oracle on 32 host threads takes ~10 s and needs no GPU - on a host with cores to spare it
-    # runs as a child process NEXT to the GPU legs (which keep one core busy launching kernels) instead of after them; the driver's wall
-    # clock around this command is then mostly GPU time.  Smaller hosts run it at the end, as before.
-    cpu_child = None
-    if world == 1 and not args.no_cpu_baseline and (os.cpu_count() or 1) >= 48:
-        import subprocess
-        cpu_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--height", str(H), "--width", str(W),
-                                      "--encoder", args.encoder, "--flow-scale", str(args.flow_scale), "--flow-iters", str(args.flow_iters)],
-                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-
     # one synthetic clip per rank (a seeded noise texture shifted by a known step per frame, so the flow is not degenerate),
     # resident in HBM before the timed region; one step = both bands over the whole clip
     frames = synth.frame_pair_sequence(B, H, W, seed=1000 + rank)
@@ -506,6 +496,16 @@ def main():
         return res
 
     main_res = run_mode(args.precision, args.steps, args.warmup, True)
+    # CPU baseline (rank 0 of a one-GPU run): the oracle on 32 host threads takes ~10 s and needs no GPU - on a host with cores to spare it
+    # runs as a child process NEXT to the remaining GPU legs (clock probe, the other precision mode's child, optional legs) instead of after
+    # them; the driver's wall clock around this command is then mostly GPU time.  It starts only now: beside the timed
+    # region it cost the depth band 20 ms of launch gaps on one box (r05z, first attempt).  Smaller hosts run it at the end, as before.
+    cpu_child = None
+    if world == 1 and not args.no_cpu_baseline and (os.cpu_count() or 1) >= 48:
+        import subprocess
+        cpu_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--height", str(H), "--width", str(W),
+                                      "--encoder", args.encoder, "--flow-scale", str(args.flow_scale), "--flow-iters", str(args.flow_iters)],
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     # effective shader clock under the band's dominant GEMM shape: per-tile s_memtime / s_memrealtime stamps of one
     # launch of the ping-pong kernel at the ViT's fc1 + GELU shape, right after the timed region (chip warm).  The 2.5 PF the fractions are
     # quoted against assume 2.4 GHz; on data the part is power-limited (profiles/r04a_clock_mfma_peak.txt: 1.63-1.65 GHz in a bare MFMA loop).
