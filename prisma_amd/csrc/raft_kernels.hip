@@ -555,10 +555,13 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__
             c[ky] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? *(const f16x8 *)(base + ((int64_t)iy * W + ix) * 256) : zero;
         }
     };
-    f16x8 c0[3], c1[3], c2[3];
-    col(xa - 1, c0); col(xa, c1);
+    // the window's columns are loaded TWO steps ahead (round 5: at 202 registers the kernel runs two waves per SIMD, so a column requested at the
+    // top of the step that needs it could expose an L2 round trip per pixel).  Measured: 3.28 -> 3.18 ms per step - the kernel is bound by its
+    // two 72-deep v_dot2 chains per pixel pair, not by that latency
+    f16x8 c0[3], c1[3], c2[3], c3[3];
+    col(xa - 1, c0); col(xa, c1); col(xa + 1, c2);
     for (int ix = xa; ix < xb; ++ix) {
-        col(ix + 1, c2);
+        col(ix + 2, c3);
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__
             flow[p * 2] += a0 + b0; flow[p * 2 + 1] += a1 + b1;
         }
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) { c0[ky] = c1[ky]; c1[ky] = c2[ky]; }
+        for (int ky = 0; ky < 3; ++ky) { c0[ky] = c1[ky]; c1[ky] = c2[ky]; c2[ky] = c3[ky]; }
     }
 }
 
