@@ -562,6 +562,12 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__
     col(xa - 1, c0); col(xa, c1); col(xa + 1, c2);
     for (int ix = xa; ix < xb; ++ix) {
         col(ix + 2, c3);
+        // the pixel's current flow is requested here, with the window column, instead of as a dependent load in front of the store.
+        // (Round 5 went through this kernel's suspects - this round trip, column prefetch depth, eight instead of two accumulation chains,
+        // XCD-contiguous block order, run lengths 8 ... 90: 3.06-3.38 ms per step whatever is changed (profiles/r05r_flow_head2_sweep.txt);
+        // what is left is the issue rate of its 144 v_dot2 per pixel pair.)
+        const int64_t p = ((int64_t)img * H + y) * W + ix;
+        const f32x2 old = *(const f32x2 *)(flow + p * 2);
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -586,8 +592,9 @@ __global__ __launch_bounds__(256) void flow_head2_kernel(const f16 *__restrict__
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
         if (cl == 0) {
-            const int64_t p = ((int64_t)img * H + y) * W + ix;
-            flow[p * 2] += a0 + b0; flow[p * 2 + 1] += a1 + b1;
+            f32x2 o;
+            o[0] = old[0] + (a0 + b0); o[1] = old[1] + (a1 + b1);
+            *(f32x2 *)(flow + p * 2) = o;
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) { c0[ky] = c1[ky]; c1[ky] = c2[ky]; c2[ky] = c3[ky]; }
