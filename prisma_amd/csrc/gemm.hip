@@ -76,6 +76,25 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
     }
     if (epi == EPI_RESID) PB_CHECK(a.resid && (int64_t)a.M * a.ldr * 4 < (1LL << 32) - (1 << 20), -1, "residual epilogue: the stream (%d rows) must fit a 32-bit buffer resource", a.M);
     if (epi == EPI_QKV) PB_CHECK(a.D % (tile == TILE_128 ? 128 : 256) == 0 && a.ntp % 8 == 0, -1, "qkv epilogue: D=%d ntp=%d", a.D, a.ntp);
+    {   // PB_EPI_REPORT=1 (diagnostic): EPI_STD launches whose activation / skip / copy combination is not one of the
+        // straight-line epilogue copies (gemm_kernels.h direct_epilogue_any PB_FAST_CASE list; tests/test_build_checks_cpu.py holds the two
+        // lists against each other) take the run-time switched pass loop at ~2x the epilogue cost: name them, once per combination
+        static const int report = pb_env_int("PB_EPI_REPORT", 0);
+        if (report && epi == EPI_STD) {
+            static const int fast_keys[] = {ACT_NONE, ACT_RELU, ACT_GELU, ACT_GRU_ZR, ACT_GRU_Q, ACT_NONE | 64, ACT_NONE | 16, ACT_NONE | 16 | 32 | 64,
+                                            ACT_GRU_ZR | 16 | 32, ACT_GRU_Q | 16 | 32, ACT_RELU | 16 | 128, ACT_RELU | 64, ACT_RELU | 16};
+            const int key = a.act | (a.add1 ? 16 : 0) | (a.add2 ? 32 : 0) | (a.out2 ? 64 : 0) | (a.pre_relu ? 128 : 0);
+            bool hit = false;
+            for (int k : fast_keys) hit |= k == key;
+            static unsigned long long seen[8] = {};
+            if (!hit && !(seen[key >> 6 & 7] >> (key & 63) & 1)) {
+                seen[key >> 6 & 7] |= 1ull << (key & 63);
+                fprintf(stderr, "[pb_epi_report] EPI_STD launch outside the fast-epilogue list: key %d (act %d%s%s%s%s), first seen at M = %d, N = %d, K = %d, %s\n", key,
+                        a.act, a.add1 ? " + add1" : "", a.add2 ? " + add2" : "", a.out2 ? " + out2" : "", a.pre_relu ? " + pre_relu" : "", a.M, a.N, a.K,
+                        amode == A_CONV ? "conv" : "dense");
+            }
+        }
+    }
     const bool mx = a.nk16 > 0;
     // MX builds write / read split maps with e4m3 residual parts, fp16-only builds with fp16 residual parts
     PB_CHECK(!a.lo_off || (a.lo8 != 0) == mx, -1, "gemm: split-map format (lo8 = %d) does not match the weights' (nk16 = %d)", a.lo8, a.nk16);

@@ -44,3 +44,19 @@ def test_accumulator_shuffle_in_a_k_loop_is_reported(tmp_path):
     assert len(got) == 1 and got[0][1:] == (24, 128)
     assert t.acc_shuffles(_listing(tmp_path, "clean", clean)) == []
     assert t.acc_shuffles(_listing(tmp_path, "tileloop", tile_loop)) == []
+
+
+def test_fast_epilogue_key_lists_agree():
+    """The device dispatch (gemm_kernels.h direct_epilogue_any: PB_FAST_CASE list) and the host-side PB_EPI_REPORT diagnostic (gemm.hip) name the
+    launch kinds with a straight-line epilogue copy twice; a key added to one and not the other would make the report lie."""
+    import re
+    src = open(os.path.join(ROOT, "prisma_amd", "csrc", "gemm_kernels.h")).read()
+    acts = dict(re.findall(r"(ACT_\w+) = (\d+)", open(os.path.join(ROOT, "prisma_amd", "csrc", "gemm.h")).read()))
+    ev = lambda e: eval(e, {}, {k: int(v) for k, v in acts.items()})
+    sw = src[src.index("switch (key) {"):src.index("#undef PB_FAST_CASE")]
+    dev = sorted(ev(e) for e in re.findall(r"PB_FAST_CASE\(([^)]*)\)", sw))
+    host_src = open(os.path.join(ROOT, "prisma_amd", "csrc", "gemm.hip")).read()
+    lst = host_src[host_src.index("fast_keys[] = {") + len("fast_keys[] = {"):]
+    lst = lst[:lst.index("};")]
+    host = sorted(ev(e.strip()) for e in lst.replace("\n", " ").split(",") if e.strip())
+    assert dev == host and len(dev) == 13, (dev, host)

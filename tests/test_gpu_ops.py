@@ -242,3 +242,17 @@ def test_encode_still_bytes_match_the_reference(ops, golden_dir):
                 IO.write_depth(p, d.copy(), band.heat_to_rgb, normalize=True, flip=flip, heatmap=True, encode_range=True)
                 want = np.asarray(Image.open(p))
             assert np.array_equal(rgb, want), (H, W, flip, int((rgb != want).sum()))
+
+
+def test_epilogue_report_names_launch_kinds_outside_the_fast_list():
+    """PB_EPI_REPORT=1 (gemm.hip): an EPI_STD launch whose activation / skip combination has no straight-line epilogue copy is named once on
+    stderr; the kinds the bands launch are all inside the list (profiles/r05u_epilogue_report.txt: nothing reported by the depth, flow_raft,
+    flow_gmflow, mask and metric-depth suites)."""
+    import subprocess, sys
+    code = ("import numpy as np; from prisma_amd import engine; o = engine.Ops(0); A = np.ones((256, 64), np.float32); W = np.ones((128, 64), np.float32);"
+            "o.gemm(A, W, None, act=1, tile=2); o.gemm(A, W, None, act=3, tile=2); o.gemm(A, W, None, act=3, tile=2); o.close()")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PB_EPI_REPORT="1"),
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-400:]
+    lines = [l for l in r.stderr.splitlines() if "pb_epi_report" in l]
+    assert len(lines) == 1 and "key 3 " in lines[0] and "act 3" in lines[0], r.stderr[-400:]
