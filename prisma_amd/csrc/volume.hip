@@ -19,8 +19,17 @@
 // (13.6 ms); a fifth, load-only producer wave so that the compute waves never wait on their stores (28 ms).
 // Round 5, measured slower as well (profiles/r05g_volume_64row_waves.txt): 64 source rows per wave against 32-column tiles - half the LDS
 // fragment traffic per MFMA, a lane then owns one column, neighbouring lanes swap a register per row pair and store dwords, 16 lanes
-// covering 64 contiguous bytes of a row: bit-identical volume, 12.5 -> 17.6 ms per step.  The kernel is bound by its stores (half-line
-// segments cost more than the fragment reads they saved), not by what its K tiles move through the LDS like the GEMM kernels (gemm_n128.h).
+// covering 64 contiguous bytes of a row: bit-identical volume, 12.5 -> 17.6 ms per step.
+// Round 5, what the parts cost on their own (PB_VOL_ABL, profiles/r05y_volume_ablations.txt; ms per step, the 12.1 ms kernel of that
+// visit): stores only 6.2 (4.5 TB/s - tools/probe/volume_store_probe.hip reaches 4.7 with this exact pattern and 5.0 with 512-byte
+// runs: the pattern is not the problem), matrix work only 7.4, + DMA 8.3, DMA + stores 9.4, all three 12.1: the parts ADD rather than
+// overlap.  Two changes came out of it: buffer stores (flat 64-bit addresses cost a v_mad_u64_u32 + v_lshl_add_u64 per store; and the
+// descriptor has to be built from readfirstlane'd halves or every store sits in a waterfall loop) 12.7 -> 11.9 ms, and fragment reads
+// issued a quarter tile ahead (see the K loop) 11.9 -> 11.65.  Measured without gain, removed: pad loads so that a tile of stores may
+// stay in flight across the wait (16 out-of-range single-lane LDS-DMA loads per tile raise the number of LOADS behind the stage the
+// wait is about: 12.4 ms, with 32: 12.9), stores spread two per k-step over the first half of the tile (11.66 = unchanged) or one per
+// k-step over the whole tile (12.15), one 8-wave workgroup per CU sharing the target tiles (half the DMA bytes: 13.4 ms, matrix work
+// alone 8.6 - the barrier spans twice the waves).
 #include "common.h"
 #include "raft_kernels.h"
 #include "../../include/prisma_bands.h"
@@ -42,6 +51,7 @@ namespace {
 
 constexpr int VBM = 128, VBN = 64, VNT = 256, VSTAGES = 4, VSTAGE_BYTES = 2 * VBN * 128;     // a stage = two K tiles of 64 columns
 
+template <int ABL>
 __global__ __launch_bounds__(VNT, 2) void corr_volume_kernel(const f16 *__restrict__ A, int M, const f16 *__restrict__ W, int N, int w_rows,
                                                              f16 *__restrict__ out, int64_t ldo, int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,6 +91,7 @@ __global__ __launch_bounds__(VNT, 2) void corr_volume_kernel(const f16 *__restri
         b_voff[i] = (2 * (r & 31) + (r >> 5)) * 512 + cg * 16;
     }
     auto stage = [&](int g) {
+        if (ABL & 4) return;
         const int nt = nt0 + (g >> 1), h = g & 1;
         char *dst = smem + (g & (VSTAGES - 1)) * VSTAGE_BYTES + wave * 1024;
         const int soff = nt * (VBN * 512) + h * 256;
@@ -104,30 +115,50 @@ __global__ __launch_bounds__(VNT, 2) void corr_volume_kernel(const f16 *__restri
     stage(0);
     stage(1);
     if (G > 2) stage(2);
-    // af is indexed with compile-time k-steps inside each half (a runtime index would put it in scratch)
-#define PB_VOL_HALF(H)                                                                                                  \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                    \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                  \
-        const int c = kk * (VBN * 128) + ((2 * ks + lh) ^ fsw) * 16;                                                    \
-        const f16x8 b0 = *(const f16x8 *)(sb + b_off[0] + c), b1 = *(const f16x8 *)(sb + b_off[1] + c);                 \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[H * 8 + kk * 4 + ks], b0, acc[0], 0, 0, 0);                  \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[H * 8 + kk * 4 + ks], b1, acc[1], 0, 0, 0);                  \
-    }
+    // Fragment reads run ahead of the MFMAs through two quarter buffers (a quarter = one K tile of 64 = 4 k-steps x 2 column halves = 8
+    // ds_read_b128 = 32 registers): the quarters of a tile are q0, q1 (stage g) and q2, q3 (stage g + 1, landed as well when the tile
+    // starts); q0 and q1 are requested together, q2 / q3 are requested k-step by k-step into the registers q0 / q1's MFMAs have just
+    // consumed.  Written as "two reads, two MFMAs" the compiler kept ONE pair of fragments in flight (118 registers, as if four waves per
+    // SIMD were possible - the LDS allows two) and every k-step waited out the LDS latency: the matrix work alone, no DMA and no stores,
+    // took 7.4 ms per step against 2.8 ms of MFMA cycles (PB_VOL_ABL, profiles/r05y_volume_ablations.txt).
+    // af is indexed with compile-time k-steps (a runtime index would put it in scratch).
+    f16x8 qa[8], qb[8];
+#define PB_VOL_C(KK, KS) ((KK) * (VBN * 128) + ((2 * (KS) + lh) ^ fsw) * 16)
+#define PB_VOL_RD(Q, SB, KK, KS)                                                  \
+    Q[2 * (KS)] = *(const f16x8 *)((SB) + b_off[0] + PB_VOL_C(KK, KS));           \
+    Q[2 * (KS) + 1] = *(const f16x8 *)((SB) + b_off[1] + PB_VOL_C(KK, KS));
+#define PB_VOL_MM(Q, A0, KS)                                                                       \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[(A0) + (KS)], Q[2 * (KS)], acc[0], 0, 0, 0);     \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[(A0) + (KS)], Q[2 * (KS) + 1], acc[1], 0, 0, 0);
+#define PB_VOL_PIN() __builtin_amdgcn_sched_barrier(0)
     // A lane owns columns 2 li, 2 li + 1 of a tile (acc[0], acc[1]) for 16 rows: 32 lanes write 128 B of a row.  A tile's stores are issued
     // one tile LATE (from `pk`), right after the wait of the next tile's first step: the wait that has to count them - loads and stores
     // share vmcnt and return out of order with respect to each other, so a wait that must see a DMA land can only be "everything but the
     // newest stage" - is then a whole tile (two steps) away, and they drain under that tile's MFMAs.
+    // The stores are buffer stores through a resource that spans exactly this wave's rows (base out + m0 * ldo, range = its valid rows): a
+    // 32-bit lane offset + a scalar row offset per store, and rows past M fall outside the range.  Flat 64-bit addresses cost a
+    // v_mad_u64_u32 + v_lshl_add_u64 pair per store, which next to a wave that keeps the matrix pipe busy is what
+    // tools/probe/store_probe.hip prices at ~770 cycles per access (buffer-addressed: 35).
     f16x2 pk[16];
     int pk_n = -1;                                              // first column of the tile held in pk, -1: none
-    auto flush = [&]() {
-        if (pk_n >= 0 && pk_n < N) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < M) *(f16x2 *)(out + (int64_t)m * ldo + pk_n) = pk[r];
-            }
-        }
+    const int rows_w = (M - m0) < 32 ? (M - m0 < 0 ? 0 : M - m0) : 32;
+    const int ldb = (int)ldo * 2;                               // row stride in bytes (launch_corr_volume checks 32 rows fit 31 bits)
+    // (built from readfirstlane'd halves: left to itself the compiler keeps the descriptor in VGPRs and wraps every store in a waterfall loop)
+    const uint64_t ob = (uint64_t)(out + (int64_t)m0 * ldo);
+    const uint64_t ob_u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(ob >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)ob);
+    const __amdgpu_buffer_rsrc_t rsO = make_rsrc((const void *)ob_u, (unsigned)__builtin_amdgcn_readfirstlane(rows_w * ldb));
+    const int vo_lane = 4 * lh * ldb + 4 * li;
+    // Lanes without a tile to store (none yet, columns past N) carry an offset outside the resource: the store is dropped by the range check.
+    constexpr int VO_NONE = 0x7ffff000;
+    int vo_st = VO_NONE;
+    auto st1 = [&](int r) {
+        if (!(ABL & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk[r]), rsO, vo_st, ((r & 3) + 8 * (r >> 2)) * ldb, 0);
     };
+    auto flush = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st1(r);
+    };
+    unsigned keep = 0;                                          // (PB_VOL_ABL: keeps the matrix work alive when the stores are ablated)
     for (int j = 0; j < ntl; ++j) {
         const int g = 2 * j;
         // ---- step g: stages g and g + 1 must have landed; only stage g + 2 (4 DMAs) may stay in flight - and none of the stores ----
@@ -136,36 +167,59 @@ __global__ __launch_bounds__(VNT, 2) void corr_volume_kernel(const f16 *__restri
         VOL_BAR();                                              // ... for every wave; slot (g + 3) & 3 = (g - 1) & 3 is free
         if (g + 3 < G) stage(g + 3);
         flush();                                                // the previous tile's results
-        {
-            const char *sb = smem + (g & (VSTAGES - 1)) * VSTAGE_BYTES;
-            PB_VOL_HALF(0)
+        const char *sb0 = smem + (g & (VSTAGES - 1)) * VSTAGE_BYTES, *sb1 = smem + ((g + 1) & (VSTAGES - 1)) * VSTAGE_BYTES;
+        if (!(ABL & 2)) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { PB_VOL_RD(qa, sb0, 0, ks) }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { PB_VOL_RD(qb, sb0, 1, ks) }
+            PB_VOL_PIN();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { PB_VOL_MM(qa, 0, ks) PB_VOL_RD(qa, sb1, 0, ks) PB_VOL_PIN(); }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { PB_VOL_MM(qb, 4, ks) PB_VOL_RD(qb, sb1, 1, ks) PB_VOL_PIN(); }
         }
-        // ---- step g + 1: landed already (waited for above); the barrier frees slot g & 3 for stage g + 4 ----
+        // ---- every read of stage g has been consumed: the barrier frees slot g & 3 for stage g + 4 ----
         VOL_BAR();
         if (g + 4 < G) stage(g + 4);
-        {
-            const char *sb = smem + ((g + 1) & (VSTAGES - 1)) * VSTAGE_BYTES;
-            PB_VOL_HALF(1)
+        if (!(ABL & 2)) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { PB_VOL_MM(qa, 8, ks) }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { PB_VOL_MM(qb, 12, ks) }
         }
         pk_n = (nt0 + j) * VBN + 2 * li;
+        vo_st = pk_n < N ? vo_lane + (nt0 + j) * (VBN * 2) : VO_NONE;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             pk[r] = f16x2{(f16)acc[0][r], (f16)acc[1][r]};
             acc[0][r] = 0.f; acc[1][r] = 0.f;
+            if (ABL & 1) keep ^= __builtin_bit_cast(unsigned, pk[r]);
         }
     }
-#undef PB_VOL_HALF
+#undef PB_VOL_C
+#undef PB_VOL_RD
+#undef PB_VOL_MM
+#undef PB_VOL_PIN
     flush();
+    if ((ABL & 1) && keep == 0x12345679u) out[0] = (f16)1.f;
 }
 
 }  // namespace
 
 int launch_corr_volume(hipStream_t s, const f16 *A, int M, const f16 *W, int N, int w_rows, f16 *out, int64_t ldo) {
-    PB_CHECK(A && W && out && M > 0 && N > 0 && N % 8 == 0 && ldo >= N && w_rows >= N, PB_ERR_ARG, "corr_volume: bad arguments");
+    PB_CHECK(A && W && out && M > 0 && N > 0 && N % 8 == 0 && ldo >= N && w_rows >= N && ldo < (1 << 24), PB_ERR_ARG, "corr_volume: bad arguments");
     static bool once = false;
     const int smem = VSTAGES * VSTAGE_BYTES;
+    static int abl = 0;                                         // PB_VOL_ABL (diagnostic, wrong results): 1 no stores, 2 no fragment reads / MFMAs, 4 no DMA
     if (!once) {
-        PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        abl = pb_env_int("PB_VOL_ABL", 0);
+        PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         once = true;
     }
     const int tilesM = (M + VBM - 1) / VBM, tilesN = (N + VBN - 1) / VBN;
@@ -174,6 +228,15 @@ int launch_corr_volume(hipStream_t s, const f16 *A, int M, const f16 *W, int N, 
     groups = groups < 1 ? 1 : (groups > tilesN ? tilesN : groups);
     const int tpw = (tilesN + groups - 1) / groups;
     groups = (tilesN + tpw - 1) / tpw;
-    hipLaunchKernelGGL(corr_volume_kernel, dim3(tilesM * groups), dim3(VNT), smem, s, A, M, W, N, w_rows, out, ldo, tpw);
+#define PB_VOL_LAUNCH(X) hipLaunchKernelGGL(corr_volume_kernel<X>, dim3(tilesM * groups), dim3(VNT), smem, s, A, M, W, N, w_rows, out, ldo, tpw)
+    switch (abl) {
+        case 1: PB_VOL_LAUNCH(1); break;
+        case 2: PB_VOL_LAUNCH(2); break;
+        case 4: PB_VOL_LAUNCH(4); break;
+        case 5: PB_VOL_LAUNCH(5); break;
+        case 6: PB_VOL_LAUNCH(6); break;
+        default: PB_VOL_LAUNCH(0);
+    }
+#undef PB_VOL_LAUNCH
     LAUNCH_CHECK();
 }
