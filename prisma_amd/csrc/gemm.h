@@ -77,6 +77,7 @@ struct GemmArgs {
     float qscale = 1.f;
     // EPI_PIXSHUF: rows = (b, y, x) of a [B, ps_h, ps_w] grid; cols = (dy, dx, co); kernel == stride == ps_s
     int ps_s = 1, ps_h = 0, ps_w = 0, ps_co = 0;
+    int ps_buf = 0;     // set by launch_gemm: the buffer-addressed pixel-shuffle epilogue applies (gemm_kernels.h pixshuf_epilogue_buf)
     // EPI_PATCH: rows = (b, patch); writes resid[b*ntp + 1 + patch] = v + bias + pos[1 + patch]
     const float *pos = nullptr;
     int ppi = 0;

@@ -47,6 +47,14 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         const int est = (3200 * nk + 24000) / 8 / 64;
         a.stagger = env_st > 0 ? est * env_st / 100 : 0;    // measured: no gain (0.97-1.0x), so off unless requested
     }
+    if (epi == EPI_PIXSHUF) {
+        // buffer-addressed pixel-shuffle epilogue (gemm_kernels.h pixshuf_epilogue_buf): at most TM <= 4 grid rows per wave tile, and the
+        // window a wave addresses (128 rows x s pixels + 4 wraps of s (s - 1) ps_w pixels) well inside the 2 GB a resource spans
+        static int env_pb = -1;
+        if (env_pb < 0) env_pb = pb_env_int("PB_PIXSHUF_BUF", 1);
+        const int64_t pbytes = a.ldo * 2, window = (int64_t)(128 * a.ps_s + 4 * a.ps_s * (a.ps_s - 1) * (int64_t)a.ps_w) * pbytes;
+        a.ps_buf = env_pb && a.ps_w >= 32 && a.ps_co % 64 == 0 && window < (1LL << 30) ? 1 : 0;
+    }
     if (tile == TILE_AUTO) {
         // 256x256 needs wide N and enough tiles to fill 256 CUs; the q/k/v split needs D % BN == 0
         const bool wide = a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256;

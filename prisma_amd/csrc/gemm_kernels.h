@@ -913,6 +913,83 @@ __device__ __forceinline__ void direct_epilogue_buf(const GemmArgs &p, f32x16 (&
     }
 }
 
+// ---- round 5: the pixel-shuffle epilogue through a buffer resource --------------------------------------------------------------------
+// Row m = (b, y, x) of the [B, ps_h, ps_w] grid lands at output pixel P(m) = s m + s (s - 1) ps_w Y(m) + (dy ps_w s + dx), Y = m / ps_w
+// (image rows run on across the batch: b ps_h + y).  The flat epilogue divides twice per row (64 rows per lane and tile: ~5k instructions
+// of integer division) and carries 64-bit offsets; the stem of the flow band's encoder (K = 9 tiles, the epilogue IS the kernel) ran at
+// 0.7 TB/s of output.  Here the wave divides ONCE (its first row), the resource starts at that row's pixel, a row is
+//     scalar offset (s x tile-local row)  +  lane offset (its half's 4 rows, its channel pair)  +  wraps x (s (s - 1) ps_w pixels)
+// where wraps = how many grid rows the lane's row lies past the wave's first one: sum over k of (x0 + d >= k ps_w), k <= TM (ps_w >= 32).
+// Arithmetic, rounding and store order are those of direct_epilogue_f16_impl: the same bits.
+template <int TM, bool CHECK, int LOM>
+__device__ __forceinline__ void pixshuf_epilogue_buf(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int n = wave_n0 + 2 * li;
+    const bool nok = !CHECK || n < p.N;
+    const int tap = wave_n0 / p.ps_co;                           // a wave's 64 columns never straddle a tap (ps_co % 64 == 0)
+    const int co = wave_n0 - tap * p.ps_co + 2 * li;
+    const int tap_dy = tap / p.ps_s, tap_dx = tap - tap_dy * p.ps_s;
+    float b0 = 0.f, b1 = 0.f;
+    if (p.bias) { const int bi = nok ? co : 0; b0 = p.bias[bi]; b1 = p.bias[bi + 1]; }
+    const int s = p.ps_s, psw = p.ps_w;
+    const int pb = (int)p.ldo * 2;                               // bytes per output pixel
+    const int Y0 = wave_m0 / psw, x0 = wave_m0 - Y0 * psw;
+    const int64_t pix0 = (int64_t)s * wave_m0 + (int64_t)s * (s - 1) * psw * Y0 + (int64_t)tap_dy * psw * s + tap_dx;
+    const BufT td = buf_of(p.out, pix0 * pb, 0);
+    const unsigned wrapb = (unsigned)(s * (s - 1) * psw) * (unsigned)pb;
+    const unsigned vrow = (unsigned)(4 * lh * s * pb);
+    const unsigned v16 = vrow + (unsigned)(co * 2), vlo16 = v16 + (unsigned)(p.lo_off * 2);
+    const unsigned v8hi = vrow + (unsigned)(2 * p.lo_off + co), v8lo = v8hi + (unsigned)p.lo_off;
+    const float lo8_shi = __builtin_ldexpf(1.f, p.lo8_pa), lo8_slo = __builtin_ldexpf(1.f, p.lo8_pa + 12);
+    const int xl = x0 + 4 * lh;
+    const bool relu = p.act == ACT_RELU;
+#pragma unroll
+    for (int th = 0; th < TM * 2; ++th) {
+        const int tm = th >> 1, r0 = (th & 1) * 8;
+        float v0[8], v1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { v0[q] = acc[tm][0][r0 + q] + b0; v1[q] = acc[tm][1][r0 + q] + b1; }
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+        }
+        unsigned wv[8], pz[8];
+        int so[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = r0 + q;
+            const int rowc = tm * 32 + (r & 3) + 8 * (r >> 2);
+            const int t = xl + rowc;
+            int w = 0;
+#pragma unroll
+            for (int k = 1; k <= TM; ++k) w += t >= k * psw ? 1 : 0;
+            wv[q] = (unsigned)w * wrapb;
+            pz[q] = (!CHECK || (nok && wave_m0 + rowc + 4 * lh < p.M)) ? 0u : PB_POISON;       // OR-ed in: an add would wrap around
+            so[q] = rowc * s * pb;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            f16x2 o;
+            o[0] = (f16)v0[q]; o[1] = (f16)v1[q];
+            bs_h2(td, (v16 + wv[q]) | pz[q], so[q], o);
+        }
+        if constexpr (LOM == 1 || LOM == 2) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if constexpr (LOM == 2) {
+                    const f16 h0 = (f16)v0[q], h1 = (f16)v1[q];
+                    bs_u16(td, (v8hi + wv[q]) | pz[q], so[q], pb_fp8x2((float)h0 * lo8_shi, (float)h1 * lo8_shi));
+                    bs_u16(td, (v8lo + wv[q]) | pz[q], so[q], pb_fp8x2((v0[q] - (float)h0) * lo8_slo, (v1[q] - (float)h1) * lo8_slo));
+                } else {
+                    f16x2 o;
+                    o[0] = (f16)(v0[q] - (float)(f16)v0[q]); o[1] = (f16)(v1[q] - (float)(f16)v1[q]);
+                    bs_h2(td, (vlo16 + wv[q]) | pz[q], so[q], o);
+                }
+            }
+        }
+    }
+}
+
 template <int EPI, int TM, bool CHECK, int LOM>
 __device__ __forceinline__ void direct_epilogue_any(const GemmArgs &p, f32x16 (&acc)[TM][2], int wave_m0, int wave_n0, int lane) {
 #ifdef PB_EPI_FLAT_STD      // A/B builds only (make EXTRA=-DPB_EPI_FLAT_STD): the round-3 flat-addressed epilogue for EPI_STD
@@ -938,6 +1015,11 @@ __device__ __forceinline__ void direct_epilogue_any(const GemmArgs &p, f32x16 (&
         }
         direct_epilogue_buf<EPI, TM, CHECK, LOM>(p, acc, wave_m0, wave_n0, lane);
     } else if constexpr (EPI == EPI_QKV) direct_epilogue_buf<EPI, TM, CHECK, LOM>(p, acc, wave_m0, wave_n0, lane);
+    else if constexpr (EPI == EPI_PIXSHUF && LOM != 3) {
+        // (ps_buf: set by the launcher when ps_w >= 32 and TM x 32 rows of output pixels + the wraps stay inside a 2 GB window)
+        if (p.ps_buf) pixshuf_epilogue_buf<TM, CHECK, LOM>(p, acc, wave_m0, wave_n0, lane);
+        else direct_epilogue_f16_impl<EPI, TM, CHECK, LOM>(p, acc, wave_m0, wave_n0, lane);
+    }
     else direct_epilogue_f16_impl<EPI, TM, CHECK, LOM>(p, acc, wave_m0, wave_n0, lane);
 }
 
