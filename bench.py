@@ -16,6 +16,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL between processes needs dmabuf IPC on this driver (the image exports it; kept here for a shell that does not)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (plumbing: device sync + torch.distributed over RCCL)
