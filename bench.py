@@ -341,6 +341,7 @@ def main():
     ap.add_argument("--latency", action="store_true", default=True,
                     help="also time one 1280x720 frame at batch 1 (BASELINE configs[1]; on by default since round 4: eight batch-1 calls, ~0.1 s)")
     ap.add_argument("--no-latency", dest="latency", action="store_false")
+    ap.add_argument("--concurrent-bands", action="store_true", help="experiment: run the two bands of a step concurrently (two host threads, two streams); per-launch durations then include the other band's interference")
     ap.add_argument("--no-clock", action="store_true", help="skip the effective-clock probe behind roofline.effective_clock_ghz")
     ap.add_argument("--host-clips", type=int, default=3,
                     help="clips pushed through the host-pointer entry points of both bands (page-locked frames in, page-locked results out) for "
@@ -416,11 +417,21 @@ def main():
 
         def step():
             a = time.perf_counter()
-            depth()
-            b = time.perf_counter()
-            flow()
-            c = time.perf_counter()
-            band_s[0] += b - a; band_s[1] += c - b
+            if args.concurrent_bands:          # experiment (EXPERIMENTS.md 5.12): both bands at once, each on its own stream, from two host threads
+                import threading
+                tf = threading.Thread(target=flow)
+                tf.start()
+                depth()
+                b = time.perf_counter()
+                tf.join()
+                c = time.perf_counter()
+                band_s[0] += b - a; band_s[1] += c - a
+            else:
+                depth()
+                b = time.perf_counter()
+                flow()
+                c = time.perf_counter()
+                band_s[0] += b - a; band_s[1] += c - b
             if R.dist is not None:
                 R.all_gather(gathered, scal)                              # the only exchange: 12 bytes per frame
 
