@@ -17,7 +17,7 @@ WHAT = {
     "depth/gemm8_kernel<0, 0, 0, true, true>": "ViT fc1 + GELU, DPT 1 x 1 projections / out_convs",
     "depth/gemm8_kernel<1, 0, 0, true, true>": "DPT head 3 x 3 convolutions with N = 256",
     "flow/conv3x3_c64_mx2_kernel": "encoder stage 1 (halo-tiled direct 3 x 3, 64 -> 64 at 1/2 resolution)",
-    "flow/corr_volume_kernel": "all-pairs correlation, 4 pyramid levels x 31 pairs (store-bound: 27.7 GB)",
+    "flow/corr_volume_kernel": "all-pairs correlation, 4 pyramid levels x 31 pairs (27.7 GB written; stores 6.2 ms + matrix work and DMA 8.0 ms that do not overlap)",
     "depth/gemm8_kernel<0, 2, 0, true, false>": "ViT qkv",
     "depth/gemm_kernel<128, 128, 2, 2, 1, 0, true, 2, true>": "DPT head N <= 128 and low-resolution convolutions (output_conv1, layer3/4_rn, refinenet3/4)",
     "depth/elementwise": "bilinear upsampling of the head's split maps",
