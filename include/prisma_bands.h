@@ -286,6 +286,10 @@ int pb_op_gemm(pb_ctx *ctx, const float *A, const float *W, const float *bias, f
 /* Kernel micro-benchmark on device-resident uniform[-1,1) fp16 data: mean ms per launch over iters.
  * epi: 0 fp16 store, 1 bias+GELU fp16 store, 2 LayerScale + fp32 residual read-modify-write. */
 int pb_op_gemm_bench(pb_ctx *ctx, int M, int N, int K, int tile, int epi, int iters, double *ms_out);
+/* The flow band's all-pairs correlation kernel on its own (bands/raft/corr.py:52-60, without the 1/sqrt(256) factor the band folds into the
+ * features): out[m, n] = fp16(sum_k fp16(A[m, k]) fp16(W[n, k])), A [M, 256], W [N, 256] fp32 on the host, N % 8 == 0, ldo >= N.
+ * `out` holds (M + guard_rows) x ldo floats; everything the kernel must not touch - columns N..ldo-1 and the guard rows - is preset to NaN. */
+int pb_op_corr_volume(pb_ctx *ctx, const float *A, int M, const float *W, int N, int ldo, int guard_rows, float *out);
 /* LayerNorm over the last dim, eps 1e-6 (vision_transformer.py:95). */
 /* times `iters` launches of the fused attention kernel on random Q, K, V (variant 0 = default); ms per launch */
 int pb_op_attention_bench(pb_ctx *ctx, int B, int heads, int N, int variant, int iters, double *ms_out);

@@ -100,6 +100,7 @@ SYMBOLS = {
     "pb_get_kernel_stats": (C.c_int, [_P, C.POINTER(pb_kernel_stat), C.c_int]),
     "pb_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pb_op_gemm_bench": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "pb_op_corr_volume": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "pb_op_attention_bench": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "pb_op_layernorm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),
     "pb_op_attention": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),

@@ -728,6 +728,27 @@ int pb_op_gemm(pb_ctx *c, const float *A, const float *W, const float *bias, flo
     return 0;
 }
 
+int pb_op_corr_volume(pb_ctx *c, const float *A, int M, const float *W, int N, int ldo, int guard_rows, float *out) {
+    PB_CHECK(c && A && W && out && M > 0 && N > 0 && N % 8 == 0 && ldo >= N && guard_rows >= 0, PB_ERR_ARG, "op_corr_volume: bad arguments");
+    PB_HIP(hipSetDevice(c->device));
+    const int64_t rows = (int64_t)M + guard_rows, Np = round_up(N, 64);
+    DevMem a32, w32, a16, w16, o16, o32;
+    PB_TRY(a32.alloc((size_t)M * 256 * 4)); PB_TRY(w32.alloc((size_t)N * 256 * 4));
+    PB_TRY(a16.alloc((size_t)M * 256 * 2)); PB_TRY(w16.alloc((size_t)Np * 256 * 2));
+    PB_TRY(o16.alloc((size_t)rows * ldo * 2)); PB_TRY(o32.alloc((size_t)rows * ldo * 4));
+    PB_HIP(hipMemcpy(a32.p, A, (size_t)M * 256 * 4, hipMemcpyHostToDevice));
+    PB_HIP(hipMemcpy(w32.p, W, (size_t)N * 256 * 4, hipMemcpyHostToDevice));
+    PB_HIP(hipMemsetAsync(w16.p, 0, (size_t)Np * 256 * 2, c->stream));
+    PB_HIP(hipMemsetAsync(o16.p, 0x7e, (size_t)rows * ldo * 2, c->stream));          // 0x7e7e: a NaN in fp16
+    PB_TRY(launch_f32_to_f16(c->stream, a32.as<float>(), a16.as<f16>(), M, 256, 256));
+    PB_TRY(launch_f32_to_f16(c->stream, w32.as<float>(), w16.as<f16>(), N, 256, 256));
+    PB_TRY(launch_corr_volume(c->stream, a16.as<f16>(), M, w16.as<f16>(), N, (int)Np, o16.as<f16>(), ldo));
+    PB_TRY(launch_f16_to_f32(c->stream, o16.as<f16>(), o32.as<float>(), rows, ldo, ldo));
+    PB_HIP(hipStreamSynchronize(c->stream));
+    PB_HIP(hipMemcpy(out, o32.p, (size_t)rows * ldo * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int pb_op_gemm_bench(pb_ctx *c, int M, int N, int K, int tile, int epi, int iters, double *ms_out) {
     PB_CHECK(c && M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0 && iters > 0 && ms_out, PB_ERR_ARG, "gemm_bench: bad arguments");
     PB_HIP(hipSetDevice(c->device));

@@ -149,14 +149,26 @@ __global__ __launch_bounds__(VNT, 2) void corr_volume_kernel(const f16 *__restri
     const __amdgpu_buffer_rsrc_t rsO = make_rsrc((const void *)ob_u, (unsigned)__builtin_amdgcn_readfirstlane(rows_w * ldb));
     const int vo_lane = 4 * lh * ldb + 4 * li;
     // Lanes without a tile to store (none yet, columns past N) carry an offset outside the resource: the store is dropped by the range check.
+    // The row of a store travels in the SCALAR offset, which the compiler's builtin documents as excluded from bounds checking: the last
+    // row tile (fewer than 32 valid rows) therefore marks its rows past M in the lane offset as well.  (Measured: gfx950 drops such stores
+    // on its own - tests/test_gpu_ops.py::test_corr_volume_kernel_values_and_untouched_memory passes without the mask - but nothing
+    // guarantees it, and the mask costs a wave-uniform branch.)
     constexpr int VO_NONE = 0x7ffff000;
     int vo_st = VO_NONE;
-    auto st1 = [&](int r) {
-        if (!(ABL & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk[r]), rsO, vo_st, ((r & 3) + 8 * (r >> 2)) * ldb, 0);
-    };
+    const bool rows_full = __builtin_amdgcn_readfirstlane(rows_w) == 32;
     auto flush = [&]() {
+        if (ABL & 1) return;
+        if (rows_full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st1(r);
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk[r]), rsO, vo_st, ((r & 3) + 8 * (r >> 2)) * ldb, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk[r]), rsO, row + 4 * lh < rows_w ? vo_st : VO_NONE, row * ldb, 0);
+            }
+        }
     };
     unsigned keep = 0;                                          // (PB_VOL_ABL: keeps the matrix work alive when the stores are ablated)
     for (int j = 0; j < ntl; ++j) {

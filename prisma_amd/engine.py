@@ -130,6 +130,15 @@ class Ops(_Ctx):
         check(self.lib.pb_op_gemm(self.ctx, _ptr(A), _ptr(W), _ptr(b), _ptr(out), M, N, K, act, tile))
         return out
 
+    def corr_volume(self, A, W, ldo: int = 0, guard_rows: int = 32) -> np.ndarray:
+        """the flow band's all-pairs correlation kernel alone: [M + guard_rows, ldo] floats, NaN wherever the kernel must not write."""
+        A, W = _f32(A), _f32(W)
+        M, N = A.shape[0], W.shape[0]
+        ldo = ldo or N
+        out = np.empty((M + guard_rows, ldo), np.float32)
+        check(self.lib.pb_op_corr_volume(self.ctx, _ptr(A), M, _ptr(W), N, ldo, guard_rows, _ptr(out)))
+        return out
+
     def gemm_bench(self, M: int, N: int, K: int, tile: int = 0, epi: int = 0, iters: int = 20) -> float:
         """mean milliseconds per launch on device-resident random data."""
         ms = C.c_double()

@@ -256,3 +256,23 @@ def test_epilogue_report_names_launch_kinds_outside_the_fast_list():
     assert r.returncode == 0, r.stderr[-400:]
     lines = [l for l in r.stderr.splitlines() if "pb_epi_report" in l]
     assert len(lines) == 1 and "key 3 " in lines[0] and "act 3" in lines[0], r.stderr[-400:]
+
+
+@pytest.mark.parametrize("M,N,ldo", [(391, 392, 576), (128, 64, 64), (77, 136, 192), (300, 1288, 1344)])
+def test_corr_volume_kernel_values_and_untouched_memory(M, N, ldo):
+    """volume.hip on its own (pb_op_corr_volume): every entry of the [M, N] volume against fp32 numpy on the fp16-rounded operands, and
+    nothing written outside it - the padding columns of a row and 32 guard rows behind the last one stay NaN.  The kernel's stores carry
+    their row in the scalar offset of a buffer store (documented as outside the bounds check): last row tiles with fewer than 32 valid
+    rows (M = 391, 77, 300) mask them in the lane offset."""
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, 256)).astype(np.float32) * 0.25
+    W = rng.standard_normal((N, 256)).astype(np.float32) * 0.25
+    o = engine.Ops(0)
+    out = o.corr_volume(A, W, ldo=ldo, guard_rows=32)
+    o.close()
+    ref = A.astype(np.float16).astype(np.float32) @ W.astype(np.float16).astype(np.float32).T
+    got = out[:M, :N]
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-3          # fp16 output rounding
+    assert np.isnan(out[:M, N:]).all(), "padding columns written"
+    assert np.isnan(out[M:]).all(), "rows past M written"
