@@ -394,6 +394,7 @@ template <int EPI, int TN>
 __host__ __device__ constexpr bool epi_interleaved() {
     return TN == 2 && (EPI == EPI_STD || EPI == EPI_QKV || EPI == EPI_PIXSHUF || EPI == EPI_RESID);
 }
+#include "pixshuf_walk.h"   // pixshuf_first_pixel / pixshuf_wraps: plain C++, also compiled on the host by tests/test_pixshuf_walk_cpu.py
 #include "conv_walk.h"      // tap_range / tap_mask / conv_ktab_word / ktab_bytes / ktab_sel: plain C++, also compiled on the host by tests/test_conv_walk_cpu.py
 constexpr int KTAB_BYTES = 2048;                                          // K <= 512 tiles (checked by the launchers)
 __device__ __forceinline__ unsigned conv_ktab_entry(const GemmArgs &p, int cld, int t) {
@@ -933,8 +934,8 @@ __device__ __forceinline__ void pixshuf_epilogue_buf(const GemmArgs &p, f32x16 (
     if (p.bias) { const int bi = nok ? co : 0; b0 = p.bias[bi]; b1 = p.bias[bi + 1]; }
     const int s = p.ps_s, psw = p.ps_w;
     const int pb = (int)p.ldo * 2;                               // bytes per output pixel
-    const int Y0 = wave_m0 / psw, x0 = wave_m0 - Y0 * psw;
-    const int64_t pix0 = (int64_t)s * wave_m0 + (int64_t)s * (s - 1) * psw * Y0 + (int64_t)tap_dy * psw * s + tap_dx;
+    const int x0 = wave_m0 - (wave_m0 / psw) * psw;
+    const int64_t pix0 = pixshuf_first_pixel(wave_m0, s, psw, tap_dy, tap_dx);
     const BufT td = buf_of(p.out, pix0 * pb, 0);
     const unsigned wrapb = (unsigned)(s * (s - 1) * psw) * (unsigned)pb;
     const unsigned vrow = (unsigned)(4 * lh * s * pb);
@@ -959,11 +960,7 @@ __device__ __forceinline__ void pixshuf_epilogue_buf(const GemmArgs &p, f32x16 (
         for (int q = 0; q < 8; ++q) {
             const int r = r0 + q;
             const int rowc = tm * 32 + (r & 3) + 8 * (r >> 2);
-            const int t = xl + rowc;
-            int w = 0;
-#pragma unroll
-            for (int k = 1; k <= TM; ++k) w += t >= k * psw ? 1 : 0;
-            wv[q] = (unsigned)w * wrapb;
+            wv[q] = (unsigned)pixshuf_wraps<TM>(xl + rowc, psw) * wrapb;
             pz[q] = (!CHECK || (nok && wave_m0 + rowc + 4 * lh < p.M)) ? 0u : PB_POISON;       // OR-ed in: an add would wrap around
             so[q] = rowc * s * pb;
         }
