@@ -60,3 +60,16 @@ def test_fast_epilogue_key_lists_agree():
     lst = lst[:lst.index("};")]
     host = sorted(ev(e.strip()) for e in lst.replace("\n", " ").split(",") if e.strip())
     assert dev == host and len(dev) == 13, (dev, host)
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """INTEGRATION.md's table of environment switches names every variable the HIP sources read (pb_env_int / getenv)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "prisma_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "prisma_amd", "csrc", "*.h")):
+        names.update(re.findall(r'(?:pb_env_int|getenv)\("([A-Z][A-Z0-9_]*)"', open(f).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert len(names) > 20 and not missing, missing
