@@ -2,9 +2,10 @@
 """bench.py - frames/sec of the depth_anything band (ViT-L/14 + DPT) on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by torch.distributed.run, one rank per GPU.  A step = one pass of the band's hot
-  path (uint8 1080p frames resident in HBM -> heat-encoded uint8 frames + per-frame min/max in
-  HBM) over one batch of synthetic frames per GPU.  Frames shard by rank with no data-path
+  N > 1 is launched by torch.distributed.run, one rank per GPU.  A step = one pass of the hot path
+  (uint8 1080p frames resident in HBM -> depth_anything: heat-encoded uint8 frames + per-frame min/max;
+  flow_raft: HSV-encoded flow of the consecutive pairs + max displacement; both in HBM, the two bands
+  enqueued at once on their own streams) over one clip of synthetic frames per GPU.  Frames shard by rank with no data-path
   collective; the only exchange is the all-gather of the per-frame min/max scalars (RCCL).
 Prints ONE JSON line on rank 0.
 """
@@ -341,7 +342,12 @@ def main():
     ap.add_argument("--latency", action="store_true", default=True,
                     help="also time one 1280x720 frame at batch 1 (BASELINE configs[1]; on by default since round 4: eight batch-1 calls, ~0.1 s)")
     ap.add_argument("--no-latency", dest="latency", action="store_false")
-    ap.add_argument("--concurrent-bands", action="store_true", help="experiment: run the two bands of a step concurrently (two host threads, two streams); per-launch durations then include the other band's interference")
+    ap.add_argument("--sequential-only", action="store_true",
+                    help="time the step the way rounds 1-5 did: depth band, then flow band, every launch bracketed by HIP events.  The default timed region "
+                         "enqueues both bands of a step at once on their two ctx streams (prisma_amd.engine.run_concurrently) without per-launch events and "
+                         "takes the per-symbol attribution (`sequential`, `roofline`, `kernel_ms_per_step`) from a second, labelled pass of this kind; "
+                         "`rocprofv3 --kernel-trace --stats -- python bench.py --sequential-only` reproduces that pass's per-symbol averages")
+    ap.add_argument("--seq-steps", type=int, default=5, help="steps of the labelled sequential pass behind `sequential` / `roofline` (default timed region only)")
     ap.add_argument("--no-clock", action="store_true", help="skip the effective-clock probe behind roofline.effective_clock_ghz")
     ap.add_argument("--host-clips", type=int, default=3,
                     help="clips pushed through the host-pointer entry points of both bands (page-locked frames in, page-locked results out) for "
@@ -397,66 +403,90 @@ def main():
     torch.cuda.synchronize()
 
     def run_mode(prec, steps, warmup, extras):
-        """K timed steps in one precision mode.  A step runs the depth band, then the flow band (each on its ctx stream, one
-        after the other: a launch's HIP-event duration is then the kernel's own, the same thing rocprofv3 reports), then the
-        12-byte-per-frame scalar all-gather.  Returns wall time, per-family launch records and per-band wall times."""
+        """K timed steps in one precision mode.  A step enqueues the depth band and the flow band at once, each on its ctx stream
+        (engine.run_concurrently: the bands are independent and share the GPU), waits for both, then runs the 12-byte-per-frame scalar
+        all-gather.  The per-symbol attribution comes from a labelled sequential pass after the timed region (bands one after the
+        other, every launch bracketed by HIP events: a launch's duration is then the kernel's own, the same thing rocprofv3 reports);
+        --sequential-only makes that pass the timed region, as in rounds 1-5.  Returns wall time, per-family launch records of the
+        sequential pass, per-band completion times and the socket power over the timed region."""
         dn = engine.DepthAnything(weights, cfg, device=local_rank, max_batch=B, precision=prec)
         dn.set_option("gemm_tile", args.gemm_tile)
         dn.set_option("conv_tile", args.conv_tile)
         fn = engine.FlowRaft(rweights, device=local_rank, precision=prec)
 
-        def depth():
+        def depth_job():
             dn.infer_dev(d_frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
-            dn.sync()
 
-        def flow():
+        def flow_job():
             fn.infer_sequence_dev(d_frames.data_ptr(), B, H, W, args.flow_scale, args.flow_iters, False, 0, f_rgb.data_ptr(), scal[2].data_ptr())
-            fn.sync()
 
         band_s = [0.0, 0.0]
 
-        def step():
+        def step_seq():                        # one band after the other: a launch's HIP-event duration is the kernel's own
             a = time.perf_counter()
-            if args.concurrent_bands:          # experiment (EXPERIMENTS.md 5.12): both bands at once, each on its own stream, from two host threads
-                import threading
-                tf = threading.Thread(target=flow)
-                tf.start()
-                depth()
-                b = time.perf_counter()
-                tf.join()
-                c = time.perf_counter()
-                band_s[0] += b - a; band_s[1] += c - a
-            else:
-                depth()
-                b = time.perf_counter()
-                flow()
-                c = time.perf_counter()
-                band_s[0] += b - a; band_s[1] += c - b
+            depth_job(); dn.sync()
+            b = time.perf_counter()
+            flow_job(); fn.sync()
+            c = time.perf_counter()
+            band_s[0] += b - a; band_s[1] += c - b
             if R.dist is not None:
                 R.all_gather(gathered, scal)                              # the only exchange: 12 bytes per frame
 
+        def step_ovl():                        # both bands of the step at once, each on its ctx stream (the engine's run_concurrently)
+            done = engine.run_concurrently([(dn, depth_job), (fn, flow_job)])
+            band_s[0] += done[0]; band_s[1] += done[1]
+            if R.dist is not None:
+                R.all_gather(gathered, scal)
+
+        def timed(step, n):
+            band_s[0] = band_s[1] = 0.0
+            R.barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step()
+            R.barrier()
+            t1 = time.perf_counter()
+            return t0, t1
+
+        def families():
+            fam = {}
+            for band, net_ in (("depth", dn), ("flow", fn)):
+                for s in net_.kernel_stats():
+                    fam[band + "/" + s["name"]] = {k: s[k] for k in ("ms", "flops", "exec_flops", "bytes", "launches")}
+                net_.set_profiling(timing=False)
+            return fam
+
+        step = step_seq if args.sequential_only else step_ovl
         for _ in range(warmup):
             step()
-        # every launch of the timed region is bracketed by HIP events on its band's stream; the records accumulate over the K
-        # steps and are read once after the closing barrier, so no event query sits inside the timed region
-        dn.set_profiling(timing=True, accumulate=True)
-        fn.set_profiling(timing=True, accumulate=True)
-        band_s[0] = band_s[1] = 0.0
-        R.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        R.barrier()
-        dt = time.perf_counter() - t0
-        fam = {}
-        for band, net_ in (("depth", dn), ("flow", fn)):
-            for s in net_.kernel_stats():
-                fam[band + "/" + s["name"]] = {k: s[k] for k in ("ms", "flops", "exec_flops", "bytes", "launches")}
-            net_.set_profiling(timing=False)
+        from prisma_amd.power import PowerSampler
+        seq = None
+        with PowerSampler(local_rank) as ps:
+            if args.sequential_only:
+                # every launch of the timed region is bracketed by HIP events on its band's stream; the records accumulate over the K
+                # steps and are read once after the closing barrier, so no event query sits inside the timed region
+                dn.set_profiling(timing=True, accumulate=True)
+                fn.set_profiling(timing=True, accumulate=True)
+            t0, t1 = timed(step, steps)
+        dt = t1 - t0
+        power = ps.window(t0, t1) if rank == 0 else None
+        depth_s, flow_s = band_s[0], band_s[1]
+        if args.sequential_only:
+            fam = families()
+            seq = {"dt": R.max_over_ranks(dt), "steps": steps, "depth_s": depth_s, "flow_s": flow_s}
+        else:
+            # the labelled sequential pass: not part of `value`; the per-symbol attribution of the same work on the same warm chip
+            ns = max(1, min(args.seq_steps, steps))
+            step_seq()
+            dn.set_profiling(timing=True, accumulate=True)
+            fn.set_profiling(timing=True, accumulate=True)
+            s0, s1 = timed(step_seq, ns)
+            fam = families()
+            seq = {"dt": R.max_over_ranks(s1 - s0), "steps": ns, "depth_s": band_s[0], "flow_s": band_s[1]}
         dt = R.max_over_ranks(dt)
         sc = scal.cpu().numpy()
         assert np.isfinite(sc).all() and (sc[1] > sc[0]).all() and (sc[2, :B - 1] > 0).all(), "degenerate depth range / flow"
-        res = {"dt": dt, "fam": fam, "depth_s": band_s[0], "flow_s": band_s[1]}
+        res = {"dt": dt, "fam": fam, "depth_s": depth_s, "flow_s": flow_s, "seq": seq, "power": power}
         if extras and rank == 0:
             # latency of BASELINE.json configs[1]: one 1280x720 frame, batch 1 (outside the timed region above)
             if args.latency:
@@ -470,20 +500,16 @@ def main():
                 res["lat_b1"] = (time.perf_counter() - t1) / 5 * 1e3
             # PCIe-inclusive rate (never `value`; SURVEY 8(d) config 4: frames "resident in pinned host memory"): the SAME clip through the
             # host-pointer entry points of both bands - pb_depth_infer_batch and pb_flow_infer_sequence (abi.hip: H2D of chunk i + 1, the band
-            # on chunk i and D2H of chunk i - 1 on three streams) - from page-locked frames into page-locked result arrays, one band after
-            # the other like the timed region (called from two threads the bands' kernels overlap and this figure EXCEEDS `value` - 124.6
-            # against 123.9, r05d - but every launch then takes longer than in the timed region, and the per-symbol averages of
-            # `rocprofv3 --stats -- python bench.py` stop matching the roofline object's).
-            # Steady state over args.host_clips clips after one untimed clip; results are compared byte for byte with the HBM-resident leg's.
+            # on chunk i and D2H of chunk i - 1 on three streams) - from page-locked frames into page-locked result arrays, with the product's
+            # DEFAULT chunking (depth: max_batch frames, flow: 16 pairs + a halo frame) and, like the timed region, both bands at once: the
+            # host-pointer calls block until their results are in host memory, so each band runs on its own host thread.  --sequential-only
+            # runs them one after the other.  Steady state over args.host_clips clips after one untimed clip; results are compared byte for
+            # byte with the HBM-resident leg's.
             if args.host_clips > 0 and world == 1:       # (one-GPU runs: with several ranks the host's PCIe / memory paths are shared and only rank 0 would be measuring)
                 hf = torch.from_numpy(frames).pin_memory()
                 h_rgb = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
                 h_frgb = torch.empty((B - 1, 1, sh, sw, 3), dtype=torch.uint8).pin_memory()
                 h_scal = [None, None]
-                # depth in two chunks (its H2D / D2H then also overlap its own kernels); flow as ONE chunk: its launches keep the shapes of the
-                # timed region, so the per-symbol averages of `rocprofv3 --stats -- python bench.py` stay those of the roofline object
-                dn.set_option("host_chunk", max(1, B // 2))
-                fn.set_option("host_chunk", B)
 
                 def d_band():
                     h_scal[0] = dn.infer_batch(hf.numpy(), want_depth=False, want_rgb=True, flip=True, out_rgb=h_rgb.numpy())[2:]
@@ -493,8 +519,15 @@ def main():
                                                   want_rgb=True, out_rgb=h_frgb.numpy())[2]
 
                 def clip():
-                    d_band()
-                    f_band()
+                    if args.sequential_only:
+                        d_band()
+                        f_band()
+                    else:
+                        import threading
+                        tf = threading.Thread(target=f_band)
+                        tf.start()
+                        d_band()
+                        tf.join()
 
                 clip()
                 same = bool((h_rgb == d_rgb.cpu()).all().item()) and bool((h_frgb[:, 0] == f_rgb.cpu()).all().item())
@@ -547,7 +580,7 @@ def main():
         osteps = max(1, min(args.steps, 3))
         cmd = [sys.executable, os.path.abspath(__file__), "--precision", str(1 - args.precision), "--one-precision", "--no-cpu-baseline",
                "--host-clips", "0", "--no-latency", "--no-clock", "--steps", str(osteps), "--warmup", "1", "--batch", str(B), "--height", str(H), "--width", str(W), "--encoder", args.encoder,
-               "--flow-scale", str(args.flow_scale), "--flow-iters", str(args.flow_iters)]
+               "--flow-scale", str(args.flow_scale), "--flow-iters", str(args.flow_iters)] + (["--sequential-only"] if args.sequential_only else ["--seq-steps", "1"])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode == 0 and r.stdout.strip():
             o = json.loads(r.stdout.strip().splitlines()[-1])
@@ -562,7 +595,11 @@ def main():
     if rank == 0:
         dt, fam = main_res["dt"], main_res["fam"]
         fps = world * B * args.steps / dt
-        # roofline kernel: the family with the most launch time in the timed region (bands run one after the other, so this is
+        # per-symbol attribution = the sequential pass (bands one after the other, every launch bracketed by HIP events): `sq` holds its
+        # wall time, step count and per-band times; the timed region itself when --sequential-only
+        sq = main_res["seq"]
+        qsteps = sq["steps"]
+        # roofline kernel: the family with the most launch time in the sequential pass (bands run one after the other, so this is
         # the kernel's own time - the criterion rocprofv3's per-symbol totals reproduce)
         # Two flow-band symbols sit within 1 % of each other, so a bare arg-max would name a different kernel from run to run: among the
         # symbols within 3 % of the largest time, the one with the most algorithmic FLOPs per step is taken (a property of the launch list).
@@ -579,7 +616,8 @@ def main():
 
         def mode_summary(res, steps):
             return {"value": round(world * B * steps / res["dt"], 3), "unit": "frames/s", "ms_per_step": round(res["dt"] / steps * 1e3, 3),
-                    "depth_ms_per_step": round(res["depth_s"] / steps * 1e3, 3), "flow_ms_per_step": round(res["flow_s"] / steps * 1e3, 3)}
+                    "depth_ms_per_step": round(res["depth_s"] / steps * 1e3, 3), "flow_ms_per_step": round(res["flow_s"] / steps * 1e3, 3),
+                    "band_ms_note": "ms from the step's start to the band's completion (in the default timed region both bands run at once)"}
 
         out = {
             "metric": "frames/sec (depth_anything ViT-L + flow_raft, 1080p)",
@@ -587,7 +625,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": PREC_NAME[args.precision], "data": "synthetic",
             "config": {"workload": f"every frame of a {B}-frame {W}x{H} synthetic uint8 clip (resident in HBM, one clip per GPU) through "
-                                   f"depth_anything {args.encoder} (DINOv2 ViT-L/14 + DPT head, one batch of {B}, heat-encoded uint8 + min/max out) and then "
+                                   f"depth_anything {args.encoder} (DINOv2 ViT-L/14 + DPT head, one batch of {B}, heat-encoded uint8 + min/max out) and "
                                    f"flow_raft (its {B - 1} consecutive forward pairs, --scale {args.flow_scale} -> {sw}x{sh}, {args.flow_iters} GRU iterations, "
                                    f"HSV-encoded uint8 + max displacement out); fused pre/post-process, seeded synthetic weights; "
                                    f"BASELINE.json configs[3] (depth, 32 frames per GPU) plus the flow band the metric names",
@@ -608,19 +646,23 @@ def main():
                          "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                          "algorithmic_bytes": round(g["bytes"] / max(g["launches"], 1)),
-                         "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5), "launches_per_step": g["launches"] / args.steps,
+                         "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5), "launches_per_step": g["launches"] / qsteps,
                          "flop_per_launch": g["flops"] / max(g["launches"], 1),
                          # the same symbol may serve both bands (the DPT head's and the update block's 256-channel convolutions): rocprofv3's
                          # per-symbol average is over all of them, so the line carries that figure too
-                         "symbol_all_bands": (lambda same: {"launches_per_step": sum(v["launches"] for v in same) / args.steps,
+                         "symbol_all_bands": (lambda same: {"launches_per_step": sum(v["launches"] for v in same) / qsteps,
                                                             "avg_launch_ms": round(sum(v["ms"] for v in same) / max(sum(v["launches"] for v in same), 1), 5)})(
                              [v for k, v in fam.items() if k.split("/", 1)[1] == dom_name.split("/", 1)[1]]),
-                         "selection": "kernel symbol with the largest summed launch time in the timed region (bands run one after the other; HIP events on the "
-                                      "band's stream; `family` = <band>/<symbol as rocprofv3 prints it>); symbols within 3 % of the largest are ranked by "
-                                      "their algorithmic FLOPs per step, so the name does not flip between runs",
-                         "step_frac": round(tot_fl / dt / 1e12 / PEAK_F16_TFLOPS, 4),
-                         "depth_frac_alone": round(band_fl["depth"] / main_res["depth_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
-                         "flow_frac_alone": round(band_fl["flow"] / main_res["flow_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
+                         "selection": ("kernel symbol with the largest summed launch time in the timed region" if args.sequential_only else
+                                       "kernel symbol with the largest summed launch time in the labelled SEQUENTIAL pass (`sequential`: the same step with the bands one "
+                                       "after the other, run right after the timed region; in the timed region both bands share the GPU and a launch's duration "
+                                       "includes the other band's interference)") +
+                                      " - HIP events on the band's stream around every launch; `family` = <band>/<symbol as rocprofv3 prints it>; symbols within "
+                                      "3 % of the largest are ranked by their algorithmic FLOPs per step, so the name does not flip between runs; "
+                                      "`rocprofv3 --kernel-trace --stats -- python bench.py --sequential-only` reproduces avg_launch_ms (profiles/)",
+                         "step_frac": round(tot_fl / qsteps * args.steps / dt / 1e12 / PEAK_F16_TFLOPS, 4),
+                         "depth_frac_alone": round(band_fl["depth"] / sq["depth_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
+                         "flow_frac_alone": round(band_fl["flow"] / sq["flow_s"] / 1e12 / PEAK_F16_TFLOPS, 4),
                          "executed_frac": round(ach * exec_mult / PEAK_F16_TFLOPS, 4),
                          "effective_clock_ghz": round(clock_ghz, 3) if clock_ghz else None,
                          "frac_at_clock": round(ach / (PEAK_F16_TFLOPS * clock_ghz / 2.4), 4) if clock_ghz else None,
@@ -629,25 +671,40 @@ def main():
                                        "(profiles/r04a_clock_mfma_peak.txt: a bare MFMA loop holds 2.39 GHz on zeros and 1.63-1.65 GHz on random operands)",
                          "note": "flops are algorithmic multiply-adds (2 M N K of the layer; padding and the extra split-fp16 passes not counted) - executed_frac "
                                  "counts the MFMA work actually issued (x2 for weight-split, x3 for weight+activation-split layers); *_frac_alone = a "
-                                 "band's flops / its wall time inside the step / peak; step_frac = all launches' flops / step wall time / peak"},
-            "model_tflops": round(tot_fl / dt / 1e12, 2),
-            "executed_tflops": round(sum(v["exec_flops"] for v in fam.values()) / dt / 1e12, 2),
+                                 "band's flops / its wall time in the sequential pass / peak; step_frac = all launches' flops / timed step wall time / peak"},
+            "model_tflops": round(tot_fl / qsteps * args.steps / dt / 1e12, 2),
+            "executed_tflops": round(sum(v["exec_flops"] for v in fam.values()) / qsteps * args.steps / dt / 1e12, 2),
+            "timed_region": ("sequential: depth band, then flow band, per-launch HIP events on (--sequential-only)" if args.sequential_only else
+                             "both bands of a step enqueued at once on their two ctx streams (prisma_amd.engine.run_concurrently), no per-launch events; "
+                             "results byte-identical to the sequential order (tests/test_gpu_edges.py)"),
+            # the same step with the bands one after the other and every launch timed: what rounds 1-5 reported as `value`
+            "sequential": {"value": round(world * B * qsteps / sq["dt"], 3), "unit": "frames/s", "steps": qsteps, "ms_per_step": round(sq["dt"] / qsteps * 1e3, 3),
+                           "depth_ms_per_step": round(sq["depth_s"] / qsteps * 1e3, 3), "flow_ms_per_step": round(sq["flow_s"] / qsteps * 1e3, 3),
+                           "kernel_ms_per_step_sum": round(sum(v["ms"] for v in fam.values()) / qsteps, 3),
+                           "note": "per-launch HIP events cost ~2 % of this pass (rocprofv3 --stats sees the same launches without them)"},
+            # socket power of this GPU over the timed region (hwmon power1_input sampled every 10 ms by prisma_amd/power.py): the part is power-limited
+            # on this workload (profiles/r06_power_clock.txt), so joules per frame, not schedule slack, is what bounds frames/s
+            "avg_power_w": main_res["power"]["avg_power_w"] if main_res.get("power") else None,
+            "avg_sclk_mhz": main_res["power"]["avg_sclk_mhz"] if main_res.get("power") else None,
+            "joules_per_frame": (round(main_res["power"]["avg_power_w"] * dt / (B * args.steps), 3)
+                                 if main_res.get("power") and main_res["power"]["avg_power_w"] else None),
             "depth_anything": {"metric": f"frames/sec (depth_anything ViT-L, 1080p, batch {B} per GPU, inside the step)",
-                               "value": round(world * B * args.steps / main_res["depth_s"], 3), "unit": "frames/s",
-                               "ms_per_step": round(main_res["depth_s"] / args.steps * 1e3, 3),
-                               "model_tflops": round(B * args.steps / main_res["depth_s"] * GFLOP_PER_FRAME / 1e3, 2)},
+                               "value": round(world * B * qsteps / sq["depth_s"], 3), "unit": "frames/s",
+                               "ms_per_step": round(sq["depth_s"] / qsteps * 1e3, 3),
+                               "model_tflops": round(B * qsteps / sq["depth_s"] * GFLOP_PER_FRAME / 1e3, 2)},
             "flow_raft": {"metric": f"frame-pairs/sec (flow_raft, 1080p x {args.flow_scale}, {args.flow_iters} iterations, forward, inside the step)",
-                          "value": round(world * (B - 1) * args.steps / main_res["flow_s"], 3), "unit": "pairs/s",
-                          "ms_per_step": round(main_res["flow_s"] / args.steps * 1e3, 3)},
+                          "value": round(world * (B - 1) * qsteps / sq["flow_s"], 3), "unit": "pairs/s",
+                          "ms_per_step": round(sq["flow_s"] / qsteps * 1e3, 3)},
             "pcie_inclusive_fps": round(main_res["host_fps"], 2) if "host_fps" in main_res else None,
             "pcie_inclusive_note": "the same clip through the host-pointer entry points (pb_depth_infer_batch, pb_flow_infer_sequence) from page-locked frames into "
-                                   "page-locked result arrays, one band after the other as in the timed region (depth in two chunks whose copies overlap its "
-                                   "own kernels, flow as one chunk: its 199 MB in and 109 MB out are exposed); results byte-identical to the HBM-resident leg's",
+                                   "page-locked result arrays with the library's default chunking (depth: two chunks of 16 frames, flow: chunks of 16 pairs + a halo "
+                                   "frame; copies of chunk i +- 1 under the kernels of chunk i), both bands at once like the timed region (one host thread per "
+                                   "band: the calls block until the results are in host memory); results byte-identical to the HBM-resident leg's",
             "latency_720p_batch1_ms": round(main_res["lat_b1"], 3) if "lat_b1" in main_res else None,
-            "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(fam.items())},
+            "kernel_ms_per_step": {k: round(v["ms"] / qsteps, 3) for k, v in sorted(fam.items())},
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items()
                               if v["flops"] > 0 and v["ms"] > 0},
-            "kernel_launches_per_step": {k: v["launches"] / args.steps for k, v in sorted(fam.items())},
+            "kernel_launches_per_step": {k: v["launches"] / qsteps for k, v in sorted(fam.items())},
             # algorithmic bytes (A + W + output once) per second of launch time: the figure to hold against HBM's ~8 TB/s for the launches
             # that move more than they compute (the K = 256 correlation-volume GEMMs sit in flow/gemm_kernel<128, 128, 2, 2, 0, 0, ...>)
             "kernel_algorithmic_tbps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e12, 3) for k, v in fam.items() if v["bytes"] > 0 and v["ms"] > 0},

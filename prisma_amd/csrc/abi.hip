@@ -83,19 +83,35 @@ struct HostPipe {
 // The caller's buffer is page-locked host memory (hipHostMalloc / hipHostRegister / torch pin_memory): the copy engines can address it
 // directly, so the host-pointer entry points skip their own pinned staging copies (a 1080p clip of 32 frames is 199 MB each way: ~20 ms of
 // one core per memcpy, which the pipeline can only hide while a LATER chunk computes)
-static bool pb_is_pinned(const void *p) {
+static bool pb_is_pinned(const void *p, size_t bytes = 1) {
     if (!p) return false;
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return at.type == hipMemoryTypeHost;
+    // both ends of the range must be page-locked (a caller may hand a pointer into the middle of a registered region whose end lies before ours)
+    for (const char *q : {(const char *)p, (const char *)p + (bytes ? bytes - 1 : 0)}) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
 }
+
+// Error exits of the host-pointer pipelines: with page-locked caller buffers the copy engines read and write CALLER memory asynchronously on the
+// pipeline's two copy streams, so no path may return - with or without an error - while a copy or a kernel that feeds one is still in flight:
+// the caller is free to release or reuse its buffers the moment the call returns.  Declared after the streams exist; its destructor drains them.
+struct PipeDrain {
+    hipStream_t a, b, c;
+    ~PipeDrain() {
+        if (a) (void)hipStreamSynchronize(a);
+        if (b) (void)hipStreamSynchronize(b);
+        if (c) (void)hipStreamSynchronize(c);
+    }
+};
 
 // pb_flow_infer_sequence: the same three-stage pipeline over chunks of frame pairs (a chunk = its pairs' frames + one halo frame)
 struct FlowPipe {
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_h2d[2] = {}, ev_comp[2] = {}, ev_d2h[2] = {};
-    void *h[4][2] = {}, *d[4][2] = {};        // 0 frames in, 1 flow out, 2 rgb out, 3 max displacement out
-    size_t cap[4] = {};
+    void *h[5][2] = {}, *d[5][2] = {};        // 0 frames in, 1 flow out, 2 rgb out, 3 max displacement out, 4 consistency masks out
+    size_t cap[5] = {};
     int grow(int k, size_t need, bool host) {
         if (need <= cap[k] && (!host || h[k][0])) return 0;
         const size_t want = need > cap[k] ? need : cap[k];
@@ -124,7 +140,7 @@ struct FlowPipe {
     }
     void release() {
         if (s_in) { hipStreamSynchronize(s_in); hipStreamSynchronize(s_out); }
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 5; ++k)
             for (int i = 0; i < 2; ++i) {
                 if (h[k][i]) hipHostFree(h[k][i]);
                 if (d[k][i]) hipFree(d[k][i]);
@@ -395,7 +411,10 @@ int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, 
     PB_CHECK(frames && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "infer: bad arguments");
     PB_HIP(hipSetDevice(c->device));
     const size_t px = (size_t)H * W;
-    const int cap = std::min(n, c->host_chunk > 0 ? std::min(c->host_chunk, c->depth->max_batch()) : c->depth->max_batch());
+    // frames per chunk: pb_set_option("host_chunk"), else max_batch - but a call of >= 16 frames that would fit ONE chunk is cut in two, so that
+    // the second half's H2D and the first half's D2H run under the other half's kernels (a frame's result does not depend on its chunk)
+    const int mb = c->depth->max_batch();
+    const int cap = std::min(n, c->host_chunk > 0 ? std::min(c->host_chunk, mb) : (n >= 16 && n <= mb ? (n + 1) / 2 : mb));
     HostPipe &hp = c->pipe;
     const size_t in_b = (size_t)cap * px * 3, d_b = depth_out ? (size_t)cap * px * 4 : 0, r_b = rgb_out ? in_b : 0,
                  m_b = (size_t)cap * 8;

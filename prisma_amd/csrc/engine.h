@@ -10,6 +10,25 @@
 #include "kernels.h"
 #include "zoe_kernels.h"
 
+// The ctx stream of a band engine.  `mask_env` names an environment variable with a CU mask as comma-separated 32-bit hex words (bit i of the
+// concatenation = CU i of the queue's mask; on gfx950 the driver deals the bits round-robin over the 8 XCDs, so 0f0f0f0f,... keeps XCDs 0-3):
+// an experiment switch for running two bands on disjoint parts of the chip (tools/overlap_bench.py --cu-masks).  Unset = the whole device.
+static inline hipError_t pb_create_stream(hipStream_t *s, const char *mask_env) {
+    const char *e = mask_env ? getenv(mask_env) : nullptr;
+    if (e && *e) {
+        uint32_t words[8];
+        int n = 0;
+        for (const char *p = e; *p && n < 8;) {
+            char *end = nullptr;
+            words[n++] = (uint32_t)strtoul(p, &end, 16);
+            if (!end || end == p) break;
+            p = *end == ',' ? end + 1 : end;
+        }
+        if (n > 0) return hipExtStreamCreateWithCUMask(s, (uint32_t)n, words);
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 struct PackedW {
     f16 *w = nullptr;        // [Npad, K] fp16, K % 64 == 0
     float *bias = nullptr;   // [N] fp32 or null

@@ -235,7 +235,7 @@ int DepthEngine::pack(const float *src, int N, int K, int Kpad, PackedW &out, co
 
 int DepthEngine::load(const pb_tensor *w, int n) {
     PB_HIP(hipSetDevice(device));
-    PB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    PB_HIP(pb_create_stream(&stream, "PB_CU_MASK_DEPTH"));
     for (int i = 0; i < n; ++i) {
         PB_CHECK(w[i].dtype == PB_F32 && w[i].data && w[i].name, PB_ERR_ARG, "weight %d: only host float32 tensors", i);
         tmap_[w[i].name] = &w[i];

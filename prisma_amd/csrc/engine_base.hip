@@ -38,7 +38,7 @@ int EngineBase::stats(pb_kernel_stat *out, int cap) {
 
 int EngineBase::begin_load(const pb_tensor *w, int n) {
     PB_HIP(hipSetDevice(device));
-    PB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    PB_HIP(pb_create_stream(&stream, "PB_CU_MASK_FLOW"));        // (the convolutional bands: flow_raft, flow_gmflow, mask_mmdet)
     cur_ = stream;
     for (int i = 0; i < n; ++i) {
         PB_CHECK(w[i].data && w[i].name, PB_ERR_ARG, "weight %d: null", i);

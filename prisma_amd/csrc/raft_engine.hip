@@ -444,8 +444,11 @@ int RaftEngine::infer(const uint8_t *frames, int F, int H, int W, float scale, i
     for (int e = 0; e < 2; ++e) {
         const Enc &E = e == 0 ? fnet_ : cnet_;
         const f16 *x = nullptr;
-        if ((r = run_encoder(E, e == 0, F, &x))) return r;
-        if ((r = dense(x, es * 128, (int64_t)F * P_, E.out, e == 0 ? fmap_ : ctx_, 256, ACT_NONE))) return r;
+        // the context network runs on the SOURCE frame of every pair (raft.py:110-115): frames 0 .. F - 2 forward, 1 .. F - 1 backward - without the
+        // backward direction the clip's last frame needs no context features (1 / F of cnet's work; per-frame results do not depend on the batch)
+        const int Fe = e == 1 && dirs == 1 ? F - 1 : F;
+        if ((r = run_encoder(E, e == 0, Fe, &x))) return r;
+        if ((r = dense(x, es * 128, (int64_t)Fe * P_, E.out, e == 0 ? fmap_ : ctx_, 256, ACT_NONE))) return r;
     }
     stages_["fmap"] = Stage{fmap_, 1, 0, 256, h8_, w8_, 256, 0};
 

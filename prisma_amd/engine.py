@@ -34,6 +34,24 @@ def net_size(H: int, W: int) -> Tuple[int, int]:
     return nh.value, nw.value
 
 
+def run_concurrently(jobs):
+    """Drive several band contexts at once: jobs = [(ctx, enqueue), ...] where `enqueue()` calls one of ctx's asynchronous device-pointer
+    entry points (`infer_dev`, `infer_sequence_dev`, `infer_batch_dev`).  Every job is enqueued on its own ctx stream from this thread
+    (an enqueue returns in a few milliseconds; the GPU then shares its CUs between the streams), then each ctx is waited for in order.
+    Returns the seconds from the first enqueue to each ctx's completion.  Results are the bytes of running the jobs one after the other:
+    contexts share no buffers (tests/test_gpu_edges.py::test_bands_run_concurrently_equal_sequential).  This replaces the reference's
+    strictly sequential band order (process.py:205-290) where the bands of one video are independent."""
+    import time
+    t0 = time.perf_counter()
+    for _, enqueue in jobs:
+        enqueue()
+    done = []
+    for ctx, _ in jobs:
+        ctx.sync()
+        done.append(time.perf_counter() - t0)
+    return done
+
+
 class _Ctx:
     def __init__(self):
         self.lib = _lib.load()

@@ -135,3 +135,52 @@ def test_depth_host_pipeline_with_page_locked_buffers(depth):
         assert np.array_equal(d2, d0) and np.array_equal(r2, r0)
     finally:
         depth.set_option("host_chunk", 0)
+
+
+def test_bands_run_concurrently_equal_sequential():
+    """engine.run_concurrently (the bench's timed region) and the two-host-thread form of the same thing: depth_anything and flow_raft on
+    their own ctx streams at once produce the bytes of running them one after the other - contexts share no buffers, and a frame's result
+    does not depend on what else the GPU is doing.  Replaces the reference's strictly sequential band order (process.py:205-290)."""
+    import threading
+    torch = pytest.importorskip("torch")
+    B, H, W = 6, 360, 640
+    frames = synth.frame_pair_sequence(B, H, W, seed=77)
+    dn = engine.DepthAnything(synth.depth_anything_weights("vits", seed=1234), "vits", max_batch=B)
+    fn = engine.FlowRaft(synth.raft_weights(seed=4321))
+    d_frames = torch.from_numpy(frames).cuda()
+    sh, sw = engine.flow_out_size(H, W, 0.75)
+
+    def buffers():
+        return (torch.zeros((B, H, W, 3), dtype=torch.uint8, device="cuda"), torch.zeros((B - 1, sh, sw, 3), dtype=torch.uint8, device="cuda"),
+                torch.zeros((3, B), dtype=torch.float32, device="cuda"))
+
+    def jobs(d_rgb, f_rgb, scal):
+        def depth_job():
+            dn.infer_dev(d_frames.data_ptr(), B, H, W, 0, d_rgb.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
+
+        def flow_job():
+            fn.infer_sequence_dev(d_frames.data_ptr(), B, H, W, 0.75, 6, False, 0, f_rgb.data_ptr(), scal[2].data_ptr())
+        return depth_job, flow_job
+
+    ref = buffers()
+    dj, fj = jobs(*ref)
+    dj(); dn.sync(); fj(); fn.sync()
+    ref = [t.cpu().numpy() for t in ref]
+    assert ref[0].any() and ref[1].any() and (ref[2][1] > ref[2][0]).all()
+    for mode in ("run_concurrently", "threads"):
+        for rep in range(3):
+            out = buffers()
+            dj, fj = jobs(*out)
+            if mode == "run_concurrently":
+                done = engine.run_concurrently([(dn, dj), (fn, fj)])
+                assert len(done) == 2 and all(t > 0 for t in done)
+            else:
+                def run(job, net):
+                    job(); net.sync()
+                th = threading.Thread(target=run, args=(fj, fn))
+                th.start()
+                run(dj, dn)
+                th.join()
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b.cpu().numpy()), (mode, rep)
+    dn.close(); fn.close()
