@@ -26,15 +26,27 @@ def load_checkpoint(path, wrappers=(), strip_prefix=""):
         with np.load(path) as z:
             sd = {k: z[k] for k in z.files}
     else:
+        import pickle
+        import sys
         import torch
+        # tensors-only unpickling first (RAFT, GMFlow, Depth-Anything, ZoeDepth checkpoints are plain tensor dicts): a .pth from an
+        # untrusted source then cannot run code.  mmdet's `meta` entry holds arbitrary Python objects and needs the full unpickler -
+        # taken only when the restricted one refuses the file, and said on stderr
         try:
-            sd = torch.load(path, map_location="cpu", weights_only=False)
+            sd = torch.load(path, map_location="cpu", weights_only=True)
         except TypeError:                       # torch < 1.13 has no weights_only
             sd = torch.load(path, map_location="cpu")
+        except (pickle.UnpicklingError, RuntimeError) as e:
+            print(f"[prisma] {path}: not a tensors-only checkpoint ({str(e).splitlines()[0][:120]}); loading it with the full unpickler - "
+                  "only do this with files you trust", file=sys.stderr)
+            sd = torch.load(path, map_location="cpu", weights_only=False)
     for w in wrappers:
         if isinstance(sd, dict) and w in sd and isinstance(sd[w], dict):
             sd = sd[w]
             break
+    if not isinstance(sd, dict):
+        raise ValueError(f"{path}: expected a state dict (optionally under one of {list(wrappers)}), found a pickled {type(sd).__name__} - "
+                         "save `model.state_dict()`, not the module")
     out = {}
     for k, v in sd.items():
         if not (hasattr(v, "detach") or isinstance(v, np.ndarray)):

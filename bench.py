@@ -289,11 +289,40 @@ def pipeline_leg(args, R):
 
     steps = max(1, args.steps // 2)
     dt = timed(step, steps)
+    # PCIe-inclusive figure of configs[4] (one-GPU runs): the same clip through the three HOST-pointer entry points - page-locked frames in,
+    # page-locked results out, the library's default chunking (depth 2 x 16 frames, flow 16 pairs + a halo frame, mask chunks of max_batch
+    # frames), one host thread per band since the calls block until their results are in host memory - compared byte for byte with the
+    # HBM-resident leg's results
+    host_fps = None
+    if world == 1 and args.host_clips > 0:
+        import threading
+        hf = frames.cpu().pin_memory()
+        h_d = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
+        h_f = torch.empty((B - 1, 1, sh, sw, 3), dtype=torch.uint8).pin_memory()
+        h_m = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
+
+        def clip():
+            ths = [threading.Thread(target=lambda: dn.infer_batch(hf.numpy(), want_depth=False, want_rgb=True, flip=True, out_rgb=h_d.numpy())),
+                   threading.Thread(target=lambda: fn.infer_sequence(hf.numpy(), scale=0.75, iters=12, backward=False, want_flow=False, want_rgb=True, out_rgb=h_f.numpy())),
+                   threading.Thread(target=lambda: mn.infer_batch(hf.numpy(), 0.5, keep, out=h_m.numpy()))]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        clip()
+        assert bool((h_d == d_rgb.cpu()).all()) and bool((h_f[:, 0] == f_rgb.cpu()).all()) and bool((h_m == m_out.cpu()).all()), \
+            "host-pointer results of the three-band pipeline differ from the HBM-resident leg's"
+        t1 = time.perf_counter()
+        for _ in range(args.host_clips):
+            clip()
+        host_fps = B * args.host_clips / (time.perf_counter() - t1)
     for n_ in (dn, fn, mn):
         n_.close()
     return {"metric": "frames/sec (depth_anything + flow_raft + mask_mmdet on every 1080p frame)", "value": round(world * B * steps / dt, 3),
             "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "frames_per_step_per_gpu": B,
-            "note": "the three bands enqueued together on their own streams (tools/pipeline_order_bench.py: 121 frames/s against 116 one after the other); flow at --scale 0.75 (816 x 1440), forward pairs only"}
+            "pcie_inclusive_fps": round(host_fps, 2) if host_fps else None,
+            "note": "the three bands enqueued together on their own streams (tools/pipeline_order_bench.py: 121 frames/s against 116 one after the other); flow at --scale 0.75 (816 x 1440), forward pairs only; "
+                    "pcie_inclusive_fps = the same clip through the three host-pointer entry points from / into page-locked memory, one host thread per band, results byte-identical"}
 
 
 def pmc_traffic(symbol):
@@ -307,6 +336,24 @@ def pmc_traffic(symbol):
         for kname, v in json.load(open(path))["kernels"].items():
             if want in kname.replace(" ", ""):
                 return round(v["fetch_bytes"] + v["write_bytes"]), "profiles/" + os.path.basename(path)
+    return None, None
+
+
+def pmc_clocks(fam_keys):
+    """per-symbol effective shader clock (GHz) of the bench's kernel families from the newest committed GRBM_GUI_ACTIVE pass over
+    `bench.py --sequential-only` (tools/pmc_clock.py; counter passes cannot run inside the timed bench): {family: GHz}, source file"""
+    import glob
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for path in sorted(glob.glob(os.path.join(here, "r??[a-z]_clock_per_symbol.json")), reverse=True):
+        ks = json.load(open(path))["kernels"]
+        out = {}
+        for fk in fam_keys:
+            sym = fk.split("/", 1)[1]
+            want = SYMBOLS.get(sym, sym).replace(" ", "").rstrip(">")      # (the attention symbol carries one more template argument than the family name)
+            hit = [v for k, v in ks.items() if want in k.replace(" ", "")]
+            if hit and "(" != want[:1]:
+                out[fk] = round(sum(h["effective_clock_ghz"] * h["total_ms"] for h in hit) / sum(h["total_ms"] for h in hit), 3)
+        return out, "profiles/" + os.path.basename(path)
     return None, None
 
 
@@ -365,7 +412,7 @@ def main():
     if args.cpu_baseline_only:
         from prisma_amd import synth
         cfg = synth.DEPTH_CFGS[args.encoder]
-        fr = synth.frame_pair_sequence(2, args.height, args.width, seed=1000)
+        fr = synth.frame_pair_sequence(args.batch, args.height, args.width, seed=1000)[:2]     # the parent's clip, its first two frames
         print(json.dumps(cpu_baseline(synth.cached_weights("depth", cfg, 1234), cfg, synth.cached_weights("raft", 4321), fr, args.flow_scale,
                                       args.flow_iters)))
         return
@@ -490,14 +537,20 @@ def main():
         if extras and rank == 0:
             # latency of BASELINE.json configs[1]: one 1280x720 frame, batch 1 (outside the timed region above)
             if args.latency:
+                # a context of its own with max_batch = 1 - what a one-frame-per-call caller creates (the band script with PRISMA_BATCH=1): such a
+                # context lends its GEMM launches a split-K workspace (engine.h sk_ws_; 20-160 tiles for 256 CUs otherwise).  The 32-frame
+                # context's figure for a one-frame call is reported beside it.
                 f1 = torch.from_numpy(synth.frames(1, 720, 1280, seed=7)).cuda()
                 r1 = torch.empty((1, 720, 1280, 3), dtype=torch.uint8, device="cuda")
-                for i in range(8):
-                    if i == 3:
-                        torch.cuda.synchronize(); t1 = time.perf_counter()
-                    dn.infer_dev(f1.data_ptr(), 1, 720, 1280, 0, r1.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
-                    dn.sync()
-                res["lat_b1"] = (time.perf_counter() - t1) / 5 * 1e3
+                d1 = engine.DepthAnything(weights, cfg, device=local_rank, max_batch=1, precision=prec)
+                for key, net_ in (("lat_b1", d1), ("lat_b1_big_ctx", dn)):
+                    for i in range(13):
+                        if i == 3:
+                            torch.cuda.synchronize(); t1 = time.perf_counter()
+                        net_.infer_dev(f1.data_ptr(), 1, 720, 1280, 0, r1.data_ptr(), scal[0].data_ptr(), scal[1].data_ptr(), True)
+                        net_.sync()
+                    res[key] = (time.perf_counter() - t1) / 10 * 1e3
+                d1.close()
             # PCIe-inclusive rate (never `value`; SURVEY 8(d) config 4: frames "resident in pinned host memory"): the SAME clip through the
             # host-pointer entry points of both bands - pb_depth_infer_batch and pb_flow_infer_sequence (abi.hip: H2D of chunk i + 1, the band
             # on chunk i and D2H of chunk i - 1 on three streams) - from page-locked frames into page-locked result arrays, with the product's
@@ -549,7 +602,7 @@ def main():
     cpu_child = None
     if world == 1 and not args.no_cpu_baseline and (os.cpu_count() or 1) >= 48:
         import subprocess
-        cpu_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--height", str(H), "--width", str(W),
+        cpu_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--batch", str(B), "--height", str(H), "--width", str(W),
                                       "--encoder", args.encoder, "--flow-scale", str(args.flow_scale), "--flow-iters", str(args.flow_iters)],
                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     # effective shader clock under the band's dominant GEMM shape: per-tile s_memtime / s_memrealtime stamps of one
@@ -701,10 +754,15 @@ def main():
                                    "frame; copies of chunk i +- 1 under the kernels of chunk i), both bands at once like the timed region (one host thread per "
                                    "band: the calls block until the results are in host memory); results byte-identical to the HBM-resident leg's",
             "latency_720p_batch1_ms": round(main_res["lat_b1"], 3) if "lat_b1" in main_res else None,
+            "latency_720p_batch1_note": "one 1280x720 frame per call on a context created with max_batch = 1 (split-K on the launches with fewer tiles than CUs); "
+                                        "the same call on the 32-frame context of the timed region, which never splits: "
+                                        + ("%.3f ms" % main_res["lat_b1_big_ctx"] if "lat_b1_big_ctx" in main_res else "n/a"),
             "kernel_ms_per_step": {k: round(v["ms"] / qsteps, 3) for k, v in sorted(fam.items())},
             "kernel_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in fam.items()
                               if v["flops"] > 0 and v["ms"] > 0},
             "kernel_launches_per_step": {k: v["launches"] / qsteps for k, v in sorted(fam.items())},
+            "kernel_effective_clock_ghz": pmc_clocks(sorted(fam))[0],
+            "kernel_effective_clock_source": pmc_clocks(sorted(fam))[1],
             # algorithmic bytes (A + W + output once) per second of launch time: the figure to hold against HBM's ~8 TB/s for the launches
             # that move more than they compute (the K = 256 correlation-volume GEMMs sit in flow/gemm_kernel<128, 128, 2, 2, 0, 0, ...>)
             "kernel_algorithmic_tbps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e12, 3) for k, v in fam.items() if v["bytes"] > 0 and v["ms"] > 0},

@@ -106,6 +106,16 @@ struct PipeDrain {
     }
 };
 
+// One host-pointer call = several engine infer() calls (one per chunk): the per-launch timer is reset ONCE per API call and accumulates over the
+// chunks, so pb_get_kernel_stats describes the whole call as it does for a device-pointer call (stage snapshots - pb_*_get_stage -
+// still describe the last chunk).  Restores the caller's accumulate setting.
+struct TimerSpan {
+    KernelTimer &t;
+    bool saved;
+    explicit TimerSpan(KernelTimer &timer) : t(timer), saved(timer.accumulate) { t.reset(); t.accumulate = true; }
+    ~TimerSpan() { t.accumulate = saved; }
+};
+
 // pb_flow_infer_sequence: the same three-stage pipeline over chunks of frame pairs (a chunk = its pairs' frames + one halo frame)
 struct FlowPipe {
     hipStream_t s_in = nullptr, s_out = nullptr;
@@ -154,6 +164,59 @@ struct FlowPipe {
     }
 };
 
+// pb_mask_infer_batch: the engine walks the batch in chunks of max_batch frames itself and takes whole-batch device pointers, so the pipeline is
+// whole-batch device buffers + one event per chunk: every chunk's H2D is enqueued up front on s_in, chunk i's kernels wait for event i, and its id
+// images leave on s_out as soon as its last launch is enqueued (MaskEngine::chunk_begin / chunk_end).  Buffers and streams stay on the ctx.
+struct MaskPipe {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    void *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+    size_t cap_d = 0, cap_hi = 0, cap_ho = 0;
+    std::vector<hipEvent_t> ev_in, ev_done;
+    int ensure(size_t bytes, bool host_in, bool host_out, int chunks) {
+        if (!s_in) {
+            PB_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+            PB_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+        }
+        if (bytes > cap_d) {
+            if (d_in) PB_HIP(hipFree(d_in));
+            if (d_out) PB_HIP(hipFree(d_out));
+            d_in = d_out = nullptr; cap_d = 0;
+            PB_HIP(hipMalloc(&d_in, bytes));
+            PB_HIP(hipMalloc(&d_out, bytes));
+            cap_d = bytes;
+        }
+        if (host_in && bytes > cap_hi) {
+            if (h_in) PB_HIP(hipHostFree(h_in));
+            h_in = nullptr; cap_hi = 0;
+            PB_HIP(hipHostMalloc(&h_in, bytes, hipHostMallocDefault));
+            cap_hi = bytes;
+        }
+        if (host_out && bytes > cap_ho) {
+            if (h_out) PB_HIP(hipHostFree(h_out));
+            h_out = nullptr; cap_ho = 0;
+            PB_HIP(hipHostMalloc(&h_out, bytes, hipHostMallocDefault));
+            cap_ho = bytes;
+        }
+        while ((int)ev_in.size() < chunks) {
+            hipEvent_t a, b;
+            PB_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            PB_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            ev_in.push_back(a); ev_done.push_back(b);
+        }
+        return 0;
+    }
+    void release() {
+        if (s_in) { hipStreamSynchronize(s_in); hipStreamSynchronize(s_out); }
+        if (d_in) hipFree(d_in);
+        if (d_out) hipFree(d_out);
+        if (h_in) hipHostFree(h_in);
+        if (h_out) hipHostFree(h_out);
+        for (auto e : ev_in) hipEventDestroy(e);
+        for (auto e : ev_done) hipEventDestroy(e);
+        if (s_in) { hipStreamDestroy(s_in); hipStreamDestroy(s_out); }
+    }
+};
+
 struct pb_ctx {
     int device = 0;
     DepthEngine *depth = nullptr;
@@ -163,9 +226,11 @@ struct pb_ctx {
     f16 *zero = nullptr;
     bool own_stream = false;
     int gemm_tile = TILE_AUTO, conv_tile = TILE_AUTO;
+    int op_splitk = 0;              // pb_set_option("op_splitk", 1): pb_op_gemm / pb_op_conv2d lend launch_gemm a split-K workspace (gemm.h splitk; op-level tests)
     int host_chunk = 0;             // pb_set_option("host_chunk"): frames (depth) / frame pairs (flow) per chunk of the host-pointer pipelines, 0 = default
     HostPipe pipe;
     FlowPipe fpipe;
+    MaskPipe mpipe;
     // pb_comm_init: RCCL communicator of the ranks (one process per GPU) for pb_gather_scalars
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -378,6 +443,7 @@ void pb_destroy(pb_ctx *c) {
     if (c->still_buf) hipFree(c->still_buf);
     c->pipe.release();
     c->fpipe.release();
+    c->mpipe.release();
     if (c->depth) delete c->depth;
     if (c->raft) delete c->raft;
     if (c->mask) delete c->mask;
@@ -419,8 +485,11 @@ int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, 
     const size_t in_b = (size_t)cap * px * 3, d_b = depth_out ? (size_t)cap * px * 4 : 0, r_b = rgb_out ? in_b : 0,
                  m_b = (size_t)cap * 8;
     // page-locked caller buffers are read / written by the copy engines directly (no staging memcpy on this thread)
-    const bool pin_in = pb_is_pinned(frames), pin_d = pb_is_pinned(depth_out), pin_r = pb_is_pinned(rgb_out);
+    const bool pin_in = pb_is_pinned(frames, (size_t)n * px * 3), pin_d = pb_is_pinned(depth_out, (size_t)n * px * 4),
+               pin_r = pb_is_pinned(rgb_out, (size_t)n * px * 3);
     PB_TRY(hp.ensure(in_b, d_b, r_b, m_b, !pin_in, !pin_d, !pin_r));
+    PipeDrain drain{hp.s_in, c->stream, hp.s_out};          // no exit, error or not, leaves a copy into caller memory in flight
+    TimerSpan span(c->depth->timer);
     const int chunks = (n + cap - 1) / cap;
     auto finish = [&](int i) -> int {           // results of chunk i: pinned -> caller
         const int slot = i & 1, s0 = i * cap, m = std::min(cap, n - s0);
@@ -484,15 +553,14 @@ int pb_flow_infer_sequence_dev(pb_ctx *c, const uint8_t *frames, int F, int H, i
     return c->raft->infer(frames, F, H, W, scale, iters, backward, flow_out, rgb_out, maxdisp_out);
 }
 
-// Host-pointer variant (reference loop bands/flow_raft.py:98-113: a decoded frame pair per iteration): a three-stage pipeline over chunks of
-// PB_FLOW_HOST_PAIRS (16) frame pairs - frames of chunk i + 1 to HBM on a copy stream, chunk i on the ctx stream, results of chunk i - 1 to the
-// host on a second copy stream; two slots per stage ordered by events, device / pinned buffers kept on the ctx (round 4 allocated, cleared and
-// freed ~0.5 GB per call).  A chunk carries one halo frame, so the frame it shares with its neighbour is encoded twice (1 / 16 of the encoders'
-// work); every pair's flow is that of one whole-sequence call (pairs do not interact).  Page-locked caller buffers are used directly.
-int pb_flow_infer_sequence(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
-                           float *flow_out, uint8_t *rgb_out, float *maxdisp_out) {
-    PB_CHECK(c && c->raft, PB_ERR_STATE, "ctx has no flow_raft band");
-    PB_CHECK(frames && F >= 2 && H > 0 && W > 0, PB_ERR_ARG, "flow infer: bad arguments");
+// Host-pointer variants (reference loop bands/flow_raft.py:98-113: a decoded frame pair per iteration; :63-64 the consistency masks of --mask):
+// a three-stage pipeline over chunks of PB_FLOW_HOST_PAIRS (16) frame pairs - frames of chunk i + 1 to HBM on a copy stream, chunk i on the ctx
+// stream, results of chunk i - 1 to the host on a second copy stream; two slots per stage ordered by events, device / pinned buffers kept on the
+// ctx.  A chunk carries one halo frame, so the frame it shares with its neighbour is encoded twice (1 / 16 of the encoders' work); every pair's
+// flow (and mask: both directions of a pair are in the same chunk) is that of one whole-sequence call - pairs do not interact.  Page-locked
+// caller buffers are used directly.  mask_out != NULL: both directions + the forward / backward consistency masks (pb_flow_infer_sequence_masks).
+static int flow_host_pipeline(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
+                              float *flow_out, uint8_t *rgb_out, float *maxdisp_out, uint8_t *mask_out, float alpha1, float alpha2) {
     PB_HIP(hipSetDevice(c->device));
     int sh, sw;
     RaftEngine::out_size(H, W, scale, &sh, &sw);
@@ -501,20 +569,25 @@ int pb_flow_infer_sequence(pb_ctx *c, const uint8_t *frames, int F, int H, int W
     int cp = c->host_chunk > 0 ? c->host_chunk : (env_cp > 0 ? env_cp : 16);
     if (pairs <= cp + cp / 4) cp = pairs;                       // a short tail is not worth a chunk of its own
     const int chunks = (pairs + cp - 1) / cp;
-    const size_t fpx = (size_t)H * W * 3, px = (size_t)sh * sw;
+    const size_t fpx = (size_t)H * W * 3, px = (size_t)sh * sw, nd = (size_t)pairs * dirs;
     FlowPipe &fp = c->fpipe;
-    const bool pin_in = pb_is_pinned(frames), pin_f = pb_is_pinned(flow_out), pin_r = pb_is_pinned(rgb_out);
+    const bool pin_in = pb_is_pinned(frames, (size_t)F * fpx), pin_f = pb_is_pinned(flow_out, nd * px * 8), pin_r = pb_is_pinned(rgb_out, nd * px * 3),
+               pin_k = pb_is_pinned(mask_out, nd * px);
     PB_TRY(fp.ensure_streams());
+    PipeDrain drain{fp.s_in, c->stream, fp.s_out};              // no exit, error or not, leaves a copy into caller memory in flight
+    TimerSpan span(c->raft->timer);
     PB_TRY(fp.grow(0, (size_t)(cp + 1) * fpx, !pin_in));
     if (flow_out) PB_TRY(fp.grow(1, (size_t)cp * dirs * px * 8, !pin_f));
     if (rgb_out) PB_TRY(fp.grow(2, (size_t)cp * dirs * px * 3, !pin_r));
     PB_TRY(fp.grow(3, (size_t)cp * dirs * 4 + 256, true));
+    if (mask_out) PB_TRY(fp.grow(4, (size_t)cp * dirs * px, !pin_k));
     auto finish = [&](int i) -> int {           // results of chunk i: pinned staging -> caller (page-locked caller buffers were written directly)
         const int slot = i & 1, p0 = i * cp, m = std::min(cp, pairs - p0);
         PB_HIP(hipEventSynchronize(fp.ev_d2h[slot]));
         if (flow_out && !pin_f) memcpy(flow_out + (size_t)p0 * dirs * px * 2, fp.h[1][slot], (size_t)m * dirs * px * 8);
         if (rgb_out && !pin_r) memcpy(rgb_out + (size_t)p0 * dirs * px * 3, fp.h[2][slot], (size_t)m * dirs * px * 3);
         if (maxdisp_out) memcpy(maxdisp_out + (size_t)p0 * dirs, fp.h[3][slot], (size_t)m * dirs * 4);
+        if (mask_out && !pin_k) memcpy(mask_out + (size_t)p0 * dirs * px, fp.h[4][slot], (size_t)m * dirs * px);
         return 0;
     };
     for (int i = 0; i < chunks; ++i) {
@@ -526,16 +599,25 @@ int pb_flow_infer_sequence(pb_ctx *c, const uint8_t *frames, int F, int H, int W
         PB_HIP(hipEventRecord(fp.ev_h2d[slot], fp.s_in));
         PB_HIP(hipStreamWaitEvent(c->stream, fp.ev_h2d[slot], 0));
         PB_TRY(c->raft->infer((const uint8_t *)fp.d[0][slot], m + 1, H, W, scale, iters, backward, (float *)(flow_out ? fp.d[1][slot] : nullptr),
-                              (uint8_t *)(rgb_out ? fp.d[2][slot] : nullptr), (float *)fp.d[3][slot]));
+                              (uint8_t *)(rgb_out ? fp.d[2][slot] : nullptr), (float *)fp.d[3][slot], (uint8_t *)(mask_out ? fp.d[4][slot] : nullptr),
+                              alpha1, alpha2));
         PB_HIP(hipEventRecord(fp.ev_comp[slot], c->stream));
         PB_HIP(hipStreamWaitEvent(fp.s_out, fp.ev_comp[slot], 0));
         if (flow_out) PB_HIP(hipMemcpyAsync(pin_f ? (void *)(flow_out + (size_t)p0 * dirs * px * 2) : fp.h[1][slot], fp.d[1][slot], (size_t)m * dirs * px * 8, hipMemcpyDeviceToHost, fp.s_out));
         if (rgb_out) PB_HIP(hipMemcpyAsync(pin_r ? (void *)(rgb_out + (size_t)p0 * dirs * px * 3) : fp.h[2][slot], fp.d[2][slot], (size_t)m * dirs * px * 3, hipMemcpyDeviceToHost, fp.s_out));
         PB_HIP(hipMemcpyAsync(fp.h[3][slot], fp.d[3][slot], (size_t)m * dirs * 4, hipMemcpyDeviceToHost, fp.s_out));
+        if (mask_out) PB_HIP(hipMemcpyAsync(pin_k ? (void *)(mask_out + (size_t)p0 * dirs * px) : fp.h[4][slot], fp.d[4][slot], (size_t)m * dirs * px, hipMemcpyDeviceToHost, fp.s_out));
         PB_HIP(hipEventRecord(fp.ev_d2h[slot], fp.s_out));
     }
     for (int i = std::max(0, chunks - 2); i < chunks; ++i) PB_TRY(finish(i));
     return 0;
+}
+
+int pb_flow_infer_sequence(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
+                           float *flow_out, uint8_t *rgb_out, float *maxdisp_out) {
+    PB_CHECK(c && c->raft, PB_ERR_STATE, "ctx has no flow_raft band");
+    PB_CHECK(frames && F >= 2 && H > 0 && W > 0, PB_ERR_ARG, "flow infer: bad arguments");
+    return flow_host_pipeline(c, frames, F, H, W, scale, iters, backward, flow_out, rgb_out, maxdisp_out, nullptr, 0.05f, 0.5f);
 }
 
 int pb_flow_infer_sequence_masks_dev(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters,
@@ -550,25 +632,7 @@ int pb_flow_infer_sequence_masks(pb_ctx *c, const uint8_t *frames, int F, int H,
                                  float alpha2, float *flow_out, uint8_t *rgb_out, float *maxdisp_out, uint8_t *mask_out) {
     PB_CHECK(c && c->raft, PB_ERR_STATE, "ctx has no flow_raft band");
     PB_CHECK(frames && F >= 2 && H > 0 && W > 0 && mask_out, PB_ERR_ARG, "flow masks: bad arguments");
-    PB_HIP(hipSetDevice(c->device));
-    int sh, sw;
-    RaftEngine::out_size(H, W, scale, &sh, &sw);
-    const size_t nd = (size_t)(F - 1) * 2, px = (size_t)sh * sw;
-    DevMem dF, dO, dR, dM, dK;
-    PB_TRY(dF.alloc((size_t)F * H * W * 3));
-    if (flow_out) PB_TRY(dO.alloc(nd * px * 8));
-    if (rgb_out) PB_TRY(dR.alloc(nd * px * 3));
-    PB_TRY(dM.alloc(nd * 4));
-    PB_TRY(dK.alloc(nd * px));
-    PB_HIP(hipMemcpy(dF.p, frames, (size_t)F * H * W * 3, hipMemcpyHostToDevice));
-    PB_TRY(c->raft->infer(dF.as<uint8_t>(), F, H, W, scale, iters, 1, dO.as<float>(), dR.as<uint8_t>(), dM.as<float>(),
-                          dK.as<uint8_t>(), alpha1, alpha2));
-    PB_HIP(hipStreamSynchronize(c->stream));
-    if (flow_out) PB_HIP(hipMemcpy(flow_out, dO.p, nd * px * 8, hipMemcpyDeviceToHost));
-    if (rgb_out) PB_HIP(hipMemcpy(rgb_out, dR.p, nd * px * 3, hipMemcpyDeviceToHost));
-    if (maxdisp_out) PB_HIP(hipMemcpy(maxdisp_out, dM.p, nd * 4, hipMemcpyDeviceToHost));
-    PB_HIP(hipMemcpy(mask_out, dK.p, nd * px, hipMemcpyDeviceToHost));
-    return 0;
+    return flow_host_pipeline(c, frames, F, H, W, scale, iters, 1, flow_out, rgb_out, maxdisp_out, mask_out, alpha1, alpha2);
 }
 
 int pb_flow_fwdbwd_mask(pb_ctx *c, const float *flows, int n, int sh, int sw, float alpha1, float alpha2, uint8_t *mask_out) {
@@ -597,19 +661,46 @@ int pb_mask_infer_batch_dev(pb_ctx *c, const uint8_t *frames, int n, int H, int 
     return c->mask->infer(frames, n, H, W, confidence, keep, n_keep, mask_out);
 }
 
+// Host-pointer variant (reference loop bands/mask_mmdet.py:131-154: a decoded frame per iteration): frames of every chunk go to HBM on a copy
+// stream up front, chunk i's kernels wait for chunk i's copy, and its id images (with the --sdf channel when tables are set) return on a second
+// copy stream while chunk i + 1 runs; device buffers, pinned staging and streams are kept on the ctx (rounds 1-5: two hipMalloc / hipFree pairs
+// and two exposed whole-batch copies per call).  Page-locked caller buffers are used directly.
 int pb_mask_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, float confidence, const int32_t *keep,
                         int n_keep, uint8_t *mask_out) {
     PB_CHECK(c && c->mask, PB_ERR_STATE, "ctx has no mask_mmdet band");
     PB_CHECK(frames && mask_out && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "mask infer: bad arguments");
     PB_HIP(hipSetDevice(c->device));
-    const size_t bytes = (size_t)n * H * W * 3;
-    DevMem dF, dO;
-    PB_TRY(dF.alloc(bytes));
-    PB_TRY(dO.alloc(bytes));
-    PB_HIP(hipMemcpy(dF.p, frames, bytes, hipMemcpyHostToDevice));
-    PB_TRY(c->mask->infer(dF.as<uint8_t>(), n, H, W, confidence, keep, n_keep, dO.as<uint8_t>()));
-    PB_HIP(hipStreamSynchronize(c->stream));
-    PB_HIP(hipMemcpy(mask_out, dO.p, bytes, hipMemcpyDeviceToHost));
+    const size_t fb = (size_t)H * W * 3, bytes = (size_t)n * fb;
+    const int cf = c->mask->frames_per_chunk(), chunks = (n + cf - 1) / cf;
+    const bool pin_in = pb_is_pinned(frames, bytes), pin_out = pb_is_pinned(mask_out, bytes);
+    MaskPipe &mp = c->mpipe;
+    PB_TRY(mp.ensure(bytes, !pin_in, !pin_out, chunks));
+    PipeDrain drain{mp.s_in, c->stream, mp.s_out};              // no exit, error or not, leaves a copy into caller memory in flight
+    for (int i = 0; i < chunks; ++i) {
+        const size_t off = (size_t)i * cf * fb, len = (size_t)std::min(cf, n - i * cf) * fb;
+        const void *src = frames + off;
+        if (!pin_in) { memcpy((char *)mp.h_in + off, src, len); src = (char *)mp.h_in + off; }
+        PB_HIP(hipMemcpyAsync((char *)mp.d_in + off, src, len, hipMemcpyHostToDevice, mp.s_in));
+        PB_HIP(hipEventRecord(mp.ev_in[i], mp.s_in));
+    }
+    hipStream_t st = c->stream;
+    char *dst = pin_out ? (char *)mask_out : (char *)mp.h_out;
+    c->mask->chunk_begin = [&mp, st, cf](int first, int) -> int {
+        PB_HIP(hipStreamWaitEvent(st, mp.ev_in[first / cf], 0));
+        return 0;
+    };
+    c->mask->chunk_end = [&mp, st, cf, fb, dst](int first, int m) -> int {
+        const size_t off = (size_t)first * fb;
+        PB_HIP(hipEventRecord(mp.ev_done[first / cf], st));
+        PB_HIP(hipStreamWaitEvent(mp.s_out, mp.ev_done[first / cf], 0));
+        PB_HIP(hipMemcpyAsync(dst + off, (char *)mp.d_out + off, (size_t)m * fb, hipMemcpyDeviceToHost, mp.s_out));
+        return 0;
+    };
+    const int r = c->mask->infer((const uint8_t *)mp.d_in, n, H, W, confidence, keep, n_keep, (uint8_t *)mp.d_out);
+    c->mask->chunk_begin = nullptr; c->mask->chunk_end = nullptr;     // (an argument error returns before infer() consumes them)
+    if (r) return r;
+    PB_HIP(hipStreamSynchronize(mp.s_out));
+    if (!pin_out) memcpy(mask_out, mp.h_out, bytes);
     return 0;
 }
 
@@ -682,6 +773,7 @@ int pb_set_option(pb_ctx *c, const char *key, int value) {
     if (!strcmp(key, "gemm_tile")) *g = value;
     else if (!strcmp(key, "conv_tile")) *v = value;
     else if (!strcmp(key, "host_chunk")) c->host_chunk = value;
+    else if (!strcmp(key, "op_splitk")) c->op_splitk = value;
     else PB_CHECK(false, PB_ERR_ARG, "unknown option '%s'", key);
     return 0;
 }
@@ -740,6 +832,8 @@ int pb_op_gemm(pb_ctx *c, const float *A, const float *W, const float *bias, flo
     GemmArgs g;
     g.A = a16.as<f16>(); g.lda = Kp; g.W = w16.as<f16>(); g.K = Kp; g.M = M; g.N = N;
     g.bias = b32.as<float>(); g.out = c16.as<f16>(); g.ldo = N; g.act = act; g.zero = c->zero;
+    DevMem skw;
+    if (c->op_splitk) { PB_TRY(skw.alloc((size_t)512 * 128 * 128 * 4)); g.sk_ws = skw.as<float>(); g.sk_cap = (int64_t)512 * 128 * 128; }
     PB_TRY(launch_gemm(c->stream, A_DENSE, EPI_STD, tile, g));
     PB_TRY(launch_f16_to_f32(c->stream, c16.as<f16>(), c32.as<float>(), M, N, N));
     PB_HIP(hipStreamSynchronize(c->stream));
@@ -980,6 +1074,8 @@ int pb_op_conv2d(pb_ctx *c, const float *x, const float *w, const float *bias, f
     g.A = dx.as<f16>(); g.W = dw.as<f16>(); g.K = K; g.M = B * OH * OW; g.N = Co;
     g.cH = H; g.cW = W; g.cC = cip; g.cOH = OH; g.cOW = OW; g.cKW = ks; g.cStride = stride; g.cPad = pad;
     g.zero = c->zero; g.bias = db.as<float>(); g.out = dy.as<f16>(); g.ldo = cop; g.act = relu_out ? ACT_RELU : ACT_NONE;
+    DevMem skw;
+    if (c->op_splitk) { PB_TRY(skw.alloc((size_t)512 * 128 * 128 * 4)); g.sk_ws = skw.as<float>(); g.sk_cap = (int64_t)512 * 128 * 128; }
     PB_TRY(launch_gemm(c->stream, A_CONV, EPI_STD, c->conv_tile ? c->conv_tile : TILE_128, g));
     PB_TRY(launch_nhwc_f16_to_nchw_f32(c->stream, dy.as<f16>(), dy32.as<float>(), B, Co, OH, OW, cop));
     PB_HIP(hipStreamSynchronize(c->stream));

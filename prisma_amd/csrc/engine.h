@@ -143,6 +143,12 @@ class DepthEngine {
     float *w2_ = nullptr;
     float b2_ = 0.f;
     f16 *zero_ = nullptr;
+    // split-K workspace (gemm.h splitk): lent to every launch of a context created with max_batch = 1 - one frame per call is the latency
+    // configuration (BASELINE.json configs[1]), its residual GEMMs and low-resolution head convolutions have 20-160 tiles for 256 CUs.
+    // Contexts with max_batch > 1 never split, so a frame's bits do not depend on the size of the batch it arrives in; they do differ (within
+    // the parity tolerance) between a max_batch = 1 context and the others.  PB_SPLITK=0 turns it off, PB_SPLITK_ALWAYS=1 lends it to every ctx.
+    float *sk_ws_ = nullptr;
+    static constexpr int64_t kSkFloats = (int64_t)512 * 128 * 128;      // 512 slices of a 128 x 128 fp32 tile: 32 MB
 
     // plan
     int pB_ = 0, pH_ = 0, pW_ = 0, last_n_ = 0;

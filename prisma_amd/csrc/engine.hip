@@ -281,6 +281,12 @@ int DepthEngine::load(const pb_tensor *w, int n) {
         owned_.push_back(z);
         zero_ = (f16 *)z;
     }
+    if ((cfg_.max_batch <= 1 || pb_env_int("PB_SPLITK_ALWAYS", 0)) && pb_env_int("PB_SPLITK", 8) > 1) {      // split-K workspace (engine.h sk_ws_)
+        void *w = nullptr;
+        PB_HIP(hipMalloc(&w, (size_t)kSkFloats * 4));
+        owned_.push_back(w);
+        sk_ws_ = (float *)w;
+    }
     const std::string P = "pretrained.";
     {   // patch embedding: conv weight [D,3,14,14] is already [N, K=588] in (c, py, px) order
         NEED(wt, P + "patch_embed.proj.weight", (int64_t)D * 588);
@@ -520,6 +526,7 @@ int DepthEngine::prepare(int B, int H, int W) {
     if (B <= pB_ && H == pH_ && W == pW_) return 0;
     B = std::max(B, (pH_ == H && pW_ == W) ? pB_ : 0);
     PB_HIP(hipStreamSynchronize(stream));
+    pB_ = 0; pH_ = 0; pW_ = 0;          // (a failure below must not leave the old plan's key on a half-written plan: raft_engine.hip prepare)
     int r = pb_depth_net_size(H, W, &nh_, &nw_);
     if (r) return r;
     if (cfg_.metric) { nh_ = 392; nw_ = 518; }      // DepthAnythingCore.prep: img_size [392, 518], aspect ratio not kept
@@ -646,6 +653,7 @@ int DepthEngine::gemm(int amode, int epi, GemmArgs &a, const PackedW &w, int til
     const double bytes = 2.0 * (a_elems + (double)a.N * w.Kreal) + (epi == EPI_HEAD ? 4.0 * a.M : 2.0 * (double)a.M * a.N);
     tic(amode == A_CONV ? F_CONV : (epi == EPI_RESID ? F_GEMM_RESID : (epi == EPI_QKV ? F_GEMM_QKV : F_GEMM)), flops, bytes, w.mx3 ? 2.0 : 1.0 + w.sa + w.sw + (w.nk16 && w.K > w.Kreal ? 0.5 : 0.0));
     if (tile == TILE_AUTO) tile = amode == A_CONV ? conv_tile : gemm_tile;
+    if (sk_ws_) { a.sk_ws = sk_ws_; a.sk_cap = kSkFloats; }
     int r = launch_gemm(stream, amode, epi, tile, a);
     if (timer.enabled && !r) timer.recs.back().name = pb_gemm_last_kernel();
     toc();

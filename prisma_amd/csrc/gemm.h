@@ -7,8 +7,8 @@ enum { EPI_STD = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_PIXSHUF = 3, EPI_PATCH = 4, 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4,
        ACT_GRU_ZR = 5,     // N = 256 = [z | r]: z = sigmoid -> out; r = sigmoid, r * gru_h -> gru_rh (ld 384), nothing to out
        ACT_GRU_Q = 6 };    // N = 128: q = tanh; h = (1 - z) h + z q with z from gru_z (ld 256), h in gru_h (fp32, ld 128); h -> out
-enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256x64 = 9,       // (4, 5, 7, 8, 10: round-1 variants, measured slower, removed)
-       TILE_256x128 = 11 };   // round 5: the ping-pong schedule for N <= 128 (gemm_n128.h; EPI_STD only)
+enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256x64 = 9 };     // (4, 5, 7, 8, 10: round-1 variants; 11: round 5's 384 x 128 ping-pong
+                                                                                       // kernel for N <= 128 - measured slower or equal, removed: EXPERIMENTS.md)
 
 struct GemmArgs {
     // operands: A row-major fp16 [M, lda] (dense) or NHWC image (conv); W fp16 [Npad, K], K % 64 == 0
@@ -95,6 +95,14 @@ struct GemmArgs {
     // (executed in the XCD's L2; every element receives exactly one per launch, so the result is deterministic) instead of a residual
     // tile load in front of the K loop and a store behind it (PB_RESID_ATOMIC)
     int resid_atomic = 0;
+    // split-K (the generic 128 x 128 tile only; launch_gemm picks the factor from the tile count when the caller provides sk_ws - the depth engine
+    // does for contexts created with max_batch = 1, where a launch has fewer tiles than the chip has CUs): TWO launches of the same kernel.  The
+    // first (sk_phase 1, tiles x splitk workgroups) lets slice s accumulate K tiles [s nk / splitk, (s + 1) nk / splitk) and park its fp32
+    // accumulators in sk_ws; the second (sk_phase 2, one workgroup per tile, no K tiles) adds the slices up in slice order on top of the bias /
+    // residual rows and runs the epilogue.  Deterministic for a given factor; sk_cap = floats sk_ws holds.
+    int splitk = 1, sk_phase = 0;
+    float *sk_ws = nullptr;
+    int64_t sk_cap = 0;
     int ablate = 0;                       // PB_GEMM_ABL (timing only, wrong results): 1 no epilogue at all, 2 bare packed-fp16 buffer stores instead of it
 };
 

@@ -4,6 +4,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 int pb_gemm_dense_std_f16(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_dense_std_mx(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_dense_resid_f16(hipStream_t s, int tile, const GemmArgs &a);
@@ -21,11 +23,6 @@ int pb_gemm_conv_pixshuf_f16(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_pixshuf_mx(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_head_f16(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_head_mx(hipStream_t s, int tile, const GemmArgs &a);
-// gemm_i7.hip: the 256 x 128 ping-pong kernel (gemm_n128.h), EPI_STD
-int pb_gemm_n128_dense_f16(hipStream_t s, const GemmArgs &a);
-int pb_gemm_n128_dense_mx(hipStream_t s, const GemmArgs &a);
-int pb_gemm_n128_conv_f16(hipStream_t s, const GemmArgs &a);
-int pb_gemm_n128_conv_mx(hipStream_t s, const GemmArgs &a);
 
 static thread_local const char *g_last_kernel = "";
 const char *pb_gemm_last_kernel() { return g_last_kernel; }
@@ -69,18 +66,30 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         static int n64_tile = -1;
         if (n64_tile < 0) { const char *e = getenv("PB_TILE_N64"); n64_tile = e ? atoi(e) : TILE_256x64; }
         if (tile == TILE_128 && epi == EPI_STD && a.N <= 64 && n64_tile != TILE_128) tile = n64_tile;
-        // 64 < N <= 128 with enough rows to fill the chip: the 256 x 128 ping-pong kernel (gemm_n128.h).  PB_TILE_N128=<min tiles>, 0 = off
-        static int n128_min = -1;
-        // Off by default.  Measured on one box (profiles/r05c_*, r05f_*): the DPT head's output_conv1 (2.5 M rows) 426 -> 528 TF/s, but the depth band's
-        // N <= 128 launches together 10.02 -> 10.0 ms; the RAFT encoders' 1/4-resolution layers (2.35 M rows, N = 96) 13.1 -> 14.5 ms and the update
-        // block's (569 k rows) 34.5 -> 35.6 ms: the K loop is faster (2200 cycles per 384 x 128 x 64 against the generic tile's ~2 x 1300 for the
-        // same work) and the one-tile workgroups give it back - ~11 k cycles of set-up per 40-85 k-cycle tile that the generic tile's second
-        // workgroup per CU hides.  Kept as a tested kernel (tile id 11) for the persistent variant that would make it pay.
-        if (n128_min < 0) { const char *e = getenv("PB_TILE_N128"); n128_min = e ? atoi(e) : 0; }
-        if (tile == TILE_128 && epi == EPI_STD && n128_min > 0 && a.N > 64 && a.N <= 128 && (a.M + 383) / 384 >= n128_min) tile = TILE_256x128;
+        // (round 5 built a 384 x 128 ping-pong kernel for 64 < N <= 128 - K loop at 70 % of the matrix pipe against this tile's ~45 % - whose one
+        // workgroup per CU exposed its set-up and epilogue: 35.5 against 34.6 ms on the bands' launches; under two-band overlap, round 6, +0.2 ... 0.8 %
+        // of a step (profiles/r06b_overlap_n128.txt, r06c_bench_n128_line.json).  Not a gain worth 1300 lines and two translation units: removed.)
         static int small_tile = -1;
         if (small_tile < 0) { const char *e = getenv("PB_TILE_SMALL"); small_tile = e ? atoi(e) : TILE_128; }
         if (tile == TILE_128 && (epi == EPI_STD || epi == EPI_F32) && small_tile != TILE_128) tile = small_tile;
+    }
+    // split-K (gemm.h splitk): only the generic 128 x 128 tile, only when the caller lent a workspace, only launches that leave CUs idle
+    a.splitk = 1;
+    if (tile == TILE_128 && a.sk_ws && (epi == EPI_STD || epi == EPI_RESID)) {
+        static int sk_max = -1, ncu = 0;
+        if (sk_max < 0) {
+            sk_max = pb_env_int("PB_SPLITK", 8);           // largest factor; 0 / 1 = off
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
+        }
+        const int64_t tiles = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        const int nk = a.K / 64;
+        if (sk_max > 1 && tiles < ncu) {
+            int S = (int)std::min<int64_t>(sk_max, 2 * (int64_t)ncu / tiles);      // two workgroups of this tile fit a CU
+            S = std::min(S, nk / 8);                                              // a slice keeps >= 8 K tiles: its prologue / reduction must stay small beside it
+            while (S > 1 && (int64_t)S * tiles * 128 * 128 > a.sk_cap) --S;
+            if (S > 1) a.splitk = S;
+        }
     }
     if (epi == EPI_RESID) PB_CHECK(a.resid && (int64_t)a.M * a.ldr * 4 < (1LL << 32) - (1 << 20), -1, "residual epilogue: the stream (%d rows) must fit a 32-bit buffer resource", a.M);
     if (epi == EPI_QKV) PB_CHECK(a.D % (tile == TILE_128 ? 128 : 256) == 0 && a.ntp % 8 == 0, -1, "qkv epilogue: D=%d ntp=%d", a.D, a.ntp);
@@ -107,11 +116,6 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
     // MX builds write / read split maps with e4m3 residual parts, fp16-only builds with fp16 residual parts
     PB_CHECK(!a.lo_off || (a.lo8 != 0) == mx, -1, "gemm: split-map format (lo8 = %d) does not match the weights' (nk16 = %d)", a.lo8, a.nk16);
     PB_CHECK(!a.o8_off || mx, -1, "gemm: an fp8 output copy needs an MX build");
-    if (tile == TILE_256x128) {
-        PB_CHECK(epi == EPI_STD, -1, "gemm: the 256 x 128 tile is built for EPI_STD only (epilogue %d)", epi);
-        if (amode == A_DENSE) return mx ? pb_gemm_n128_dense_mx(stream, a) : pb_gemm_n128_dense_f16(stream, a);
-        return mx ? pb_gemm_n128_conv_mx(stream, a) : pb_gemm_n128_conv_f16(stream, a);
-    }
     if (amode == A_DENSE && epi == EPI_STD) return mx ? pb_gemm_dense_std_mx(stream, tile, a) : pb_gemm_dense_std_f16(stream, tile, a);
     if (amode == A_DENSE && epi == EPI_RESID) return mx ? pb_gemm_dense_resid_mx(stream, tile, a) : pb_gemm_dense_resid_f16(stream, tile, a);
     if (amode == A_DENSE && epi == EPI_QKV) return mx ? pb_gemm_dense_qkv_mx(stream, tile, a) : pb_gemm_dense_qkv_f16(stream, tile, a);

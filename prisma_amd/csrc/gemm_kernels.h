@@ -1187,7 +1187,12 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     const int tilesN = (p.N + BN - 1) / BN;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int swz_all = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    // split-K (gemm.h splitk): the grid holds `sk` slices of every tile, slice-major
+    const int sk = p.sk_phase == 1 ? p.splitk : 1;
+    const int ntile = sk > 1 ? nwg / sk : nwg;
+    const int kslice = sk > 1 ? swz_all / ntile : 0;
+    const int swz = swz_all - kslice * ntile;
     const int tile_m = swz / tilesN, tile_n = swz - tile_m * tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -1224,6 +1229,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
 
     int c_ky = 0, c_kx = 0, c_c0 = 0;                       // conv tap state of the NEXT stage call (!KT builds)
     const int nk = p.K >> 6;
+    // this workgroup's K tiles [k0, k1): all of them unless the launch is split along K (only KT / dense builds: the cursor walk starts at tile 0)
+    // (the second launch of a split-K GEMM - sk_phase 2 - has none: it starts from the parked slices and runs the epilogue)
+    const int k0 = sk > 1 ? (int)((int64_t)kslice * nk / sk) : 0, k1 = sk > 1 ? (int)((int64_t)(kslice + 1) * nk / sk) : (p.sk_phase == 2 ? 0 : nk);
     // KT: the K walk comes from the table in the LDS (conv_ktab_entry).  The 256 x 64 tile keeps the cursor: its two workgroups per CU
     // use the LDS to the last byte.
     constexpr bool KT = AMODE == A_CONV && BN != 64;
@@ -1232,7 +1240,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     if constexpr (KT) {
         for (int t = tid; t < nk; t += NT) ((unsigned *)(smem + NS * STAGE))[t] = conv_ktab_entry(p, cld, t);
         __syncthreads();
-        e_nxt = ktab[0];
+        e_nxt = ktab[k0];
     }
     // BUFP: LDS-DMA through the buffer path (see gemm8_kernel); p.bufmode 1 = whole operand, 2 = two-image window (conv)
     __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, 0u), rsW = make_rsrc(p.W, 0u);
@@ -1322,7 +1330,21 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if constexpr (EPI == EPI_RESID) resid_io<TM, TN, false>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
+    if constexpr (EPI == EPI_RESID) {
+        if (p.sk_phase != 1) resid_io<TM, TN, false>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);      // (split-K: the reducing launch adds the residual rows)
+    }
+    if (p.sk_phase == 2) {          // split-K, second launch: the slices of this tile, in slice order
+        constexpr int NACC = TM * TN * 16;
+        for (int sl = 0; sl < p.splitk; ++sl) {
+            const float *part = p.sk_ws + ((int64_t)(sl * ntile + swz) * NACC) * NT + tid;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += part[(int64_t)((i * TN + j) * 16 + r) * NT];
+        }
+    }
 
     // K loop: one barrier per K tile; inside a tile the fragments of k-step ks+1 are read from LDS while the
     // MFMAs of k-step ks run (register double buffer), and the next tile's DMAs are issued behind the first reads.
@@ -1338,15 +1360,15 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     const int mxper = MX && p.mx_period > 0 ? p.mx_period : nk;
     const int n16 = MX && p.nk16 > 0 && p.nk16 < mxper ? p.nk16 : mxper;
     const int mxa = p.mx_scale_a * 0x01010101, mxb = p.mx_scale_b * 0x01010101;
-    stage(0, 0);
-    if constexpr (NS == 3) { if (nk > 1) stage(1, 1); }
+    if (k1 > k0) stage(0, k0);
+    if constexpr (NS == 3) { if (k1 - k0 > 1) stage(1, k0 + 1); }
     int cbuf = 0;                                           // buffer of tile kt
     // one K tile (fp16, or - MX builds - 128 e4m3 bytes per row).  The two kinds run in loops of their own below: with one loop and a branch
     // per tile the register allocator carried the accumulators across the back edge in VGPRs and copied all 64 of them into the AGPRs
     // and back EVERY K tile (128 v_accvgpr moves per 16-24 MFMAs in the MX build of the 128 x 128 tile - round 4, found in the ISA).
     auto ktile = [&](auto fp8_tag, int kt) {
         constexpr bool FP8 = decltype(fp8_tag)::value;
-        if (NS == 3 && kt + 1 < nk) vm_wait_halftiles((NA + NB) / 2);   // all but the newest stage (NA + NB DMAs) landed
+        if (NS == 3 && kt + 1 < k1) vm_wait_halftiles((NA + NB) / 2);   // all but the newest stage (NA + NB DMAs) landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // NS == 3: a bare barrier - __syncthreads() carries a workgroup fence for which the compiler drains vmcnt, i.e. the stage the
         // counted wait above leaves in flight (round 3: that is why the three-stage builds never beat the two-stage ones)
@@ -1356,10 +1378,10 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
         load_frags(0, sb, 0);
         if constexpr (NS == 3) {
             int nb = cbuf + 2; nb = nb >= 3 ? nb - 3 : nb;
-            if (kt + 2 < nk) stage(nb, kt + 2);
+            if (kt + 2 < k1) stage(nb, kt + 2);
             cbuf = cbuf == 2 ? 0 : cbuf + 1;
         } else {
-            if (kt + 1 < nk) stage(cbuf ^ 1, kt + 1);
+            if (kt + 1 < k1) stage(cbuf ^ 1, kt + 1);
             cbuf ^= 1;
         }
         if constexpr (FP8) {
@@ -1396,15 +1418,29 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
         }
     };
     if constexpr (!MX) {
-        for (int kt = 0; kt < nk; ++kt) ktile(std::false_type{}, kt);
+        for (int kt = k0; kt < k1; ++kt) ktile(std::false_type{}, kt);
     } else {
         for (int t0 = 0; t0 < nk; t0 += mxper) {
             const int e16 = t0 + n16 < nk ? t0 + n16 : nk, e8 = t0 + mxper < nk ? t0 + mxper : nk;
-            for (int kt = t0; kt < e16; ++kt) ktile(std::false_type{}, kt);
-            for (int kt = e16; kt < e8; ++kt) ktile(std::true_type{}, kt);
+            for (int kt = t0 > k0 ? t0 : k0; kt < (e16 < k1 ? e16 : k1); ++kt) ktile(std::false_type{}, kt);
+            for (int kt = e16 > k0 ? e16 : k0; kt < (e8 < k1 ? e8 : k1); ++kt) ktile(std::true_type{}, kt);
         }
     }
     __syncthreads();            // staging buffers are dead; reuse LDS for the epilogue patches
+
+    if (p.sk_phase == 1) {
+        // split-K, first launch: park this slice's accumulators (lane-major: a wave writes 256 contiguous bytes per register); the second
+        // launch adds the slices up in slice order and runs the epilogue (the kernel boundary orders the two across XCDs)
+        constexpr int NACC = TM * TN * 16;
+        float *mine = p.sk_ws + ((int64_t)(kslice * ntile + swz) * NACC) * NT + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(int64_t)((i * TN + j) * 16 + r) * NT] = acc[i][j][r];
+        return;
+    }
 
     if constexpr (EPI == EPI_RESID) resid_io<TM, TN, true>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
     else run_epilogue<EPI, TM, TN, MX>(p, acc, smem, wave, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, n0);
@@ -1982,6 +2018,16 @@ int launch_t(hipStream_t stream, const GemmArgs &a) {
         attr_set = true;
     }
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
+    // split-K launches (gemm.h splitk; launch_gemm sets it for the 128 x 128 tile only) carry `splitk` workgroups per tile
+    if (BM == 128 && BN == 128 && NS == 2 && a.splitk > 1) {
+        GemmArgs b = a;
+        b.sk_phase = 1;
+        hipLaunchKernelGGL(kern, dim3(tilesM * tilesN * a.splitk), dim3(NT), SMEM, stream, b);
+        b.sk_phase = 2;
+        hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(NT), SMEM, stream, b);
+        PB_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(NT), SMEM, stream, a);
     PB_HIP(hipGetLastError());
     return 0;

@@ -120,6 +120,7 @@ void shift_regions(int h8, int w8, std::vector<int8_t> &reg) {
 int GmflowEngine::prepare_g(int F, int H, int W, float scale, int dirs) {
     if (F <= gF_ && H == gH_ && W == gW_ && scale == gS_ && dirs <= gD_) return 0;
     PB_HIP(hipStreamSynchronize(stream));
+    gF_ = 0; gH_ = 0; gW_ = 0; gD_ = 0;       // (a failure below must not leave the old plan's key on a half-written geometry: raft_engine.hip prepare)
     geometry(H, W, scale, 16);
     if (isz_h_ > 0) {                 // --inference_size: the network's size is given, nothing is padded (sh_, sw_ stay the output size)
         padl_ = padt_ = 0;

@@ -1,5 +1,6 @@
 // mask_mmdet band engine (SOLOv2: ResNet + FPN + SOLOV2Head + Matrix NMS + the band's mask accumulation).
 #pragma once
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -30,6 +31,12 @@ class MaskEngine : public EngineBase {
         int candidates = 0;              // grid cells over score_thr (before the area filter)
     };
     const std::vector<Instances> &results() const { return results_; }
+    // hooks of ONE infer() call (the host-pointer pipeline of pb_mask_infer_batch, abi.hip): chunk_begin(first, m) is called before the first
+    // launch of the chunk of frames [first, first + m) - it makes the ctx stream wait for that chunk's H2D copy - and chunk_end(first, m) after
+    // the chunk's last launch has been enqueued (its id images then go back to the host while the next chunk runs).  Cleared by infer().
+    std::function<int(int, int)> chunk_begin, chunk_end;
+    int frames_per_chunk() const { return cfg_.max_batch > 0 ? cfg_.max_batch : 1; }
+    bool sdf_on() const { return sdf_ncap_ > 0; }
 
   private:
     struct GN { float *g = nullptr, *b = nullptr; int C = 0; };

@@ -190,6 +190,7 @@ int MaskEngine::prepare(int n, int H, int W) {
     const int B = std::min(n, cfg_.max_batch);
     if (B <= pB_ && H == pH_ && W == pW_) return 0;
     PB_HIP(hipStreamSynchronize(stream));
+    pB_ = 0; pH_ = 0; pW_ = 0;          // (a failure below must not leave the old plan's key on a half-written plan: raft_engine.hip prepare)
     {   // the post-processing scratch is sized by the mask-feature resolution: drop it when the geometry changes
         void **post[] = {(void **)&pk_, (void **)&bits_, (void **)&plog_, (void **)&pstat_, (void **)&inter_, (void **)&sig_,
                          (void **)&nmsf_, (void **)&pidx_, (void **)&nmsi_, (void **)&use_};
@@ -687,11 +688,18 @@ int MaskEngine::infer(const uint8_t *frames, int n, int H, int W, float confiden
     open_.clear();
     stages_.clear();
     results_.assign(n, Instances());
+    auto cb = std::move(chunk_begin), ce = std::move(chunk_end);       // hooks are per call
+    chunk_begin = nullptr; chunk_end = nullptr;
     for (int s = 0; s < n; s += pB_) {
         const int m = std::min(pB_, n - s);
+        if (cb && (r = cb(s, m))) return r;
         if ((r = run_chunk(frames + (int64_t)s * H * W * 3, m, s, confidence, keep_class, mask_out))) return r;
+        // the signed distance field is per frame (mask_kernels.hip sdf_*_kernel work on one frame's id image each), so with chunk hooks it is
+        // applied chunk by chunk and a finished chunk can leave for the host while the next one runs
+        if (ce && sdf_ncap_ > 0 && (r = sdf_green(mask_out + (int64_t)s * H * W * 3, m, H, W))) return r;
+        if (ce && (r = ce(s, m))) return r;
     }
-    if (sdf_ncap_ > 0) return sdf_green(mask_out, n, H, W);
+    if (!ce && sdf_ncap_ > 0) return sdf_green(mask_out, n, H, W);
     return 0;
 }
 

@@ -236,6 +236,10 @@ int RaftEngine::load(const pb_tensor *w, int n) {
 int RaftEngine::prepare(int F, int H, int W, float scale, int dirs) {
     if (F <= pF_ && H == pH_ && W == pW_ && scale == pS_ && dirs <= pD_) return 0;
     PB_HIP(hipStreamSynchronize(stream));
+    // from here on the plan's members are being rewritten: a failure below (a frame too small, an allocation) must not leave the OLD plan's key
+    // behind, or the next call with the old size would skip this function and run on the half-written geometry (round 6: found by
+    // tests/test_gpu_raft.py::test_pipeline_error_exit_leaves_no_copy_in_flight - wrong flows after a refused 40 x 40 call)
+    pF_ = 0; pH_ = 0; pW_ = 0; pD_ = 0;
     geometry(H, W, scale, 8);
     PB_CHECK(h8_ >= 16 && w8_ >= 16, PB_ERR_ARG, "flow_raft: %dx%d is too small (the 4-level pyramid needs >= 128 px)", sh_, sw_);
     P8_ = (P_ + 7) / 8 * 8;       // row stride of the level-0 volume (the GEMM epilogue writes 8-column groups)

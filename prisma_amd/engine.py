@@ -367,17 +367,22 @@ class FlowRaft(_Ctx):
         return flow, rgb, mx
 
     def infer_sequence_masks(self, frames: np.ndarray, scale: float = 0.75, iters: int = 12, alpha_1: float = 0.05,
-                             alpha_2: float = 0.5, want_flow: bool = True, want_rgb: bool = True):
+                             alpha_2: float = 0.5, want_flow: bool = True, want_rgb: bool = True, out_flow: Optional[np.ndarray] = None,
+                             out_rgb: Optional[np.ndarray] = None, out_mask: Optional[np.ndarray] = None):
         """Both directions plus the forward/backward consistency masks (bands/flow_raft.py:58-64):
-        -> (flow | None, rgb | None, maxdisp [F-1,2], mask bool [F-1,2,sh,sw])."""
+        -> (flow | None, rgb | None, maxdisp [F-1,2], mask bool [F-1,2,sh,sw]).  The same chunked three-stage pipeline as infer_sequence;
+        out_flow / out_rgb / out_mask (uint8): caller-owned result arrays, page-locked ones are written by the copy engines directly."""
         frames = np.ascontiguousarray(frames, np.uint8)
         F, H, W, ch = frames.shape
         assert ch == 3 and F >= 2
         sh, sw = flow_out_size(H, W, scale)
-        flow = np.empty((F - 1, 2, sh, sw, 2), np.float32) if want_flow else None
-        rgb = np.empty((F - 1, 2, sh, sw, 3), np.uint8) if want_rgb else None
+        flow = (out_flow if out_flow is not None else np.empty((F - 1, 2, sh, sw, 2), np.float32)) if want_flow else None
+        rgb = (out_rgb if out_rgb is not None else np.empty((F - 1, 2, sh, sw, 3), np.uint8)) if want_rgb else None
         mx = np.empty((F - 1, 2), np.float32)
-        mask = np.empty((F - 1, 2, sh, sw), np.uint8)
+        mask = out_mask if out_mask is not None else np.empty((F - 1, 2, sh, sw), np.uint8)
+        assert flow is None or (flow.dtype == np.float32 and flow.shape == (F - 1, 2, sh, sw, 2) and flow.flags.c_contiguous)
+        assert rgb is None or (rgb.dtype == np.uint8 and rgb.shape == (F - 1, 2, sh, sw, 3) and rgb.flags.c_contiguous)
+        assert mask.dtype == np.uint8 and mask.shape == (F - 1, 2, sh, sw) and mask.flags.c_contiguous
         check(self.lib.pb_flow_infer_sequence_masks(self.ctx, _ptr(frames), F, H, W, C.c_float(scale), iters,
                                                     C.c_float(alpha_1), C.c_float(alpha_2), _ptr(flow), _ptr(rgb), _ptr(mx),
                                                     _ptr(mask)))
@@ -481,12 +486,16 @@ class MaskMMDet(_Ctx):
         check(self.lib.pb_create(C.byref(self.ctx), device, b"mask_mmdet", arr, len(keep), C.byref(c), C.sizeof(c)))
         self._hw = None
 
-    def infer_batch(self, frames: np.ndarray, confidence: float = 0.5, keep_classes=None) -> np.ndarray:
-        """frames uint8 [n,H,W,3] RGB -> uint8 [n,H,W,3] accumulated masks of the kept classes."""
+    def infer_batch(self, frames: np.ndarray, confidence: float = 0.5, keep_classes=None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """frames uint8 [n,H,W,3] RGB -> uint8 [n,H,W,3] accumulated masks of the kept classes.  Calls of more than max_batch frames are
+        pipelined (chunk i's id images return while chunk i + 1 runs); `out`: a caller-owned result array (a page-locked one is written by
+        the copy engine directly)."""
         frames = np.ascontiguousarray(frames, np.uint8)
         n, H, W, ch = frames.shape
         assert ch == 3
-        out = np.empty_like(frames)
+        if out is None:
+            out = np.empty_like(frames)
+        assert out.dtype == np.uint8 and out.shape == frames.shape and out.flags.c_contiguous
         ids = None if keep_classes is None else np.ascontiguousarray(keep_classes, np.int32)
         check(self.lib.pb_mask_infer_batch(self.ctx, _ptr(frames), n, H, W, C.c_float(confidence), _ptr(ids),
                                            0 if ids is None else len(ids), _ptr(out)))

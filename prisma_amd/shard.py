@@ -152,13 +152,14 @@ class Relay:
         """rank 0's drain failed: it left an `abort` file so that producers blocked in put() / close() fail with its message
         instead of waiting out the relay timeout while rank 0 sits in the gather."""
         import os
-        p = os.path.join(self.dir, "abort")
-        if os.path.exists(p):
-            try:
-                msg = open(p).read().strip()
-            except OSError:
-                msg = "?"
-            raise RuntimeError(f"rank 0 aborted the relay: {msg}")
+        for d in dict.fromkeys((self.dir, self.dir2)):
+            p = os.path.join(d, "abort")
+            if os.path.exists(p):
+                try:
+                    msg = open(p).read().strip()
+                except OSError:
+                    msg = "?"
+                raise RuntimeError(f"rank 0 aborted the relay: {msg}")
 
     def put(self, start: int, arrays: dict):
         """rank > 0: publish the chunk whose first unit (frame / pair index) is `start`."""
@@ -225,14 +226,23 @@ class Relay:
             self._thread.start()
 
     def _abort(self, err):
+        """leave an `abort` file for the producers - in the spool and, when that one refuses (a full tmpfs), in the fallback directory"""
         import os
-        try:
-            tmp = os.path.join(self.dir, "abort.tmp")
-            with open(tmp, "w") as f:
-                f.write("%s: %s\n" % (type(err).__name__, err))
-            os.replace(tmp, os.path.join(self.dir, "abort"))
-        except OSError:
-            pass
+        import sys
+        wrote = False
+        for d in dict.fromkeys((self.dir, self.dir2)):
+            try:
+                os.makedirs(d, exist_ok=True)
+                tmp = os.path.join(d, "abort.tmp")
+                with open(tmp, "w") as f:
+                    f.write("%s: %s\n" % (type(err).__name__, err))
+                os.replace(tmp, os.path.join(d, "abort"))
+                wrote = True
+                break                           # the fallback directory is only used (and created) when the spool itself refuses the file
+            except OSError:
+                continue
+        if not wrote:
+            print(f"[prisma] rank 0: could not publish the relay's abort file ({type(err).__name__}: {err})", file=sys.stderr)
 
     def drain_end(self):
         """rank 0, AFTER the scalar gather: finishes (bounded) or runs (unbounded) the drain."""
@@ -243,7 +253,12 @@ class Relay:
                 err, self._thread_err = self._thread_err, None
                 raise err
         elif self._pending is not None:
-            self.drain(*self._pending)
+            pending, self._pending = self._pending, None
+            try:
+                self.drain(*pending)
+            except BaseException as e:      # noqa: BLE001 - the producers poll `done` for hours otherwise: tell them, then re-raise
+                self._abort(e)
+                raise
         self._pending = None
 
     def close(self):
@@ -278,11 +293,22 @@ def _write_owner(d: str, pid: int):
     """owner.<pid> holding `<host> <pid>`: who may be asked whether this spool is still in use (_sweep_stale_spools)."""
     import os
     import socket
+    import uuid
     p = os.path.join(d, "owner.%d" % pid)
-    if not os.path.exists(p):
-        with open(p + ".tmp", "w") as f:
+    if os.path.exists(p):
+        return
+    # several ranks may get here at once (a full tmpfs sends every producer to the fallback directory in the same moment): each writes through
+    # its OWN temporary name, and a failure is not fatal - a directory without an owner file is "unknown, keep for a day" to the sweep (ADVICE r5)
+    tmp = "%s.%d.%s.tmp" % (p, os.getpid(), uuid.uuid4().hex[:8])
+    try:
+        with open(tmp, "w") as f:
             f.write("%s %d\n" % (socket.gethostname(), pid))
-        os.replace(p + ".tmp", p)
+        os.replace(tmp, p)
+    except OSError:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
 
 
 def _pick_spool_base(out_dir: str, est_bytes: int) -> str:

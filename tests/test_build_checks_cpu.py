@@ -40,6 +40,11 @@ def test_accumulator_shuffle_in_a_k_loop_is_reported(tmp_path):
     # a persistent tile loop: K loop inside, a long epilogue that reads every accumulator once - not a shuffle
     tile_loop = [".LBB0_1:", ".LBB0_2:"] + [MFMA] * 24 + ["s_cbranch_scc1 .LBB0_2"] + ["v_accvgpr_read_b32 v%d, a%d" % (i % 200, i % 64) for i in range(64)] \
         + ["v_add_f32 v1, v1, v2"] * 1000 + ["s_cbranch_scc1 .LBB0_1", "s_endpgm"]
+    # not a loop: a block laid out behind s_endpgm that jumps back to a label in front of the (clean) K loop; the span holds the split-K store
+    # path's accumulator reads, but nothing in it repeats
+    outlined = [".LBB0_1:", ".LBB0_2:"] + [MFMA] * 16 + ["s_cbranch_scc1 .LBB0_2"] + ["v_accvgpr_read_b32 v%d, a%d" % (i, i) for i in range(64)] \
+        + ["global_store_dword v[0:1], v2, off", "s_endpgm", ".LBB0_3:", "s_mov_b32 s0, 0", "s_branch .LBB0_1"]
+    assert t.acc_shuffles(_listing(tmp_path, "outlined", outlined)) == []
     got = t.acc_shuffles(_listing(tmp_path, "shuffled", shuffled))
     assert len(got) == 1 and got[0][1:] == (24, 128)
     assert t.acc_shuffles(_listing(tmp_path, "clean", clean)) == []

@@ -288,3 +288,33 @@ def test_infer_batch_writes_the_sdf_when_asked(tiny):
     for f in range(2):
         assert np.array_equal(withsdf[f], SO.band_sdf(plain[f]))
     assert np.array_equal(net.infer_batch(frames, 0.5, KEEP), plain)          # off again
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_pipeline_equals_device_path(tiny, pinned):
+    """pb_mask_infer_batch is a pipeline over the engine's chunks of max_batch frames (every chunk's H2D up front, chunk i's id images -
+    with the --sdf channel - back on a second copy stream while chunk i + 1 runs; reference loop bands/mask_mmdet.py:131-154): the bytes of
+    the device-pointer entry point on the same frames, from pageable arrays (pinned staging on the ctx) and page-locked ones (used directly)."""
+    import torch
+    cfg, w, net = tiny                                        # max_batch 2: five frames = chunks of 2, 2, 1
+    frames = synth.frames(5, 180, 300, seed=31)
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.zeros_like(d_in)
+    for sdf in (False, True):
+        net.set_sdf(sdf)
+        try:
+            net.infer_batch_dev(d_in.data_ptr(), 5, 180, 300, 0.5, KEEP, d_out.data_ptr())
+            net.sync()
+            ref = d_out.cpu().numpy()
+            assert ref.any()
+            if pinned:
+                hf = torch.from_numpy(frames).pin_memory()
+                ho = torch.zeros(frames.shape, dtype=torch.uint8).pin_memory()
+                out = net.infer_batch(hf.numpy(), 0.5, KEEP, out=ho.numpy())
+                assert out.ctypes.data == ho.data_ptr()
+            else:
+                out = net.infer_batch(frames, 0.5, KEEP)
+            assert np.array_equal(out, ref), (sdf, pinned)
+            assert len(net.instances(4)[0]) == len(net.instances(4)[1])          # per-frame results cover the whole call
+        finally:
+            net.set_sdf(False)

@@ -35,9 +35,6 @@ def ops():
     (256, 256, 64, 0, 2), (2448, 3072, 1024, 0, 2), (777, 512, 4096, 2, 2), (513, 64, 128, 0, 1),
     (300, 256, 128, 0, 2), (1000, 512, 192, 1, 2), (515, 768, 576, 0, 2), (4096, 1024, 640, 0, 2),
     (2448, 1024, 1024, 0, 4), (640, 256, 320, 2, 4),
-    # 256 x 128 ping-pong tile (gemm_n128.h): one K tile, ragged M / N, K tiles around the three-buffer ring's period, every activation
-    (256, 128, 64, 0, 11), (300, 128, 128, 1, 11), (1000, 96, 192, 0, 11), (2448, 128, 1024, 2, 11), (777, 384, 448, 0, 11),
-    (4096, 72, 2304, 1, 11), (515, 256, 320, 0, 11),
 ])
 def test_gemm(ops, M, N, K, act, tile):
     g = np.random.default_rng(M + N + K)
@@ -110,7 +107,45 @@ def test_conv2d(ops, B, Ci, H, W, Co, ks, stride, relu_in, relu_out):
     assert relmax(out, ref.numpy()) < 1.5e-3, relmax(out, ref.numpy())
 
 
-@pytest.mark.parametrize("tile", [2, 4, 11])
+def test_split_k_equals_one_pass(ops):
+    """Split-K on the 128 x 128 tile (gemm.h splitk: launches with fewer tiles than CUs park their K slices' accumulators and a second launch adds
+    them in slice order + runs the epilogue): same answer as the one-pass launch to fp32 summation-order accuracy, against float64, run to run
+    identical, for dense GEMMs (K tiles that do not divide by the factor) and an implicit-GEMM convolution with ragged M / N edges."""
+    g = np.random.default_rng(77)
+    for (M, N, K, act) in [(2448, 1024, 4096, 0), (300, 256, 1088, 1), (515, 384, 2304, 2), (2448, 1024, 1024, 0)]:
+        A, W, b = h(g.standard_normal((M, K))), h(g.standard_normal((N, K)) / np.sqrt(K)), g.standard_normal(N).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T + b
+        if act == 1:
+            ref = np.maximum(ref, 0)
+        elif act == 2:
+            ref = F.gelu(torch.from_numpy(ref)).numpy()
+        one = ops.gemm(A, W, b, act=act, tile=1)
+        ops.set_option("op_splitk", 1)
+        try:
+            two, again = ops.gemm(A, W, b, act=act, tile=1), ops.gemm(A, W, b, act=act, tile=1)
+        finally:
+            ops.set_option("op_splitk", 0)
+        assert np.array_equal(two, again)
+        assert relmax(two, ref) < 1.5e-3 and relmax(two, one) < 1e-3, (M, N, K, relmax(two, ref), relmax(two, one))
+    ops.set_option("conv_tile", 1)
+    try:
+        for (B, Ci, H, W, Co, stride) in [(1, 1024, 19, 33, 256, 1), (1, 512, 37, 66, 1024, 2), (1, 256, 21, 30, 72, 1)]:
+            x = h(g.standard_normal((B, Ci, H, W)))
+            w = h(g.standard_normal((Co, Ci, 3, 3)) / np.sqrt(Ci * 9))
+            b = g.standard_normal(Co).astype(np.float32)
+            ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=stride, padding=1).numpy()
+            one = ops.conv2d(x, w, b, stride=stride)
+            ops.set_option("op_splitk", 1)
+            try:
+                two = ops.conv2d(x, w, b, stride=stride)
+            finally:
+                ops.set_option("op_splitk", 0)
+            assert relmax(two, ref) < 1.5e-3 and relmax(two, one) < 1e-3, (Ci, relmax(two, ref), relmax(two, one))
+    finally:
+        ops.set_option("conv_tile", 0)
+
+
+@pytest.mark.parametrize("tile", [2, 4])
 def test_conv2d_wide_tiles(ops, tile):
     ops.set_option("conv_tile", tile)
     try:

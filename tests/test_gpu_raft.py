@@ -266,3 +266,59 @@ def test_host_pipeline_chunks_equal_one_call(net, pinned):
             assert np.array_equal(flow, flow1) and np.array_equal(rgb, rgb1) and np.array_equal(mx, mx1), (chunk, pinned)
     finally:
         net.set_option("host_chunk", 0)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_masks_host_pipeline_chunks_equal_one_call(net, pinned):
+    """pb_flow_infer_sequence_masks runs the same chunked three-stage pipeline as pb_flow_infer_sequence (rounds 1-5: malloc, copy, run, copy,
+    free per call; reference loop bands/flow_raft.py:63-64,103-113): flows, encodes, maximum displacements and the forward / backward
+    consistency masks of every chunk size equal those of one whole-sequence call and of the device-pointer entry point, bit for bit."""
+    import torch
+    fr = synth.frame_pair_sequence(7, 136, 168, seed=23)
+    net.set_option("host_chunk", 64)
+    flow1, rgb1, mx1, mask1 = net.infer_sequence_masks(fr, scale=1.0, iters=3)
+    assert mask1.any() and not mask1.all()
+    try:
+        for chunk in (2, 4):
+            net.set_option("host_chunk", chunk)
+            if pinned:
+                hf = torch.from_numpy(fr).pin_memory()
+                of = torch.empty(flow1.shape, dtype=torch.float32).pin_memory()
+                og = torch.empty(rgb1.shape, dtype=torch.uint8).pin_memory()
+                ok = torch.empty(mask1.shape, dtype=torch.uint8).pin_memory()
+                flow, rgb, mx, mask = net.infer_sequence_masks(hf.numpy(), scale=1.0, iters=3, out_flow=of.numpy(), out_rgb=og.numpy(), out_mask=ok.numpy())
+                assert flow.ctypes.data == of.data_ptr() and mask.ctypes.data == ok.data_ptr()
+            else:
+                flow, rgb, mx, mask = net.infer_sequence_masks(fr, scale=1.0, iters=3)
+            assert np.array_equal(flow, flow1) and np.array_equal(rgb, rgb1) and np.array_equal(mx, mx1) and np.array_equal(mask, mask1), (chunk, pinned)
+            _, _, mx2, mask2 = net.infer_sequence_masks(fr, scale=1.0, iters=3, want_flow=False, want_rgb=False)      # masks alone
+            assert np.array_equal(mask2, mask1) and np.array_equal(mx2, mx1)
+    finally:
+        net.set_option("host_chunk", 0)
+
+
+def test_pipeline_error_exit_leaves_no_copy_in_flight(net):
+    """with page-locked caller buffers the copy engines write CALLER memory asynchronously; an error in chunk i (here: a bad
+    iteration count, refused by the engine after chunk 0's frames are already on their way) must not return while chunk i - 1's D2H or chunk
+    i's H2D is still running.  After the failed call the caller's result buffer is scribbled and must stay as scribbled (a late DMA would
+    overwrite it), and the ctx must still produce the right bytes."""
+    import time
+    import torch
+    fr = synth.frame_pair_sequence(6, 136, 168, seed=29)
+    flow0, rgb0, mx0 = net.infer_sequence(fr, scale=1.0, iters=2)
+    hf = torch.from_numpy(fr).pin_memory()
+    of = torch.empty(flow0.shape, dtype=torch.float32).pin_memory()
+    og = torch.empty(rgb0.shape, dtype=torch.uint8).pin_memory()
+    net.set_option("host_chunk", 2)
+    try:
+        with pytest.raises(engine._lib.PrismaBandsError):
+            net.infer_sequence(hf.numpy(), scale=1.0, iters=0, out_flow=of.numpy(), out_rgb=og.numpy())
+        of.fill_(123.0); og.fill_(77)
+        time.sleep(0.2)
+        assert bool((of == 123.0).all()) and bool((og == 77).all())
+        with pytest.raises(engine._lib.PrismaBandsError):       # an undersized frame: refused by the engine's geometry check inside chunk 0
+            net.infer_sequence(np.zeros((3, 40, 40, 3), np.uint8), scale=1.0, iters=2)
+        flow, rgb, mx = net.infer_sequence(hf.numpy(), scale=1.0, iters=2, out_flow=of.numpy(), out_rgb=og.numpy())
+        assert np.array_equal(flow, flow0) and np.array_equal(rgb, rgb0) and np.array_equal(mx, mx0)
+    finally:
+        net.set_option("host_chunk", 0)

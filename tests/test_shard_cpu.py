@@ -308,3 +308,59 @@ def test_cached_weights_equal_generated_ones(tmp_path, monkeypatch):
     assert isinstance(again["fnet.conv1.weight"], np.memmap)
     small = synth.cached_weights("depth", synth.DEPTH_CFGS["vits"], 7)
     assert np.array_equal(np.asarray(synth.cached_weights("depth", synth.DEPTH_CFGS["vits"], 7)["pretrained.cls_token"]), small["pretrained.cls_token"])
+
+
+def test_owner_file_survives_concurrent_writers_and_a_dead_directory(tmp_path):
+    """put()'s ENOSPC fallback calls _write_owner from every rank > 0 at once; a shared temporary name made the second os.replace
+    raise inside put()'s except-handler.  Every writer now has its own temporary name and a failed write is not fatal."""
+    import threading
+    d = tmp_path / "fallback"
+    d.mkdir()
+    errs = []
+
+    def work():
+        try:
+            for _ in range(50):
+                shard._write_owner(str(d), 4242)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work) for _ in range(16)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert sorted(os.listdir(d)) == ["owner.4242"] and (d / "owner.4242").read_text().split()[1] == "4242"
+    shard._write_owner(str(tmp_path / "does" / "not" / "exist"), 1)          # no directory: swallowed (the sweep treats "no owner" as unknown)
+
+
+def test_inline_drain_failure_publishes_abort(tmp_path):
+    """in the default unbounded mode drain_end() runs the drain inline; when it raises, the producers polling `done` in close()
+    must find an `abort` file (in the spool, or in the fallback directory when the spool refuses it) instead of waiting out the timeout."""
+    class Rk:
+        world, rank, main = 2, 0, True
+    for spool_ok in (True, False):
+        relay = shard.Relay.__new__(shard.Relay)
+        relay.rk = Rk()
+        relay.timeout, relay.max_chunks = 5.0, 0
+        relay.dir = str(tmp_path / ("spool%d" % spool_ok)) if spool_ok else str(tmp_path / "file_in_the_way" / "spool")
+        relay.dir2 = str(tmp_path / ("fallback%d" % spool_ok))
+        if spool_ok:
+            os.makedirs(relay.dir)
+        else:
+            (tmp_path / "file_in_the_way").write_text("x")            # makedirs / open below it fail: the spool refuses the abort file
+        relay._mine, relay._thread, relay._thread_err = [], None, None
+
+        def bad_drain(*a):
+            raise IOError("mux failed")
+        relay.drain = bad_drain
+        relay.drain_begin(4, 2, lambda s, c: None)
+        with pytest.raises(IOError, match="mux failed"):
+            relay.drain_end()
+        where = relay.dir if spool_ok else relay.dir2
+        assert "mux failed" in open(os.path.join(where, "abort")).read()
+        assert os.path.isdir(relay.dir2) == (not spool_ok)
+        producer = shard.Relay.__new__(shard.Relay)
+        producer.dir, producer.dir2 = relay.dir, relay.dir2
+        with pytest.raises(RuntimeError, match="aborted the relay"):
+            producer._check_abort()

@@ -91,6 +91,9 @@ Fr, pairs = B, B - 1
 h2, w2, h4, w4, h8, w8 = Hp // 2, Wp // 2, Hp // 4, Wp // 4, Hp // 8, Wp // 8
 Pp = h8 * w8
 for enc in ("fnet", "cnet"):
+    Fall = Fr
+    # round 6: forward pairs only -> the context network skips the clip's last frame (it is no pair's source frame; raft_engine.hip infer)
+    Fr = Fall - 1 if enc == "cnet" else Fall
     add("flow", (CONV, PIXSHUF), f"{enc} stem 7x7 s2 (space-to-depth 3x3, N = 4 x 64)", Fr * h4 * w4, 256, 147)
     add("flow", (CONV, STD), f"{enc} layer1 3x3 64->64 @1/2", Fr * h2 * w2, 64, 9 * 64, 4)
     add("flow", (CONV, STD), f"{enc} layer2.0.conv1 3x3 s2 64->96", Fr * h4 * w4, 96, 9 * 64)
@@ -100,6 +103,7 @@ for enc in ("fnet", "cnet"):
     add("flow", (CONV, STD), f"{enc} layer3 3x3 128->128 @1/8", Fr * Pp, 128, 9 * 128, 3)
     add("flow", (CONV, STD), f"{enc} layer3 downsample 1x1 s2", Fr * Pp, 128, 96)
     add("flow", (DENSE, STD), f"{enc} conv2 1x1 128->256", Fr * Pp, 256, 128)
+    Fr = Fall
 def vol_stride(a, b):
     # raft_engine.hip prepare(): targets in 8 x 8 tiles; rounded up to a multiple of 256 when that costs under 2 % (ping-pong kernel)
     p = ((a + 7) // 8 * 8) * ((b + 7) // 8 * 8)
