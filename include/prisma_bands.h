@@ -137,6 +137,9 @@ int pb_depth_infer_batch(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W
 int pb_depth_infer_batch_dev(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W,
                              float *depth_out, uint8_t *rgb_out, float *min_out, float *max_out, int flip);
 int pb_sync(pb_ctx *ctx);
+/* Several bands at once: contexts share nothing, every *_dev entry point returns after the enqueue, so a caller enqueues on two or three
+ * contexts and then pb_sync()s each (prisma_amd.engine.run_concurrently; replaces the reference's strictly sequential band order,
+ * process.py:205-290, where the bands of one video are independent).  Results are those of running the bands one after the other. */
 
 /* Multi-GPU: one process and one pb_ctx per GPU; frames shard by rank and never cross GPUs.  The only
  * exchange is the all-gather of the per-frame scalars the CSV files need in frame order - depth (min, max), flow max
@@ -185,7 +188,9 @@ int pb_flow_infer_sequence_dev(pb_ctx *ctx, const uint8_t *frames, int F, int H,
  * BORDER_CONSTANT arithmetic, and mask = |f + f'| < alpha1 (|f| + |f'|) + alpha2 (reference defaults 0.05, 0.5).
  *   pb_flow_infer_sequence_masks*: both directions are always computed (dirs = 2); flow_out / rgb_out / maxdisp_out
  *     as above (any may be NULL), mask_out [F-1, 2, sh, sw] bytes of 0 / 1 (index 0 = forward mask, 1 = backward).
- *   pb_flow_fwdbwd_mask: the mask step alone on host flows [n, 2, sh, sw, 2]. */
+ *   pb_flow_fwdbwd_mask: the mask step alone on host flows [n, 2, sh, sw, 2].
+ * The host-pointer variant is the same chunked three-stage pipeline as pb_flow_infer_sequence (both directions of a pair are in one
+ * chunk; page-locked caller buffers are used directly); every host-pointer pipeline drains its streams before it returns, error or not. */
 int pb_flow_infer_sequence_masks(pb_ctx *ctx, const uint8_t *frames, int F, int H, int W, float scale, int iters,
                                  float alpha1, float alpha2, float *flow_out, uint8_t *rgb_out, float *maxdisp_out,
                                  uint8_t *mask_out);
@@ -223,7 +228,9 @@ int pb_flow_set_inference_size(pb_ctx *ctx, int h, int w);
  * pb_mask_get_instances: what format_results held for frame `frame` of the last call, score-descending: up to cap
  *   scores / labels; returns the count.  masks_out (optional, [count, H, W] bytes of 0 / 1) needs
  *   pb_set_profiling(ctx, 2) before the infer call.
- * pb_mask_net_size: resized (nh, nw) and padded (Hp, Wp) network input for an H x W frame. */
+ * pb_mask_net_size: resized (nh, nw) and padded (Hp, Wp) network input for an H x W frame.
+ * The host-pointer variant (reference loop bands/mask_mmdet.py:131-154) pipelines over the engine's chunks of max_batch frames: every
+ * chunk's frames go to the device up front on a copy stream, chunk i's id images return on a second one while chunk i + 1 runs. */
 int pb_mask_infer_batch(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W, float confidence,
                         const int32_t *keep_classes, int n_keep, uint8_t *mask_out);
 int pb_mask_infer_batch_dev(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W, float confidence,

@@ -320,8 +320,11 @@ int launch_attention(hipStream_t stream, const f16 *q, const f16 *k, const f16 *
     AttnArgs a{q, k, vt, o, ntp, ntok, heads, ldo, nq, B, o8_off, o8_scale};
     dim3 grid(8 * nq * ((B * heads + 7) / 8));
     // template arguments: NQB, minimum workgroups per CU the register allocation must allow, ablation, prefetch, NW
+    // the shipped library carries the two geometries the engines use; the experiment / ablation variants of tools/attn_bench.py (3-7, 11-16, 21, 23:
+    // wrong results for the ablations) are compiled with -DPB_DIAG only (make EXTRA=-DPB_DIAG BUILD=build_diag LIB=../libprisma_bands_diag.so)
     switch (variant) {
     case 2: hipLaunchKernelGGL((attnq_kernel<1, 4, 0, false, 4>), grid, dim3(256), 0, stream, a); break;
+#ifdef PB_DIAG
     case 3: hipLaunchKernelGGL((attnq_kernel<2, 2, 0, false, 4>), grid, dim3(256), 0, stream, a); break;
     case 4: hipLaunchKernelGGL((attnq_kernel<1, 3, 0, true, 4>), grid, dim3(256), 0, stream, a); break;
     case 5: hipLaunchKernelGGL((attnq_kernel<2, 1, 0, false, 8>), grid, dim3(512), 0, stream, a); break;
@@ -336,7 +339,9 @@ int launch_attention(hipStream_t stream, const f16 *q, const f16 *k, const f16 *
     case 14: hipLaunchKernelGGL((attnq_kernel<1, 4, 4, false, 4>), grid, dim3(256), 0, stream, a); break;
     case 15: hipLaunchKernelGGL((attnq_kernel<1, 4, 5, false, 4>), grid, dim3(256), 0, stream, a); break;
     case 16: hipLaunchKernelGGL((attnq_kernel<1, 4, 6, false, 4>), grid, dim3(256), 0, stream, a); break;
-    default: hipLaunchKernelGGL((attnq_kernel<1, 2, 0, false, 8>), grid, dim3(512), 0, stream, a); break;
+#endif
+    case 0: case 1: hipLaunchKernelGGL((attnq_kernel<1, 2, 0, false, 8>), grid, dim3(512), 0, stream, a); break;
+    default: PB_CHECK(false, -1, "attention: variant %d is an experiment of the -DPB_DIAG build", variant);
     }
     PB_HIP(hipGetLastError());
     return 0;

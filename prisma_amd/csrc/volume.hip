@@ -223,15 +223,17 @@ int launch_corr_volume(hipStream_t s, const f16 *A, int M, const f16 *W, int N, 
     PB_CHECK(A && W && out && M > 0 && N > 0 && N % 8 == 0 && ldo >= N && w_rows >= N && ldo < (1 << 24), PB_ERR_ARG, "corr_volume: bad arguments");
     static bool once = false;
     const int smem = VSTAGES * VSTAGE_BYTES;
-    static int abl = 0;                                         // PB_VOL_ABL (diagnostic, wrong results): 1 no stores, 2 no fragment reads / MFMAs, 4 no DMA
+    static int abl = 0;                                         // PB_VOL_ABL (-DPB_DIAG builds only; wrong results): 1 no stores, 2 no fragment reads / MFMAs, 4 no DMA
     if (!once) {
-        abl = pb_env_int("PB_VOL_ABL", 0);
         PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+#ifdef PB_DIAG
+        abl = pb_env_int("PB_VOL_ABL", 0);
         PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         PB_HIP(hipFuncSetAttribute((const void *)corr_volume_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+#endif
         once = true;
     }
     const int tilesM = (M + VBM - 1) / VBM, tilesN = (N + VBN - 1) / VBN;
@@ -242,11 +244,13 @@ int launch_corr_volume(hipStream_t s, const f16 *A, int M, const f16 *W, int N, 
     groups = (tilesN + tpw - 1) / tpw;
 #define PB_VOL_LAUNCH(X) hipLaunchKernelGGL(corr_volume_kernel<X>, dim3(tilesM * groups), dim3(VNT), smem, s, A, M, W, N, w_rows, out, ldo, tpw)
     switch (abl) {
+#ifdef PB_DIAG
         case 1: PB_VOL_LAUNCH(1); break;
         case 2: PB_VOL_LAUNCH(2); break;
         case 4: PB_VOL_LAUNCH(4); break;
         case 5: PB_VOL_LAUNCH(5); break;
         case 6: PB_VOL_LAUNCH(6); break;
+#endif
         default: PB_VOL_LAUNCH(0);
     }
 #undef PB_VOL_LAUNCH

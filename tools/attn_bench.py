@@ -1,5 +1,6 @@
 """Attention kernel microbenchmark (ViT-L shape of the bench: B=32, 16 heads, 2443 tokens).
-python tools/attn_bench.py [variant ...]      (variants: see launch_attention in attention.hip)"""
+python tools/attn_bench.py [variant ...]      (variants: see launch_attention in attention.hip; everything but 0 and 2 needs a -DPB_DIAG build of the library:
+cd prisma_amd/csrc && make EXTRA=-DPB_DIAG BUILD=build_diag LIB=../libprisma_bands_diag.so; PRISMA_BANDS_LIB=prisma_amd/libprisma_bands_diag.so python tools/attn_bench.py 0 6 7)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from prisma_amd import engine
