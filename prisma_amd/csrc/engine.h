@@ -26,6 +26,16 @@ static inline hipError_t pb_create_stream(hipStream_t *s, const char *mask_env) 
         }
         if (n > 0) return hipExtStreamCreateWithCUMask(s, (uint32_t)n, words);
     }
+    // <mask_env>_PRIO = -1 / 1: a higher- / lower-priority queue (hipStreamCreateWithPriority; 0 or unset = default).  Experiment switch: with two
+    // bands at once the band with the large persistent GEMMs gets more than half of the chip (tools/overlap_bench.py 2way-fprio / 2way-dprio)
+    if (mask_env) {
+        const std::string pe = std::string(mask_env) + "_PRIO";
+        const char *p = getenv(pe.c_str());
+        if (p && *p && atoi(p) != 0) {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) return hipStreamCreateWithPriority(s, hipStreamNonBlocking, atoi(p) < 0 ? hi : lo);
+        }
+    }
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 

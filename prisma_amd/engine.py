@@ -43,8 +43,18 @@ def run_concurrently(jobs):
     strictly sequential band order (process.py:205-290) where the bands of one video are independent."""
     import time
     t0 = time.perf_counter()
-    for _, enqueue in jobs:
-        enqueue()
+    started = []
+    try:
+        for ctx, enqueue in jobs:
+            started.append(ctx)
+            enqueue()
+    except BaseException:
+        for ctx in started:                 # an enqueue failed: nothing may stay in flight on the contexts that did start
+            try:
+                ctx.sync()
+            except Exception:               # noqa: BLE001 - the first error is the one to report
+                pass
+        raise
     done = []
     for ctx, _ in jobs:
         ctx.sync()

@@ -11,6 +11,7 @@ enqueue layouts - every layout runs exactly the work of one bench step and produ
   flow1 / flow2, depth1 / depth2   one band alone: whole clip on one context / two half clips on two contexts
   2way-xcd   2way with the depth stream on XCDs 0-3 and the flow stream on XCDs 4-7 (PB_CU_MASK_DEPTH / PB_CU_MASK_FLOW, engine.h pb_create_stream)
   2way-cu    2way with every XCD's CUs dealt alternately to the two streams
+  2way-fprio / 2way-dprio / 2way-flow-low   2way with the flow / depth stream on a high-priority queue, the flow stream on a low-priority one
 
 python tools/overlap_bench.py [--steps 6] [--layouts seq,2way,...]"""
 import argparse
@@ -54,8 +55,14 @@ def main():
         threaded = layout.endswith("-thr")
         nd = {"4way": 2, "depth2": 2, "flow1": 0, "flow2": 0}.get(base, 1)
         nf = {"3way": 2, "4way": 2, "flow2": 2, "depth1": 0, "depth2": 0}.get(base, 1)
-        for k in ("PB_CU_MASK_DEPTH", "PB_CU_MASK_FLOW"):
+        for k in ("PB_CU_MASK_DEPTH", "PB_CU_MASK_FLOW", "PB_CU_MASK_DEPTH_PRIO", "PB_CU_MASK_FLOW_PRIO"):
             os.environ.pop(k, None)
+        if base == "2way-fprio":
+            os.environ["PB_CU_MASK_FLOW_PRIO"] = "-1"
+        if base == "2way-dprio":
+            os.environ["PB_CU_MASK_DEPTH_PRIO"] = "-1"
+        if base == "2way-flow-low":
+            os.environ["PB_CU_MASK_FLOW_PRIO"] = "1"
         if base == "2way-xcd":
             os.environ["PB_CU_MASK_DEPTH"] = ",".join(["0f0f0f0f"] * 8); os.environ["PB_CU_MASK_FLOW"] = ",".join(["f0f0f0f0"] * 8)
         if base == "2way-cu":
@@ -78,6 +85,8 @@ def main():
                 net.infer_sequence_dev(d_frames.data_ptr() + a * fbytes, b - a + 1, H, W, 0.75, 12, False, 0, f_rgb[a:].data_ptr(), scal[2, a:].data_ptr())
             jobs.append((net, job))
 
+        done_ms = [0.0] * len(jobs)
+
         def step():
             if base == "seq":
                 for net, job in jobs:
@@ -92,13 +101,17 @@ def main():
                 for t in ths:
                     t.join()
             else:
+                t_ = time.perf_counter()
                 for net, job in jobs:
                     job()
-                for net, job in jobs:
+                for i, (net, job) in enumerate(jobs):
                     net.sync()
+                    done_ms[i] += (time.perf_counter() - t_) * 1e3
 
         step(); step()
         torch.cuda.synchronize()
+        for i in range(len(done_ms)):
+            done_ms[i] = 0.0
         with PowerSampler() as ps:
             t0 = time.perf_counter()
             for _ in range(args.steps):
@@ -115,7 +128,8 @@ def main():
             same = all(np.array_equal(x, y) for x, y, on in zip(ref, out, (nd, nf, 0)) if on) and (not nd or np.array_equal(ref[2][:2], out[2][:2])) \
                 and (not nf or np.array_equal(ref[2][2], out[2][2]))
         results[layout] = {"ms_per_step": round(dt * 1e3, 2), "fps": round(B / dt, 2), "bytes_equal_to_first": same, **pw,
-                           "joules_per_frame": round(pw["avg_power_w"] * dt / B, 2) if pw["avg_power_w"] else None}
+                           "joules_per_frame": round(pw["avg_power_w"] * dt / B, 2) if pw["avg_power_w"] else None,
+                           "ctx_done_ms": [round(x / args.steps, 1) for x in done_ms] if any(done_ms) else None}
         print(layout, results[layout], flush=True)
         for n in dns + fns:
             n.close()
