@@ -290,7 +290,7 @@ def pipeline_leg(args, R):
     steps = max(1, args.steps // 2)
     dt = timed(step, steps)
     # PCIe-inclusive figure of configs[4] (one-GPU runs): the same clip through the three HOST-pointer entry points - page-locked frames in,
-    # page-locked results out, the library's default chunking (depth 2 x 16 frames, flow 16 pairs + a halo frame, mask chunks of max_batch
+    # page-locked results out, the library's default chunking (depth max_batch frames, flow 32 pairs + a halo frame, mask chunks of max_batch
     # frames), one host thread per band since the calls block until their results are in host memory - compared byte for byte with the
     # HBM-resident leg's results
     host_fps = None
@@ -551,46 +551,53 @@ def main():
                         net_.sync()
                     res[key] = (time.perf_counter() - t1) / 10 * 1e3
                 d1.close()
-            # PCIe-inclusive rate (never `value`; SURVEY 8(d) config 4: frames "resident in pinned host memory"): the SAME clip through the
-            # host-pointer entry points of both bands - pb_depth_infer_batch and pb_flow_infer_sequence (abi.hip: H2D of chunk i + 1, the band
-            # on chunk i and D2H of chunk i - 1 on three streams) - from page-locked frames into page-locked result arrays, with the product's
-            # DEFAULT chunking (depth: max_batch frames, flow: 16 pairs + a halo frame) and, like the timed region, both bands at once: the
-            # host-pointer calls block until their results are in host memory, so each band runs on its own host thread.  --sequential-only
-            # runs them one after the other.  Steady state over args.host_clips clips after one untimed clip; results are compared byte for
-            # byte with the HBM-resident leg's.
+            # PCIe-inclusive rate (never `value`; SURVEY 8(d) config 4: frames "resident in pinned host memory"): the SAME clip through the host-pointer
+            # entry points of both bands (abi.hip: H2D, the band and D2H of a chunk on three streams) from page-locked frames into page-locked result
+            # arrays, with the library's default chunking (a 32-frame clip is one chunk per band).
             if args.host_clips > 0 and world == 1:       # (one-GPU runs: with several ranks the host's PCIe / memory paths are shared and only rank 0 would be measuring)
+                # Streamed clips (round 6): the asynchronous host-pointer entry points (pb_depth_submit_batch / pb_flow_submit_sequence / pb_wait) keep two
+                # clips in flight per band - clip k + 1's uploads run under clip k's kernels, clip k's downloads under clip k + 1's - which is how a caller
+                # that decodes a video feeds the engine; both bands are submitted from this one thread.  --sequential-only uses the blocking calls, one
+                # band after the other.  Results are compared byte for byte with the HBM-resident leg's.
+                pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()      # noqa: E731
                 hf = torch.from_numpy(frames).pin_memory()
-                h_rgb = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
-                h_frgb = torch.empty((B - 1, 1, sh, sw, 3), dtype=torch.uint8).pin_memory()
-                h_scal = [None, None]
+                sets = [dict(rgb=pin((B, H, W, 3), torch.uint8), mn=pin((B,), torch.float32), mx=pin((B,), torch.float32),
+                             frgb=pin((B - 1, 1, sh, sw, 3), torch.uint8), fmx=pin((B - 1, 1), torch.float32)) for _ in range(2)]
 
-                def d_band():
-                    h_scal[0] = dn.infer_batch(hf.numpy(), want_depth=False, want_rgb=True, flip=True, out_rgb=h_rgb.numpy())[2:]
+                def submit(k):
+                    s = sets[k % 2]
+                    dn.submit_batch(hf.numpy(), out_rgb=s["rgb"].numpy(), out_min=s["mn"].numpy(), out_max=s["mx"].numpy(), flip=True)
+                    fn.submit_sequence(hf.numpy(), scale=args.flow_scale, iters=args.flow_iters, backward=False, out_rgb=s["frgb"].numpy(), out_max=s["fmx"].numpy())
 
-                def f_band():
-                    h_scal[1] = fn.infer_sequence(hf.numpy(), scale=args.flow_scale, iters=args.flow_iters, backward=False, want_flow=False,
-                                                  want_rgb=True, out_rgb=h_frgb.numpy())[2]
+                def blocking(k):
+                    s = sets[k % 2]
+                    dn.infer_batch(hf.numpy(), want_depth=False, want_rgb=True, flip=True, out_rgb=s["rgb"].numpy())
+                    fn.infer_sequence(hf.numpy(), scale=args.flow_scale, iters=args.flow_iters, backward=False, want_flow=False, want_rgb=True, out_rgb=s["frgb"].numpy())
 
-                def clip():
-                    if args.sequential_only:
-                        d_band()
-                        f_band()
-                    else:
-                        import threading
-                        tf = threading.Thread(target=f_band)
-                        tf.start()
-                        d_band()
-                        tf.join()
+                def same(k):
+                    s = sets[k % 2]
+                    return bool((s["rgb"] == d_rgb.cpu()).all().item()) and bool((s["frgb"][:, 0] == f_rgb.cpu()).all().item())
 
-                clip()
-                same = bool((h_rgb == d_rgb.cpu()).all().item()) and bool((h_frgb[:, 0] == f_rgb.cpu()).all().item())
-                assert same, "host-pointer results differ from the HBM-resident leg's"
-                t1 = time.perf_counter()
-                for _ in range(args.host_clips):
-                    clip()
-                res["host_fps"] = world * B * args.host_clips / (time.perf_counter() - t1)
-                assert np.isfinite(h_scal[0][0]).all() and (np.asarray(h_scal[1]) > 0).all()
-                del hf, h_rgb, h_frgb
+                if args.sequential_only:
+                    blocking(0)
+                    assert same(0), "host-pointer results differ from the HBM-resident leg's"
+                    t1 = time.perf_counter()
+                    for k in range(args.host_clips):
+                        blocking(k)
+                    res["host_fps"] = world * B * args.host_clips / (time.perf_counter() - t1)
+                else:
+                    submit(0); dn.wait(); fn.wait()
+                    assert same(0), "host-pointer results differ from the HBM-resident leg's"
+                    n_clips = max(args.host_clips, 2)
+                    t1 = time.perf_counter()
+                    submit(0)
+                    for k in range(1, n_clips):
+                        submit(k)                      # clip k is enqueued before clip k - 1 is waited for
+                        dn.wait(); fn.wait()
+                    dn.wait(); fn.wait()
+                    res["host_fps"] = world * B * n_clips / (time.perf_counter() - t1)
+                    assert same(n_clips - 1) and np.isfinite(sets[(n_clips - 1) % 2]["mn"].numpy()).all() and (sets[(n_clips - 1) % 2]["fmx"].numpy() > 0).all()
+                del hf, sets
         dn.close(); fn.close()
         return res
 
@@ -749,10 +756,10 @@ def main():
                           "value": round(world * (B - 1) * qsteps / sq["flow_s"], 3), "unit": "pairs/s",
                           "ms_per_step": round(sq["flow_s"] / qsteps * 1e3, 3)},
             "pcie_inclusive_fps": round(main_res["host_fps"], 2) if "host_fps" in main_res else None,
-            "pcie_inclusive_note": "the same clip through the host-pointer entry points (pb_depth_infer_batch, pb_flow_infer_sequence) from page-locked frames into "
-                                   "page-locked result arrays with the library's default chunking (depth: two chunks of 16 frames, flow: chunks of 16 pairs + a halo "
-                                   "frame; copies of chunk i +- 1 under the kernels of chunk i), both bands at once like the timed region (one host thread per "
-                                   "band: the calls block until the results are in host memory); results byte-identical to the HBM-resident leg's",
+            "pcie_inclusive_note": "clips streamed through the asynchronous host-pointer entry points (pb_depth_submit_batch, pb_flow_submit_sequence, pb_wait) from page-locked "
+                                   "frames into page-locked result arrays, the library's default chunking (a 32-frame clip is one chunk per band), "
+                                   "two clips in flight per band so that a clip's uploads and downloads run under its neighbours' kernels, both bands at once like "
+                                   "the timed region; results byte-identical to the HBM-resident leg's (--sequential-only: the blocking calls, one band after the other)",
             "latency_720p_batch1_ms": round(main_res["lat_b1"], 3) if "lat_b1" in main_res else None,
             "latency_720p_batch1_note": "one 1280x720 frame per call on a context created with max_batch = 1 (split-K on the launches with fewer tiles than CUs); "
                                         "the same call on the 32-frame context of the timed region, which never splits: "

@@ -137,6 +137,18 @@ int pb_depth_infer_batch(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W
 int pb_depth_infer_batch_dev(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W,
                              float *depth_out, uint8_t *rgb_out, float *min_out, float *max_out, int flip);
 int pb_sync(pb_ctx *ctx);
+/* Asynchronous host-pointer calls (round 6).  pb_depth_submit_batch / pb_flow_submit_sequence take the arguments of pb_depth_infer_batch /
+ * pb_flow_infer_sequence, enqueue the whole three-stage pipeline (H2D, band, D2H of every chunk) and return; pb_wait(ctx) blocks until the
+ * OLDEST submission of the ctx not yet waited for has its results in host memory (PB_ERR_STATE when none is outstanding).  Every buffer
+ * handed to a submit - frames and each non-NULL output, the per-frame scalars included - must be page-locked host memory and stay valid and
+ * untouched until the matching pb_wait returns.  Two submissions of one ctx may be in flight: the second one's uploads run under the first
+ * one's kernels, the first one's downloads under the second one's, so a caller that streams clips (bands/depth_anything.py:203-225,
+ * bands/flow_raft.py:98-113: the reference's frame loops) hides every copy.  Results are those of the blocking calls, bit for bit. */
+int pb_depth_submit_batch(pb_ctx *ctx, const uint8_t *frames, int n, int H, int W,
+                          float *depth_out, uint8_t *rgb_out, float *min_out, float *max_out, int flip);
+int pb_flow_submit_sequence(pb_ctx *ctx, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
+                            float *flow_out, uint8_t *rgb_out, float *maxdisp_out);
+int pb_wait(pb_ctx *ctx);
 /* Several bands at once: contexts share nothing, every *_dev entry point returns after the enqueue, so a caller enqueues on two or three
  * contexts and then pb_sync()s each (prisma_amd.engine.run_concurrently; replaces the reference's strictly sequential band order,
  * process.py:205-290, where the bands of one video are independent).  Results are those of running the bands one after the other. */

@@ -66,6 +66,9 @@ SYMBOLS = {
     "pb_depth_infer_batch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int]),
     "pb_depth_infer_batch_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int]),
     "pb_sync": (C.c_int, [_P]),
+    "pb_depth_submit_batch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int]),
+    "pb_flow_submit_sequence": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
+    "pb_wait": (C.c_int, [_P]),
     "pb_comm_unique_id": (C.c_int, [_P]),
     "pb_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "pb_gather_scalars": (C.c_int, [_P, _P, C.c_int, _P]),

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -31,6 +32,7 @@ struct HostPipe {
     void *h_in[2] = {}, *h_depth[2] = {}, *h_rgb[2] = {}, *h_mm[2] = {};
     void *d_in[2] = {}, *d_depth[2] = {}, *d_rgb[2] = {}, *d_mm[2] = {};
     size_t cap_in = 0, cap_d = 0, cap_r = 0, cap_m = 0;
+    unsigned seq = 0;               // chunks enqueued so far: chunk i of a call takes slot (seq + i) & 1, so consecutive one-chunk calls alternate slots
     // device slots always; the pinned staging halves only for callers whose own buffers are pageable (`host`)
     int grow(void **h, void **d, size_t &cap, size_t need, bool host = true) {
         if (need <= cap && (!host || h[0] || !need)) return 0;
@@ -122,6 +124,7 @@ struct FlowPipe {
     hipEvent_t ev_h2d[2] = {}, ev_comp[2] = {}, ev_d2h[2] = {};
     void *h[5][2] = {}, *d[5][2] = {};        // 0 frames in, 1 flow out, 2 rgb out, 3 max displacement out, 4 consistency masks out
     size_t cap[5] = {};
+    unsigned seq = 0;               // chunks enqueued so far (slot of chunk i of a call: (seq + i) & 1)
     int grow(int k, size_t need, bool host) {
         if (need <= cap[k] && (!host || h[k][0])) return 0;
         const size_t want = need > cap[k] ? need : cap[k];
@@ -231,6 +234,7 @@ struct pb_ctx {
     HostPipe pipe;
     FlowPipe fpipe;
     MaskPipe mpipe;
+    std::deque<hipEvent_t> pending;     // completion events of pb_*_submit_* calls not yet waited for (pb_wait pops the oldest)
     // pb_comm_init: RCCL communicator of the ranks (one process per GPU) for pb_gather_scalars
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -441,6 +445,7 @@ void pb_destroy(pb_ctx *c) {
     if (c->comm_buf) hipFree(c->comm_buf);
     if (c->still_stream) { hipStreamSynchronize(c->still_stream); hipStreamDestroy(c->still_stream); }
     if (c->still_buf) hipFree(c->still_buf);
+    for (hipEvent_t e : c->pending) { hipEventSynchronize(e); hipEventDestroy(e); }
     c->pipe.release();
     c->fpipe.release();
     c->mpipe.release();
@@ -471,28 +476,40 @@ int pb_depth_infer_batch_dev(pb_ctx *c, const uint8_t *frames, int n, int H, int
 // into a pinned staging buffer and DMAs them to HBM on a copy stream, stage 2 is the band on the ctx stream, stage 3
 // DMAs the results into pinned memory on a second copy stream and hands them to the caller's arrays.  Two slots per
 // stage, ordered by events, so the PCIe traffic of chunks i+1 and i-1 overlaps the compute of chunk i.
-int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, float *depth_out, uint8_t *rgb_out,
-                         float *min_out, float *max_out, int flip) {
-    PB_CHECK(c && c->depth, PB_ERR_STATE, "ctx has no depth_anything band");
-    PB_CHECK(frames && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "infer: bad arguments");
+// `submit`: the asynchronous form (pb_depth_submit_batch) - every caller buffer must be page-locked, nothing in the loop waits on the host (slot
+// reuse is ordered by events on the streams: the H2D into a slot waits for the compute that last read it, the compute into a slot for the D2H
+// that last emptied it), the min / max floats are DMAed straight into the caller's arrays, and the call returns after the enqueue with a
+// completion event queued for pb_wait().  The blocking form keeps its host-side finish() for pageable buffers and drains on every exit.
+static int depth_host_pipeline(pb_ctx *c, const uint8_t *frames, int n, int H, int W, float *depth_out, uint8_t *rgb_out, float *min_out,
+                               float *max_out, int flip, bool submit) {
     PB_HIP(hipSetDevice(c->device));
     const size_t px = (size_t)H * W;
-    // frames per chunk: pb_set_option("host_chunk"), else max_batch - but a call of >= 16 frames that would fit ONE chunk is cut in two, so that
-    // the second half's H2D and the first half's D2H run under the other half's kernels (a frame's result does not depend on its chunk)
+    // frames per chunk: pb_set_option("host_chunk"), else max_batch.  (Round 6 first cut calls of >= 16 frames in two so that one half's copies ran
+    // under the other half's kernels: on the bench clip the 16-frame launches' longer tails cost more than the hidden copies gave -
+    // profiles/r06j_pcie_entry_points.txt; copies are hidden ACROSS calls by the asynchronous form instead.)
     const int mb = c->depth->max_batch();
-    const int cap = std::min(n, c->host_chunk > 0 ? std::min(c->host_chunk, mb) : (n >= 16 && n <= mb ? (n + 1) / 2 : mb));
+    const int cap = std::min(n, c->host_chunk > 0 ? std::min(c->host_chunk, mb) : mb);
     HostPipe &hp = c->pipe;
     const size_t in_b = (size_t)cap * px * 3, d_b = depth_out ? (size_t)cap * px * 4 : 0, r_b = rgb_out ? in_b : 0,
                  m_b = (size_t)cap * 8;
     // page-locked caller buffers are read / written by the copy engines directly (no staging memcpy on this thread)
     const bool pin_in = pb_is_pinned(frames, (size_t)n * px * 3), pin_d = pb_is_pinned(depth_out, (size_t)n * px * 4),
                pin_r = pb_is_pinned(rgb_out, (size_t)n * px * 3);
+    const bool pin_mm = (!min_out || pb_is_pinned(min_out, (size_t)n * 4)) && (!max_out || pb_is_pinned(max_out, (size_t)n * 4));
+    if (submit) PB_CHECK(pin_in && (!depth_out || pin_d) && (!rgb_out || pin_r) && pin_mm, PB_ERR_ARG,
+                         "depth submit: every buffer of an asynchronous call must be page-locked host memory (hipHostMalloc / hipHostRegister / torch pin_memory)");
     PB_TRY(hp.ensure(in_b, d_b, r_b, m_b, !pin_in, !pin_d, !pin_r));
-    PipeDrain drain{hp.s_in, c->stream, hp.s_out};          // no exit, error or not, leaves a copy into caller memory in flight
+    PipeDrain drain{submit ? nullptr : hp.s_in, submit ? nullptr : c->stream, submit ? nullptr : hp.s_out};      // blocking form: no exit leaves a copy into caller memory in flight
+    struct SubmitGuard {            // asynchronous form: an error exit drains too (the caller gets an error, not a half-enqueued call)
+        hipStream_t a, b, c; bool armed;
+        ~SubmitGuard() { if (armed) { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(c); } }
+    } guard{hp.s_in, c->stream, hp.s_out, submit};
     TimerSpan span(c->depth->timer);
     const int chunks = (n + cap - 1) / cap;
+    const unsigned base = hp.seq;
+    hp.seq += (unsigned)chunks;
     auto finish = [&](int i) -> int {           // results of chunk i: pinned -> caller
-        const int slot = i & 1, s0 = i * cap, m = std::min(cap, n - s0);
+        const int slot = (int)((base + i) & 1), s0 = i * cap, m = std::min(cap, n - s0);
         PB_HIP(hipEventSynchronize(hp.ev_d2h[slot]));
         if (depth_out && !pin_d) memcpy(depth_out + (size_t)s0 * px, hp.h_depth[slot], (size_t)m * px * 4);
         if (rgb_out && !pin_r) memcpy(rgb_out + (size_t)s0 * px * 3, hp.h_rgb[slot], (size_t)m * px * 3);
@@ -502,13 +519,15 @@ int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, 
         return 0;
     };
     for (int i = 0; i < chunks; ++i) {
-        const int slot = i & 1, s0 = i * cap, m = std::min(cap, n - s0);
-        if (i >= 2) PB_TRY(finish(i - 2));       // frees this slot's pinned output and (through ev_d2h) its device buffers
+        const int slot = (int)((base + i) & 1), s0 = i * cap, m = std::min(cap, n - s0);
+        if (!submit && i >= 2) PB_TRY(finish(i - 2));       // frees this slot's pinned output and (through ev_d2h) its device buffers
+        if (submit) PB_HIP(hipStreamWaitEvent(hp.s_in, hp.ev_comp[slot], 0));      // the compute that last read this input slot (this call's chunk i - 2 or an earlier submission's)
         const void *src = frames + (size_t)s0 * px * 3;
         if (!pin_in) { memcpy(hp.h_in[slot], src, (size_t)m * px * 3); src = hp.h_in[slot]; }
         PB_HIP(hipMemcpyAsync(hp.d_in[slot], src, (size_t)m * px * 3, hipMemcpyHostToDevice, hp.s_in));
         PB_HIP(hipEventRecord(hp.ev_h2d[slot], hp.s_in));
         PB_HIP(hipStreamWaitEvent(c->stream, hp.ev_h2d[slot], 0));
+        if (submit) PB_HIP(hipStreamWaitEvent(c->stream, hp.ev_d2h[slot], 0));     // the D2H that last emptied this output slot
         float *mn = (float *)hp.d_mm[slot], *mx = mn + cap;
         PB_TRY(c->depth->infer((const uint8_t *)hp.d_in[slot], m, H, W, (float *)(d_b ? hp.d_depth[slot] : nullptr),
                                (uint8_t *)(r_b ? hp.d_rgb[slot] : nullptr), mn, mx, flip));
@@ -516,10 +535,49 @@ int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, 
         PB_HIP(hipStreamWaitEvent(hp.s_out, hp.ev_comp[slot], 0));
         if (d_b) PB_HIP(hipMemcpyAsync(pin_d ? (void *)(depth_out + (size_t)s0 * px) : hp.h_depth[slot], hp.d_depth[slot], (size_t)m * px * 4, hipMemcpyDeviceToHost, hp.s_out));
         if (r_b) PB_HIP(hipMemcpyAsync(pin_r ? (void *)(rgb_out + (size_t)s0 * px * 3) : hp.h_rgb[slot], hp.d_rgb[slot], (size_t)m * px * 3, hipMemcpyDeviceToHost, hp.s_out));
-        PB_HIP(hipMemcpyAsync(hp.h_mm[slot], hp.d_mm[slot], m_b, hipMemcpyDeviceToHost, hp.s_out));
+        if (submit) {
+            if (min_out) PB_HIP(hipMemcpyAsync(min_out + s0, mn, (size_t)m * 4, hipMemcpyDeviceToHost, hp.s_out));
+            if (max_out) PB_HIP(hipMemcpyAsync(max_out + s0, mx, (size_t)m * 4, hipMemcpyDeviceToHost, hp.s_out));
+        } else {
+            PB_HIP(hipMemcpyAsync(hp.h_mm[slot], hp.d_mm[slot], m_b, hipMemcpyDeviceToHost, hp.s_out));
+        }
         PB_HIP(hipEventRecord(hp.ev_d2h[slot], hp.s_out));
     }
+    if (submit) {
+        hipEvent_t done;
+        PB_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        PB_HIP(hipEventRecord(done, hp.s_out));               // s_out runs its copies in order: the last chunk's results are the last thing it does
+        c->pending.push_back(done);
+        guard.armed = false;
+        return 0;
+    }
     for (int i = std::max(0, chunks - 2); i < chunks; ++i) PB_TRY(finish(i));
+    return 0;
+}
+
+int pb_depth_infer_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, float *depth_out, uint8_t *rgb_out,
+                         float *min_out, float *max_out, int flip) {
+    PB_CHECK(c && c->depth, PB_ERR_STATE, "ctx has no depth_anything band");
+    PB_CHECK(frames && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "infer: bad arguments");
+    return depth_host_pipeline(c, frames, n, H, W, depth_out, rgb_out, min_out, max_out, flip, false);
+}
+
+int pb_depth_submit_batch(pb_ctx *c, const uint8_t *frames, int n, int H, int W, float *depth_out, uint8_t *rgb_out,
+                          float *min_out, float *max_out, int flip) {
+    PB_CHECK(c && c->depth, PB_ERR_STATE, "ctx has no depth_anything band");
+    PB_CHECK(frames && n > 0 && H > 0 && W > 0, PB_ERR_ARG, "submit: bad arguments");
+    return depth_host_pipeline(c, frames, n, H, W, depth_out, rgb_out, min_out, max_out, flip, true);
+}
+
+int pb_wait(pb_ctx *c) {
+    PB_CHECK(c, PB_ERR_ARG, "null ctx");
+    PB_CHECK(!c->pending.empty(), PB_ERR_STATE, "pb_wait: no submission is outstanding on this ctx");
+    PB_HIP(hipSetDevice(c->device));
+    hipEvent_t done = c->pending.front();
+    c->pending.pop_front();
+    const hipError_t e = hipEventSynchronize(done);
+    (void)hipEventDestroy(done);
+    PB_CHECK(e == hipSuccess, PB_ERR_DEVICE, "pb_wait: %s", hipGetErrorString(e));
     return 0;
 }
 
@@ -560,13 +618,15 @@ int pb_flow_infer_sequence_dev(pb_ctx *c, const uint8_t *frames, int F, int H, i
 // flow (and mask: both directions of a pair are in the same chunk) is that of one whole-sequence call - pairs do not interact.  Page-locked
 // caller buffers are used directly.  mask_out != NULL: both directions + the forward / backward consistency masks (pb_flow_infer_sequence_masks).
 static int flow_host_pipeline(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
-                              float *flow_out, uint8_t *rgb_out, float *maxdisp_out, uint8_t *mask_out, float alpha1, float alpha2) {
+                              float *flow_out, uint8_t *rgb_out, float *maxdisp_out, uint8_t *mask_out, float alpha1, float alpha2, bool submit = false) {
     PB_HIP(hipSetDevice(c->device));
     int sh, sw;
     RaftEngine::out_size(H, W, scale, &sh, &sw);
     const int dirs = backward ? 2 : 1, pairs = F - 1;
-    static const int env_cp = pb_env_int("PB_FLOW_HOST_PAIRS", 16);
-    int cp = c->host_chunk > 0 ? c->host_chunk : (env_cp > 0 ? env_cp : 16);
+    // (default 32 pairs since round 6 - was 16: a chunk's launches are the same kernels on fewer rows, and 16-pair chunks cost the bench clip more in
+    // launch tails and re-encoded halo frames than their hidden copies gave; profiles/r06j_pcie_entry_points.txt)
+    static const int env_cp = pb_env_int("PB_FLOW_HOST_PAIRS", 32);
+    int cp = c->host_chunk > 0 ? c->host_chunk : (env_cp > 0 ? env_cp : 32);
     if (pairs <= cp + cp / 4) cp = pairs;                       // a short tail is not worth a chunk of its own
     const int chunks = (pairs + cp - 1) / cp;
     const size_t fpx = (size_t)H * W * 3, px = (size_t)sh * sw, nd = (size_t)pairs * dirs;
@@ -574,15 +634,24 @@ static int flow_host_pipeline(pb_ctx *c, const uint8_t *frames, int F, int H, in
     const bool pin_in = pb_is_pinned(frames, (size_t)F * fpx), pin_f = pb_is_pinned(flow_out, nd * px * 8), pin_r = pb_is_pinned(rgb_out, nd * px * 3),
                pin_k = pb_is_pinned(mask_out, nd * px);
     PB_TRY(fp.ensure_streams());
-    PipeDrain drain{fp.s_in, c->stream, fp.s_out};              // no exit, error or not, leaves a copy into caller memory in flight
+    // `submit`: the asynchronous form (pb_flow_submit_sequence; depth_host_pipeline above has the rules)
+    if (submit) PB_CHECK(pin_in && (!flow_out || pin_f) && (!rgb_out || pin_r) && (!mask_out || pin_k) && (!maxdisp_out || pb_is_pinned(maxdisp_out, nd * 4)), PB_ERR_ARG,
+                         "flow submit: every buffer of an asynchronous call must be page-locked host memory (hipHostMalloc / hipHostRegister / torch pin_memory)");
+    PipeDrain drain{submit ? nullptr : fp.s_in, submit ? nullptr : c->stream, submit ? nullptr : fp.s_out};      // blocking form: no exit leaves a copy into caller memory in flight
+    struct SubmitGuard {
+        hipStream_t a, b, c; bool armed;
+        ~SubmitGuard() { if (armed) { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(c); } }
+    } guard{fp.s_in, c->stream, fp.s_out, submit};
     TimerSpan span(c->raft->timer);
     PB_TRY(fp.grow(0, (size_t)(cp + 1) * fpx, !pin_in));
     if (flow_out) PB_TRY(fp.grow(1, (size_t)cp * dirs * px * 8, !pin_f));
     if (rgb_out) PB_TRY(fp.grow(2, (size_t)cp * dirs * px * 3, !pin_r));
     PB_TRY(fp.grow(3, (size_t)cp * dirs * 4 + 256, true));
     if (mask_out) PB_TRY(fp.grow(4, (size_t)cp * dirs * px, !pin_k));
+    const unsigned base = fp.seq;
+    fp.seq += (unsigned)chunks;
     auto finish = [&](int i) -> int {           // results of chunk i: pinned staging -> caller (page-locked caller buffers were written directly)
-        const int slot = i & 1, p0 = i * cp, m = std::min(cp, pairs - p0);
+        const int slot = (int)((base + i) & 1), p0 = i * cp, m = std::min(cp, pairs - p0);
         PB_HIP(hipEventSynchronize(fp.ev_d2h[slot]));
         if (flow_out && !pin_f) memcpy(flow_out + (size_t)p0 * dirs * px * 2, fp.h[1][slot], (size_t)m * dirs * px * 8);
         if (rgb_out && !pin_r) memcpy(rgb_out + (size_t)p0 * dirs * px * 3, fp.h[2][slot], (size_t)m * dirs * px * 3);
@@ -591,13 +660,15 @@ static int flow_host_pipeline(pb_ctx *c, const uint8_t *frames, int F, int H, in
         return 0;
     };
     for (int i = 0; i < chunks; ++i) {
-        const int slot = i & 1, p0 = i * cp, m = std::min(cp, pairs - p0);
-        if (i >= 2) PB_TRY(finish(i - 2));       // frees this slot's staging and (through ev_d2h) its device buffers
+        const int slot = (int)((base + i) & 1), p0 = i * cp, m = std::min(cp, pairs - p0);
+        if (!submit && i >= 2) PB_TRY(finish(i - 2));       // frees this slot's staging and (through ev_d2h) its device buffers
+        if (submit) PB_HIP(hipStreamWaitEvent(fp.s_in, fp.ev_comp[slot], 0));      // the compute that last read this input slot
         const void *src = frames + (size_t)p0 * fpx;
         if (!pin_in) { memcpy(fp.h[0][slot], src, (size_t)(m + 1) * fpx); src = fp.h[0][slot]; }
         PB_HIP(hipMemcpyAsync(fp.d[0][slot], src, (size_t)(m + 1) * fpx, hipMemcpyHostToDevice, fp.s_in));
         PB_HIP(hipEventRecord(fp.ev_h2d[slot], fp.s_in));
         PB_HIP(hipStreamWaitEvent(c->stream, fp.ev_h2d[slot], 0));
+        if (submit) PB_HIP(hipStreamWaitEvent(c->stream, fp.ev_d2h[slot], 0));     // the D2H that last emptied this output slot
         PB_TRY(c->raft->infer((const uint8_t *)fp.d[0][slot], m + 1, H, W, scale, iters, backward, (float *)(flow_out ? fp.d[1][slot] : nullptr),
                               (uint8_t *)(rgb_out ? fp.d[2][slot] : nullptr), (float *)fp.d[3][slot], (uint8_t *)(mask_out ? fp.d[4][slot] : nullptr),
                               alpha1, alpha2));
@@ -605,12 +676,28 @@ static int flow_host_pipeline(pb_ctx *c, const uint8_t *frames, int F, int H, in
         PB_HIP(hipStreamWaitEvent(fp.s_out, fp.ev_comp[slot], 0));
         if (flow_out) PB_HIP(hipMemcpyAsync(pin_f ? (void *)(flow_out + (size_t)p0 * dirs * px * 2) : fp.h[1][slot], fp.d[1][slot], (size_t)m * dirs * px * 8, hipMemcpyDeviceToHost, fp.s_out));
         if (rgb_out) PB_HIP(hipMemcpyAsync(pin_r ? (void *)(rgb_out + (size_t)p0 * dirs * px * 3) : fp.h[2][slot], fp.d[2][slot], (size_t)m * dirs * px * 3, hipMemcpyDeviceToHost, fp.s_out));
-        PB_HIP(hipMemcpyAsync(fp.h[3][slot], fp.d[3][slot], (size_t)m * dirs * 4, hipMemcpyDeviceToHost, fp.s_out));
+        if (submit) { if (maxdisp_out) PB_HIP(hipMemcpyAsync(maxdisp_out + (size_t)p0 * dirs, fp.d[3][slot], (size_t)m * dirs * 4, hipMemcpyDeviceToHost, fp.s_out)); }
+        else PB_HIP(hipMemcpyAsync(fp.h[3][slot], fp.d[3][slot], (size_t)m * dirs * 4, hipMemcpyDeviceToHost, fp.s_out));
         if (mask_out) PB_HIP(hipMemcpyAsync(pin_k ? (void *)(mask_out + (size_t)p0 * dirs * px) : fp.h[4][slot], fp.d[4][slot], (size_t)m * dirs * px, hipMemcpyDeviceToHost, fp.s_out));
         PB_HIP(hipEventRecord(fp.ev_d2h[slot], fp.s_out));
     }
+    if (submit) {
+        hipEvent_t done;
+        PB_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        PB_HIP(hipEventRecord(done, fp.s_out));
+        c->pending.push_back(done);
+        guard.armed = false;
+        return 0;
+    }
     for (int i = std::max(0, chunks - 2); i < chunks; ++i) PB_TRY(finish(i));
     return 0;
+}
+
+int pb_flow_submit_sequence(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,
+                            float *flow_out, uint8_t *rgb_out, float *maxdisp_out) {
+    PB_CHECK(c && c->raft, PB_ERR_STATE, "ctx has no flow_raft band");
+    PB_CHECK(frames && F >= 2 && H > 0 && W > 0, PB_ERR_ARG, "flow submit: bad arguments");
+    return flow_host_pipeline(c, frames, F, H, W, scale, iters, backward, flow_out, rgb_out, maxdisp_out, nullptr, 0.05f, 0.5f, true);
 }
 
 int pb_flow_infer_sequence(pb_ctx *c, const uint8_t *frames, int F, int H, int W, float scale, int iters, int backward,

@@ -117,6 +117,18 @@ class _Ctx:
     def sync(self):
         check(self.lib.pb_sync(self.ctx))
 
+    def wait(self):
+        """Blocks until the OLDEST submit_* call of this context not yet waited for has its results in the caller's (page-locked) arrays
+        and returns what that call returned (pb_wait)."""
+        check(self.lib.pb_wait(self.ctx))
+        return self._inflight.pop(0)[0] if getattr(self, "_inflight", None) else None
+
+    def _hold(self, result, *arrays):
+        # the arrays of a submission must outlive it: keep references until wait() hands the results back
+        if not hasattr(self, "_inflight"):
+            self._inflight = []
+        self._inflight.append((result, arrays))
+
     def encode_still(self, depth: np.ndarray, flip: bool = True, encode_range: bool = True):
         """write_depth(heatmap=True) of one float32 depth map on the GPU (bands/common/io.py:138-172): -> (rgb u8 [H,W,3], min, max)."""
         depth = _f32(depth)
@@ -302,6 +314,18 @@ class DepthAnything(_Ctx):
                                             _ptr(mx), int(flip)))
         return depth, rgb, mn, mx
 
+    def submit_batch(self, frames: np.ndarray, out_rgb: Optional[np.ndarray] = None, out_depth: Optional[np.ndarray] = None,
+                     out_min: Optional[np.ndarray] = None, out_max: Optional[np.ndarray] = None, flip: bool = True):
+        """Asynchronous infer_batch (pb_depth_submit_batch): every array - `frames` and each given output - must be a C-contiguous view of
+        PAGE-LOCKED memory (torch `pin_memory()` + `.numpy()`); returns after the enqueue, `wait()` returns (depth, rgb, min, max) once they are
+        filled.  Up to two submissions may be in flight per context: the second one's uploads run under the first one's kernels."""
+        n, H, W, ch = frames.shape
+        assert ch == 3 and frames.dtype == np.uint8 and frames.flags.c_contiguous
+        for a, dt, shp in ((out_rgb, np.uint8, (n, H, W, 3)), (out_depth, np.float32, (n, H, W)), (out_min, np.float32, (n,)), (out_max, np.float32, (n,))):
+            assert a is None or (a.dtype == dt and a.shape == shp and a.flags.c_contiguous)
+        check(self.lib.pb_depth_submit_batch(self.ctx, _ptr(frames), n, H, W, _ptr(out_depth), _ptr(out_rgb), _ptr(out_min), _ptr(out_max), int(flip)))
+        self._hold((out_depth, out_rgb, out_min, out_max), frames, out_depth, out_rgb, out_min, out_max)
+
     def infer(self, img: np.ndarray, normalize: bool = False) -> np.ndarray:
         """bands/depth_anything.py:100-143 `infer(img, normalize)` for the relative model."""
         d = self.infer_batch(img[None], want_depth=True, want_rgb=False)[0][0]
@@ -375,6 +399,19 @@ class FlowRaft(_Ctx):
         check(self.lib.pb_flow_infer_sequence(self.ctx, _ptr(frames), F, H, W, C.c_float(scale), iters, int(backward),
                                               _ptr(flow), _ptr(rgb), _ptr(mx)))
         return flow, rgb, mx
+
+    def submit_sequence(self, frames: np.ndarray, scale: float = 0.75, iters: int = 12, backward: bool = False,
+                        out_flow: Optional[np.ndarray] = None, out_rgb: Optional[np.ndarray] = None, out_max: Optional[np.ndarray] = None):
+        """Asynchronous infer_sequence (pb_flow_submit_sequence): page-locked arrays only (see DepthAnything.submit_batch); `wait()` returns
+        (flow, rgb, maxdisp)."""
+        F, H, W, ch = frames.shape
+        assert ch == 3 and F >= 2 and frames.dtype == np.uint8 and frames.flags.c_contiguous
+        sh, sw = flow_out_size(H, W, scale)
+        d = 2 if backward else 1
+        for a, dt, shp in ((out_flow, np.float32, (F - 1, d, sh, sw, 2)), (out_rgb, np.uint8, (F - 1, d, sh, sw, 3)), (out_max, np.float32, (F - 1, d))):
+            assert a is None or (a.dtype == dt and a.shape == shp and a.flags.c_contiguous)
+        check(self.lib.pb_flow_submit_sequence(self.ctx, _ptr(frames), F, H, W, C.c_float(scale), iters, int(backward), _ptr(out_flow), _ptr(out_rgb), _ptr(out_max)))
+        self._hold((out_flow, out_rgb, out_max), frames, out_flow, out_rgb, out_max)
 
     def infer_sequence_masks(self, frames: np.ndarray, scale: float = 0.75, iters: int = 12, alpha_1: float = 0.05,
                              alpha_2: float = 0.5, want_flow: bool = True, want_rgb: bool = True, out_flow: Optional[np.ndarray] = None,

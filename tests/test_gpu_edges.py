@@ -184,3 +184,52 @@ def test_bands_run_concurrently_equal_sequential():
             for a, b in zip(ref, out):
                 assert np.array_equal(a, b.cpu().numpy()), (mode, rep)
     dn.close(); fn.close()
+
+
+def test_submit_wait_streams_clips_with_the_bytes_of_the_blocking_calls():
+    """pb_depth_submit_batch / pb_flow_submit_sequence / pb_wait: asynchronous host-pointer calls on page-locked buffers, two submissions in flight
+    per context (the second one's uploads under the first one's kernels) - three different clips streamed through both bands give, clip by clip,
+    the bytes of the blocking entry points; pageable buffers are refused; pb_wait without a submission is an error."""
+    torch = pytest.importorskip("torch")
+    B, H, W = 6, 200, 328
+    dn = engine.DepthAnything(synth.depth_anything_weights("vits", seed=1234), "vits", max_batch=B)
+    fn = engine.FlowRaft(synth.raft_weights(seed=4321))
+    dn.set_option("host_chunk", 2); fn.set_option("host_chunk", 2)          # three chunks per call: slot reuse inside a submission as well
+    sh, sw = engine.flow_out_size(H, W, 1.0)
+    clips = [synth.frame_pair_sequence(B, H, W, seed=80 + k) for k in range(3)]
+    ref = []
+    for fr in clips:
+        d, rgb, mn, mx = dn.infer_batch(fr)
+        fl, frgb, fmx = fn.infer_sequence(fr, scale=1.0, iters=3)
+        ref.append((d, rgb, mn, mx, fl, frgb, fmx))
+    pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()      # noqa: E731
+    sets = [dict(fr=pin((B, H, W, 3), torch.uint8), d=pin((B, H, W), torch.float32), rgb=pin((B, H, W, 3), torch.uint8), mn=pin((B,), torch.float32),
+                 mx=pin((B,), torch.float32), fl=pin((B - 1, 1, sh, sw, 2), torch.float32), frgb=pin((B - 1, 1, sh, sw, 3), torch.uint8),
+                 fmx=pin((B - 1, 1), torch.float32)) for _ in range(2)]
+
+    def submit(k):
+        s = sets[k % 2]
+        s["fr"].copy_(torch.from_numpy(clips[k]))
+        for key in ("d", "rgb", "mn", "mx", "fl", "frgb", "fmx"):
+            s[key].zero_()
+        dn.submit_batch(s["fr"].numpy(), out_rgb=s["rgb"].numpy(), out_depth=s["d"].numpy(), out_min=s["mn"].numpy(), out_max=s["mx"].numpy())
+        fn.submit_sequence(s["fr"].numpy(), scale=1.0, iters=3, out_flow=s["fl"].numpy(), out_rgb=s["frgb"].numpy(), out_max=s["fmx"].numpy())
+
+    def check_clip(k):
+        d, rgb, mn, mx = dn.wait()
+        fl, frgb, fmx = fn.wait()
+        for got, want in zip((d, rgb, mn, mx, fl, frgb, fmx), ref[k]):
+            assert np.array_equal(got, want), k
+    submit(0)
+    submit(1)                       # two submissions in flight on each context
+    check_clip(0)
+    submit(2)                       # re-uses clip 0's host buffers and both device slots while clip 1 is still running
+    check_clip(1)
+    check_clip(2)
+    with pytest.raises(Err):
+        dn.wait()
+    with pytest.raises(Err, match="page-locked"):
+        dn.submit_batch(clips[0], out_rgb=sets[0]["rgb"].numpy())
+    d, rgb, mn, mx = dn.infer_batch(clips[1])            # the blocking call after the asynchronous ones
+    assert np.array_equal(d, ref[1][0]) and np.array_equal(rgb, ref[1][1])
+    dn.close(); fn.close()
