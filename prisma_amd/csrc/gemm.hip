@@ -54,7 +54,14 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
     }
     if (tile == TILE_AUTO) {
         // 256x256 needs wide N and enough tiles to fill 256 CUs; the q/k/v split needs D % BN == 0
-        const bool wide = a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256;
+        // PB_WIDE_MIN=<tiles>: the fewest 256 x 256 tiles a launch must have to take the ping-pong kernel; default 256 = one per CU.  A one-frame
+        // context (the caller lent a split-K workspace: gemm.h sk_ws) takes it from 128 tiles on: fc1 of a 720p frame (144 tiles) and the head's
+        // full-resolution convolutions run one round of 256 x 256 tiles faster than 1.25 rounds of 128 x 128 ones (7.11 -> 6.93 ms per frame,
+        // profiles/r06p_latency_knobs.txt; 100 - qkv as well - is slower again).  Same bits either way: every tile shape walks K in one order.
+        static int wide_tiles = -1;
+        if (wide_tiles < 0) wide_tiles = pb_env_int("PB_WIDE_MIN", 256);
+        const int wide_need = a.sk_ws ? std::min(wide_tiles, 128) : wide_tiles;
+        const bool wide = a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= wide_need;
         tile = wide && (epi != EPI_QKV || a.D % 256 == 0) ? TILE_256 : TILE_128;
         // N = 192 (RAFT's convc2): two 128-wide tiles of which the second is half empty, or one 256-wide tile that is a quarter empty - the
         // ping-pong kernel's K loop runs ~2460 cycles per 256 x 256 x 64 against the generic tile's ~1000 per 128 x 128 x 64.  Measured (r04p, one box):
