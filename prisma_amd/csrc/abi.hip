@@ -521,13 +521,13 @@ static int depth_host_pipeline(pb_ctx *c, const uint8_t *frames, int n, int H, i
     for (int i = 0; i < chunks; ++i) {
         const int slot = (int)((base + i) & 1), s0 = i * cap, m = std::min(cap, n - s0);
         if (!submit && i >= 2) PB_TRY(finish(i - 2));       // frees this slot's pinned output and (through ev_d2h) its device buffers
-        if (submit) PB_HIP(hipStreamWaitEvent(hp.s_in, hp.ev_comp[slot], 0));      // the compute that last read this input slot (this call's chunk i - 2 or an earlier submission's)
+        PB_HIP(hipStreamWaitEvent(hp.s_in, hp.ev_comp[slot], 0));      // the compute that last read this input slot: this call's chunk i - 2 or an earlier submission's (also in the blocking form: a submission may still be in flight)
         const void *src = frames + (size_t)s0 * px * 3;
         if (!pin_in) { memcpy(hp.h_in[slot], src, (size_t)m * px * 3); src = hp.h_in[slot]; }
         PB_HIP(hipMemcpyAsync(hp.d_in[slot], src, (size_t)m * px * 3, hipMemcpyHostToDevice, hp.s_in));
         PB_HIP(hipEventRecord(hp.ev_h2d[slot], hp.s_in));
         PB_HIP(hipStreamWaitEvent(c->stream, hp.ev_h2d[slot], 0));
-        if (submit) PB_HIP(hipStreamWaitEvent(c->stream, hp.ev_d2h[slot], 0));     // the D2H that last emptied this output slot
+        PB_HIP(hipStreamWaitEvent(c->stream, hp.ev_d2h[slot], 0));     // the D2H that last emptied this output slot
         float *mn = (float *)hp.d_mm[slot], *mx = mn + cap;
         PB_TRY(c->depth->infer((const uint8_t *)hp.d_in[slot], m, H, W, (float *)(d_b ? hp.d_depth[slot] : nullptr),
                                (uint8_t *)(r_b ? hp.d_rgb[slot] : nullptr), mn, mx, flip));
@@ -662,13 +662,13 @@ static int flow_host_pipeline(pb_ctx *c, const uint8_t *frames, int F, int H, in
     for (int i = 0; i < chunks; ++i) {
         const int slot = (int)((base + i) & 1), p0 = i * cp, m = std::min(cp, pairs - p0);
         if (!submit && i >= 2) PB_TRY(finish(i - 2));       // frees this slot's staging and (through ev_d2h) its device buffers
-        if (submit) PB_HIP(hipStreamWaitEvent(fp.s_in, fp.ev_comp[slot], 0));      // the compute that last read this input slot
+        PB_HIP(hipStreamWaitEvent(fp.s_in, fp.ev_comp[slot], 0));      // the compute that last read this input slot (both forms: a submission may still be in flight)
         const void *src = frames + (size_t)p0 * fpx;
         if (!pin_in) { memcpy(fp.h[0][slot], src, (size_t)(m + 1) * fpx); src = fp.h[0][slot]; }
         PB_HIP(hipMemcpyAsync(fp.d[0][slot], src, (size_t)(m + 1) * fpx, hipMemcpyHostToDevice, fp.s_in));
         PB_HIP(hipEventRecord(fp.ev_h2d[slot], fp.s_in));
         PB_HIP(hipStreamWaitEvent(c->stream, fp.ev_h2d[slot], 0));
-        if (submit) PB_HIP(hipStreamWaitEvent(c->stream, fp.ev_d2h[slot], 0));     // the D2H that last emptied this output slot
+        PB_HIP(hipStreamWaitEvent(c->stream, fp.ev_d2h[slot], 0));     // the D2H that last emptied this output slot
         PB_TRY(c->raft->infer((const uint8_t *)fp.d[0][slot], m + 1, H, W, scale, iters, backward, (float *)(flow_out ? fp.d[1][slot] : nullptr),
                               (uint8_t *)(rgb_out ? fp.d[2][slot] : nullptr), (float *)fp.d[3][slot], (uint8_t *)(mask_out ? fp.d[4][slot] : nullptr),
                               alpha1, alpha2));

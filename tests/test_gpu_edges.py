@@ -232,4 +232,9 @@ def test_submit_wait_streams_clips_with_the_bytes_of_the_blocking_calls():
         dn.submit_batch(clips[0], out_rgb=sets[0]["rgb"].numpy())
     d, rgb, mn, mx = dn.infer_batch(clips[1])            # the blocking call after the asynchronous ones
     assert np.array_equal(d, ref[1][0]) and np.array_equal(rgb, ref[1][1])
+    submit(0)                                            # ... and a blocking call WHILE a submission is in flight: it queues behind it on the device
+    d, rgb, mn, mx = dn.infer_batch(clips[2])
+    fl, frgb, fmx = fn.infer_sequence(clips[2], scale=1.0, iters=3)
+    assert np.array_equal(d, ref[2][0]) and np.array_equal(rgb, ref[2][1]) and np.array_equal(fl, ref[2][4]) and np.array_equal(fmx, ref[2][6])
+    check_clip(0)
     dn.close(); fn.close()
