@@ -49,3 +49,32 @@ def test_run_concurrently_drains_started_contexts_when_an_enqueue_fails():
     log.clear()
     done = engine.run_concurrently([(a, lambda: log.append("enq a")), (c, lambda: log.append("enq c"))])
     assert log == ["enq a", "enq c", "sync a", "sync c"] and len(done) == 2 and done[0] <= done[1]
+
+
+def test_pmc_clock_summary_divides_by_the_xcds_and_the_duration(tmp_path):
+    """tools/pmc_clock.py: GRBM_GUI_ACTIVE is summed over the 8 XCDs, so a dispatch's clock is counter / 8 / duration; symbols are ranked by time."""
+    import importlib.util
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path / "run" / "host" ; d.mkdir(parents=True)
+    rows = ["Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp",
+            "gemmA,GRBM_GUI_ACTIVE,16000000,1000,1001000",        # 1 ms, 16e6 / 8 / 1e6 ns = 2.0 GHz
+            "gemmA,GRBM_GUI_ACTIVE,12000000,2000000,3000000",      # 1 ms at 1.5 GHz -> symbol: 1.75 GHz over 2 ms
+            "copyB,GRBM_GUI_ACTIVE,1920000,5000000,5100000",       # 0.1 ms at 2.4 GHz
+            "gemmA,SQ_WAVES,5,1000,1001000"]
+    (d / "1_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    spec = importlib.util.spec_from_file_location("pmc_clock", os.path.join(root, "tools", "pmc_clock.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    out = tmp_path / "clk.json"
+    argv, sys.argv = sys.argv, ["pmc_clock.py", str(tmp_path / "run"), str(out)]
+    try:
+        m.main()
+    finally:
+        sys.argv = argv
+    k = json.load(open(out))["kernels"]
+    assert list(k) == ["gemmA", "copyB"]
+    assert k["gemmA"]["launches"] == 2 and abs(k["gemmA"]["effective_clock_ghz"] - 1.75) < 1e-9 and abs(k["gemmA"]["total_ms"] - 2.0) < 1e-9
+    assert abs(k["copyB"]["effective_clock_ghz"] - 2.4) < 1e-9
