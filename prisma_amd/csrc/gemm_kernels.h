@@ -1279,6 +1279,16 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             e_nxt = ktab[kt + 1 < nk ? kt + 1 : nk - 1];
             tapoff2 = ktab_bytes(e); tapsel = ktab_sel(e);
         }
+#ifdef PB_DIAG
+        // PB_GEMM_ABL=4 (timing only, wrong results): the A DMAs of the taps with kx != 0 fetch nothing (an impossible tap test sends them out of
+        // range: zeros arrive in the LDS without an L2 / HBM access) - the fetch side of what a staging that shares one (rows + 2)-pixel window
+        // between the kx taps of a (slice, ky) would save (EXPERIMENTS.md 6.5).  Scalar select: no register, no branch.
+        // PB_GEMM_ABL=8: the same taps read a 32 KB window at the start of the operand instead (cache hits; random data, so the MFMAs keep
+        // their switching activity where the zeros of mode 4 lower it).  PB_GEMM_ABL=16: their DMAs are not issued at all (the MFMAs multiply
+        // what an earlier K tile left in the LDS stage: random data as well) - the upper bound of a shared window, LDS writes included
+        if constexpr (AMODE == A_CONV) tapsel = ((p.ablate & 4) && (tapsel >> 8) != 1u) ? 0xFFFFFFFFu : tapsel;
+        const bool abl_near = AMODE == A_CONV && (p.ablate & 8) && (tapsel >> 8) != 1u;
+#endif
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if constexpr (AMODE == A_DENSE) {
@@ -1287,6 +1297,10 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             } else {
                 const bool ok = (a_msk[i] & tapsel) == tapsel;
                 if constexpr (BUFP) {      // branch-free: an out-of-range offset makes the load return zeros
+#ifdef PB_DIAG
+                    if (abl_near) { glds16_buf(rsA, (int)((unsigned)tid * 16u + (tapoff2 & 0x7000u)), 0, sA + i * (NT * 16)); continue; }
+                    if ((p.ablate & 16) && (tapsel >> 8) != 1u) continue;
+#endif
                     glds16_buf(rsA, (int)(ok ? a_voff[i] + tapoff2 : 0xFFFFFF00u), 0, sA + i * (NT * 16));
                 } else {
                     glds16(ok ? a_ptr[i] + (a_pix0[i] + (int)(tapoff2 >> 1)) : p.zero, sA + i * (NT * 16));
@@ -1628,6 +1642,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
                 e_nxt = ktab[ktc + 1 < nk ? ktc + 1 : nk - 1];
             }
             tapoff2 = ktab_bytes(e_cur); tapsel = ktab_sel(e_cur);
+#ifdef PB_DIAG
+            // PB_GEMM_ABL=4, see gemm_kernel's stage() (modes 8 and 16 cost this kernel registers it does not have: spills inside the K loop)
+            tapsel = ((p.ablate & 4) && (tapsel >> 8) != 1u) ? 0xFFFFFFFFu : tapsel;
+#endif
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1878,7 +1896,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         // epilogue address arithmetic out of the tile loop and carry it (in VGPRs the K loop needs) across the MFMA phases
         int elane = lane;
         asm volatile("" : "+v"(elane));
+#ifdef PB_DIAG
+        if (!MX && (pe.ablate & 3)) {
+#else
         if (!MX && pe.ablate) {                  // (fp16-only builds: the MX builds have no register to spare for a diagnostic)
+#endif
             // timing-only ablations (PB_GEMM_ABL): what a tile costs with no epilogue at all (1) / with the cheapest imaginable one (2:
             // 64 packed-fp16 buffer stores in the MFMA layout, no bias, no activation, no copies)
             if (pe.ablate == 2 && pe.out) {
