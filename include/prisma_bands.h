@@ -293,8 +293,10 @@ typedef struct {
  * masks, bit 2 = accumulate the timings over successive infer calls (pb_get_kernel_stats then reports the sums since
  * this call) instead of restarting at every infer call. */
 int pb_set_profiling(pb_ctx *ctx, int enabled);
-/* Tuning / A-B switches: "gemm_tile", "conv_tile" = 0 auto, 1 128x128, 2 256x256 ping-pong, 3 256x32, 9 256x64
- * (prisma_amd/csrc/gemm.h; the other round-1 variants were measured slower and removed). */
+/* Tuning / A-B switches: "gemm_tile", "conv_tile" = 0 auto, 1 128x128, 2 256x256 ping-pong, 3 256x32, 9 256x64,
+ * 12 128x96 (convolutions with N <= 96) (prisma_amd/csrc/gemm.h; the other round-1 variants were measured slower and
+ * removed); "tile_n96" = 0 / 1: whether auto gives convolutions with 64 < N <= 96 the 128x96 tile (process-wide,
+ * default 1); "host_chunk", "op_splitk": see INTEGRATION.md. */
 int pb_set_option(pb_ctx *ctx, const char *key, int value);
 int pb_get_kernel_stats(pb_ctx *ctx, pb_kernel_stat *out, int cap);
 

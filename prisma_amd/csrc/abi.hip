@@ -861,6 +861,7 @@ int pb_set_option(pb_ctx *c, const char *key, int value) {
     else if (!strcmp(key, "conv_tile")) *v = value;
     else if (!strcmp(key, "host_chunk")) c->host_chunk = value;
     else if (!strcmp(key, "op_splitk")) c->op_splitk = value;
+    else if (!strcmp(key, "tile_n96")) pb_gemm_set_n96(value);         // process-wide (gemm.h): A/B of the 128 x 96 tile inside one test process
     else PB_CHECK(false, PB_ERR_ARG, "unknown option '%s'", key);
     return 0;
 }

@@ -7,7 +7,7 @@ enum { EPI_STD = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_PIXSHUF = 3, EPI_PATCH = 4, 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4,
        ACT_GRU_ZR = 5,     // N = 256 = [z | r]: z = sigmoid -> out; r = sigmoid, r * gru_h -> gru_rh (ld 384), nothing to out
        ACT_GRU_Q = 6 };    // N = 128: q = tanh; h = (1 - z) h + z q with z from gru_z (ld 256), h in gru_h (fp32, ld 128); h -> out
-enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256x64 = 9 };     // (4, 5, 7, 8, 10: round-1 variants; 11: round 5's 384 x 128 ping-pong
+enum { TILE_AUTO = 0, TILE_128 = 1, TILE_256 = 2, TILE_N32 = 3, TILE_256x64 = 9, TILE_128x96 = 12 };     // (4, 5, 7, 8, 10: round-1 variants; 11: round 5's 384 x 128 ping-pong
                                                                                        // kernel for N <= 128 - measured slower or equal, removed: EXPERIMENTS.md)
 
 struct GemmArgs {
@@ -117,4 +117,6 @@ int launch_conv3x3_c64(hipStream_t stream, const GemmArgs &a);
 // Name of the kernel the last launch_gemm call of this thread launched, spelled like the symbol rocprofv3 reports
 // ("gemm8_kernel<1, 0, 0, true, false>"): the engines' per-launch timers are keyed by it, so a bench family IS one symbol.
 const char *pb_gemm_last_kernel();
+// 1 (default; PB_TILE_N96=0 turns it off): TILE_AUTO gives convolutions with 64 < N <= 96 the 128 x 96 tile.  Process-wide; pb_set_option "tile_n96".
+void pb_gemm_set_n96(int on);
 void pb_gemm_set_last_kernel(const char *name);

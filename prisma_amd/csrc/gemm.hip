@@ -24,6 +24,8 @@ int pb_gemm_conv_pixshuf_mx(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_head_f16(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_head_mx(hipStream_t s, int tile, const GemmArgs &a);
 
+static int g_n96 = -1;                          // -1: not read yet (PB_TILE_N96, default 1)
+void pb_gemm_set_n96(int on) { g_n96 = on ? 1 : 0; }
 static thread_local const char *g_last_kernel = "";
 const char *pb_gemm_last_kernel() { return g_last_kernel; }
 void pb_gemm_set_last_kernel(const char *name) { g_last_kernel = name; }
@@ -76,6 +78,11 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         // (round 5 built a 384 x 128 ping-pong kernel for 64 < N <= 128 - K loop at 70 % of the matrix pipe against this tile's ~45 % - whose one
         // workgroup per CU exposed its set-up and epilogue: 35.5 against 34.6 ms on the bands' launches; under two-band overlap, round 6, +0.2 ... 0.8 %
         // of a step (profiles/r06b_overlap_n128.txt, r06c_bench_n128_line.json).  Not a gain worth 1300 lines and two translation units: removed.)
+        // 64 < N <= 96 (RAFT / GMFlow encoder stage 2 carries 96 channels): the 128 x 96 tile - a quarter fewer MFMAs, B rows and fragment reads than
+        // the 128-wide tile spends on 32 padding columns; its third column block has a plain single-column epilogue (gemm_kernels.h single_col_epilogue)
+        if (g_n96 < 0) g_n96 = pb_env_int("PB_TILE_N96", 1);
+        if (tile == TILE_128 && g_n96 && amode == A_CONV && epi == EPI_STD && a.N > 64 && a.N <= 96 && (a.act == ACT_NONE || a.act == ACT_RELU) && !a.out2 && !a.o8_off)
+            tile = TILE_128x96;
         static int small_tile = -1;
         if (small_tile < 0) { const char *e = getenv("PB_TILE_SMALL"); small_tile = e ? atoi(e) : TILE_128; }
         if (tile == TILE_128 && (epi == EPI_STD || epi == EPI_F32) && small_tile != TILE_128) tile = small_tile;
@@ -98,6 +105,9 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
             if (S > 1) a.splitk = S;
         }
     }
+    if (tile == TILE_128x96)
+        PB_CHECK(amode == A_CONV && epi == EPI_STD && a.N <= 96 && (a.act == ACT_NONE || a.act == ACT_RELU) && !a.out2 && !a.o8_off, -1,
+                 "gemm: the 128 x 96 tile serves convolutions with N <= 96, a linear / ReLU output and no copies (N = %d, act %d)", a.N, a.act);
     if (epi == EPI_RESID) PB_CHECK(a.resid && (int64_t)a.M * a.ldr * 4 < (1LL << 32) - (1 << 20), -1, "residual epilogue: the stream (%d rows) must fit a 32-bit buffer resource", a.M);
     if (epi == EPI_QKV) PB_CHECK(a.D % (tile == TILE_128 ? 128 : 256) == 0 && a.ntp % 8 == 0, -1, "qkv epilogue: D=%d ntp=%d", a.D, a.ntp);
     {   // PB_EPI_REPORT=1 (diagnostic): EPI_STD launches whose activation / skip / copy combination is not one of the

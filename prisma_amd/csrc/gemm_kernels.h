@@ -390,9 +390,10 @@ __device__ __forceinline__ void resid_io_atomic(const GemmArgs &p, f32x16 (&acc)
 // column 2j + tn : lane li then holds columns 2 li and 2 li + 1 of a row in acc[.][0] / acc[.][1], packs them
 // into one dword, and 32 lanes cover 64 consecutive fp16 columns = 128 bytes.  Only the DMA source rows of
 // the weight operand change; nothing moves between lanes.
+// TN == 3 (the 128 x 96 tile, EPI_STD): the first two column blocks of a wave are such a pair, the third keeps its natural order (col_map3)
 template <int EPI, int TN>
 __host__ __device__ constexpr bool epi_interleaved() {
-    return TN == 2 && (EPI == EPI_STD || EPI == EPI_QKV || EPI == EPI_PIXSHUF || EPI == EPI_RESID);
+    return (TN == 2 && (EPI == EPI_STD || EPI == EPI_QKV || EPI == EPI_PIXSHUF || EPI == EPI_RESID)) || (TN == 3 && EPI == EPI_STD);
 }
 #include "pixshuf_walk.h"   // pixshuf_first_pixel / pixshuf_wraps: plain C++, also compiled on the host by tests/test_pixshuf_walk_cpu.py
 #include "conv_walk.h"      // tap_range / tap_mask / conv_ktab_word / ktab_bytes / ktab_sel: plain C++, also compiled on the host by tests/test_conv_walk_cpu.py
@@ -403,6 +404,84 @@ __device__ __forceinline__ unsigned conv_ktab_entry(const GemmArgs &p, int cld, 
 
 __device__ __forceinline__ int col_map(int r, bool il) {        // tile-local B row -> tile-local output column
     return il ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;
+}
+template <int TN>
+__device__ __forceinline__ int col_map_tn(int r, bool il) {     // ... of a wave that owns TN column blocks: an odd third block is not part of a pair
+    return (TN == 3 && r >= 64) ? r : col_map(r, il);
+}
+
+// The third column block of a 128 x 96 tile's wave (TN == 3): a lane owns ONE column (li) and 16 rows of it.  EPI_STD with what the layers that
+// have 64 < N <= 96 use (RAFT / GMFlow encoder stage 2: bias, ReLU in front of / behind one or two skip tensors, plain / [hi | lo] / [hi | hi8 | lo8]
+// maps) - launch_gemm refuses the tile for anything else.  Same arithmetic, in the same order, as direct_epilogue_*: a launch's bytes do not
+// depend on the tile it ran on (tests/test_gpu_ops.py).
+template <int TM, bool MX>
+__device__ __forceinline__ void single_col_epilogue(const GemmArgs &p, f32x16 (&acc)[TM][3], int wave_m0, int col0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int n = col0 + li;
+    if (n >= p.N) return;
+    const float b = p.bias ? p.bias[n] : 0.f;
+    const int C = p.lo_off;
+    const float s_hi = __builtin_ldexpf(1.f, p.lo8_pa), s_lo = __builtin_ldexpf(1.f, p.lo8_pa + 12), inv_lo = __builtin_ldexpf(1.f, -(p.lo8_pa + 12));
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        int64_t pix[16];
+        float v[16];
+        bool ok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = wave_m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            ok[r] = m < p.M;
+            pix[r] = (int64_t)(ok[r] ? m : p.M - 1) * p.ldo;
+            v[r] = acc[tm][2][r] + b;
+        }
+        if (p.pre_relu) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const f16 *add = k == 0 ? p.add1 : p.add2;
+            if (!add) continue;
+            f16 h[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[r] = add[pix[r] + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += (float)h[r];
+            if (C) {
+                if constexpr (MX) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned char u = *((const unsigned char *)(add + pix[r]) + 3 * C + n);
+                        v[r] += __builtin_amdgcn_cvt_f32_fp8((int)u, 0) * inv_lo;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h[r] = add[pix[r] + n + C];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += (float)h[r];
+                }
+            }
+        }
+        if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (!ok[r]) continue;
+            const f16 h = (f16)v[r];
+            p.out[pix[r] + n] = h;
+            if (C) {
+                if constexpr (MX) {
+                    unsigned char *bp = (unsigned char *)(p.out + pix[r]);
+                    bp[2 * C + n] = (unsigned char)pb_fp8x2((float)h * s_hi, 0.f);
+                    bp[3 * C + n] = (unsigned char)pb_fp8x2((v[r] - (float)h) * s_lo, 0.f);
+                } else {
+                    p.out[pix[r] + n + C] = (f16)(v[r] - (float)h);
+                }
+            }
+        }
+    }
 }
 
 // LOM: 0 plain outputs, 1 split maps with fp16 residuals ([hi | lo]), 2 split maps with e4m3 residual parts (gemm.h lo8); each mode
@@ -1049,6 +1128,15 @@ __device__ __forceinline__ void direct_epilogue_f16(const GemmArgs &p, f32x16 (&
 template <int EPI, int TM, int TN, bool MX>
 __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM][TN], char *smem, int wave, int lane,
                                              int wave_m0, int wave_n0, int n0) {
+    if constexpr (TN == 3) {              // 128 x 96 tile: an interleaved pair of column blocks + a single one
+        static_assert(EPI == EPI_STD, "the 96-wide tile is built for EPI_STD");
+        f32x16 pair[TM][2];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) { pair[tm][0] = acc[tm][0]; pair[tm][1] = acc[tm][1]; }
+        direct_epilogue_f16<EPI, TM, MX>(p, pair, wave_m0, wave_n0, lane);
+        single_col_epilogue<TM, MX>(p, acc, wave_m0, wave_n0 + 64, lane);
+        return;
+    }
     constexpr int ES = TN * 32 + 4;
     constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * ES * 4;
     constexpr bool IL = epi_interleaved<EPI, TN>();
@@ -1095,7 +1183,7 @@ __device__ __forceinline__ void run_epilogue(const GemmArgs &p, f32x16 (&acc)[TM
         }
     }
 
-    if constexpr (IL) {
+    if constexpr (IL && TN == 2) {
         const bool direct = EPI != EPI_PIXSHUF || (p.ps_co & 63) == 0;
         if (direct) {
             direct_epilogue_f16<EPI, TM, MX>(p, acc, wave_m0, wave_n0, lane);
@@ -1225,7 +1313,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     const f16 *b_ptr[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-        b_ptr[i] = p.W + (int64_t)(n0 + col_map(srow + i * (NT / 8), epi_interleaved<EPI, TN>())) * p.K + cg * 8;
+        b_ptr[i] = p.W + (int64_t)(n0 + col_map_tn<TN>(srow + i * (NT / 8), epi_interleaved<EPI, TN>())) * p.K + cg * 8;
 
     int c_ky = 0, c_kx = 0, c_c0 = 0;                       // conv tap state of the NEXT stage call (!KT builds)
     const int nk = p.K >> 6;
@@ -2023,7 +2111,7 @@ int launch_t(hipStream_t stream, const GemmArgs &a) {
     constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * (TN * 32 + 4) * 4;
     constexpr int STG = NS * STAGE + (AMODE == A_CONV && BN != 64 ? KTAB_BYTES : 0);          // (+ the conv K-walk table, gemm_kernel KT)
     constexpr int SMEM = STG > WM * WN * EPIB ? STG : WM * WN * EPIB;
-    if constexpr (!BUFP && ((BM == 128 && BN == 128) || NS == 3 || BN == 64)) {       // the small tiles also have a buffer-path build (BN == 64: 256 x 64 and 64 x 64)
+    if constexpr (!BUFP && ((BM == 128 && BN == 128) || NS == 3 || BN == 64 || BN == 96)) {       // the small tiles also have a buffer-path build (BN == 64: 256 x 64 and 64 x 64)
         GemmArgs b = a;
         b.bufmode = buffer_mode(AMODE, a, BM);
         if (b.bufmode) return launch_t<BM, BN, WM, WN, AMODE, EPI, MX, true, NS>(stream, b);
@@ -2063,6 +2151,8 @@ int launch_tile(hipStream_t s, int tile, const GemmArgs &a) {
         if (tile == TILE_256) return launch_g8<AMODE, EPI, MX>(s, a);
         if constexpr (EPI == EPI_STD) {
             if (tile == TILE_256x64) return launch_t<256, 64, 4, 1, AMODE, EPI, MX>(s, a);
+            // 64 < N <= 96 (RAFT / GMFlow encoder stage 2): four waves of 32 x 96, a quarter fewer MFMAs and B rows than the 128-wide tile spends on padding columns
+            if constexpr (AMODE == A_CONV) if (tile == TILE_128x96) return launch_t<128, 96, 4, 1, AMODE, EPI, MX>(s, a);
             // (round 3, measured and removed: launch_t<256, 128, 4, 2, AMODE, EPI, MX, false, 3> - 8 waves of 64 x 64, three LDS stages two K
             // tiles ahead behind bare barriers, 144 KB, one workgroup per CU - against this tile's two workgroups per CU: update block 35.4 ->
             // 36.7 ms, RAFT encoders 19.1 -> 20.0, DPT head 12.5 -> 13.4 on one box; these launches are not waiting on DMA latency)

@@ -80,6 +80,20 @@ def test_sequence_batching_and_directions_agree(net):
     assert f75.shape == (1, 1, 90, 126, 2) and rgb75.shape == (1, 1, 90, 126, 3) and np.isfinite(f75).all()
 
 
+def test_backbone_96_wide_tile_does_not_change_a_bit(net):
+    """CNNEncoder's 96-channel stage (bands/gmflow/backbone.py:66-72) on the 128 x 96 tile (gemm.h TILE_128x96; fp16 residual planes here, where
+    flow_raft's maps carry e4m3 ones): the bytes of the 128 x 128 tile ("tile_n96" = 0)."""
+    fr = synth.frame_pair_sequence(2, 120, 168, seed=9)
+    got = net.infer_sequence(fr, scale=1.0, backward=True)
+    net.set_option("tile_n96", 0)
+    try:
+        ref = net.infer_sequence(fr, scale=1.0, backward=True)
+    finally:
+        net.set_option("tile_n96", 1)
+    for a, b in zip(got, ref):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_fast_mode_runs(golden_dir):
     z = np.load(os.path.join(golden_dir, "gmflow_125x157.npz"))
     h, w = [int(v) for v in z["hw"]]

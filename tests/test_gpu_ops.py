@@ -145,6 +145,30 @@ def test_split_k_equals_one_pass(ops):
         ops.set_option("conv_tile", 0)
 
 
+def test_conv2d_n96_tile_equals_128_tile(ops):
+    """The 128 x 96 tile (gemm.h TILE_128x96: convolutions with 64 < N <= 96 - RAFT / GMFlow encoder stage 2) walks K in the order of the 128 x 128
+    tile and its two epilogues (an interleaved pair of column blocks + a single block) do the pair epilogue's arithmetic: same bytes, ragged rows
+    and columns included, and within tolerance of torch."""
+    g = np.random.default_rng(96)
+    for (B, Ci, H, W, Co, ks, stride, relu) in [(2, 64, 40, 56, 96, 3, 2, False), (1, 128, 33, 47, 96, 3, 1, True), (3, 64, 19, 31, 72, 3, 1, False),
+                                                (1, 64, 24, 40, 96, 1, 2, False), (1, 192, 17, 23, 88, 3, 1, True)]:
+        x = h(g.standard_normal((B, Ci, H, W)))
+        w = h(g.standard_normal((Co, Ci, ks, ks)) / np.sqrt(Ci * ks * ks))
+        b = g.standard_normal(Co).astype(np.float32)
+        ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=stride, padding=ks // 2).numpy()
+        if relu:
+            ref = np.maximum(ref, 0)
+        outs = {}
+        for tile in (1, 12):
+            ops.set_option("conv_tile", tile)
+            try:
+                outs[tile] = ops.conv2d(x, w, b, stride=stride, relu_out=relu)
+            finally:
+                ops.set_option("conv_tile", 0)
+        assert np.array_equal(outs[1], outs[12]), (Ci, Co, ks, stride, float(np.abs(outs[1] - outs[12]).max()))
+        assert relmax(outs[12], ref) < 1.5e-3, (Ci, Co, relmax(outs[12], ref))
+
+
 @pytest.mark.parametrize("tile", [2, 4])
 def test_conv2d_wide_tiles(ops, tile):
     ops.set_option("conv_tile", tile)

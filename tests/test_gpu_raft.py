@@ -243,6 +243,27 @@ def test_volume_kernel_is_bit_identical_to_the_generic_gemm(tmp_path):
     assert np.array_equal(np.load(out), flow)
 
 
+@pytest.mark.parametrize("prec", [1, 0])
+def test_encoder_96_wide_tile_does_not_change_a_bit(prec):
+    """Stage 2 of both encoders (64 -> 96 and 96 -> 96 convolutions, 96 carried as 128 channels in the maps) runs on the 128 x 96 tile
+    (gemm.h TILE_128x96: a quarter fewer MFMAs than the 128-wide tile spends on padding columns).  Same K order, same epilogue arithmetic:
+    the flow of a ragged three-frame clip is the byte string the 128 x 128 tile gives ("tile_n96" = 0), in split-fp16 (e4m3 residual
+    maps, instance norm in fnet, folded BatchNorm + skip adds in cnet) and in the single-pass mode."""
+    fr = synth.frame_pair_sequence(3, 131, 181, seed=34)
+    n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0, precision=prec)
+    try:
+        got = n.infer_sequence(fr, scale=1.0, iters=4, backward=True)
+        n.set_option("tile_n96", 0)
+        try:
+            ref = n.infer_sequence(fr, scale=1.0, iters=4, backward=True)
+        finally:
+            n.set_option("tile_n96", 1)
+    finally:
+        n.close()
+    for a, b in zip(got, ref):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 def test_host_pipeline_chunks_equal_one_call(net, pinned):
     """pb_flow_infer_sequence is a three-stage pipeline over chunks of frame pairs (H2D of chunk i + 1, the band on chunk i, D2H of chunk
