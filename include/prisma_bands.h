@@ -295,8 +295,9 @@ typedef struct {
 int pb_set_profiling(pb_ctx *ctx, int enabled);
 /* Tuning / A-B switches: "gemm_tile", "conv_tile" = 0 auto, 1 128x128, 2 256x256 ping-pong, 3 256x32, 9 256x64,
  * 12 128x96 (convolutions with N <= 96) (prisma_amd/csrc/gemm.h; the other round-1 variants were measured slower and
- * removed); "tile_n96" = 0 / 1: whether auto gives convolutions with 64 < N <= 96 the 128x96 tile (process-wide,
- * default 1); "host_chunk", "op_splitk": see INTEGRATION.md. */
+ * removed); "tile_n96" (process-wide) = 0: convolutions with 64 < N <= 96 stay on the 128x128 tile, 1: auto gives them
+ * the 128x96 tile (same bytes), 2 (default): ... and the packed-channel K axis where the weights carry one (RAFT encoder
+ * stage 2: another summation order); "host_chunk", "op_splitk": see INTEGRATION.md. */
 int pb_set_option(pb_ctx *ctx, const char *key, int value);
 int pb_get_kernel_stats(pb_ctx *ctx, pb_kernel_stat *out, int cap);
 

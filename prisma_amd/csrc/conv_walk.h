@@ -38,3 +38,35 @@ PB_CW unsigned conv_ktab_word(int tapin, int cKH, int cKW, int cC, int cW, int c
 }
 PB_CW unsigned ktab_bytes(unsigned e) { return (e >> 6) << 4; }
 PB_CW unsigned ktab_sel(unsigned e) { return (1u << ((e >> 3) & 7)) | (256u << (e & 7)); }
+
+// ---- chunk walk (the 128 x 96 tile: gemm_kernels.h CW builds): one table word PER 16-BYTE CHUNK of a K tile's 128-byte row (8 per tile; a lane always
+// stages the same chunk index, so it reads its own word), which lets a K tile take its chunks from several taps.  Word format as above, the chunk's own
+// offset inside the pixel included; kNoChunk = a chunk of padding (the DMA reads zeros, the weights hold zeros).
+constexpr unsigned kNoChunk = 0xFFFFFFFFu;
+PB_CW unsigned ktab_sel_chunk(unsigned e) { return e == kNoChunk ? kNoChunk : ktab_sel(e); }       // bits no tap mask has: the tap test fails for every pixel
+// classic K layouts (everything conv_ktab_word describes): the tile's word plus the chunk
+PB_CW unsigned conv_ctab_classic(unsigned tile_word, int c) { return tile_word + ((unsigned)c << 6); }
+// Packed-channel K axis over mx3 maps (pixel = [hi fp16 (cpad) | hi8 (cpad bytes) | lo8 (cpad bytes)], gemm.h lo8) whose cpad channels hold creal < cpad
+// real ones (creal % 16 == 0: RAFT's encoder stage 2 carries 96 channels as 128): only real channels are walked.  First every tap's fp16 chunks
+// (creal / 8 per tap, tap-major), padded to whole tiles - cw3_tiles16 of them - then, per tap, its hi8 chunks and its lo8 chunks (creal / 16 each), padded
+// again (cw3_tiles8).  9 taps x 96 channels: 14 + 14 tiles where the per-tap layout walks 9 x (2 + 2).  q = tile * 8 + chunk.
+PB_CW int cw3_tiles16(int taps, int creal) { return (taps * (creal / 8) + 7) / 8; }
+PB_CW int cw3_tiles8(int taps, int creal) { return (taps * 2 * (creal / 16) + 7) / 8; }
+PB_CW unsigned conv_cw3_word(int cKW, int taps, int creal, int cpad, int cW, int cld, int q) {
+    const int n16 = taps * (creal / 8), q8 = cw3_tiles16(taps, creal) * 8;
+    int tp, off;                                            // tap, byte offset inside the pixel
+    if (q < q8) {
+        if (q >= n16) return kNoChunk;
+        const int per = creal / 8;
+        tp = q / per; off = (q - tp * per) * 16;
+    } else {
+        const int per = creal / 16, r = q - q8;
+        if (r >= taps * 2 * per) return kNoChunk;
+        tp = r / (2 * per);
+        const int rr = r - tp * 2 * per, part = rr / per;
+        off = (2 + part) * cpad + (rr - part * per) * 16;
+    }
+    const int ky = tp / cKW, kx = tp - ky * cKW;
+    const unsigned bytes = (unsigned)((ky * cW + kx) * cld * 2 + off);
+    return ((bytes >> 4) << 6) | (unsigned)(ky << 3) | (unsigned)kx;
+}

@@ -54,6 +54,10 @@ struct PackedW {
     int mx2 = 0;             // weights-only split with the residual as e4m3: per tap [w_hi fp16 (Cseg) | w_lo8 (Cseg bytes)] = 1.5 Cseg halfs
     // conv weights in slice-major K order (gemm.h cTapInner): the (taps x K / (64 taps)) grid of 128-byte blocks of every row, transposed
     int tapin = 0, taps = 1;
+    // packed-channel copy (gemm.h Wcw, conv_walk.h conv_cw3_word): mx3 convolution weights whose Cseg input channels hold cwC < Cseg real ones, with a K axis
+    // that lists only those - read by the 128 x 96 tile's chunk walk (EngineBase::pack_conv builds it for 64 < N <= 96)
+    f16 *wcw = nullptr;
+    int Kcw = 0, nk16cw = 0, cwC = 0;
 };
 unsigned char pb_f32_to_e4m3(float x);     // OCP e4m3fn, round to nearest even, saturating (engine.hip)
 // slice-major K order of packed conv weights (gemm.h cTapInner): every row of `rowlen` halfs is a (taps x S) grid of 128-byte blocks; transposed in place

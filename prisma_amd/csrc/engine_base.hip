@@ -1,4 +1,5 @@
 #include "engine_base.h"
+#include "conv_walk.h"      // cw3_tiles16 / cw3_tiles8: the packed-channel K axis the kernels walk
 
 #include <math.h>
 
@@ -196,7 +197,33 @@ int EngineBase::pack_conv(const std::string &name, bool has_bias, const float *s
     }
     int r = pack(g.data(), co, K, K, out, bb.data(), kh * kw, sa);
     out.Kreal = kh * kw * ci;
-    return r;
+    if (r) return r;
+    // RAFT's encoder stage 2: 96 -> 96 channels carried as 128.  The per-tap layout walks 9 x (2 + 2) K tiles of which a quarter multiply padding
+    // channels; the packed-channel copy (conv_walk.h conv_cw3_word: 14 + 14 tiles) is what the 128 x 96 tile reads (PB_CW3=0: not built)
+    static const int cw3 = pb_env_int("PB_CW3", 1);
+    if (cw3 && out.mx3 && !out.tapin && kh * kw > 1 && ci % 16 == 0 && ci < cip && co > 64 && co <= 96) {
+        const int taps = kh * kw, nk16 = cw3_tiles16(taps, ci), nk8 = cw3_tiles8(taps, ci), pw = out.mx_pw;
+        const int64_t Kc = (int64_t)(nk16 + nk8) * 64, Np = round_up(co, 256);
+        std::vector<f16> h((size_t)Np * Kc, (f16)0.f);
+        for (int o = 0; o < co; ++o) {
+            f16 *row = h.data() + (size_t)o * Kc;
+            unsigned char *row8 = (unsigned char *)(row + (size_t)nk16 * 64);
+            for (int tp = 0; tp < taps; ++tp)
+                for (int c = 0; c < ci; ++c) {
+                    const float v = g[(size_t)o * K + tp * cip + c];
+                    const f16 hi = (f16)v;
+                    row[tp * ci + c] = hi;                                                   // fp16 chunks: tap-major, ci / 8 per tap
+                    row8[(tp * 2 + 0) * ci + c] = pb_f32_to_e4m3(ldexpf(v - (float)hi, pw));   // meets the map's hi8 chunks
+                    row8[(tp * 2 + 1) * ci + c] = pb_f32_to_e4m3(ldexpf((float)hi, pw - 12));  // ... and its lo8 chunks
+                }
+        }
+        void *pc = nullptr;
+        PB_HIP(hipMalloc(&pc, h.size() * 2));
+        owned_.push_back(pc);
+        PB_HIP(hipMemcpy(pc, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        out.wcw = (f16 *)pc; out.Kcw = (int)Kc; out.nk16cw = nk16; out.cwC = ci;
+    }
+    return 0;
 }
 
 void EngineBase::set_weights(GemmArgs &a, const PackedW &w, bool is_conv) const {
@@ -220,6 +247,7 @@ void EngineBase::set_weights(GemmArgs &a, const PackedW &w, bool is_conv) const 
             a.cC = 2 * w.Cseg;
             a.mx_period = 2 * w.Cseg / 64;
             if (tapin) { a.mx_period = 0; a.nk16 = w.nk16 * w.taps; }
+            if (w.wcw) { a.Wcw = w.wcw; a.Kcw = w.Kcw; a.nk16cw = w.nk16cw; a.cwC = w.cwC; a.cwPad = w.Cseg; a.cwTaps = w.taps; }
         }
         return;
     }

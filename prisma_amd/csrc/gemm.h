@@ -103,6 +103,11 @@ struct GemmArgs {
     int splitk = 1, sk_phase = 0;
     float *sk_ws = nullptr;
     int64_t sk_cap = 0;
+    // packed-channel K axis (conv_walk.h conv_cw3_word; the 128 x 96 tile only): a second copy of the weights whose K axis lists only the cwC real
+    // channels of every tap of an mx3 map that carries them as cwPad; launch_gemm switches W / K / nk16 to it when it gives the launch that tile
+    // (and sets cwalk = 1: the kernel then builds its chunk table from cwC / cwPad / cwTaps)
+    const f16 *Wcw = nullptr;
+    int Kcw = 0, nk16cw = 0, cwC = 0, cwPad = 0, cwTaps = 0, cwalk = 0;
     int ablate = 0;                       // PB_GEMM_ABL (timing only, wrong results): 1 no epilogue at all, 2 bare packed-fp16 buffer stores instead of it
 };
 
@@ -117,6 +122,7 @@ int launch_conv3x3_c64(hipStream_t stream, const GemmArgs &a);
 // Name of the kernel the last launch_gemm call of this thread launched, spelled like the symbol rocprofv3 reports
 // ("gemm8_kernel<1, 0, 0, true, false>"): the engines' per-launch timers are keyed by it, so a bench family IS one symbol.
 const char *pb_gemm_last_kernel();
-// 1 (default; PB_TILE_N96=0 turns it off): TILE_AUTO gives convolutions with 64 < N <= 96 the 128 x 96 tile.  Process-wide; pb_set_option "tile_n96".
-void pb_gemm_set_n96(int on);
+// PB_TILE_N96 / pb_set_option "tile_n96" (process-wide): 0 = convolutions with 64 < N <= 96 stay on the 128 x 128 tile; 1 = TILE_AUTO gives them the
+// 128 x 96 tile (same bytes); 2 (default) = ... and the packed-channel K axis where the weights carry one (GemmArgs::Wcw: another summation order)
+void pb_gemm_set_n96(int mode);
 void pb_gemm_set_last_kernel(const char *name);

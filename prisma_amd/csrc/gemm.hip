@@ -24,8 +24,8 @@ int pb_gemm_conv_pixshuf_mx(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_head_f16(hipStream_t s, int tile, const GemmArgs &a);
 int pb_gemm_conv_head_mx(hipStream_t s, int tile, const GemmArgs &a);
 
-static int g_n96 = -1;                          // -1: not read yet (PB_TILE_N96, default 1)
-void pb_gemm_set_n96(int on) { g_n96 = on ? 1 : 0; }
+static int g_n96 = -1;                          // -1: not read yet (PB_TILE_N96, default 2: gemm.h pb_gemm_set_n96)
+void pb_gemm_set_n96(int mode) { g_n96 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 static thread_local const char *g_last_kernel = "";
 const char *pb_gemm_last_kernel() { return g_last_kernel; }
 void pb_gemm_set_last_kernel(const char *name) { g_last_kernel = name; }
@@ -80,7 +80,7 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
         // of a step (profiles/r06b_overlap_n128.txt, r06c_bench_n128_line.json).  Not a gain worth 1300 lines and two translation units: removed.)
         // 64 < N <= 96 (RAFT / GMFlow encoder stage 2 carries 96 channels): the 128 x 96 tile - a quarter fewer MFMAs, B rows and fragment reads than
         // the 128-wide tile spends on 32 padding columns; its third column block has a plain single-column epilogue (gemm_kernels.h single_col_epilogue)
-        if (g_n96 < 0) g_n96 = pb_env_int("PB_TILE_N96", 1);
+        if (g_n96 < 0) pb_gemm_set_n96(pb_env_int("PB_TILE_N96", 2));
         if (tile == TILE_128 && g_n96 && amode == A_CONV && epi == EPI_STD && a.N > 64 && a.N <= 96 && (a.act == ACT_NONE || a.act == ACT_RELU) && !a.out2 && !a.o8_off)
             tile = TILE_128x96;
         static int small_tile = -1;
@@ -105,6 +105,10 @@ int launch_gemm(hipStream_t stream, int amode, int epi, int tile, const GemmArgs
             if (S > 1) a.splitk = S;
         }
     }
+    if (tile == TILE_128x96 && a.Wcw && g_n96 >= 2 && !a.cTapInner) {        // packed-channel K axis (gemm.h Wcw)
+        a.W = a.Wcw; a.K = a.Kcw; a.nk16 = a.nk16cw; a.mx_period = 0; a.kwrap = 0; a.kshift = 0; a.cwalk = 1;
+    }
+    if (tile == TILE_128x96) PB_CHECK(a.K / 64 <= 128, -1, "conv: the 128 x 96 tile's chunk table holds 128 K tiles (K = %d)", a.K);
     if (tile == TILE_128x96)
         PB_CHECK(amode == A_CONV && epi == EPI_STD && a.N <= 96 && (a.act == ACT_NONE || a.act == ACT_RELU) && !a.out2 && !a.o8_off, -1,
                  "gemm: the 128 x 96 tile serves convolutions with N <= 96, a linear / ReLU output and no copies (N = %d, act %d)", a.N, a.act);

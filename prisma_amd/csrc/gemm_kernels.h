@@ -398,6 +398,7 @@ __host__ __device__ constexpr bool epi_interleaved() {
 #include "pixshuf_walk.h"   // pixshuf_first_pixel / pixshuf_wraps: plain C++, also compiled on the host by tests/test_pixshuf_walk_cpu.py
 #include "conv_walk.h"      // tap_range / tap_mask / conv_ktab_word / ktab_bytes / ktab_sel: plain C++, also compiled on the host by tests/test_conv_walk_cpu.py
 constexpr int KTAB_BYTES = 2048;                                          // K <= 512 tiles (checked by the launchers)
+constexpr int KTAB_CW_BYTES = 4096;                                       // the 128 x 96 tile's chunk table: 8 words per tile, K <= 128 tiles
 __device__ __forceinline__ unsigned conv_ktab_entry(const GemmArgs &p, int cld, int t) {
     return conv_ktab_word(p.cTapInner, p.cKH, p.cKW, p.cC, p.cW, cld, p.kwrap, p.kshift, t);
 }
@@ -1288,6 +1289,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     const int cld = p.cLd ? p.cLd : p.cC, padx = p.cPadX >= 0 ? p.cPadX : p.cPad;
     const int srow = tid >> 3;                              // + i * (NT/8)
     const int cg = (tid & 7) ^ ((tid >> 4) & 7);            // swizzled global chunk for this LDS slot
+    // CW (the 128 x 96 tile's convolutions): the K walk is a table word per 16-byte CHUNK of a tile (conv_walk.h chunk walk) - a lane stages chunk cg
+    // of every tile and reads its own word - so that a K tile may mix taps (the packed-channel K axis of gemm.h Wcw); classic layouts expand into it
+    constexpr bool CW = AMODE == A_CONV && BN == 96;
     const f16 *a_ptr[NA];
     // conv: a_msk = tap_mask of the row's pixel (0 for rows >= M), a_pix0 = element offset of its tap (0, 0) inside the image (may be negative)
     unsigned a_msk[NA];
@@ -1307,7 +1311,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
             const int iy0 = oy * p.cStride - p.cPad, ix0 = ox * p.cStride - padx;
             a_msk[i] = m < p.M ? tap_mask(iy0, ix0, p.cH, p.cW) : 0u;
             a_pix0[i] = (iy0 * p.cW + ix0) * cld;
-            a_ptr[i] = p.A + (int64_t)b * p.cH * p.cW * cld + cg * 8;
+            a_ptr[i] = p.A + (int64_t)b * p.cH * p.cW * cld + (CW ? 0 : cg * 8);       // (CW: the chunk's offset comes from its table word)
         }
     }
     const f16 *b_ptr[NB];
@@ -1326,9 +1330,15 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
     const unsigned *ktab = (const unsigned *)(smem + NS * STAGE);
     unsigned e_nxt = 0;                                     // table word of the next stage call, read one call ahead
     if constexpr (KT) {
-        for (int t = tid; t < nk; t += NT) ((unsigned *)(smem + NS * STAGE))[t] = conv_ktab_entry(p, cld, t);
+        if constexpr (CW) {
+            for (int q = tid; q < nk * 8; q += NT)
+                ((unsigned *)(smem + NS * STAGE))[q] = p.cwalk ? conv_cw3_word(p.cKW, p.cwTaps, p.cwC, p.cwPad, p.cW, cld, q)
+                                                               : conv_ctab_classic(conv_ktab_entry(p, cld, q >> 3), q & 7);
+        } else {
+            for (int t = tid; t < nk; t += NT) ((unsigned *)(smem + NS * STAGE))[t] = conv_ktab_entry(p, cld, t);
+        }
         __syncthreads();
-        e_nxt = ktab[k0];
+        e_nxt = CW ? ktab[k0 * 8 + cg] : ktab[k0];
     }
     // BUFP: LDS-DMA through the buffer path (see gemm8_kernel); p.bufmode 1 = whole operand, 2 = two-image window (conv)
     __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, 0u), rsW = make_rsrc(p.W, 0u);
@@ -1348,7 +1358,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if constexpr (AMODE == A_DENSE) a_voff[i] = (unsigned)((a_ptr[i] - p.A) * 2);
-            else a_voff[i] = (unsigned)((int64_t)((m0 + srow + i * (NT / 8)) / (p.cOH * p.cOW) - b0) * p.cH * p.cW * cld * 2) + cg * 16 + (unsigned)(a_pix0[i] * 2);
+            else a_voff[i] = (unsigned)((int64_t)((m0 + srow + i * (NT / 8)) / (p.cOH * p.cOW) - b0) * p.cH * p.cW * cld * 2) + (CW ? 0 : cg * 16) + (unsigned)(a_pix0[i] * 2);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) b_voff[i] = (unsigned)((b_ptr[i] - p.W) * 2);
@@ -1362,7 +1372,11 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmArgs p) {
         // scalar per K tile: the tap's element offset and its two bits of tap_mask - a DMA then costs an AND, a compare, an add and a select
         // (round 4: the per-DMA (iy * W + ix) * ld was a 64-bit mad + a 32-bit multiply, ~70 VALU cycles per DMA, 4 DMAs per 16 MFMAs)
         unsigned tapoff2 = (unsigned)(((c_ky * p.cW + c_kx) * cld + cs) * 2), tapsel = (1u << c_ky) | (256u << c_kx);
-        if constexpr (KT) {
+        if constexpr (CW) {                         // per lane: this lane's chunk of tile kt
+            const unsigned e = e_nxt;
+            e_nxt = ktab[(kt + 1 < nk ? kt + 1 : nk - 1) * 8 + cg];
+            tapoff2 = ktab_bytes(e); tapsel = ktab_sel_chunk(e);
+        } else if constexpr (KT) {
             const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)e_nxt);
             e_nxt = ktab[kt + 1 < nk ? kt + 1 : nk - 1];
             tapoff2 = ktab_bytes(e); tapsel = ktab_sel(e);
@@ -2109,7 +2123,7 @@ int launch_t(hipStream_t stream, const GemmArgs &a) {
     constexpr int TN = BN / WN / 32;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int EPIB = (EPI == EPI_QKV) ? TN * 32 * 36 * 4 : 32 * (TN * 32 + 4) * 4;
-    constexpr int STG = NS * STAGE + (AMODE == A_CONV && BN != 64 ? KTAB_BYTES : 0);          // (+ the conv K-walk table, gemm_kernel KT)
+    constexpr int STG = NS * STAGE + (AMODE == A_CONV && BN != 64 ? (BN == 96 ? KTAB_CW_BYTES : KTAB_BYTES) : 0);          // (+ the conv K-walk table, gemm_kernel KT)
     constexpr int SMEM = STG > WM * WN * EPIB ? STG : WM * WN * EPIB;
     if constexpr (!BUFP && ((BM == 128 && BN == 128) || NS == 3 || BN == 64 || BN == 96)) {       // the small tiles also have a buffer-path build (BN == 64: 256 x 64 and 64 x 64)
         GemmArgs b = a;

@@ -89,7 +89,7 @@ def test_backbone_96_wide_tile_does_not_change_a_bit(net):
     try:
         ref = net.infer_sequence(fr, scale=1.0, backward=True)
     finally:
-        net.set_option("tile_n96", 1)
+        net.set_option("tile_n96", 2)
     for a, b in zip(got, ref):
         assert np.array_equal(np.asarray(a), np.asarray(b))
 

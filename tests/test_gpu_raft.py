@@ -246,22 +246,33 @@ def test_volume_kernel_is_bit_identical_to_the_generic_gemm(tmp_path):
 @pytest.mark.parametrize("prec", [1, 0])
 def test_encoder_96_wide_tile_does_not_change_a_bit(prec):
     """Stage 2 of both encoders (64 -> 96 and 96 -> 96 convolutions, 96 carried as 128 channels in the maps) runs on the 128 x 96 tile
-    (gemm.h TILE_128x96: a quarter fewer MFMAs than the 128-wide tile spends on padding columns).  Same K order, same epilogue arithmetic:
-    the flow of a ragged three-frame clip is the byte string the 128 x 128 tile gives ("tile_n96" = 0), in split-fp16 (e4m3 residual
-    maps, instance norm in fnet, folded BatchNorm + skip adds in cnet) and in the single-pass mode."""
+    (gemm.h TILE_128x96: a quarter fewer MFMAs than the 128-wide tile spends on padding columns).  With the K axis of the 128 x 128 tile
+    ("tile_n96" = 1) it walks K in the same order and its epilogues do the same arithmetic: the flow of a ragged three-frame clip is the byte
+    string the 128 x 128 tile gives ("tile_n96" = 0), in split-fp16 (e4m3 residual maps, instance norm in fnet, folded BatchNorm + skip adds
+    in cnet) and in the single-pass mode.  The default ("tile_n96" = 2) also walks a packed-channel K axis on the 96 -> 96 convolutions of
+    the split mode (conv_walk.h conv_cw3_word: only the 96 real channels of every tap, 28 K tiles instead of 36): another summation order,
+    so equal to what a K order is worth in this precision scheme, not to the bit - measured 3.3e-4 of the range here, where the slice-major
+    order of the SAME tiles (PB_TAPIN=2) is 1.8e-4 L2 from the tap-major one on the 125 x 157 vector and the packed-channel one 1.8e-4
+    (tools/diag_cw3b.py; all three sit 2.2-2.4e-4 L2 from the reference) - and the single-pass mode, which has no such copy of the weights,
+    stays equal to the bit."""
     fr = synth.frame_pair_sequence(3, 131, 181, seed=34)
     n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0, precision=prec)
     try:
-        got = n.infer_sequence(fr, scale=1.0, iters=4, backward=True)
-        n.set_option("tile_n96", 0)
-        try:
-            ref = n.infer_sequence(fr, scale=1.0, iters=4, backward=True)
-        finally:
-            n.set_option("tile_n96", 1)
+        out = {}
+        for mode in (2, 1, 0):
+            n.set_option("tile_n96", mode)
+            out[mode] = [np.asarray(a) for a in n.infer_sequence(fr, scale=1.0, iters=4, backward=True)]
     finally:
+        n.set_option("tile_n96", 2)
         n.close()
-    for a, b in zip(got, ref):
-        assert np.array_equal(np.asarray(a), np.asarray(b))
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a, b)
+    e = relmax(out[2][0], out[1][0])
+    print("\n  packed-channel K axis against the per-tap one, precision %d: relmax %.2e" % (prec, e), end="")
+    if prec == 0:
+        assert np.array_equal(out[2][0], out[1][0])
+    else:
+        assert 0 < e < 6e-4, e          # (0 would mean the packed-channel path did not run)
 
 
 @pytest.mark.parametrize("pinned", [False, True])

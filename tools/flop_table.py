@@ -31,6 +31,8 @@ def symbol(amode, epi, M, N, mx, halo=False):
         if halo:                                         # 3x3, 64 -> 64, stride 1 on mx3 maps: the halo-tiled direct kernel (halo_conv.hip)
             return "conv3x3_c64_mx2_kernel"
         return f"gemm_kernel<256, 64, 4, 1, {amode}, {epi}, true, 2, {m}>"
+    if amode == CONV and epi == STD and 64 < N <= 96:     # round 6: RAFT / GMFlow encoder stage 2 on the 128 x 96 tile (PB_TILE_N96)
+        return f"gemm_kernel<128, 96, 4, 1, {amode}, {epi}, true, 2, {m}>"
     return f"gemm_kernel<128, 128, 2, 2, {amode}, {epi}, true, 2, {m}>"
 
 

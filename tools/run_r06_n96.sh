@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the 128 x 96 tile (gemm.h TILE_128x96) on one box: its tests, then the bench with PB_TILE_N96=0 / 1 alternating
+# A/B of the 128 x 96 tile (gemm.h TILE_128x96) on one box: its tests, then the bench with PB_TILE_N96=0 / 1 / 2 alternating
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export PYTHONUNBUFFERED=1
@@ -8,7 +8,7 @@ timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_raft.py tests/
 cat $O/r06r_n96_tests.txt
 D="--steps 10 --warmup 3 --one-precision --no-cpu-baseline --host-clips 0 --no-latency --no-clock"
 for rep in 1 2; do
-  for v in 0 1; do
+  for v in 0 1 2; do
     PB_TILE_N96=$v timeout 600 python bench.py $D > $O/r06r_n96_${v}_${rep}.log 2> $O/r06r_n96_${v}_${rep}.err
     tail -1 $O/r06r_n96_${v}_${rep}.log > $O/r06r_n96_${v}_${rep}.json
   done
