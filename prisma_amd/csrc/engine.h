@@ -43,6 +43,7 @@ struct PackedW {
     f16 *w = nullptr;        // [Npad, K] fp16, K % 64 == 0
     float *bias = nullptr;   // [N] fp32 or null
     int N = 0, K = 0, Kreal = 0;
+    int Nreal = 0;           // output columns that are the layer's own when N holds padding rows (RAFT's motion conv: 126 of 128); 0 = N.  Only the FLOP / byte counters read it
     // split-fp16 packing (gemm.h kwrap): per tap the K axis holds the segments [w_hi | w_hi (if sa) | w_lo (if sw)] of Cseg
     // channels each; the activation operand must then be [hi | lo (if sa)] with Cseg channels per part
     int sa = 0, sw = 0, Cseg = 0;

@@ -300,7 +300,8 @@ int EngineBase::conv(const f16 *in, int cC, int cLd, int n, int H, int W, int kh
     const bool wide = conv_tile == TILE_256 || (conv_tile == TILE_AUTO && a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) >= 256);
     // algorithmic bytes: the input map once, the weights once, the output once (fp16)
     // one family per kernel symbol launch_gemm picks: 256 x 256 ping-pong, 256 x 64 (N <= 64), 128 x 128
-    tic(wide ? F_CONV : (conv_tile == TILE_AUTO && a.N <= 64 ? F_CONV64 : F_CONV128), 2.0 * a.M * (double)a.N * w.Kreal, 2.0 * ((double)n * H * W * cC + (double)a.N * w.Kreal + (double)a.M * a.N), w.mx3 ? 2.0 : (w.mx2 ? 1.5 : 1.0 + w.sa + w.sw));
+    const double nr = w.Nreal ? w.Nreal : a.N;       // (padding rows of the weights are not the layer's work)
+    tic(wide ? F_CONV : (conv_tile == TILE_AUTO && a.N <= 64 ? F_CONV64 : F_CONV128), 2.0 * a.M * nr * w.Kreal, 2.0 * ((double)n * H * W * cC + nr * w.Kreal + (double)a.M * nr), w.mx3 ? 2.0 : (w.mx2 ? 1.5 : 1.0 + w.sa + w.sw));
     // 64 -> 64 channels at half resolution: the halo-tiled direct kernel (halo_conv.hip) instead of the implicit GEMM
     int r = kh == 3 && kw == 3 && conv_tile == TILE_AUTO && conv3x3_c64_supported(a) ? launch_conv3x3_c64(cur_, a) : launch_gemm(cur_, A_CONV, EPI_STD, conv_tile, a);
     if (timer.enabled && !r) timer.recs[open_.back()].name = pb_gemm_last_kernel();

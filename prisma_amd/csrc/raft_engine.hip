@@ -129,7 +129,7 @@ int RaftEngine::load(const pb_tensor *w, int n) {
     if ((r = pack_conv(u + "encoder.convc2", true, nullptr, nullptr, convc2_))) return r;
     if ((r = pack_conv(u + "encoder.convf2", true, nullptr, nullptr, convf2_))) return r;
     if ((r = pack_conv(u + "encoder.conv", true, nullptr, nullptr, convm_))) return r;
-    convm_.N = 128;                                         // 126 real outputs + 2 zero rows (N must be a multiple of 8)
+    convm_.N = 128; convm_.Nreal = 126;                     // 126 real outputs + 2 zero rows (N must be a multiple of 8)
     {   // convf1 7x7 on the 2-channel flow: im2col order k = tap*2 + c, K 98 -> 128
         auto iw = tmap_.find(u + "encoder.convf1.weight"), ib = tmap_.find(u + "encoder.convf1.bias");
         PB_CHECK(iw != tmap_.end() && ib != tmap_.end(), PB_ERR_ARG, "missing convf1");
