@@ -243,6 +243,25 @@ def test_volume_kernel_is_bit_identical_to_the_generic_gemm(tmp_path):
     assert np.array_equal(np.load(out), flow)
 
 
+def test_flat_addressed_gemm_builds_give_the_same_bytes(tmp_path):
+    """Every GEMM / convolution launch whose operands fit a buffer resource stages through the buffer path (`buffer_load ... lds`, out-of-range taps
+    read zeros); operands beyond 4 GB take the flat-addressed build of the same kernel (padding taps read a zero page).  PB_GEMM_BUFFER=0 (read once
+    per process) sends every launch down the flat builds - the 128 x 96 tile's chunk walk included: same K order, same bytes."""
+    import subprocess
+    import sys
+    fr = synth.frame_pair_sequence(3, 131, 181, seed=35)
+    n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0, precision=1)
+    flow, rgb, mx = n.infer_sequence(fr, scale=1.0, iters=3, backward=True)
+    n.close()
+    out = str(tmp_path / "flat.npy")
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from prisma_amd import engine, synth; "
+            "fr = synth.frame_pair_sequence(3, 131, 181, seed=35); n = engine.FlowRaft(synth.raft_weights(seed=4321), device=0, precision=1); "
+            "f, _, _ = n.infer_sequence(fr, scale=1.0, iters=3, backward=True); np.save(%r, f)" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PB_GEMM_BUFFER="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert np.array_equal(np.load(out), flow)
+
+
 @pytest.mark.parametrize("prec", [1, 0])
 def test_encoder_96_wide_tile_does_not_change_a_bit(prec):
     """Stage 2 of both encoders (64 -> 96 and 96 -> 96 convolutions, 96 carried as 128 channels in the maps) runs on the 128 x 96 tile
