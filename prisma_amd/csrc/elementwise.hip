@@ -473,6 +473,108 @@ int launch_preprocess(hipStream_t s, const uint8_t *frames, int B, int H, int W,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// DPT head tail at the network resolution, from a LOW-resolution map (dpt.py:158-160: output_conv1 -> F.interpolate(bilinear, align_corners=True) ->
+// output_conv2 = conv3x3(F/2 -> 32), ReLU, conv1x1(32 -> 1), ReLU).  A convolution is linear and the resize is linear, so the 3 x 3 convolution's nine
+// tap products W[t] y can be taken BEFORE the resize: z[t * 32 + c] = sum_k W[c, k, t] y[k] is one 1 x 1 GEMM over output_conv1's map (288 columns, at
+// a third of the pixels), and a network pixel p is
+//     depth(p) = relu(b2 + sum_c w2[c] relu(bias[c] + sum_t [p + t inside the upsampled map] bilerp(z[t * 32 + c]; p + t))),
+// the zero padding of the convolution being "the tap's sample lies outside".  Against resizing to a [hi | hi8 | lo8] map of 128 channels (7.8 GB
+// written and read back per 32 frames) and an implicit GEMM with N = 32 over it: a third of the matrix work, a third of the bytes, and no rounding of the
+// upsampled map at all (the bilinear weights meet fp32 values).  4 lanes x 8 channels per pixel, 16 consecutive pixels of a row per wave, 4 rows per block.
+// z: [B, H, W] pixels of ldz halfs - plain fp16 (lo_off = 0), [hi | lo] fp16 pairs (lo8_pa < 0) or [hi | hi8 | lo8] (gemm.h lo8).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dpt_tail_kernel(const f16 *__restrict__ z, int H, int W, int ldz, int lo_off, int lo8_pa, float sy, float sx,
+                                                       const float *__restrict__ bias, const float *__restrict__ w2, float b2,
+                                                       float *__restrict__ out, int OH, int OW) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q4 = lane & 3, px = lane >> 2;
+    const int X = blockIdx.x * 16 + px, Y = blockIdx.y * 4 + wave, b = blockIdx.z;
+    const bool live = X < OW && Y < OH;
+    const int Xc = live ? X : 0, Yc = live ? Y : 0;
+    // the three rows / columns the taps sample: source cells and weights of F.interpolate(align_corners=True)
+    int y0[3], y1[3], x0[3], x1[3];
+    float ly[3], lx[3];
+    bool oky[3], okx[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int qy = Yc + t - 1, qx = Xc + t - 1;
+        oky[t] = qy >= 0 && qy < OH; okx[t] = qx >= 0 && qx < OW;
+        bilerp_src(oky[t] ? qy : 0, sy, H, 1, y0[t], y1[t], ly[t]);
+        bilerp_src(okx[t] ? qx : 0, sx, W, 1, x0[t], x1[t], lx[t]);
+    }
+    // one buffer resource per image: the loads below carry a 32-bit lane offset (a flat load spends two 64-bit adds per address, and there are 72 of them)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(z + (int64_t)b * H * W * ldz, (unsigned)((int64_t)H * W * ldz * 2));
+    const int lane_ch = q4 * 8;
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    typedef int i32x2v __attribute__((ext_vector_type(2)));
+    const float inv = __builtin_ldexpf(1.f, -(lo8_pa + 12));
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            if (!(oky[ky] && okx[kx])) continue;
+            const int ch = (ky * 3 + kx) * 32;
+            const int o[4] = {(y0[ky] * W + x0[kx]) * ldz, (y0[ky] * W + x1[kx]) * ldz, (y1[ky] * W + x0[kx]) * ldz, (y1[ky] * W + x1[kx]) * ldz};
+            // the four cells' weights once per tap, then acc += w hi + (w 2^-(pa + 12)) lo8 per cell: two FMAs and half a conversion per (cell, channel)
+            const float hy = 1.f - ly[ky], hx = 1.f - lx[kx];
+            const float w4[4] = {hy * hx, hy * lx[kx], ly[ky] * hx, ly[ky] * lx[kx]};
+            f16x8 h[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) h[n] = __builtin_bit_cast(f16x8, (i32x4v)__builtin_amdgcn_raw_buffer_load_b128(rs, (o[n] + ch + lane_ch) * 2, 0, 0));
+            if (lo_off && lo8_pa >= 0) {
+                int2 u[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const i32x2v t2 = (i32x2v)__builtin_amdgcn_raw_buffer_load_b64(rs, o[n] * 2 + 3 * lo_off + ch + lane_ch, 0, 0);
+                    u[n].x = t2[0]; u[n].y = t2[1];
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const float wl = w4[n] * inv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += w4[n] * (float)h[n][j];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int wv = hh ? u[n].y : u[n].x;
+                        const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(wv, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(wv, true);
+                        acc[4 * hh + 0] += wl * a[0]; acc[4 * hh + 1] += wl * a[1]; acc[4 * hh + 2] += wl * d[0]; acc[4 * hh + 3] += wl * d[1];
+                    }
+                }
+            } else if (lo_off) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const f16x8 l = __builtin_bit_cast(f16x8, (i32x4v)__builtin_amdgcn_raw_buffer_load_b128(rs, (o[n] + ch + lane_ch + lo_off) * 2, 0, 0));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += w4[n] * ((float)h[n][j] + (float)l[j]);
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += w4[n] * (float)h[n][j];
+            }
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += fmaxf(acc[j] + bias[q4 * 8 + j], 0.f) * w2[q4 * 8 + j];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (live && q4 == 0) out[((int64_t)b * OH + Y) * OW + X] = fmaxf(s + b2, 0.f);
+}
+
+int launch_dpt_tail(hipStream_t s, const f16 *z, int B, int H, int W, int ldz, int lo_off, int lo8_pa, const float *bias, const float *w2, float b2,
+                    float *out, int OH, int OW) {
+    PB_CHECK(ldz % 8 == 0 && lo_off % 8 == 0 && (int64_t)H * W * ldz * 2 < (1LL << 31), -1, "dpt tail: pixel stride %d / residual offset %d must be multiples of 8, an image below 2 GB", ldz, lo_off);
+    const float sy = bilerp_scale(H, OH, 1), sx = bilerp_scale(W, OW, 1);
+    hipLaunchKernelGGL(dpt_tail_kernel, dim3((OW + 15) / 16, (OH + 3) / 4, B), dim3(256), 0, s, z, H, W, ldz, lo_off, lo8_pa, sy, sx, bias, w2, b2, out, OH, OW);
+    PB_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_bilinear_nhwc(hipStream_t s, const f16 *x, f16 *y, int B, int H, int W, int OH, int OW, int C, int ldc,
                          int align, int lo_off, int lo8_pa) {
     PB_CHECK(C % 8 == 0 && ldc % 8 == 0, -1, "bilinear: C=%d ldc=%d must be multiples of 8", C, ldc);

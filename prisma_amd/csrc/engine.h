@@ -155,6 +155,13 @@ class DepthEngine {
     std::vector<Block> blocks_;
     float *normg_ = nullptr, *normb_ = nullptr;
     PackedW proj_[4], rs0_, rs1_, rs3_, rn_[4], outc_[4], rcu_[4][2][2], oc1_, oc2_;
+    // output_conv2's 3 x 3 weights as a 1 x 1 GEMM [9 x 32, F / 2] over output_conv1's LOW-resolution map: row t * 32 + c = tap t of output channel c
+    // (the convolution commutes with the bilinear resize in front of it; elementwise.hip dpt_tail_kernel sums the resized tap products).  PB_HEAD_TAIL=0:
+    // the round-1..5 formulation (resize to the network size, implicit GEMM with the fused 1 x 1 there); the metric head keeps that one (it needs the
+    // 32-channel activation at the network resolution)
+    PackedW wz_;
+    int head_tail_ = 1;
+    f16 *z_ = nullptr;
     float *w2_ = nullptr;
     float b2_ = 0.f;
     f16 *zero_ = nullptr;

@@ -389,6 +389,18 @@ int DepthEngine::load(const pb_tensor *w, int n) {
     if ((r = pack_conv(Hh + "resize_layers.3", oc[3], oc[3], 3, true, rs3_))) return r;
     if ((r = pack_conv(Hh + "scratch.output_conv1", F / 2, F, 3, true, oc1_))) return r;
     if ((r = pack_conv(Hh + "scratch.output_conv2.0", 32, F / 2, 3, true, oc2_))) return r;
+    head_tail_ = pb_env_int("PB_HEAD_TAIL", 1) && !cfg_.metric;
+    if (head_tail_) {
+        const int ci = F / 2, cip = cp64(ci);
+        const float *wt = need(Hh + "scratch.output_conv2.0.weight", (int64_t)32 * ci * 9);
+        if (!wt) return PB_ERR_ARG;
+        std::vector<float> g((size_t)288 * cip, 0.f);
+        for (int c = 0; c < 32; ++c)
+            for (int k = 0; k < ci; ++k)
+                for (int t = 0; t < 9; ++t) g[((size_t)t * 32 + c) * cip + k] = wt[((size_t)c * ci + k) * 9 + t];
+        if ((r = pack(g.data(), 288, cip, cip, wz_, nullptr, 1, head_sa_, head_sw_))) return r;
+        wz_.Kreal = ci;
+    }
     UP(w2_, Hh + "scratch.output_conv2.2.weight", 32);
     { NEED(b2, Hh + "scratch.output_conv2.2.bias", 1); b2_ = b2[0]; }
 #undef NEED
@@ -574,7 +586,8 @@ int DepthEngine::prepare(int B, int H, int W) {
             path_[i] = (f16 *)carve((size_t)round_up((int64_t)HB * th * tw, 256) * Fp * 2 * hs_);
         }
         o1_ = (f16 *)carve((size_t)round_up((int64_t)HB * 4 * lh_[0] * lw_[0], 256) * F2p * 2 * hs_);
-        up_ = (f16 *)carve((size_t)round_up((int64_t)HB * nh_ * nw_, 256) * F2p * 2 * hs_);
+        if (head_tail_) z_ = (f16 *)carve((size_t)round_up((int64_t)HB * 4 * lh_[0] * lw_[0], 256) * cp64(288) * 2 * hs_);
+        else up_ = (f16 *)carve((size_t)round_up((int64_t)HB * nh_ * nw_, 256) * F2p * 2 * hs_);
         netd_ = (float *)carve((size_t)HB * nh_ * nw_ * 4);
         full_ = (float *)carve((size_t)HB * H * W * 4);
         mm_ = (unsigned *)carve((size_t)HB * 8);
@@ -814,6 +827,19 @@ int DepthEngine::head(int f0, int n) {
     const int h1 = 2 * lh_[0], w1 = 2 * lw_[0];
     if ((r = conv3(path_[0], Fp, n, h1, w1, oc1_, o1_, nullptr, nullptr, nullptr, ACT_NONE, 1, F2p))) return r;
     nhwc("output_conv1", o1_, F2, h1, w1, F2p);
+    if (head_tail_) {   // output_conv2's nine tap products at the low resolution, then resize + sum + ReLU + 1 x 1 + ReLU in one pass (engine.h wz_)
+        const int Zp = cp64(288);
+        GemmArgs a;
+        a.A = o1_; a.lda = hs * F2p; a.M = n * h1 * w1; a.out = z_; a.ldo = hs * Zp; a.lo_off = lo(Zp); a.N = 288;
+        // (K = F / 2 is two to four K tiles: the launch is its epilogue - 1.5 ms per 16 frames on the 128 x 128 tile, 1.75 on the ping-pong kernel)
+        if ((r = gemm(A_DENSE, EPI_STD, a, wz_))) return r;
+        tic(F_ELT, 0, (double)n * ((double)h1 * w1 * 288 * (head_sa_ ? 3.0 : 2.0) + (double)nh_ * nw_ * 4.0));
+        r = launch_dpt_tail(stream, z_, n, h1, w1, hs * Zp, lo(Zp), head_mx_ ? kLo8Pa : -1, oc2_.bias, w2_, b2_, netd_, nh_, nw_);
+        toc();
+        if (r) return r;
+        stages_["net_depth"] = Stage{netd_, 2, last_n_, 1, nh_, nw_, 0, 0};
+        return 0;
+    }
     if ((r = bil(o1_, up_, h1, w1, nh_, nw_, F2, F2p))) return r;
     if (cfg_.metric) {   // the metric head needs the 32-channel activation ("out_conv" hook): 3x3 + ReLU, then the 1x1 + ReLU
         GemmArgs a;

@@ -26,6 +26,11 @@ int launch_preprocess(hipStream_t s, const uint8_t *frames, int B, int H, int W,
 int launch_bilinear_nhwc(hipStream_t s, const f16 *x, f16 *y, int B, int H, int W, int OH, int OW, int C, int ldc,
                          int align_corners, int lo_off = 0, int lo8_pa = -1);
 
+// DPT head tail from the low-resolution tap-product map z (elementwise.hip dpt_tail_kernel): bilinear(align_corners=True) resize to [OH, OW], sum of the nine
+// taps with the 3 x 3 convolution's zero padding, + bias -> ReLU -> 1 x 1 (w2, b2) -> ReLU -> out [B, OH, OW] fp32.  z pixel layouts as launch_bilinear_nhwc's.
+int launch_dpt_tail(hipStream_t s, const f16 *z, int B, int H, int W, int ldz, int lo_off, int lo8_pa, const float *bias, const float *w2, float b2,
+                    float *out, int OH, int OW);
+
 // net depth [B, nh, nw] fp32 -> bilinear(align_corners=False) -> [B, H, W] fp32 (optional) and
 // per-frame min/max (ordered-uint atomics in mm[2*B]); then heat encode to uint8 RGB.
 int launch_depth_resize_minmax(hipStream_t s, const float *net, int B, int nh, int nw, float *out, int H, int W,

@@ -127,6 +127,39 @@ def test_latency_context_splits_k_and_stays_within_tolerance():
 
 
 @pytest.mark.parametrize("prec", [1, 0])
+def test_head_tail_at_low_resolution_equals_the_reference_order(prec, monkeypatch, golden_dir):
+    """dpt.py:158-160: output_conv1 -> bilinear resize to the network size -> output_conv2 (3 x 3, ReLU, 1 x 1, ReLU).  The engine takes the 3 x 3
+    convolution's nine tap products at output_conv1's LOW resolution (one 1 x 1 GEMM with 288 columns) and resizes, sums, activates and projects
+    them in one pass (engine.h wz_, elementwise.hip dpt_tail_kernel: both maps are linear, so they commute - a third of the matrix work and of the
+    bytes, and the resized map is never rounded).  PB_HEAD_TAIL=0 (read at pb_create) keeps the reference's order: the two agree to rounding and
+    are equally far from the reference's own output."""
+    z = np.load(os.path.join(golden_dir, "depth_vitl_720p.npz"))
+    c = synth.DEPTH_CFGS["vitl"]
+    w = synth.depth_anything_weights(c, seed=1234)
+    frame = synth.frames(1, 720, 1280, seed=int(z["frame_seed"]))
+    new = engine.DepthAnything(w, c, device=0, max_batch=2, precision=prec)
+    new.set_profiling(True)
+    d_new = new.infer_batch(frame)[0]
+    names_new = [k["name"] for k in new.kernel_stats()]
+    new.close()
+    monkeypatch.setenv("PB_HEAD_TAIL", "0")
+    old = engine.DepthAnything(w, c, device=0, max_batch=2, precision=prec)
+    old.set_profiling(True)
+    d_old = old.infer_batch(frame)[0]
+    names_old = [k["name"] for k in old.kernel_stats()]
+    old.close()
+    assert any("gemm_kernel<256, 32" in n for n in names_old) and not any("gemm_kernel<256, 32" in n for n in names_new), (names_old, names_new)
+    print()
+    report("vitl 720p p%d low-resolution head tail vs reference order" % prec, d_new[0], d_old[0])
+    report("vitl 720p p%d low-resolution head tail vs reference" % prec, d_new[0][::8, ::8], z["depth_s8"])
+    report("vitl 720p p%d reference-order head tail vs reference" % prec, d_old[0][::8, ::8], z["depth_s8"])
+    tol = 4e-4 if prec else 1.5e-3
+    assert relmax(d_new[0], d_old[0]) < tol, relmax(d_new[0], d_old[0])
+    for d in (d_new, d_old):
+        assert relmax(d[0][::8, ::8], z["depth_s8"]) < TOL[prec][0] and rell2(d[0][::8, ::8], z["depth_s8"]) < TOL[prec][1]
+
+
+@pytest.mark.parametrize("prec", [1, 0])
 def test_vitl_batch_32_at_1080p_equals_single_frames(prec):
     """BASELINE configs[3]: ViT-L on a batch of 32 1920x1080 frames (one engine call, max_batch 32 - the bench's shape).  Frame i
     of the batch equals the same frame run alone, bit for bit: depth, encoded bytes, min and max; and the frame that has a

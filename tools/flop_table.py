@@ -83,7 +83,10 @@ for lv in range(3, -1, -1):
     add("depth", (CONV, STD), f"refinenet{lv + 1} RCU convs 3x3", B * lh[lv] * lw[lv], F, 9 * F, 4 if lv < 3 else 2)
     add("depth", (DENSE, STD), f"refinenet{lv + 1} out_conv 1x1 (before the upsample)", B * lh[lv] * lw[lv], F, F)
 add("depth", (CONV, STD), "output_conv1 3x3", B * 4 * lh[0] * lw[0], F // 2, 9 * F)
-add("depth", (CONV, HEAD), "output_conv2 3x3 + ReLU + 1x1 + ReLU", B * 518 * 924, 32, 9 * F // 2)
+# round 6: output_conv2's nine tap products as a 1 x 1 GEMM over output_conv1's low-resolution map (288 columns); the bilinear resize to 518 x 924, the tap
+# sum, ReLU, the 1 x 1 and the last ReLU are one elementwise pass (engine.h wz_, dpt_tail_kernel).  The reference's formulation (PB_HEAD_TAIL=0) is the
+# (CONV, HEAD) launch: B * 518 * 924 rows, N = 32, K = 9 * F / 2.
+add("depth", (DENSE, STD), "output_conv2 tap products 1x1 at low resolution (F/2 -> 9 x 32)", B * 4 * lh[0] * lw[0], 288, F // 2)
 
 B = B_ALL
 # ---- flow_raft at --scale 0.75: (H, W) -> (sh, sw) padded to /8
